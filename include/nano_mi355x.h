@@ -1,0 +1,152 @@
+/*
+ * nano_mi355x.h -- C-ABI of the MI355X (gfx950) device backend for Nano's decode hot path.
+ *
+ * This is the boundary the reference's host code binds to: plain C, plain pointers and sizes,
+ * no C++ or framework types.  It replaces the *inside* of the reference's
+ *
+ *     float *llm_forward(Nano_Context*, uint32_t token, uint32_t pos, uint32_t max_seq_len,
+ *                        uint32_t is_causal, LLM*, LoRA*)              (reference infer/infer.c:971)
+ *
+ * and of the operators it is built from (reference infer/infer.c:589-706, infer/tensor.c:15-471):
+ * weights, KV cache and scratch become device resident; (token, pos) go in; logits[vocab] (or
+ * the arg-max index) come out.  The engine API above it (llm_context_init, generate_next_token,
+ * llm_session_step ... reference infer/infer.h:253-282) is declared in nano_infer_abi.h and
+ * implemented in host C on top of the entry points below.
+ *
+ * All functions return 0 on success or a negative NANO_HIP_E* code; nano_hip_last_error() gives
+ * the text.  There is NO CPU fallback: if no gfx950 device / HIP runtime is usable the create
+ * call fails.  Not thread-safe per model (the reference engine is single-caller).
+ */
+#ifndef NANO_MI355X_H
+#define NANO_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NANO_ARCH_NANO  0u     /* reference infer/infer.h:45-47 */
+#define NANO_ARCH_QWEN2 2u
+#define NANO_ARCH_QWEN3 3u
+
+#define NANO_QUANT_F32 0x00u   /* reference infer/tensor.h:73-77 */
+#define NANO_QUANT_Q80 0x80u
+#define NANO_QUANT_Q4K 0x42u
+
+#define NANO_HIP_OK        0
+#define NANO_HIP_EINVAL   -1   /* bad argument / unsupported shape */
+#define NANO_HIP_ERUNTIME -2   /* HIP runtime error (text in nano_hip_last_error) */
+#define NANO_HIP_ENODEV   -3   /* no usable device */
+#define NANO_HIP_ENOMEM   -4
+
+#define NANO_MAX_BATCH 64u
+
+/* Model hyper-parameters = header words 4..16 of the .bin file (reference infer/infer.c:231-251),
+ * i.e. LLM_Config + arch/quant_type/group_size of the reference's LLM struct (infer/infer.h:89-99,167-180). */
+typedef struct NanoModelDesc {
+    uint32_t arch;
+    uint32_t block_size;
+    uint32_t vocab_size;
+    uint32_t n_layer;
+    uint32_t n_embd;
+    uint32_t n_head;
+    uint32_t n_kv_head;
+    uint32_t n_hidden;
+    uint32_t is_shared_classifier;
+    uint32_t head_dim;        /* header word 14; used for Qwen3 only */
+    uint32_t quant_type;
+    uint32_t group_size;
+} NanoModelDesc;
+
+typedef struct NanoHipModel NanoHipModel;   /* opaque: device weights + KV cache + scratch + graphs */
+
+/* ---- device / errors ------------------------------------------------------------------------- */
+int         nano_hip_device_count(void);
+const char *nano_hip_last_error(void);
+/* fills name[0..cap) with the device's gcnArchName ("gfx950..."), returns CU count or <0 */
+int         nano_hip_device_info(int device, char *name, size_t cap, uint64_t *total_mem_bytes);
+
+/* ---- model lifetime ---------------------------------------------------------------------------
+ * `params` is the parameter blob exactly as it sits in the model file after the header and the
+ * tokenizer section (what the reference's memory_map_params() walks, infer/infer.c:100-217); it
+ * may be unaligned.  params_on_device != 0 means `params` is a DEVICE pointer on `device` (e.g. a
+ * buffer filled by an RCCL broadcast); the backend then copies device-to-device.
+ * max_batch independent sequences get their own FP32 KV cache [L][max_seq_len][kv_dim] x2
+ * (reference infer/infer.c:46-51) and scratch; the weights are shared.
+ * Replaces: memory_map_params + malloc_fwd_buffer (reference infer/infer.c:15-85,100-217). */
+int  nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *desc, const void *params, size_t params_bytes,
+                           int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch);
+void nano_hip_model_destroy(NanoHipModel *m);
+/* number of parameter-blob bytes the backend expects for `desc` (0 if it cannot be derived
+ * without reading the blob, i.e. Q4K whose tensor frames carry their own sizes) */
+size_t nano_hip_params_bytes(const NanoModelDesc *desc);
+/* algorithmic weight bytes streamed per decode step: P*(1+4/gs), P*160/256 or 4P */
+uint64_t nano_hip_weight_bytes_per_step(const NanoHipModel *m);
+
+/* ---- the forward ------------------------------------------------------------------------------
+ * One decode step for `batch` independent sequences (slot i = sequence i): feeds tokens[i] at
+ * position pos[i].  Positions of a slot must arrive strictly increasing from 0 within a session
+ * (a new session restarts at 0 and overwrites the cache, no reset call -- reference semantics).
+ * is_causal = 0 attends over all max_seq_len cache rows (only used by seq2seq, infer.c:849).
+ * logits_out: NULL or host buffer of batch*vocab floats.  argmax_out: NULL or host buffer of
+ * batch uint32 (first maximum, strict '>' scan order = reference sample_argmax, infer.c:1026-1037).
+ * If want_logits == 0 && argmax_out == NULL the classifier GEMV is skipped (prefill positions
+ * whose logits the reference computes and discards, infer.c:1146-1149).
+ * Replaces: llm_forward (reference infer/infer.c:971-1018) and, for batch > 1, adds the batch
+ * entry SURVEY 8b asks for. */
+int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
+                     uint32_t is_causal, float *logits_out, uint32_t *argmax_out);
+
+/* Greedy on-device decode: starting from tokens[i] at pos[i], run `steps` steps feeding each
+ * slot's arg-max back in, without host round trips (tokens/positions live on the device, each
+ * step is one HIP-graph replay).  out_ids: host buffer [steps][batch].  Equivalent to calling
+ * generate_next_token() `steps` times with temperature 0 and repetition_penalty 1
+ * (reference infer/infer.c:1135-1193). */
+int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
+                           uint32_t steps, uint32_t *out_ids);
+
+/* Blocks until all work queued on the model's stream has finished. */
+int nano_hip_sync(NanoHipModel *m);
+
+/* ---- measurement -------------------------------------------------------------------------------
+ * Launches the classifier GEMV (the dominant kernel: vocab x n_embd rows) `iters` times back to
+ * back on the model's stream between two HIP events and returns the average milliseconds per
+ * launch and the algorithmic bytes one launch streams. */
+int nano_hip_time_classifier(NanoHipModel *m, uint32_t batch, uint32_t iters, float *ms_per_launch, uint64_t *bytes_per_launch);
+/* Same for one whole decode step (graph replay), `iters` replays between two events. */
+int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_step);
+/* Device read-bandwidth microbenchmark: streams `bytes` of device memory `iters` times; GB/s out. */
+int nano_hip_membw(int device, size_t bytes, uint32_t iters, float *gbps);
+
+/* ---- debugging / parity access -----------------------------------------------------------------
+ * Copy a scratch tensor of slot `slot` to the host after a forward.  which: 0=x 1=q 2=xba 3=hb
+ * 4=logits 5=k cache row (layer,pos) 6=v cache row (layer,pos).  n floats are copied. */
+int nano_hip_read_state(NanoHipModel *m, uint32_t slot, int which, uint32_t layer, uint32_t pos, float *out, size_t n);
+
+/* ---- single operators (host pointers in/out; same device kernels as the forward) ---------------
+ * These exist so that every kernel can be checked against the oracle on oracle-fed inputs.
+ * Replaces, in order: rmsnorm (infer.c:601), matmul (infer.c:637), quantize (tensor.c:21),
+ * matmul_quant (infer.c:654), quantize_tensor_q4k_in_situ (tensor.c:281, 1-D), matmul_q4k
+ * (tensor.c:438), rope / rope_qwen3 (infer.c:681/692), the attention loop (infer.c:842-879). */
+int nano_hip_op_rmsnorm(int device, float *out, const float *x, const float *w, uint32_t n);
+int nano_hip_op_matmul_f32(int device, float *out, const float *x, const float *w, uint32_t n, uint32_t d);
+int nano_hip_op_quantize_q80(int device, const float *x, uint32_t n, uint32_t gs, int8_t *q, float *s);
+int nano_hip_op_matmul_q80(int device, float *out, const int8_t *xq, const float *xs, const int8_t *wq,
+                           const float *ws, uint32_t n, uint32_t d, uint32_t gs);
+/* blocks_out: ceil(n/256)*160 bytes (the block array of a 1-D Q4k_Tensor, frame prefix excluded) */
+int nano_hip_op_quantize_q4k(int device, const float *x, uint32_t n, uint8_t *blocks_out);
+/* w_blocks: d*ceil(n/256)*160 bytes; x_blocks: ceil(n/256)*160 bytes */
+int nano_hip_op_matmul_q4k(int device, float *out, const uint8_t *x_blocks, const uint8_t *w_blocks, uint32_t n, uint32_t d);
+int nano_hip_op_rope(int device, float *head, uint32_t head_dim, const float *fcr, const float *fci, int qwen3_style);
+/* q[n_head*hd] (already normed+roped), k/v caches [range][kv_dim]; out[n_head*hd] */
+int nano_hip_op_attention(int device, float *out, const float *q, const float *k_cache, const float *v_cache,
+                          uint32_t n_head, uint32_t n_kv_head, uint32_t head_dim, uint32_t range);
+int nano_hip_op_swiglu(int device, float *hb, const float *hb2, uint32_t n);
+int nano_hip_op_argmax(int device, const float *x, uint32_t n, uint32_t *idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANO_MI355X_H */

@@ -1,0 +1,250 @@
+"""ctypes binding of the C-ABI device backend (``include/nano_mi355x.h``) and of the host C engine
+(``include/nano_infer_abi.h``).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950) into
+``nano_amd/lib/libnano_mi355x.so``.  There is no Python or CPU fallback: if the library is missing,
+or no gfx950 device is visible when a model is created, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libnano_mi355x.so")
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+class NanoModelDesc(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "arch", "block_size", "vocab_size", "n_layer", "n_embd", "n_head", "n_kv_head", "n_hidden",
+        "is_shared_classifier", "head_dim", "quant_type", "group_size")]
+
+
+class NanoHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the native library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NanoHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+
+    def fn(name, restype, argtypes):
+        f = getattr(L, name)
+        f.restype, f.argtypes = restype, argtypes
+        return f
+
+    fn("nano_hip_device_count", C.c_int, [])
+    fn("nano_hip_last_error", C.c_char_p, [])
+    fn("nano_hip_device_info", C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)])
+    fn("nano_hip_model_create", C.c_int, [C.POINTER(vp), C.POINTER(NanoModelDesc), vp, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_uint32])
+    fn("nano_hip_model_destroy", None, [vp])
+    fn("nano_hip_params_bytes", C.c_size_t, [C.POINTER(NanoModelDesc)])
+    fn("nano_hip_weight_bytes_per_step", C.c_uint64, [vp])
+    fn("nano_hip_forward", C.c_int, [vp, u32p, u32p, C.c_uint32, C.c_uint32, vp, vp])
+    fn("nano_hip_decode_greedy", C.c_int, [vp, u32p, u32p, C.c_uint32, C.c_uint32, vp])
+    fn("nano_hip_sync", C.c_int, [vp])
+    fn("nano_hip_time_classifier", C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64)])
+    fn("nano_hip_time_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)])
+    fn("nano_hip_membw", C.c_int, [C.c_int, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)])
+    fn("nano_hip_read_state", C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, f32p, C.c_size_t])
+    fn("nano_hip_op_rmsnorm", C.c_int, [C.c_int, f32p, f32p, f32p, C.c_uint32])
+    fn("nano_hip_op_matmul_f32", C.c_int, [C.c_int, f32p, f32p, f32p, C.c_uint32, C.c_uint32])
+    fn("nano_hip_op_quantize_q80", C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, i8p, f32p])
+    fn("nano_hip_op_matmul_q80", C.c_int, [C.c_int, f32p, i8p, f32p, i8p, f32p, C.c_uint32, C.c_uint32, C.c_uint32])
+    fn("nano_hip_op_quantize_q4k", C.c_int, [C.c_int, f32p, C.c_uint32, u8p])
+    fn("nano_hip_op_matmul_q4k", C.c_int, [C.c_int, f32p, u8p, u8p, C.c_uint32, C.c_uint32])
+    fn("nano_hip_op_rope", C.c_int, [C.c_int, f32p, C.c_uint32, f32p, f32p, C.c_int])
+    fn("nano_hip_op_attention", C.c_int, [C.c_int, f32p, f32p, f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32])
+    fn("nano_hip_op_swiglu", C.c_int, [C.c_int, f32p, f32p, C.c_uint32])
+    fn("nano_hip_op_argmax", C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)])
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise NanoHipError(f"nano_hip error {rc}: {lib().nano_hip_last_error().decode(errors='replace')}")
+
+
+def device_count() -> int:
+    return int(lib().nano_hip_device_count())
+
+
+def device_info(device: int = 0):
+    name = C.create_string_buffer(64)
+    mem = C.c_uint64(0)
+    cus = lib().nano_hip_device_info(device, name, 64, C.byref(mem))
+    if cus < 0:
+        check(cus)
+    return {"arch": name.value.decode(), "cus": int(cus), "mem_bytes": int(mem.value)}
+
+
+def membw(device: int = 0, nbytes: int = 1 << 30, iters: int = 10) -> float:
+    g = C.c_float(0)
+    check(lib().nano_hip_membw(device, nbytes, iters, C.byref(g)))
+    return float(g.value)
+
+
+STATE_IDS = {"x": 0, "q": 1, "xba": 2, "hb": 3, "logits": 4, "k": 5, "v": 6}
+
+
+class DeviceModel:
+    """A model resident on one GPU: mirrors what the reference keeps in ``LLM`` (weights + FwdBuffer)."""
+
+    def __init__(self, desc: NanoModelDesc, params, params_bytes: int, *, on_device: bool = False,
+                 device: int = 0, max_seq_len: int = 512, max_batch: int = 1):
+        self.desc = desc
+        self.h = C.c_void_p(None)
+        ptr = params if isinstance(params, int) else params.ctypes.data
+        check(lib().nano_hip_model_create(C.byref(self.h), C.byref(desc), C.c_void_p(ptr), params_bytes,
+                                          1 if on_device else 0, device, max_seq_len, max_batch))
+        self.vocab = int(desc.vocab_size)
+        self.max_seq_len, self.max_batch, self.device = max_seq_len, max_batch, device
+
+    def close(self):
+        if self.h:
+            lib().nano_hip_model_destroy(self.h)
+            self.h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def weight_bytes_per_step(self) -> int:
+        return int(lib().nano_hip_weight_bytes_per_step(self.h))
+
+    def forward(self, tokens: Sequence[int], pos: Sequence[int], is_causal: int = 1, want_logits: bool = True,
+                want_argmax: bool = False):
+        t = np.ascontiguousarray(tokens, np.uint32).reshape(-1)
+        p = np.ascontiguousarray(pos, np.uint32).reshape(-1)
+        B = t.size
+        logits = np.empty((B, self.vocab), np.float32) if want_logits else None
+        amax = np.empty(B, np.uint32) if want_argmax else None
+        check(lib().nano_hip_forward(self.h, t, p, B, is_causal,
+                                     logits.ctypes.data if want_logits else None,
+                                     amax.ctypes.data if want_argmax else None))
+        return logits, amax
+
+    def decode_greedy(self, tokens: Sequence[int], pos: Sequence[int], steps: int, fetch: bool = True) -> Optional[np.ndarray]:
+        t = np.ascontiguousarray(tokens, np.uint32).reshape(-1)
+        p = np.ascontiguousarray(pos, np.uint32).reshape(-1)
+        out = np.empty((steps, t.size), np.uint32) if fetch else None
+        check(lib().nano_hip_decode_greedy(self.h, t, p, t.size, steps, out.ctypes.data if fetch else None))
+        return out
+
+    def sync(self):
+        check(lib().nano_hip_sync(self.h))
+
+    def time_classifier(self, batch: int = 1, iters: int = 20):
+        ms, nbytes = C.c_float(0), C.c_uint64(0)
+        check(lib().nano_hip_time_classifier(self.h, batch, iters, C.byref(ms), C.byref(nbytes)))
+        return float(ms.value), int(nbytes.value)
+
+    def time_step(self, batch: int = 1, pos: int = 0, iters: int = 20) -> float:
+        ms = C.c_float(0)
+        check(lib().nano_hip_time_step(self.h, batch, pos, iters, C.byref(ms)))
+        return float(ms.value)
+
+    def read_state(self, name: str, n: int, slot: int = 0, layer: int = 0, pos: int = 0) -> np.ndarray:
+        out = np.empty(n, np.float32)
+        check(lib().nano_hip_read_state(self.h, slot, STATE_IDS[name], layer, pos, out, n))
+        return out
+
+
+def desc_from_spec(spec) -> NanoModelDesc:
+    """``nano_amd.modelfile.ModelSpec`` -> C struct."""
+    return NanoModelDesc(spec.arch, spec.block_size, spec.vocab_size, spec.n_layer, spec.n_embd, spec.n_head,
+                         spec.n_kv_head, spec.n_hidden, spec.shared_classifier, spec.head_dim, spec.quant_type,
+                         spec.group_size)
+
+
+def load_model_file(path: str, *, device: int = 0, max_seq_len: int = 512, max_batch: int = 1) -> DeviceModel:
+    """Open a Nano ``.bin`` (header + tokenizer section + parameter blob) and upload it.
+    The tokenizer section is skipped: this entry works on token ids."""
+    from . import modelfile as mf
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    spec = mf.read_header(bytes(raw[:256]))
+    tok_bytes = int(np.frombuffer(bytes(raw[256:260]), "<u4")[0])
+    off = 256 + tok_bytes
+    params = np.ascontiguousarray(raw[off:])         # private, aligned copy of the blob
+    m = DeviceModel(desc_from_spec(spec), params, params.size, device=device, max_seq_len=max_seq_len, max_batch=max_batch)
+    m.spec = spec
+    return m
+
+
+# ---- single operators ---------------------------------------------------------------------------------
+def op_rmsnorm(x, w, device=0):
+    x = np.ascontiguousarray(x, np.float32); out = np.empty_like(x)
+    check(lib().nano_hip_op_rmsnorm(device, out, x, np.ascontiguousarray(w, np.float32), x.size)); return out
+
+
+def op_matmul_f32(x, w, device=0):
+    d, n = w.shape; out = np.empty(d, np.float32)
+    check(lib().nano_hip_op_matmul_f32(device, out, np.ascontiguousarray(x, np.float32), np.ascontiguousarray(w, np.float32), n, d)); return out
+
+
+def op_quantize_q80(x, gs, device=0):
+    x = np.ascontiguousarray(x, np.float32)
+    q = np.empty(x.size, np.int8); s = np.empty(x.size // gs, np.float32)
+    check(lib().nano_hip_op_quantize_q80(device, x, x.size, gs, q, s)); return q, s
+
+
+def op_matmul_q80(xq, xs, wq, ws, n, d, gs, device=0):
+    out = np.empty(d, np.float32)
+    check(lib().nano_hip_op_matmul_q80(device, out, np.ascontiguousarray(xq), np.ascontiguousarray(xs),
+                                       np.ascontiguousarray(wq), np.ascontiguousarray(ws), n, d, gs)); return out
+
+
+def op_quantize_q4k(x, device=0):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(((x.size + 255) // 256) * 160, np.uint8)
+    check(lib().nano_hip_op_quantize_q4k(device, x, x.size, out)); return out
+
+
+def op_matmul_q4k(x_blocks, w_blocks, n, d, device=0):
+    out = np.empty(d, np.float32)
+    check(lib().nano_hip_op_matmul_q4k(device, out, np.ascontiguousarray(x_blocks), np.ascontiguousarray(w_blocks), n, d)); return out
+
+
+def op_rope(head, fcr, fci, qwen3, device=0):
+    h = np.array(head, np.float32, copy=True)
+    check(lib().nano_hip_op_rope(device, h, h.size, np.ascontiguousarray(fcr, np.float32), np.ascontiguousarray(fci, np.float32), int(qwen3))); return h
+
+
+def op_attention(q, k_cache, v_cache, n_head, n_kv_head, head_dim, device=0):
+    rng = k_cache.shape[0]
+    out = np.empty(n_head * head_dim, np.float32)
+    check(lib().nano_hip_op_attention(device, out, np.ascontiguousarray(q, np.float32), np.ascontiguousarray(k_cache, np.float32),
+                                      np.ascontiguousarray(v_cache, np.float32), n_head, n_kv_head, head_dim, rng)); return out
+
+
+def op_swiglu(hb, hb2, device=0):
+    h = np.array(hb, np.float32, copy=True)
+    check(lib().nano_hip_op_swiglu(device, h, np.ascontiguousarray(hb2, np.float32), h.size)); return h
+
+
+def op_argmax(x, device=0):
+    i = C.c_uint32(0)
+    x = np.ascontiguousarray(x, np.float32)
+    check(lib().nano_hip_op_argmax(device, x, x.size, C.byref(i))); return int(i.value)

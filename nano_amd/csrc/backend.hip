@@ -1,0 +1,547 @@
+// backend.hip -- the C-ABI device backend declared in include/nano_mi355x.h.
+//
+// Owns: the device copy of the model's parameter blob (each tensor re-based to a 256-byte aligned
+// address; Q4K tensors lose their 44-byte frame prefix so that 160-byte blocks are 16-byte aligned;
+// otherwise the row-major weight blocks stay byte-for-byte as in the model file), the per-sequence
+// FP32 KV cache and scratch, and the HIP graphs of one decode step.  One decode step is
+//   embed -> L x [ QKV GEMV | attention | Wo GEMV(+residual) | W1/W3 GEMV(+SwiGLU) | W2 GEMV(+residual) ]
+//         -> classifier GEMV -> arg-max
+// = 5L+3 kernels, all on one stream, captured once per (batch, mode) and replayed.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nano_mi355x.h"
+#include "kernels.h"
+
+using namespace nano;
+
+static thread_local std::string g_err;
+extern "C" const char *nano_hip_last_error(void) { return g_err.c_str(); }
+extern "C" void nano_hip_set_error_(const char *msg) { g_err = msg ? msg : ""; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            char _b[512];                                                                          \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            g_err = _b;                                                                            \
+            return NANO_HIP_ERUNTIME;                                                              \
+        }                                                                                          \
+    } while (0)
+
+#define FAIL(code, ...)                                                                            \
+    do {                                                                                           \
+        char _b[512];                                                                              \
+        snprintf(_b, sizeof _b, __VA_ARGS__);                                                      \
+        g_err = _b;                                                                                \
+        return (code);                                                                             \
+    } while (0)
+
+enum { WQ = 0, WK, WV, WO, W1, W2, W3, WCOUNT };
+
+struct TensorRef { const void *w = nullptr; const float *s = nullptr; };
+
+struct NanoHipModel {
+    NanoModelDesc d{};
+    int device = 0, cus = 0;
+    uint32_t S = 0, maxB = 0, hd = 0, QD = 0, KD = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t *arena = nullptr;
+    size_t arena_bytes = 0;
+    const float *rms_attn = nullptr, *rms_ffn = nullptr, *rms_final = nullptr;
+    const float *q_norm = nullptr, *k_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    TensorRef tok, cls;
+    std::vector<TensorRef> W[WCOUNT];
+    // per-sequence state
+    float *x = nullptr, *q = nullptr, *kraw = nullptr, *xba = nullptr, *hb = nullptr, *logits = nullptr;
+    float *kcache = nullptr, *vcache = nullptr;
+    uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *step = nullptr;
+    uint32_t trace_cap = 0;
+    // pinned host staging
+    uint32_t *h_tokens = nullptr, *h_pos = nullptr, *h_amax = nullptr;
+    float *h_logits = nullptr;
+    std::map<uint64_t, hipGraphExec_t> graphs;
+    uint64_t weight_bytes_per_step = 0;
+    bool use_graph = true;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device info
+// ------------------------------------------------------------------------------------------------
+extern "C" int nano_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int nano_hip_device_info(int device, char *name, size_t cap, uint64_t *total_mem) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && cap) { strncpy(name, p.gcnArchName, cap - 1); name[cap - 1] = 0; }
+    if (total_mem) *total_mem = p.totalGlobalMem;
+    return p.multiProcessorCount;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameter blob layout (reference infer/infer.c:100-217)
+// ------------------------------------------------------------------------------------------------
+struct Piece { size_t src_off, bytes, dst_off; };
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void shapes(const NanoModelDesc &d, uint32_t &hd, uint32_t &QD, uint32_t &KD) {
+    if (d.arch == NANO_ARCH_QWEN3) { hd = d.head_dim; QD = hd * d.n_head; KD = hd * d.n_kv_head; }
+    else { hd = d.n_embd / d.n_head; QD = d.n_embd; KD = (d.n_embd * d.n_kv_head) / d.n_head; }
+}
+
+extern "C" size_t nano_hip_params_bytes(const NanoModelDesc *d) {
+    if (!d || d->quant_type == NANO_QUANT_Q4K) return 0;
+    uint32_t hd, QD, KD; shapes(*d, hd, QD, KD);
+    const size_t L = d->n_layer, E = d->n_embd, H = d->n_hidden, V = d->vocab_size;
+    const size_t P = V * E + L * (2 * (size_t)QD * E + 2 * (size_t)KD * E + 3 * H * E);
+    size_t sz = 4 * (2 * L * E + E);
+    sz += (d->quant_type == NANO_QUANT_F32) ? 4 * P : P + 4 * (P / d->group_size);
+    if (d->arch == NANO_ARCH_QWEN2) sz += 4 * L * ((size_t)QD + 2 * KD);
+    if (d->arch == NANO_ARCH_QWEN3) sz += 8 * L * hd;
+    sz += 8 * ((size_t)d->block_size * hd / 2);
+    if (!d->is_shared_classifier) sz += (d->quant_type == NANO_QUANT_F32) ? 4 * V * E : V * E + 4 * (V * E / d->group_size);
+    return sz;
+}
+
+static int copy_in(void *dst, const void *src, size_t bytes, int src_on_device) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return 0;
+}
+static int peek(void *host_dst, const uint8_t *src, size_t bytes, int src_on_device) {
+    if (src_on_device) { HIP_TRY(hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost)); }
+    else memcpy(host_dst, src, bytes);
+    return 0;
+}
+
+static void destroy(NanoHipModel *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->st) (void)hipStreamSynchronize(m->st);
+    for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
+                    m->tokens, m->pos, m->amax, m->trace, m->step };
+    for (void *p : dev) if (p) (void)hipFree(p);
+    void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
+    for (void *p : host) if (p) (void)hipHostFree(p);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->st) (void)hipStreamDestroy(m->st);
+    delete m;
+}
+
+extern "C" void nano_hip_model_destroy(NanoHipModel *m) { destroy(m); }
+
+extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *desc, const void *params, size_t params_bytes,
+                                     int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch) {
+    if (!out || !desc || !params) FAIL(NANO_HIP_EINVAL, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(NANO_HIP_ENODEV, "no HIP device visible (this backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) FAIL(NANO_HIP_EINVAL, "device %d out of range (%d devices)", device, ndev);
+    const NanoModelDesc &d = *desc;
+    if (d.quant_type != NANO_QUANT_F32 && d.quant_type != NANO_QUANT_Q80 && d.quant_type != NANO_QUANT_Q4K)
+        FAIL(NANO_HIP_EINVAL, "unknown quant type 0x%x", d.quant_type);
+    if (max_batch == 0 || max_batch > NANO_MAX_BATCH || max_seq_len == 0) FAIL(NANO_HIP_EINVAL, "bad max_batch/max_seq_len");
+    uint32_t hd, QD, KD; shapes(d, hd, QD, KD);
+    if (d.n_head == 0 || d.n_kv_head == 0 || d.n_head % d.n_kv_head) FAIL(NANO_HIP_EINVAL, "bad head counts");
+    if (hd == 0 || hd % 4 || hd > 256) FAIL(NANO_HIP_EINVAL, "head_dim %u unsupported (needs %%4==0, <=256)", hd);
+    if (d.n_embd % 16 || QD % 16 || d.n_hidden % 16) FAIL(NANO_HIP_EINVAL, "n_embd/q_dim/n_hidden must be multiples of 16");
+    if (d.quant_type == NANO_QUANT_Q80) {
+        const uint32_t gs = d.group_size;
+        if (!(gs == 32 || gs == 64 || gs == 128 || gs == 256)) FAIL(NANO_HIP_EINVAL, "Q80 group size %u unsupported (32/64/128/256)", gs);
+        if (d.n_embd % gs || QD % gs || d.n_hidden % gs) FAIL(NANO_HIP_EINVAL, "group size must divide n_embd, q_dim, n_hidden");
+    }
+    if (!d.is_shared_classifier && d.quant_type == NANO_QUANT_Q4K) FAIL(NANO_HIP_EINVAL, "Q4K classifier is always shared (reference infer.c:211)");
+
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        FAIL(NANO_HIP_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+
+    NanoHipModel *m = new NanoHipModel();
+    m->d = d; m->device = device; m->cus = prop.multiProcessorCount;
+    m->S = max_seq_len; m->maxB = max_batch; m->hd = hd; m->QD = QD; m->KD = KD;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(params);
+    const size_t L = d.n_layer, E = d.n_embd, H = d.n_hidden, V = d.vocab_size;
+    const size_t each[WCOUNT] = { (size_t)QD * E, (size_t)KD * E, (size_t)KD * E, E * QD, H * E, E * H, H * E };
+    const size_t rows_of[WCOUNT] = { QD, KD, KD, E, H, E, H };
+    const size_t cols_of[WCOUNT] = { E, E, E, QD, E, H, E };
+
+    // ---- pass 1: walk the blob, record pieces -----------------------------------------------------
+    std::vector<Piece> pieces;
+    size_t so = 0, doff = 0;
+    auto add = [&](size_t bytes, size_t skip_prefix = 0) -> size_t {
+        doff = align_up(doff, 256);
+        Piece p{ so + skip_prefix, bytes - skip_prefix, doff };
+        pieces.push_back(p);
+        so += bytes; doff += bytes - skip_prefix;
+        return p.dst_off;
+    };
+    size_t o_rms_attn = add(4 * L * E), o_rms_ffn = add(4 * L * E), o_rms_final = add(4 * E);
+    size_t o_tok_w = 0, o_tok_s = 0, o_cls_w = 0, o_cls_s = 0;
+    std::vector<size_t> o_w[WCOUNT], o_s[WCOUNT];
+    int rc = 0;
+    if (d.quant_type == NANO_QUANT_Q80) {
+        o_tok_w = add(V * E); o_tok_s = add(4 * (V * E / d.group_size));
+        for (int k = 0; k < WCOUNT; k++)
+            for (size_t l = 0; l < L; l++) { o_w[k].push_back(add(each[k])); o_s[k].push_back(add(4 * (each[k] / d.group_size))); }
+    } else if (d.quant_type == NANO_QUANT_Q4K) {
+        for (int k = -1; k < WCOUNT; k++) {
+            uint64_t frame = 0;
+            if (so + 8 > params_bytes) { destroy(m); FAIL(NANO_HIP_EINVAL, "parameter blob truncated (Q4K frame)"); }
+            if ((rc = peek(&frame, src + so, 8, params_on_device))) { destroy(m); return rc; }
+            const size_t rows = (k < 0) ? V : L * rows_of[k], cols = (k < 0) ? E : cols_of[k];
+            const size_t expect = 44 + rows * ((cols + 255) / 256) * 160;
+            if (frame != expect) { destroy(m); FAIL(NANO_HIP_EINVAL, "Q4K tensor %d: frame %llu bytes, expected %zu", k, (unsigned long long)frame, expect); }
+            size_t o = add(frame, 44);
+            if (k < 0) o_tok_w = o; else o_w[k].push_back(o);
+        }
+    } else {
+        o_tok_w = add(4 * V * E);
+        for (int k = 0; k < WCOUNT; k++) o_w[k].push_back(add(4 * L * each[k]));
+    }
+    size_t o_qn = 0, o_kn = 0;
+    if (d.arch == NANO_ARCH_QWEN2) so += 4 * L * ((size_t)QD + 2 * KD);        // biases: mapped, never applied (infer.c:788-790)
+    if (d.arch == NANO_ARCH_QWEN3) { o_qn = add(4 * L * hd); o_kn = add(4 * L * hd); }
+    const size_t rope_file_n = (size_t)d.block_size * hd / 2;
+    const size_t rope_rows = (d.block_size < max_seq_len) ? d.block_size : max_seq_len;   // rows actually indexable
+    size_t o_cos = 0, o_sin = 0;
+    if (d.arch == NANO_ARCH_QWEN3) {
+        so += 8 * rope_file_n;                                                   // skipped and recomputed (infer.c:189-204)
+        doff = align_up(doff, 256); o_cos = doff; doff += 4 * rope_rows * hd / 2;
+        doff = align_up(doff, 256); o_sin = doff; doff += 4 * rope_rows * hd / 2;
+    } else {
+        o_cos = add(4 * rope_file_n); o_sin = add(4 * rope_file_n);
+    }
+    if (!d.is_shared_classifier) {
+        if (d.quant_type == NANO_QUANT_Q80) { o_cls_w = add(V * E); o_cls_s = add(4 * (V * E / d.group_size)); }
+        /* FP32 un-shared: the reference aliases the START of the blob (stale pointer, infer.c:215) */
+    }
+    if (so > params_bytes) { destroy(m); FAIL(NANO_HIP_EINVAL, "parameter blob too small: need %zu bytes, got %zu", so, params_bytes); }
+
+    // ---- pass 2: allocate + upload -------------------------------------------------------------------
+    m->arena_bytes = align_up(doff, 256) + 256;
+    if (hipMalloc(&m->arena, m->arena_bytes) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc(%zu) for weights failed", m->arena_bytes); }
+    for (const Piece &p : pieces)
+        if ((rc = copy_in(m->arena + p.dst_off, src + p.src_off, p.bytes, params_on_device))) { destroy(m); return rc; }
+    if (d.arch == NANO_ARCH_QWEN3) {
+        // same libm calls as the reference loader (infer.c:193-201), host side
+        std::vector<float> c(rope_rows * hd / 2), s(rope_rows * hd / 2);
+        for (uint32_t pos = 0; pos < rope_rows; pos++)
+            for (uint32_t i = 0; i < hd / 2; i++) {
+                float freq = 1.0f / powf(1000000.0f, (float)(i * 2) / (float)hd);
+                c[(size_t)pos * hd / 2 + i] = cosf(pos * freq);
+                s[(size_t)pos * hd / 2 + i] = sinf(pos * freq);
+            }
+        if ((rc = copy_in(m->arena + o_cos, c.data(), c.size() * 4, 0)) || (rc = copy_in(m->arena + o_sin, s.data(), s.size() * 4, 0))) { destroy(m); return rc; }
+    }
+    auto F = [&](size_t o) { return reinterpret_cast<const float *>(m->arena + o); };
+    m->rms_attn = F(o_rms_attn); m->rms_ffn = F(o_rms_ffn); m->rms_final = F(o_rms_final);
+    m->rope_cos = F(o_cos); m->rope_sin = F(o_sin);
+    if (d.arch == NANO_ARCH_QWEN3) { m->q_norm = F(o_qn); m->k_norm = F(o_kn); }
+    m->tok.w = m->arena + o_tok_w; m->tok.s = (d.quant_type == NANO_QUANT_Q80) ? F(o_tok_s) : nullptr;
+    for (int k = 0; k < WCOUNT; k++) {
+        m->W[k].resize(L);
+        for (size_t l = 0; l < L; l++) {
+            if (d.quant_type == NANO_QUANT_Q80) { m->W[k][l].w = m->arena + o_w[k][l]; m->W[k][l].s = F(o_s[k][l]); }
+            else if (d.quant_type == NANO_QUANT_Q4K) m->W[k][l].w = m->arena + o_w[k][0] + l * rows_of[k] * ((cols_of[k] + 255) / 256) * 160;
+            else m->W[k][l].w = m->arena + o_w[k][0] + 4 * l * each[k];
+        }
+    }
+    if (d.is_shared_classifier) m->cls = m->tok;
+    else if (d.quant_type == NANO_QUANT_Q80) { m->cls.w = m->arena + o_cls_w; m->cls.s = F(o_cls_s); }
+    else m->cls.w = m->arena + o_rms_attn;   /* sic (see above) */
+
+    {   // algorithmic weight bytes per decode step
+        const uint64_t P = (uint64_t)V * E + L * (2 * (uint64_t)QD * E + 2 * (uint64_t)KD * E + 3 * (uint64_t)H * E);
+        m->weight_bytes_per_step = (d.quant_type == NANO_QUANT_F32) ? 4 * P
+                                 : (d.quant_type == NANO_QUANT_Q80) ? P + 4 * (P / d.group_size) : P * 160 / 256;
+    }
+
+    // ---- state ---------------------------------------------------------------------------------------
+    const size_t B = max_batch;
+    const size_t kvn = B * L * max_seq_len * KD;
+    m->trace_cap = max_seq_len * max_batch;
+    bool ok = hipMalloc(&m->x, B * E * 4) == hipSuccess && hipMalloc(&m->q, B * QD * 4) == hipSuccess &&
+              hipMalloc(&m->kraw, B * KD * 4) == hipSuccess && hipMalloc(&m->xba, B * QD * 4) == hipSuccess &&
+              hipMalloc(&m->hb, B * H * 4) == hipSuccess && hipMalloc(&m->logits, B * V * 4) == hipSuccess &&
+              hipMalloc(&m->kcache, kvn * 4) == hipSuccess && hipMalloc(&m->vcache, kvn * 4) == hipSuccess &&
+              hipMalloc(&m->tokens, B * 4) == hipSuccess && hipMalloc(&m->pos, B * 4) == hipSuccess &&
+              hipMalloc(&m->amax, B * 4) == hipSuccess && hipMalloc(&m->trace, (size_t)m->trace_cap * 4) == hipSuccess &&
+              hipMalloc(&m->step, 4) == hipSuccess;
+    if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
+    // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
+    if (hipMemset(m->kcache, 0, kvn * 4) != hipSuccess || hipMemset(m->vcache, 0, kvn * 4) != hipSuccess ||
+        hipMemset(m->x, 0, B * E * 4) != hipSuccess || hipMemset(m->logits, 0, B * V * 4) != hipSuccess ||
+        hipMemset(m->tokens, 0, B * 4) != hipSuccess || hipMemset(m->pos, 0, B * 4) != hipSuccess ||
+        hipMemset(m->step, 0, 4) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "hipMemset failed"); }
+    ok = hipHostMalloc(&m->h_tokens, B * 4) == hipSuccess && hipHostMalloc(&m->h_pos, B * 4) == hipSuccess &&
+         hipHostMalloc(&m->h_amax, (size_t)m->trace_cap * 4) == hipSuccess && hipHostMalloc(&m->h_logits, B * V * 4) == hipSuccess;
+    if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipHostMalloc failed"); }
+    if (hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
+        hipEventCreate(&m->ev1) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "stream/event creation failed"); }
+    if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
+    HIP_TRY(hipDeviceSynchronize());
+    *out = m;
+    return NANO_HIP_OK;
+}
+
+extern "C" uint64_t nano_hip_weight_bytes_per_step(const NanoHipModel *m) { return m ? m->weight_bytes_per_step : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// one decode step, enqueued on m->st
+// ------------------------------------------------------------------------------------------------
+enum StepMode : uint32_t { MODE_NOCLS = 0, MODE_LOGITS = 1, MODE_ARGMAX = 2, MODE_LOOP = 3 };
+
+static GemvSeg mkseg(const TensorRef &t, float *out, uint32_t rows, uint32_t bstride, uint32_t pstride = 0) {
+    GemvSeg s{}; s.w = t.w; s.ws = t.s; s.out = out; s.rows = rows; s.out_bstride = bstride; s.out_pstride = pstride;
+    return s;
+}
+
+static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
+    const uint32_t max_wg = (uint32_t)m->cus * 8;
+    if (m->d.quant_type == NANO_QUANT_Q4K) return launch_gemv_q4k(a, max_wg, m->st);
+    return launch_gemv(m->d.quant_type, a, max_wg, m->st);
+}
+
+static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb) {
+    GemvArgs a{};
+    a.nseg = 1; a.seg[0] = mkseg(m->cls, m->logits, m->d.vocab_size, m->d.vocab_size);
+    a.n = m->d.n_embd; a.gs = m->d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = m->d.n_embd;
+    a.epi = GEMV_EPI_STORE; a.norm_w = m->rms_final; a.pos = m->pos;
+    return gemv(m, a);
+}
+
+static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode) {
+    const NanoModelDesc &d = m->d;
+    const uint32_t E = d.n_embd, H = d.n_hidden, QD = m->QD, KD = m->KD, L = d.n_layer, S = m->S;
+    hipError_t e;
+    EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E };
+    if ((e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
+
+    for (uint32_t l = 0; l < L; l++) {
+        const size_t layer_rows = (size_t)l * S;                    // cache row offset of this layer within a slot
+        {   // q | raw k | v (straight into the cache row)   reference infer.c:758-786
+            GemvArgs a{};
+            a.nseg = 3;
+            a.seg[0] = mkseg(m->W[WQ][l], m->q, QD, QD);
+            a.seg[1] = mkseg(m->W[WK][l], m->kraw, KD, KD);
+            a.seg[2] = mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
+            a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_STORE;
+            a.norm_w = m->rms_attn + (size_t)l * E; a.pos = m->pos;
+            if ((e = gemv(m, a)) != hipSuccess) return e;
+        }
+        {   // qk-norm, rope, k-cache write, attention   reference infer.c:810-879
+            AttnArgs a{};
+            a.q = m->q; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
+            a.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
+            a.k_norm = m->k_norm ? m->k_norm + (size_t)l * m->hd : nullptr;
+            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.out = m->xba;
+            a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
+            a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
+            a.cache_bstride_rows = L * S; a.fixed_range = 0;
+            if ((e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
+        }
+        {   // x += Wo . xba   reference infer.c:885-908
+            GemvArgs a{};
+            a.nseg = 1; a.seg[0] = mkseg(m->W[WO][l], m->x, E, E);
+            a.n = QD; a.gs = d.group_size; a.nb = nb; a.xin = m->xba; a.xin_bstride = QD; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
+            if ((e = gemv(m, a)) != hipSuccess) return e;
+        }
+        {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
+            GemvArgs a{};
+            a.nseg = 2; a.seg[0] = mkseg(m->W[W1][l], m->hb, H, H); a.seg[1] = mkseg(m->W[W3][l], m->hb, H, H);
+            a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_SWIGLU;
+            a.norm_w = m->rms_ffn + (size_t)l * E; a.pos = m->pos;
+            if ((e = gemv(m, a)) != hipSuccess) return e;
+        }
+        {   // x += W2 . hb   reference infer.c:950-965
+            GemvArgs a{};
+            a.nseg = 1; a.seg[0] = mkseg(m->W[W2][l], m->x, E, E);
+            a.n = H; a.gs = d.group_size; a.nb = nb; a.xin = m->hb; a.xin_bstride = H; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
+            if ((e = gemv(m, a)) != hipSuccess) return e;
+        }
+    }
+    if (mode == MODE_NOCLS) return hipSuccess;
+    if ((e = enqueue_classifier(m, nb)) != hipSuccess) return e;      // final rmsnorm fused in the prologue (infer.c:999-1015)
+    if (mode == MODE_ARGMAX || mode == MODE_LOOP) {
+        ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, nullptr, nullptr, m->step, nb };
+        if (mode == MODE_LOOP) { aa.tokens = m->tokens; aa.pos = m->pos; aa.trace = m->trace; }
+        if ((e = launch_argmax(aa, nb, m->st)) != hipSuccess) return e;
+        if (mode == MODE_LOOP && (e = launch_step_inc(m->step, m->st)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode) {
+    if (!m->use_graph) { HIP_TRY(enqueue_step(m, nb, is_causal, mode)); return 0; }
+    const uint64_t key = ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
+    auto it = m->graphs.find(key);
+    if (it == m->graphs.end()) {
+        // first use: run eagerly once (sets kernel attributes, validates launches) then capture
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
+        hipError_t e = enqueue_step(m, nb, is_causal, mode);
+        hipError_t e2 = hipStreamEndCapture(m->st, &g);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            FAIL(NANO_HIP_ERUNTIME, "graph capture failed: %s / %s", hipGetErrorString(e), hipGetErrorString(e2));
+        }
+        HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        it = m->graphs.emplace(key, ge).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, m->st));
+    return 0;
+}
+
+extern "C" int nano_hip_sync(NanoHipModel *m) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    return 0;
+}
+
+static int check_batch(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, uint32_t extra_steps) {
+    if (!m || !tokens || !pos) FAIL(NANO_HIP_EINVAL, "null argument");
+    if (batch == 0 || batch > m->maxB || batch > 8) FAIL(NANO_HIP_EINVAL, "batch %u out of range (max %u, kernel capacity 8)", batch, m->maxB);
+    for (uint32_t i = 0; i < batch; i++) {
+        if (tokens[i] >= m->d.vocab_size) FAIL(NANO_HIP_EINVAL, "token %u out of vocabulary", tokens[i]);
+        if ((uint64_t)pos[i] + (extra_steps ? extra_steps - 1 : 0) >= (uint64_t)m->S) FAIL(NANO_HIP_EINVAL, "position %u (+%u steps) exceeds max_seq_len %u", pos[i], extra_steps, m->S);
+    }
+    return 0;
+}
+
+extern "C" int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
+                                uint32_t is_causal, float *logits_out, uint32_t *argmax_out) {
+    int rc;
+    if ((rc = check_batch(m, tokens, pos, batch, 0))) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    memcpy(m->h_tokens, tokens, batch * 4); memcpy(m->h_pos, pos, batch * 4);
+    HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
+    const uint32_t mode = argmax_out ? MODE_ARGMAX : (logits_out ? MODE_LOGITS : MODE_NOCLS);
+    if ((rc = run_step(m, batch, is_causal ? 1u : 0u, mode))) return rc;
+    const size_t V = m->d.vocab_size;
+    if (logits_out) HIP_TRY(hipMemcpyAsync(m->h_logits, m->logits, batch * V * 4, hipMemcpyDeviceToHost, m->st));
+    if (argmax_out) HIP_TRY(hipMemcpyAsync(m->h_amax, m->amax, batch * 4, hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    if (logits_out) memcpy(logits_out, m->h_logits, batch * V * 4);
+    if (argmax_out) memcpy(argmax_out, m->h_amax, batch * 4);
+    return 0;
+}
+
+extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
+                                      uint32_t steps, uint32_t *out_ids) {
+    int rc;
+    if (steps == 0) return 0;
+    if ((rc = check_batch(m, tokens, pos, batch, steps))) return rc;
+    if ((uint64_t)steps * batch > m->trace_cap) FAIL(NANO_HIP_EINVAL, "steps*batch exceeds trace capacity %u", m->trace_cap);
+    HIP_TRY(hipSetDevice(m->device));
+    memcpy(m->h_tokens, tokens, batch * 4); memcpy(m->h_pos, pos, batch * 4);
+    HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemsetAsync(m->step, 0, 4, m->st));
+    for (uint32_t s = 0; s < steps; s++)
+        if ((rc = run_step(m, batch, 1, MODE_LOOP))) return rc;
+    if (out_ids) {
+        HIP_TRY(hipMemcpyAsync(m->h_amax, m->trace, (size_t)steps * batch * 4, hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        memcpy(out_ids, m->h_amax, (size_t)steps * batch * 4);
+    } else {
+        HIP_TRY(hipStreamSynchronize(m->st));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------------
+extern "C" int nano_hip_time_classifier(NanoHipModel *m, uint32_t batch, uint32_t iters, float *ms_per_launch, uint64_t *bytes_per_launch) {
+    if (!m || !iters || batch == 0 || batch > 8 || batch > m->maxB) FAIL(NANO_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(enqueue_classifier(m, batch));                               // warm
+    HIP_TRY(hipEventRecord(m->ev0, m->st));
+    for (uint32_t i = 0; i < iters; i++) HIP_TRY(enqueue_classifier(m, batch));
+    HIP_TRY(hipEventRecord(m->ev1, m->st));
+    HIP_TRY(hipEventSynchronize(m->ev1));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+    if (ms_per_launch) *ms_per_launch = ms / iters;
+    if (bytes_per_launch) {
+        const uint64_t VE = (uint64_t)m->d.vocab_size * m->d.n_embd;
+        *bytes_per_launch = (m->d.quant_type == NANO_QUANT_F32) ? 4 * VE
+                          : (m->d.quant_type == NANO_QUANT_Q80) ? VE + 4 * (VE / m->d.group_size) : VE * 160 / 256;
+    }
+    return 0;
+}
+
+extern "C" int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_step) {
+    if (!m || !iters || batch == 0 || batch > 8 || batch > m->maxB || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    for (uint32_t i = 0; i < batch; i++) { m->h_tokens[i] = 1 % m->d.vocab_size; m->h_pos[i] = pos; }
+    HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
+    int rc;
+    if ((rc = run_step(m, batch, 1, MODE_ARGMAX))) return rc;            // warm / capture
+    HIP_TRY(hipEventRecord(m->ev0, m->st));
+    for (uint32_t i = 0; i < iters; i++) if ((rc = run_step(m, batch, 1, MODE_ARGMAX))) return rc;
+    HIP_TRY(hipEventRecord(m->ev1, m->st));
+    HIP_TRY(hipEventSynchronize(m->ev1));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+    if (ms_per_step) *ms_per_step = ms / iters;
+    return 0;
+}
+
+extern "C" int nano_hip_membw(int device, size_t bytes, uint32_t iters, float *gbps) {
+    if (!iters || bytes < (1u << 20)) FAIL(NANO_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    void *buf = nullptr; float *sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, bytes));
+    HIP_TRY(hipMalloc(&sink, 4));
+    HIP_TRY(hipMemset(buf, 1, bytes));
+    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(launch_stream_read(buf, bytes, sink, 0));
+    HIP_TRY(hipEventRecord(e0, 0));
+    for (uint32_t i = 0; i < iters; i++) HIP_TRY(launch_stream_read(buf, bytes, sink, 0));
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (gbps) *gbps = (float)((double)bytes * iters / (ms * 1e-3) / 1e9);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(buf); (void)hipFree(sink);
+    return 0;
+}
+
+extern "C" int nano_hip_read_state(NanoHipModel *m, uint32_t slot, int which, uint32_t layer, uint32_t pos, float *out, size_t n) {
+    if (!m || !out || slot >= m->maxB) FAIL(NANO_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    const float *src = nullptr; size_t cap = 0;
+    const size_t row = (((size_t)slot * m->d.n_layer + layer) * m->S + pos) * m->KD;
+    switch (which) {
+    case 0: src = m->x + (size_t)slot * m->d.n_embd; cap = m->d.n_embd; break;
+    case 1: src = m->q + (size_t)slot * m->QD; cap = m->QD; break;
+    case 2: src = m->xba + (size_t)slot * m->QD; cap = m->QD; break;
+    case 3: src = m->hb + (size_t)slot * m->d.n_hidden; cap = m->d.n_hidden; break;
+    case 4: src = m->logits + (size_t)slot * m->d.vocab_size; cap = m->d.vocab_size; break;
+    case 5: if (layer >= m->d.n_layer || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad layer/pos"); src = m->kcache + row; cap = m->KD; break;
+    case 6: if (layer >= m->d.n_layer || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad layer/pos"); src = m->vcache + row; cap = m->KD; break;
+    default: FAIL(NANO_HIP_EINVAL, "unknown state id %d", which);
+    }
+    if (n > cap) FAIL(NANO_HIP_EINVAL, "n too large");
+    HIP_TRY(hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,95 @@
+// kernels.h -- host-visible argument blocks and launchers of the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nano {
+
+constexpr int GEMV_RB = 4;          // rows per wave tile
+
+enum : uint32_t { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_SWIGLU = 2 };
+
+// One weight tensor (or a run of them sharing the input vector) of a fused GEMV launch.
+struct GemvSeg {
+    const void *w;          // FP32: float[rows][n]; Q80: int8[rows][n]; Q4K: 160-byte blocks, 16-B aligned
+    const float *ws;        // Q80: float[rows][n/gs]
+    float *out;             // output base
+    uint32_t rows;
+    uint32_t out_bstride;   // floats between sequence slots
+    uint32_t out_pstride;   // floats per position (KV-cache rows); 0 = not position indexed
+    uint32_t _pad;
+};
+
+struct GemvArgs {
+    GemvSeg seg[3];
+    uint32_t nseg;
+    uint32_t n;             // row length (input vector length)
+    uint32_t gs;            // Q80 group size
+    uint32_t nb;            // live sequences (<= template capacity)
+    const float *xin;       // fp32 input vectors
+    uint32_t xin_bstride;
+    uint32_t epi;
+    const float *norm_w;    // rmsnorm weight or nullptr
+    const uint32_t *pos;    // device positions [nb] (for out_pstride)
+    uint32_t tiles;         // filled by the launcher
+    uint32_t _pad;
+    // operator-test inputs: an already quantized activation (skips the quantizing prologue)
+    const int8_t *xq_in;    // Q80 int8[n]
+    const float *xs_in;     // Q80 float[n/gs]
+    const uint8_t *x4_in;   // Q4K blocks[ceil(n/256)*160]
+};
+
+size_t gemv_lds_bytes(uint32_t quant, uint32_t n, uint32_t gs, int B);
+hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t st);
+hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
+
+// ---- attention ------------------------------------------------------------------------------------
+struct AttnArgs {
+    float *q;               // [nb][q_dim] raw q (normed + roped in place, head-local)
+    const float *kraw;      // [nb][kv_dim] raw k of the current position (nullptr: k row already final in cache)
+    float *kcache;          // [nb][L][S][kv_dim]
+    float *vcache;
+    const uint32_t *pos;    // [nb]
+    const float *q_norm;    // [hd] for this layer or nullptr
+    const float *k_norm;
+    const float *rope_cos;  // [rows][hd/2] or nullptr (no rope)
+    const float *rope_sin;
+    float *out;             // [nb][q_dim]
+    uint32_t layer, n_layer, S, hd, n_head, n_kv_head, q_dim, kv_dim;
+    uint32_t rope_qwen3;    // 1: (i, i+hd/2) pairs, 0: adjacent pairs
+    uint32_t is_causal;
+    uint32_t cache_bstride_rows;   // = L*S rows between slots (in units of kv_dim floats)
+    uint32_t fixed_range;          // op-test mode: attend over rows [0, fixed_range) of an externally filled cache
+};
+hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
+
+// ---- small kernels ----------------------------------------------------------------------------------
+struct EmbedArgs {
+    const void *tok;        // FP32 float[V][E] | Q80 int8[V][E] | Q4K blocks
+    const float *tok_s;     // Q80 scales
+    const uint32_t *tokens; // [nb]
+    float *x;               // [nb][E]
+    uint32_t E, gs, quant, x_bstride;
+};
+hipError_t launch_embed(const EmbedArgs &a, uint32_t nb, hipStream_t st);
+
+// argmax over logits[b][V] -> out[b]; optionally advances the decode loop state:
+// tokens[b] = argmax, pos[b] += 1, trace[step*nb + b] = argmax
+struct ArgmaxArgs {
+    const float *logits; uint32_t V, bstride;
+    uint32_t *out;
+    uint32_t *tokens; uint32_t *pos; uint32_t *trace; const uint32_t *step; uint32_t nb;
+};
+hipError_t launch_argmax(const ArgmaxArgs &a, uint32_t nb, hipStream_t st);
+
+hipError_t launch_rmsnorm(float *out, const float *x, const float *w, uint32_t n, hipStream_t st);
+hipError_t launch_quantize_q80(const float *x, uint32_t n, uint32_t gs, int8_t *q, float *s, hipStream_t st);
+hipError_t launch_quantize_q4k(const float *x, uint32_t n, uint8_t *blocks, hipStream_t st);
+hipError_t launch_swiglu(float *hb, const float *hb2, uint32_t n, hipStream_t st);
+hipError_t launch_rope(float *head, uint32_t hd, const float *fcr, const float *fci, int qwen3, hipStream_t st);
+hipError_t launch_stream_read(const void *buf, size_t bytes, float *sink, hipStream_t st);
+hipError_t launch_step_inc(uint32_t *step, hipStream_t st);
+
+}  // namespace nano

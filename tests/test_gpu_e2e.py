@@ -1,0 +1,141 @@
+"""GPU parity tests, end to end: the HIP forward (through the C-ABI) vs the CPU oracle and vs the golden
+vectors generated from the compiled reference, on the same seeded model + prompt.
+
+Tolerances (DESIGN.md "Parity"):
+  FP32      logits within 1e-4 * max|logit| at every step (north-star), greedy ids identical.
+  Q80/Q4K   single forward at pos 0 from identical state within 2e-2 * max|logit| and reported against the
+            reference's own inter-build noise floor (1e-2 / 0.15): rounding-boundary flips of the
+            activation quantizer make tighter end-to-end bounds uncertifiable even between two CPU builds of
+            the reference; the quantized kernels themselves are bit-exact (test_gpu_ops.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, rel_err, synth_model
+from nano_amd import binding as nb
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 1e-4, "q80": 2e-2, "q4k": 2e-1}
+CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano", "q4k", 0),
+         ("tiny-nano-odd", "f32", 0), ("tiny-nano-odd", "q80", 32), ("tiny-nano-odd", "q4k", 0),
+         ("tiny-qwen3", "f32", 0), ("tiny-qwen3", "q80", 64), ("tiny-qwen3", "q4k", 0)]
+
+
+@pytest.mark.parametrize("preset,quant,gs", CASES)
+def test_teacher_forced_logits_vs_golden(model_dir, preset, quant, gs):
+    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{quant}.npz"))
+    path, spec = synth_model(model_dir, preset, quant, gs)
+    m = nb.load_model_file(path, max_seq_len=int(g["max_seq_len"]), max_batch=1)
+    ids, gl = g["ids"], g["logits"]
+    n_prompt = len(g["prompt"])
+    worst = 0.0
+    for pos in range(len(ids) - 1):
+        want = pos >= n_prompt - 1
+        logits, _ = m.forward([int(ids[pos])], [pos], want_logits=want)
+        if want:
+            worst = max(worst, rel_err(logits[0], gl[pos - (n_prompt - 1)]))
+    m.close()
+    print(f"{preset}/{quant}: worst max|dlogit|/max|logit| over {len(gl)} teacher-forced steps = {worst:.3e}")
+    assert worst < TOL[quant]
+
+
+@pytest.mark.parametrize("preset,quant,gs", [c for c in CASES if c[1] == "f32"])
+def test_greedy_ids_identical_fp32(model_dir, preset, quant, gs):
+    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{quant}.npz"))
+    path, spec = synth_model(model_dir, preset, quant, gs)
+    m = nb.load_model_file(path, max_seq_len=int(g["max_seq_len"]), max_batch=1)
+    prompt = g["prompt"]
+    for pos in range(len(prompt) - 1):
+        m.forward([int(prompt[pos])], [pos], want_logits=False)
+    n_decode = len(g["ids"]) - len(prompt)
+    out = m.decode_greedy([int(prompt[-1])], [len(prompt) - 1], n_decode)
+    m.close()
+    assert np.array_equal(out[:, 0], g["ids"][len(prompt):])
+
+
+@pytest.mark.parametrize("preset,quant,gs", CASES)
+def test_first_forward_state_vs_oracle(oracle, model_dir, preset, quant, gs):
+    """pos 0: no history, identical inputs -> compare logits and the layer-0 KV rows."""
+    path, spec = synth_model(model_dir, preset, quant, gs)
+    m = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    o = ob.OracleCtx(oracle, path, max_seq_len=16)
+    tok = 17
+    logits, amax = m.forward([tok], [0], want_logits=True, want_argmax=True)
+    ref = o.forward(tok, 0)
+    e = rel_err(logits[0], ref)
+    kv_dim = o.kv_dim
+    k0 = m.read_state("k", kv_dim, layer=0, pos=0); v0 = m.read_state("v", kv_dim, layer=0, pos=0)
+    rk = o.state("k_cache", kv_dim); rv = o.state("v_cache", kv_dim)
+    print(f"{preset}/{quant}: logits {e:.3e}  k0 {rel_err(k0, rk):.3e}  v0 {rel_err(v0, rv):.3e}")
+    assert e < TOL[quant]
+    assert rel_err(k0, rk) < 1e-3 and rel_err(v0, rv) < 1e-3
+    assert int(amax[0]) == int(np.argmax(logits[0]))
+    m.close(); o.close()
+
+
+def test_batch_slots_are_independent(oracle, model_dir):
+    """Four sequences decoded as one batch == the same four decoded one by one (weights shared, KV private)."""
+    path, spec = synth_model(model_dir, "tiny-qwen3", "q80", 64)
+    from nano_amd import modelfile as mf
+    B, T = 4, 10
+    seqs = [mf.prompt_ids(100 + b, T, spec.vocab_size) for b in range(B)]
+    mb = nb.load_model_file(path, max_seq_len=16, max_batch=B)
+    batched = []
+    for pos in range(T):
+        lg, _ = mb.forward([int(s[pos]) for s in seqs], [pos] * B)
+        batched.append(lg)
+    mb.close()
+    m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    for b in range(B):
+        for pos in range(T):
+            lg, _ = m1.forward([int(seqs[b][pos])], [pos])
+            assert np.array_equal(lg[0], batched[pos][b]), (b, pos)
+    m1.close()
+
+
+def test_ragged_positions_in_one_batch(model_dir):
+    """Slots at different positions in the same step (pos is per slot)."""
+    path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)
+    from nano_amd import modelfile as mf
+    s0 = mf.prompt_ids(1, 8, spec.vocab_size); s1 = mf.prompt_ids(2, 8, spec.vocab_size)
+    m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    ref0 = [m1.forward([int(s0[p])], [p])[0][0] for p in range(8)]
+    m1.close()
+    m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    ref1 = [m1.forward([int(s1[p])], [p])[0][0] for p in range(8)]
+    m1.close()
+    m2 = nb.load_model_file(path, max_seq_len=16, max_batch=2)
+    for p in range(3):                       # slot 1 gets a 3-token head start
+        m2.forward([int(s0[0]), int(s1[p])], [0, p], want_logits=False) if p < 3 else None
+    # now advance both: slot 0 at pos p, slot 1 at pos p+3
+    # (slot 0 re-feeds pos 0 above each time: same token, same KV row -> idempotent)
+    for p in range(5):
+        lg, _ = m2.forward([int(s0[p]), int(s1[p + 3])], [p, p + 3])
+        assert np.array_equal(lg[0], ref0[p]) and np.array_equal(lg[1], ref1[p + 3])
+    m2.close()
+
+
+def test_sort_model_known_answer_on_gpu():
+    """The reference's only real-weights golden: non-causal seq2seq of infer/main_sort.c on the HIP path."""
+    import json
+    from test_oracle_golden import sort_vocab
+    exp = json.load(open(os.path.join(GOLD, "sort6_expected.json")))
+    raw = open(os.path.join(GOLD, "sort6_model.bin"), "rb").read()
+    path = os.path.join(GOLD, "sort6_model.bin")
+    vocab = sort_vocab(raw); inv = {v: k for k, v in vocab.items()}
+    ids = [vocab[c] for c in exp["input"]]
+    S = exp["max_seq_len"]
+    m = nb.load_model_file(path, max_seq_len=S, max_batch=1)
+    L = m.spec.n_layer
+    for _ in range(L):                       # reference infer.c:1379-1384
+        for pos in range(S):
+            m.forward([ids[pos]], [pos], is_causal=0, want_logits=False)
+    out = []
+    for pos in range(S):                     # reference infer.c:1387-1396
+        _, am = m.forward([ids[pos]], [pos], is_causal=0, want_logits=False, want_argmax=True)
+        out.append(inv[int(am[0])])
+    m.close()
+    assert "".join(out) == exp["output"] == "112225"

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ from the COMPILED REFERENCE.
+
+Runs only in the build container (needs /root/reference and oracle/_ref, built by
+``make -C oracle ref``).  Nothing here runs on the GPU box; the fixtures it writes travel instead.
+
+Fixtures
+--------
+sort6_model.bin      the reference's only real-weights known answer: the trained 2-layer FP32
+                     "sort" model embedded as a byte array in infer/main_sort.c:6-3098 (a data
+                     fixture, extracted verbatim), input "251212" -> "112225" (:3126-3131).
+sort6_expected.json  what the compiled reference's seq2seq() printed for it here.
+e2e_<model>_<quant>.npz   seeded synthetic model (nano_amd.modelfile, sha256 recorded), prompt ids,
+                     greedy ids and per-step logits of the strict reference build.
+ops.npz              per-operator input seeds and reference outputs (Q80/Q4K codecs, GEMVs,
+                     rmsnorm, softmax, rope).
+"""
+import hashlib
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nano_amd import modelfile as mf          # noqa: E402
+from oracle import binding as ob              # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_SORT_C = "/root/reference/infer/main_sort.c"
+
+E2E_CASES = [
+    # (preset, quant, gs, max_seq_len, n_prompt, n_decode)
+    ("tiny-nano", "f32", 0, 32, 8, 12),
+    ("tiny-nano", "q80", 32, 32, 8, 12),
+    ("tiny-nano", "q4k", 0, 32, 8, 12),
+    ("tiny-nano-odd", "f32", 0, 32, 8, 12),
+    ("tiny-nano-odd", "q80", 32, 32, 8, 12),
+    ("tiny-nano-odd", "q4k", 0, 32, 8, 12),
+    ("tiny-qwen3", "f32", 0, 32, 8, 12),
+    ("tiny-qwen3", "q80", 64, 32, 8, 12),
+    ("tiny-qwen3", "q4k", 0, 32, 8, 12),
+]
+# sampler variants: (preset, quant, gs, S, n_prompt, n_decode, rep_pen, temperature, top_p, tag)
+SAMPLER_CASES = [
+    ("tiny-nano", "f32", 0, 32, 8, 20, 1.3, 0.0, 1.0, "rp13"),
+    ("tiny-qwen3", "q80", 64, 32, 8, 20, 1.3, 0.0, 1.0, "rp13"),
+    ("tiny-nano", "f32", 0, 32, 8, 20, 1.1, 0.8, 0.9, "t08p09"),
+    ("tiny-qwen3", "q4k", 0, 32, 8, 20, 1.0, 1.0, 0.5, "t10p05"),
+]
+
+
+def sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def extract_sort_model():
+    src = open(REF_SORT_C, "r", encoding="utf-8").read()
+    m = re.search(r"SORT_6_MODEL\[\]\s*=\s*\{(.*?)\};", src, re.S)
+    data = bytes(int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{2})", m.group(1)))
+    out = os.path.join(GOLD, "sort6_model.bin")
+    with open(out, "wb") as f:
+        f.write(data)
+    ref = ob.load_ref()
+    buf = np.frombuffer(data, np.uint8).copy()
+    ctx = ob.OracleCtx(ref, buffer=buf, max_seq_len=6, rep_pen=0.0, temperature=0.0, top_p=0.0, top_k=1, seed=39)
+    inp = np.array([ord(c) for c in "251212"], np.uint32)
+    outcp = np.zeros(6, np.uint32)
+    ref.seq2seq(ctx.h, inp, 6, outcp, 6)
+    result = "".join(chr(c) for c in outcp)
+    print("sort model:", len(data), "bytes ->", result)
+    assert result == "112225"
+    json.dump({"input": "251212", "output": result, "max_seq_len": 6, "bytes": len(data),
+               "sha256": hashlib.sha256(data).hexdigest(),
+               "source": "reference infer/main_sort.c:6-3098 (SORT_6_MODEL), expected :3126-3131"},
+              open(os.path.join(GOLD, "sort6_expected.json"), "w"), indent=1)
+
+
+def make_e2e(tmpdir):
+    ref = ob.load_ref()
+    for (name, quant, gs, S, n_prompt, n_decode) in E2E_CASES:
+        spec = mf.preset(name, quant, group_size=gs)
+        path = os.path.join(tmpdir, f"{name}-{quant}.bin")
+        mf.write_model(path, spec, seed=39)
+        ctx = ob.OracleCtx(ref, path, max_seq_len=S)
+        prompt = mf.prompt_ids(39, n_prompt, spec.vocab_size)
+        ids, logits, _ = ctx.generate(prompt, n_decode, want_logits=True)
+        ctx.close()
+        np.savez_compressed(os.path.join(GOLD, f"e2e_{name}_{quant}.npz"), preset=name, quant=quant, gs=spec.group_size,
+                            seed=39, max_seq_len=S, prompt=prompt, ids=ids, logits=logits, model_sha256=sha256(path))
+        print("e2e", name, quant, "ids", ids[n_prompt:].tolist())
+    for (name, quant, gs, S, n_prompt, n_decode, rp, temp, top_p, tag) in SAMPLER_CASES:
+        spec = mf.preset(name, quant, group_size=gs)
+        path = os.path.join(tmpdir, f"{name}-{quant}.bin")
+        mf.write_model(path, spec, seed=39)
+        ctx = ob.OracleCtx(ref, path, max_seq_len=S, rep_pen=rp, temperature=temp, top_p=top_p, top_k=0, seed=39)
+        prompt = mf.prompt_ids(39, n_prompt, spec.vocab_size)
+        ids, _, _ = ctx.generate(prompt, n_decode, want_logits=False)
+        ctx.close()
+        np.savez_compressed(os.path.join(GOLD, f"sample_{name}_{quant}_{tag}.npz"), preset=name, quant=quant,
+                            gs=spec.group_size, seed=39, max_seq_len=S, prompt=prompt, ids=ids, rep_pen=rp,
+                            temperature=temp, top_p=top_p, model_sha256=sha256(path))
+        print("sample", name, quant, tag, "ids", ids[n_prompt:].tolist())
+
+
+def make_ops():
+    ref = ob.load_ref()
+    rng = np.random.default_rng(1234)
+    out = {}
+    # Q80 activation quantizer incl. an all-zero group and exact .5 ties
+    x = rng.standard_normal(1024).astype(np.float32) * 3
+    x[64:128] = 0.0
+    x[128:192] = np.float32(127.0) * np.sign(rng.standard_normal(64)).astype(np.float32)
+    x[130] = 63.5; x[131] = -63.5; x[132] = 0.5; x[133] = -0.5
+    for gs in (32, 64, 128):
+        q, s = ref.quantize_q80(x, gs)
+        out[f"q80_quant_gs{gs}_q"], out[f"q80_quant_gs{gs}_s"] = q, s
+    out["q80_quant_x"] = x
+    # Q80 GEMV
+    n, d, gs = 1024, 96, 64
+    w = (0.02 * rng.standard_normal(d * n)).astype(np.float32)
+    wq, ws = mf.quantize_q80_weights(w, gs)
+    xq, xs = ref.quantize_q80(x, gs)
+    out["q80_gemv_wq"], out["q80_gemv_ws"] = wq, ws
+    out["q80_gemv_out"] = ref.matmul_q80(xq, xs, wq, ws, n, d, gs)
+    # Q4K codec: full blocks and a ragged row (1408 = 5*256 + 128, the Nano-56M hidden size)
+    for n4 in (1024, 1408, 192):
+        v = rng.standard_normal(n4).astype(np.float32)
+        v[:32] = np.abs(v[:32]) + 0.1          # an all-positive group (bias 0 branch)
+        v[32:64] = 0.0                          # an all-zero group (scale 0 branch)
+        v[64:96] = -np.abs(v[64:96]) - 0.1      # an all-negative group (FLT_TRUE_MIN max quirk)
+        T = ref.quantize_q4k(v, [n4])
+        out[f"q4k_x_{n4}"], out[f"q4k_T_{n4}"] = v, T
+        out[f"q4k_deq_{n4}"] = ref.dequantize_q4k(T, n4)
+    # Q4K GEMV on a 3-D weight tensor, both layers
+    Lq, dq, nq = 2, 40, 1024
+    wf = (0.02 * rng.standard_normal(Lq * dq * nq)).astype(np.float32)
+    WT = ref.quantize_q4k(wf, [Lq, dq, nq])
+    out["q4k_gemv_w"] = wf
+    out["q4k_gemv_WT"] = WT
+    for layer in range(Lq):
+        out[f"q4k_gemv_out_l{layer}"] = ref.matmul_q4k(out["q4k_T_1024"], WT, layer, dq)
+    # ragged Q4K GEMV (n = 1408)
+    wf2 = (0.02 * rng.standard_normal(24 * 1408)).astype(np.float32)
+    WT2 = ref.quantize_q4k(wf2, [24, 1408])
+    out["q4k_gemv1408_w"] = wf2
+    out["q4k_gemv1408_out"] = ref.matmul_q4k(out["q4k_T_1408"], WT2, 0, 24)
+    # float ops
+    xf = rng.standard_normal(1024).astype(np.float32)
+    wf3 = (1 + 0.1 * rng.standard_normal(1024)).astype(np.float32)
+    out["rms_x"], out["rms_w"], out["rms_out"] = xf, wf3, ref.rmsnorm(xf, wf3)
+    sm = (4 * rng.standard_normal(300)).astype(np.float32)
+    out["softmax_x"], out["softmax_out"] = sm, ref.softmax(sm)
+    wm = (0.02 * rng.standard_normal((48, 768))).astype(np.float32)
+    xm = rng.standard_normal(768).astype(np.float32)
+    out["f32_gemv_w"], out["f32_gemv_x"], out["f32_gemv_out"] = wm, xm, ref.matmul_f32(xm, wm)
+    for hd, fn, key in ((48, ref.op_rope, "rope"), (128, ref.op_rope_qwen3, "rope_qwen3")):
+        h = rng.standard_normal(hd).astype(np.float32)
+        ang = rng.uniform(0, 6.28, hd // 2).astype(np.float32)
+        c, s = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+        o = h.copy(); fn(o, hd, 7, c, s)
+        out[f"{key}_in"], out[f"{key}_cos"], out[f"{key}_sin"], out[f"{key}_out"] = h, c, s, o
+    # xorshift64* stream
+    st = ob.C.c_uint64(39)
+    out["rng_u32"] = np.array([ref.random_u32(ob.C.byref(st)) for _ in range(16)], np.uint32)
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **out)
+    print("ops:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    tmp = "/tmp/nano_golden"
+    os.makedirs(tmp, exist_ok=True)
+    assert ob.load_ref() is not None, "build oracle/_ref first: make -C oracle ref"
+    extract_sort_model()
+    make_e2e(tmp)
+    make_ops()
