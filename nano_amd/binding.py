@@ -248,3 +248,75 @@ def op_argmax(x, device=0):
     i = C.c_uint32(0)
     x = np.ascontiguousarray(x, np.float32)
     check(lib().nano_hip_op_argmax(device, x, x.size, C.byref(i))); return int(i.value)
+
+
+# ---- host C engine (include/nano_infer_abi.h) -----------------------------------------------------------
+class Engine:
+    """The reference's engine API (llm_context_init / generate_next_token / sessions) as implemented by
+    the host C code of this library; ids in, ids out (no tokenizer linked in the stand-alone library)."""
+
+    def __init__(self, path: str, max_seq_len: int = 512, rep_pen: float = 1.0, temperature: float = 0.0,
+                 top_p: float = 1.0, top_k: int = 0, seed: int = 39, device: int = 0, max_batch: int = 1):
+        L = lib()
+        vp = C.c_void_p
+        L.nano_set_device.argtypes = [C.c_int]; L.nano_set_max_batch.argtypes = [C.c_uint32]
+        L.llm_context_init.restype = vp
+        L.llm_context_init.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint64]
+        L.llm_context_free.argtypes = [vp]
+        L.generate_next_token.restype = C.c_uint32
+        L.generate_next_token.argtypes = [vp, u32p, C.c_uint32, C.c_int]
+        L.nano_session_init_ids.restype = vp
+        L.nano_session_init_ids.argtypes = [vp, u32p, C.c_uint32, C.c_uint32]
+        L.nano_session_step_ids.restype = C.c_int32
+        L.nano_session_step_ids.argtypes = [vp, vp]
+        L.llm_session_free.argtypes = [vp]
+        L.nano_forward_batch.restype = C.c_int
+        L.nano_forward_batch.argtypes = [vp, u32p, u32p, C.c_uint32, vp, vp]
+        L.nano_set_device(device)
+        L.nano_set_max_batch(max_batch)
+        self.L = L
+        self.ctx = L.llm_context_init(path.encode(), None, max_seq_len, rep_pen, temperature, top_p, top_k, seed)
+        self.max_seq_len = max_seq_len
+
+    def close(self):
+        if self.ctx:
+            self.L.llm_context_free(self.ctx); self.ctx = None
+
+    def next_token(self, ids: np.ndarray, pos: int, is_prefilling: int) -> int:
+        return int(self.L.generate_next_token(self.ctx, ids, pos, is_prefilling))
+
+    def generate(self, prompt: Sequence[int], n_decode: int) -> np.ndarray:
+        """Greedy/sampled generation through generate_next_token, like the reference's session loop."""
+        n_prompt = len(prompt)
+        ids = np.zeros(n_prompt + n_decode + 1, np.uint32)
+        ids[:n_prompt] = prompt
+        for pos in range(n_prompt - 1):
+            self.next_token(ids, pos, 1)
+        for i in range(n_decode):
+            pos = n_prompt - 1 + i
+            ids[pos + 1] = self.next_token(ids, pos, 0)
+        return ids[:n_prompt + n_decode]
+
+    def run_session(self, prompt: Sequence[int], max_steps: int):
+        """nano_session_init_ids + nano_session_step_ids until stop; returns (generated ids, last status)."""
+        p = np.ascontiguousarray(prompt, np.uint32)
+        s = self.L.nano_session_init_ids(self.ctx, p, p.size, self.max_seq_len)
+        assert s, "session init failed"
+        out, status = [], 0
+        for _ in range(max_steps):
+            status = int(self.L.nano_session_step_ids(self.ctx, s))
+            sess = C.cast(s, C.POINTER(NanoSession)).contents
+            if status == 12 or (status == -10 and not sess.is_prefilling):
+                out.append(int(sess.next_token))
+            if status < 0:
+                break
+        self.L.llm_session_free(s)
+        return out, status
+
+
+class NanoSession(C.Structure):
+    """Nano_Session (include/nano_infer_abi.h = reference infer/infer.h:237-250)."""
+    _fields_ = [("prompt", C.c_void_p), ("num_prompt_tokens", C.c_uint32), ("max_seq_len", C.c_uint32),
+                ("output_ids", C.POINTER(C.c_uint32)), ("output_count", C.c_uint32), ("output_text", C.c_void_p),
+                ("next_token", C.c_uint32), ("pos", C.c_uint32), ("is_prefilling", C.c_int32),
+                ("t_0", C.c_uint64), ("t_1", C.c_uint64), ("tps", C.c_float)]

@@ -1,0 +1,488 @@
+/*
+ * nano_engine.c -- host side of the drop-in: the reference's engine API (include/nano_infer_abi.h,
+ * = reference infer/infer.h:253-282) implemented in C on top of the device C-ABI (include/nano_mi355x.h).
+ *
+ * Host work kept here, as in the reference: model-file header parsing, session bookkeeping, the
+ * samplers (repetition penalty, temperature, softmax, top-p, xorshift64* coin).  Everything the
+ * reference does inside llm_forward() runs on the GPU.
+ *
+ * Mirrored reference behaviour: top_k is stored and ignored; the top-p branch is always
+ * taken; the repetition penalty divides regardless of sign.  Greedy decoding with penalty 1.0 uses
+ * the device arg-max (4 bytes back instead of vocab*4).
+ */
+#define _GNU_SOURCE
+#include "../../../include/nano_infer_abi.h"
+#include "../../../include/nano_mi355x.h"
+
+#include <fcntl.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+/* ---- the front-end's tokenizer.c / utils.c (weak: absent when the library is used stand-alone) ------ */
+#define WEAK __attribute__((weak))
+WEAK void build_bpe_tokenizer(Tokenizer *t, uint8_t *tokenizer_buffer, int vocab_size);
+WEAK void free_bpe_tokenizer(Tokenizer *t);
+WEAK wchar_t *decode_bpe(Tokenizer *t, uint32_t *ids, uint32_t len);
+WEAK uint32_t *apply_qwen_chat_template(Tokenizer *t, wchar_t *user_prompt, uint32_t *prompt_length, int32_t enable_thinking);
+WEAK uint32_t *encode_nano(Tokenizer *t, wchar_t *text, uint32_t *n_tokens_ptr);
+WEAK wchar_t *decode_nano(Tokenizer *t, uint32_t *ids, uint32_t len);
+WEAK void free_tokenizer(Tokenizer *tk);
+WEAK uint32_t *string_to_ids(struct Map *unicode_to_id_map, wchar_t *utext);
+WEAK struct Map *new_map(uint32_t bucket_num);
+WEAK uint32_t map_set(struct Map *m, uint32_t key, uint32_t value);
+WEAK struct Trie *new_trie(uint32_t vocab_size, uint8_t is_end_of_token);
+WEAK int add_token(struct Trie *trie, uint32_t *token, uint32_t token_len, uint32_t token_id);
+
+#define QWEN_TOKENIZER_ENTRIES 151669      /* reference infer/infer.c:313 */
+
+/* ---- process-wide knobs + LLM -> device model registry ---------------------------------------------- */
+static int g_device = -1;
+static uint32_t g_max_batch = 1;
+
+void nano_set_device(int device) { g_device = device; }
+void nano_set_max_batch(uint32_t b) { g_max_batch = b ? b : 1; }
+
+static int pick_device(void) {
+    if (g_device >= 0) return g_device;
+    const char *e = getenv("NANO_HIP_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+#define MAX_MODELS 64
+static struct { const LLM *llm; NanoHipModel *dev; uint32_t max_seq_len; } g_reg[MAX_MODELS];
+
+static void reg_put(const LLM *llm, NanoHipModel *dev, uint32_t max_seq_len) {
+    for (int i = 0; i < MAX_MODELS; i++)
+        if (!g_reg[i].llm) { g_reg[i].llm = llm; g_reg[i].dev = dev; g_reg[i].max_seq_len = max_seq_len; return; }
+    fprintf(stderr, "too many models loaded\n");
+    exit(EXIT_FAILURE);
+}
+static NanoHipModel *reg_get(const LLM *llm) {
+    for (int i = 0; i < MAX_MODELS; i++) if (g_reg[i].llm == llm) return g_reg[i].dev;
+    return NULL;
+}
+static void reg_del(const LLM *llm) {
+    for (int i = 0; i < MAX_MODELS; i++) if (g_reg[i].llm == llm) { g_reg[i].llm = NULL; g_reg[i].dev = NULL; }
+}
+void *nano_device_model(const LLM *llm) { return reg_get(llm); }
+
+static void die_hip(const char *what) {
+    fprintf(stderr, "%s: %s\n", what, nano_hip_last_error());
+    exit(EXIT_FAILURE);
+}
+
+/* =====================================================================================================
+ * loading (reference infer/infer.c:220-363)
+ * =================================================================================================== */
+
+/* Nano tokenizer section -> Tokenizer, through the front-end's own map/trie (reference infer.c:263-311).
+ * Stand-alone (no utils.c linked) only token_list is filled, which is all decode needs. */
+static void build_nano_tokenizer(Tokenizer *tk, const uint8_t *sec) {
+    uint32_t total, vocab;
+    memcpy(&total, sec, 4);
+    memcpy(&vocab, sec + 4, 4);
+    tk->vocab_size = vocab;
+    tk->token_list = (wchar_t **)calloc(vocab, sizeof(wchar_t *));
+    tk->unicode_charset = (wchar_t *)calloc(vocab, sizeof(wchar_t));
+    const int have_utils = new_map && new_trie && map_set && add_token && string_to_ids;
+    if (have_utils) {
+        tk->unicode_to_id_map = new_map(vocab);
+        tk->token_to_id_map = new_map(vocab);
+        tk->vocab_trie = new_trie(vocab, 0);
+    }
+    const uint8_t *p = sec + 8, *end = sec + total;
+    uint32_t nchar = 0;
+    while (p + 8 <= end) {
+        uint32_t hdr, id;
+        memcpy(&hdr, p, 4); memcpy(&id, p + 4, 4); p += 8;
+        uint32_t len = hdr & 0xffu;
+        if (id >= vocab || p + 4 * (size_t)len > end) break;
+        wchar_t *tok = (wchar_t *)calloc(len + 1, sizeof(wchar_t));
+        for (uint32_t i = 0; i < len; i++) { uint32_t cp; memcpy(&cp, p + 4 * i, 4); tok[i] = (wchar_t)cp; }
+        if (len == 1) {
+            tk->unicode_charset[nchar++] = tok[0];
+            if (have_utils) map_set(tk->unicode_to_id_map, (uint32_t)tok[0], id);
+        }
+        tk->token_list[id] = tok;
+        p += 4 * (size_t)len;
+    }
+    if (have_utils)
+        for (uint32_t i = 0; i < vocab; i++) {
+            wchar_t *t = tk->token_list[i];
+            uint32_t len = t ? (uint32_t)wcslen(t) : 0;
+            if (len > 1) { uint32_t *ids = string_to_ids(tk->unicode_to_id_map, t); add_token(tk->vocab_trie, ids, len, i); free(ids); }
+        }
+}
+
+void load_llm_from_buffer(LLM *llm, Tokenizer *tk, uint8_t *buffer, uint32_t max_seq_len) {
+    uint32_t h[17];
+    memcpy(h, buffer, sizeof h);                       /* 256-byte header of LE u32 (infer.c:231-251) */
+    llm->arch = h[4];
+    LLM_Config *c = &llm->config;
+    c->block_size = h[6]; c->vocab_size = h[7]; c->n_layer = h[8]; c->n_embd = h[9]; c->n_head = h[10];
+    c->n_kv_head = h[11]; c->n_hidden = h[12]; c->is_shared_classifier = h[13]; c->head_dim = h[14];
+    llm->quant_type = (h[15] == QUANT_TYPE_F32 || h[15] == QUANT_TYPE_Q80 || h[15] == QUANT_TYPE_Q4K) ? h[15] : QUANT_TYPE_Q80;
+    llm->group_size = h[16];
+
+    const uint8_t *tok_sec = buffer + 256;
+    uint32_t tok_bytes;
+    memcpy(&tok_bytes, tok_sec, 4);
+    if (tk) {
+        if (llm->arch == LLM_ARCH_NANO) build_nano_tokenizer(tk, tok_sec);
+        else if ((llm->arch == LLM_ARCH_QWEN2 || llm->arch == LLM_ARCH_QWEN3) && build_bpe_tokenizer)
+            build_bpe_tokenizer(tk, (uint8_t *)tok_sec, QWEN_TOKENIZER_ENTRIES);
+    }
+
+    NanoModelDesc d;
+    d.arch = llm->arch; d.block_size = c->block_size; d.vocab_size = c->vocab_size; d.n_layer = c->n_layer;
+    d.n_embd = c->n_embd; d.n_head = c->n_head; d.n_kv_head = c->n_kv_head; d.n_hidden = c->n_hidden;
+    d.is_shared_classifier = c->is_shared_classifier; d.head_dim = c->head_dim;
+    d.quant_type = llm->quant_type; d.group_size = llm->group_size;
+
+    const uint8_t *params = tok_sec + tok_bytes;
+    size_t avail = (llm->file_size > (size_t)(params - buffer)) ? llm->file_size - (size_t)(params - buffer) : (size_t)-1 / 2;
+    size_t need = nano_hip_params_bytes(&d);
+    if (llm->file_size == 0 && need) avail = need;     /* caller-owned buffer of unknown length: trust the header */
+    NanoHipModel *dev = NULL;
+    if (nano_hip_model_create(&dev, &d, params, avail, 0, pick_device(), max_seq_len, g_max_batch) != NANO_HIP_OK)
+        die_hip("model upload failed");
+    reg_put(llm, dev, max_seq_len);
+
+    llm->state.logits = (float *)calloc((size_t)c->vocab_size * g_max_batch, sizeof(float));
+    if (!llm->state.logits) { fprintf(stderr, "mem alloc failed!\n"); exit(EXIT_FAILURE); }
+}
+
+void load_llm(LLM *llm, Tokenizer *tk, char *model_path, uint32_t max_seq_len) {
+    int fd = open(model_path, O_RDONLY);
+    if (fd == -1) { fprintf(stderr, "Couldn't open file %s\n", model_path); exit(EXIT_FAILURE); }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { fprintf(stderr, "open failed!\n"); exit(EXIT_FAILURE); }
+    llm->file_size = (size_t)st.st_size;
+    uint8_t *buf = (uint8_t *)mmap(NULL, llm->file_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (buf == MAP_FAILED) { fprintf(stderr, "mmap failed!\n"); exit(EXIT_FAILURE); }
+    llm->fd = fd;
+    llm->buffer = buf;
+    load_llm_from_buffer(llm, tk, buf, max_seq_len);
+    /* the weights now live in HBM: the mapping is only kept for the tokenizer strings' lifetime */
+}
+
+void free_llm(LLM *llm, Tokenizer *tk) {
+    NanoHipModel *dev = reg_get(llm);
+    if (dev) nano_hip_model_destroy(dev);
+    reg_del(llm);
+    if (llm->buffer && llm->buffer != MAP_FAILED && llm->file_size) munmap(llm->buffer, llm->file_size);
+    if (llm->fd > 0) close(llm->fd);
+    if (tk) {
+        if (llm->arch == LLM_ARCH_NANO) {
+            if (free_tokenizer && tk->vocab_trie) free_tokenizer(tk);
+            else if (tk->token_list) {
+                for (uint32_t i = 0; i < tk->vocab_size; i++) free(tk->token_list[i]);
+                free(tk->token_list); free(tk->unicode_charset);
+            }
+        } else if (free_bpe_tokenizer && tk->vocab) free_bpe_tokenizer(tk);
+    }
+    free(llm->state.logits);
+    free(llm);
+}
+
+/* LoRA side branches (reference infer/infer.c:408-545,792-808,898-903) are SURVEY 8f-4 "next": not on
+ * the device yet.  Loading is refused loudly instead of silently running without the adapter. */
+LoRA *load_lora_from_buffer(LLM *llm, uint8_t *buffer) {
+    (void)llm; (void)buffer;
+    fprintf(stderr, "Error: LoRA modules are not supported by the MI355X backend yet.\n");
+    exit(EXIT_FAILURE);
+}
+LoRA *load_lora(LLM *llm, char *lora_path) { (void)lora_path; return load_lora_from_buffer(llm, NULL); }
+void free_lora(LLM *llm, LoRA *lora) { (void)llm; (void)lora; }
+
+/* =====================================================================================================
+ * context (reference infer/infer.c:552-581)
+ * =================================================================================================== */
+
+static Nano_Context *ctx_alloc(uint32_t max_seq_len, uint64_t seed) {
+    Nano_Context *ctx = (Nano_Context *)calloc(1, sizeof(Nano_Context));
+    ctx->max_seq_len = max_seq_len;
+    ctx->random_seed = seed;
+    ctx->llm = (LLM *)calloc(1, sizeof(LLM));
+    ctx->tokenizer = (Tokenizer *)calloc(1, sizeof(Tokenizer));
+    ctx->lora = NULL;
+    return ctx;
+}
+
+Nano_Context *llm_context_init_from_buffer(uint8_t *buffer, uint32_t max_seq_len, float repetition_penalty, float temperature,
+                                           float top_p, uint32_t top_k, uint64_t random_seed) {
+    Nano_Context *ctx = ctx_alloc(max_seq_len, random_seed);
+    load_llm_from_buffer(ctx->llm, ctx->tokenizer, buffer, max_seq_len);
+    ctx->sampler = build_sampler((int)ctx->llm->config.vocab_size, repetition_penalty, temperature, top_p, top_k, random_seed);
+    return ctx;
+}
+
+Nano_Context *llm_context_init(char *model_path, char *lora_path, uint32_t max_seq_len, float repetition_penalty, float temperature,
+                               float top_p, uint32_t top_k, uint64_t random_seed) {
+    Nano_Context *ctx = ctx_alloc(max_seq_len, random_seed);
+    load_llm(ctx->llm, ctx->tokenizer, model_path, max_seq_len);
+    ctx->sampler = build_sampler((int)ctx->llm->config.vocab_size, repetition_penalty, temperature, top_p, top_k, random_seed);
+    ctx->lora = lora_path ? load_lora(ctx->llm, lora_path) : NULL;
+    return ctx;
+}
+
+void llm_context_free(Nano_Context *ctx) {
+    free_llm(ctx->llm, ctx->tokenizer);
+    free(ctx->tokenizer);
+    free_sampler(ctx->sampler);
+    free(ctx);
+}
+
+/* =====================================================================================================
+ * forward seam
+ * =================================================================================================== */
+
+static inline void observe(Nano_Context *ctx, int32_t layer, int32_t phase) {
+    if (ctx && ctx->observation) {
+        Nano_Observation o; memset(&o, 0, sizeof o);
+        o.layer = layer; o.phase = phase;
+        ctx->observation(o, ctx->observation_env);
+    }
+}
+
+float *llm_forward(Nano_Context *ctx, uint32_t token, uint32_t pos, uint32_t max_seq_len, uint32_t is_causal, LLM *llm, LoRA *lora) {
+    (void)max_seq_len; (void)lora;
+    NanoHipModel *dev = reg_get(llm);
+    if (!dev) { fprintf(stderr, "llm_forward: model is not resident on a device\n"); exit(EXIT_FAILURE); }
+    /* The fused device forward has no per-layer host boundary: phase hooks fire at token granularity. */
+    observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
+    if (nano_hip_forward(dev, &token, &pos, 1, is_causal, llm->state.logits, NULL) != NANO_HIP_OK) die_hip("llm_forward");
+    observe(ctx, (int32_t)llm->config.n_layer, NANO_LLM_PHASE_FINAL_NORM);
+    observe(ctx, (int32_t)llm->config.n_layer, NANO_LLM_PHASE_CLASSIFY);
+    return llm->state.logits;
+}
+
+int nano_forward_batch(Nano_Context *ctx, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, float *logits, uint32_t *argmax) {
+    NanoHipModel *dev = reg_get(ctx->llm);
+    if (!dev) return NANO_HIP_EINVAL;
+    return nano_hip_forward(dev, tokens, pos, batch, 1, logits, argmax);
+}
+
+/* =====================================================================================================
+ * sampling (reference infer/infer.c:1026-1127; RNG infer/utils.c:959-970)
+ * =================================================================================================== */
+
+static uint32_t xorshift_u32(uint64_t *s) {
+    *s ^= *s >> 12; *s ^= *s << 25; *s ^= *s >> 27;
+    return (uint32_t)((*s * 0x2545F4914F6CDD1Dull) >> 32);
+}
+static float xorshift_f32(uint64_t *s) { return (xorshift_u32(s) >> 8) / 16777216.0f; }
+
+static void softmax_inplace(float *x, int n) {
+    float m = x[0];
+    for (int i = 1; i < n; i++) if (x[i] > m) m = x[i];
+    float sum = 0.0f;
+    for (int i = 0; i < n; i++) { x[i] = expf(x[i] - m); sum += x[i]; }
+    for (int i = 0; i < n; i++) x[i] /= sum;
+}
+
+static int argmax_first(const float *p, int n) {
+    int bi = 0; float bp = p[0];
+    for (int i = 1; i < n; i++) if (p[i] > bp) { bi = i; bp = p[i]; }
+    return bi;
+}
+
+static int by_prob_desc(const void *a, const void *b) {
+    const ProbIndex *x = (const ProbIndex *)a, *y = (const ProbIndex *)b;
+    if (x->prob > y->prob) return -1;
+    if (x->prob < y->prob) return 1;
+    return 0;
+}
+
+static int nucleus(Nano_Context *ctx, const float *p, int n, float top_p, ProbIndex *pi, float coin) {
+    int n0 = 0;
+    const float cutoff = (1.0f - top_p) / (n - 1);
+    for (int i = 0; i < n; i++) if (p[i] >= cutoff) { pi[n0].index = i; pi[n0].prob = p[i]; n0++; }
+    qsort(pi, (size_t)n0, sizeof(ProbIndex), by_prob_desc);
+    float cum = 0.0f;
+    int last = n0 - 1;
+    for (int i = 0; i < n0; i++) { cum += pi[i].prob; if (cum > top_p) { last = i; break; } }
+    if (ctx && ctx->observation) {
+        Nano_Observation o; memset(&o, 0, sizeof o);
+        o.layer = -1; o.phase = NANO_LLM_PHASE_SAMPLE;
+        o.token_0 = n0 > 0 ? (uint32_t)pi[0].index : 0; o.token_1 = n0 > 1 ? (uint32_t)pi[1].index : 0;
+        o.token_2 = n0 > 2 ? (uint32_t)pi[2].index : 0; o.token_3 = n0 > 3 ? (uint32_t)pi[3].index : 0;
+        o.token_4 = n0 > 4 ? (uint32_t)pi[4].index : 0; o.token_5 = n0 > 5 ? (uint32_t)pi[5].index : 0;
+        ctx->observation(o, ctx->observation_env);
+    }
+    float r = coin * cum, cdf = 0.0f;
+    for (int i = 0; i <= last; i++) { cdf += pi[i].prob; if (r < cdf) return pi[i].index; }
+    return pi[last].index;
+}
+
+Sampler *build_sampler(int vocab_size, float repetition_penalty, float temperature, float top_p, uint32_t top_k, uint64_t rng_seed) {
+    Sampler *s = (Sampler *)calloc(1, sizeof(Sampler));
+    s->vocab_size = vocab_size; s->repetition_penalty = repetition_penalty; s->temperature = temperature;
+    s->top_p = top_p; s->top_k = top_k; s->rng_state = rng_seed;
+    s->probindex = (ProbIndex *)calloc((size_t)vocab_size, sizeof(ProbIndex));
+    return s;
+}
+void free_sampler(Sampler *s) { if (s) { free(s->probindex); free(s); } }
+
+/* reference infer/infer.c:1135-1193 */
+uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t pos, int is_prefilling) {
+    LLM *llm = ctx->llm;
+    Sampler *sp = ctx->sampler;
+    NanoHipModel *dev = reg_get(llm);
+    if (!dev) { fprintf(stderr, "generate_next_token: model is not resident on a device\n"); exit(EXIT_FAILURE); }
+    uint32_t token = output_ids[pos];
+
+    if (is_prefilling == 1) {
+        /* the reference computes the logits of prompt positions and discards them (infer.c:1146-1149):
+         * skip the classifier, the KV rows written are the same */
+        observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
+        if (nano_hip_forward(dev, &token, &pos, 1, 1, NULL, NULL) != NANO_HIP_OK) die_hip("generate_next_token");
+        return output_ids[pos + 1];
+    }
+
+    if (sp->temperature == 0.0f && sp->repetition_penalty == 1.0f) {
+        uint32_t best = 0;                                 /* x/1.0f is exact: arg-max on the device */
+        observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
+        if (nano_hip_forward(dev, &token, &pos, 1, 1, NULL, &best) != NANO_HIP_OK) die_hip("generate_next_token");
+        observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
+        return best;
+    }
+
+    float *logits = llm_forward(ctx, token, pos, ctx->max_seq_len, 1, llm, ctx->lora);
+    observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
+    const int V = sp->vocab_size;
+    uint32_t *seen = (uint32_t *)calloc((size_t)V, sizeof(uint32_t));
+    if (seen) {
+        for (uint32_t i = 0; i < pos; i++) seen[output_ids[i]] = 1;
+        for (int id = 0; id < V; id++) if (seen[id] == 1) logits[id] /= sp->repetition_penalty;
+        free(seen);
+    }
+    if (sp->temperature == 0.0f) return (uint32_t)argmax_first(logits, V);
+    for (int i = 0; i < V; i++) logits[i] /= sp->temperature;
+    softmax_inplace(logits, V);
+    float coin = xorshift_f32(&sp->rng_state);
+    return (uint32_t)nucleus(ctx, logits, V, sp->top_p, sp->probindex, coin);   /* top-p always (infer.c:1183) */
+}
+
+/* =====================================================================================================
+ * sessions (reference infer/infer.c:1196-1361)
+ * =================================================================================================== */
+
+static Nano_Session *session_alloc(uint32_t max_seq_len) {
+    Nano_Session *s = (Nano_Session *)calloc(1, sizeof(Nano_Session));
+    s->prompt = (wchar_t *)calloc(max_seq_len + 1, sizeof(wchar_t));
+    s->max_seq_len = max_seq_len;
+    s->output_ids = (uint32_t *)calloc(max_seq_len + 1, sizeof(uint32_t));
+    return s;
+}
+
+Nano_Session *nano_session_init_ids(Nano_Context *ctx, const uint32_t *prompt_ids, uint32_t n_prompt, uint32_t max_seq_len) {
+    (void)ctx;
+    if (n_prompt == 0 || n_prompt > max_seq_len) return NULL;
+    Nano_Session *s = session_alloc(max_seq_len);
+    s->num_prompt_tokens = n_prompt;
+    memcpy(s->output_ids, prompt_ids, n_prompt * sizeof(uint32_t));
+    s->next_token = prompt_ids[0];
+    return s;
+}
+
+Nano_Session *llm_session_init(Nano_Context *ctx, wchar_t *prompt, uint32_t max_seq_len, int32_t is_thinking_enabled) {
+    Nano_Session *s = session_alloc(max_seq_len);
+    if (prompt) wcsncpy(s->prompt, prompt, max_seq_len); else s->prompt[0] = 0;
+    uint32_t *ids = NULL;
+    if (ctx->llm->arch == LLM_ARCH_NANO) {
+        if (!encode_nano) { fprintf(stderr, "Error: no tokenizer linked (encode_nano); use nano_session_init_ids.\n"); llm_session_free(s); return NULL; }
+        ids = encode_nano(ctx->tokenizer, s->prompt, &s->num_prompt_tokens);
+    } else if (ctx->llm->arch == LLM_ARCH_QWEN2 || ctx->llm->arch == LLM_ARCH_QWEN3) {
+        if (!apply_qwen_chat_template) { fprintf(stderr, "Error: no tokenizer linked (apply_qwen_chat_template); use nano_session_init_ids.\n"); llm_session_free(s); return NULL; }
+        ids = apply_qwen_chat_template(ctx->tokenizer, s->prompt, &s->num_prompt_tokens, is_thinking_enabled);
+    } else {
+        printf("Error: unknown LLM arch.\n");
+        llm_session_free(s);
+        return NULL;
+    }
+    for (uint32_t i = 0; i < s->num_prompt_tokens && i <= max_seq_len; i++) s->output_ids[i] = ids[i];
+    s->next_token = ids[0];
+    free(ids);
+    return s;
+}
+
+static int32_t step_core(Nano_Context *ctx, Nano_Session *s, int with_text) {
+    if (s->pos >= s->max_seq_len) return LLM_STOPPED_WITH_ERROR;
+    if (s->output_text) { free(s->output_text); s->output_text = NULL; }
+    s->is_prefilling = (s->pos < s->num_prompt_tokens - 1) ? 1 : 0;
+    s->next_token = generate_next_token(ctx, s->output_ids, s->pos, s->is_prefilling);
+    const uint32_t arch = ctx->llm->arch;
+    if (arch != LLM_ARCH_NANO && arch != LLM_ARCH_QWEN2 && arch != LLM_ARCH_QWEN3) { printf("Error: unknown LLM arch.\n"); return LLM_STOPPED_WITH_ERROR; }
+    uint32_t *text_ids; uint32_t text_n;
+    if (s->is_prefilling == 1) { text_ids = s->output_ids; text_n = s->pos; }
+    else {
+        s->output_ids[s->num_prompt_tokens + (s->output_count)++] = s->next_token;
+        text_ids = s->output_ids + s->num_prompt_tokens; text_n = s->output_count;
+    }
+    if (with_text) {
+        if (arch == LLM_ARCH_NANO && decode_nano) s->output_text = decode_nano(ctx->tokenizer, text_ids, text_n);
+        else if (arch != LLM_ARCH_NANO && decode_bpe) s->output_text = decode_bpe(ctx->tokenizer, text_ids, text_n);
+    }
+    s->pos++;
+    if (arch == LLM_ARCH_NANO && (s->next_token == 0 || s->next_token == 3)) return LLM_STOPPED_NORMALLY;
+    if (arch != LLM_ARCH_NANO && s->is_prefilling == 0 && (s->next_token == 151643 || s->next_token == 151645)) return LLM_STOPPED_NORMALLY;
+    return (s->is_prefilling == 1) ? LLM_RUNNING_IN_PREFILLING : LLM_RUNNING_IN_DECODING;
+}
+
+int32_t llm_session_step(Nano_Context *ctx, Nano_Session *s) { return step_core(ctx, s, 1); }
+int32_t nano_session_step_ids(Nano_Context *ctx, Nano_Session *s) { return step_core(ctx, s, 0); }
+
+void llm_session_free(Nano_Session *s) {
+    if (!s) return;
+    free(s->prompt); free(s->output_ids); free(s->output_text); free(s);
+}
+
+int32_t generate_sync(Nano_Context *ctx, wchar_t *prompt, uint32_t max_seq_len,
+                      int32_t (*on_prefilling)(Nano_Session *), int32_t (*on_decoding)(Nano_Session *),
+                      int32_t (*on_finished)(Nano_Session *)) {
+    Nano_Session *s = llm_session_init(ctx, prompt, max_seq_len, 1);
+    if (!s) return LLM_STOPPED_WITH_ERROR;
+    int32_t status;
+    for (;;) {
+        status = llm_session_step(ctx, s);
+        if (status == LLM_RUNNING_IN_PREFILLING) {
+            if (on_prefilling(s) == LLM_STOPPED_IN_PREFILLING) { status = LLM_STOPPED_IN_PREFILLING; break; }
+        } else if (status == LLM_RUNNING_IN_DECODING) {
+            if (on_decoding(s) == LLM_STOPPED_IN_DECODING) { status = LLM_STOPPED_IN_DECODING; break; }
+        } else if (status == LLM_STOPPED_NORMALLY) {
+            status = on_finished(s);
+            break;
+        } else {
+            on_finished(s);
+            status = LLM_STOPPED_WITH_ERROR;
+            break;
+        }
+    }
+    llm_session_free(s);
+    return status;
+}
+
+/* reference infer/infer.c:1365-1402: L passes of non-causal forwards to fill every layer's KV, one more
+ * pass for the logits, per-position arg-max.  Needs the front-end's Nano tokenizer. */
+void seq2seq(Nano_Context *ctx, wchar_t *input_list, wchar_t *output_list, uint32_t max_seq_len) {
+    if (!encode_nano || !decode_nano) { fprintf(stderr, "Error: seq2seq needs the Nano tokenizer (tokenizer.c) linked.\n"); exit(EXIT_FAILURE); }
+    uint32_t n = 0;
+    uint32_t *in = encode_nano(ctx->tokenizer, input_list, &n);
+    uint32_t *out = (uint32_t *)calloc(max_seq_len, sizeof(uint32_t));
+    NanoHipModel *dev = reg_get(ctx->llm);
+    for (uint32_t l = 0; l < ctx->llm->config.n_layer; l++)
+        for (uint32_t pos = 0; pos < max_seq_len; pos++)
+            if (nano_hip_forward(dev, &in[pos], &pos, 1, 0, NULL, NULL) != NANO_HIP_OK) die_hip("seq2seq");
+    for (uint32_t pos = 0; pos < max_seq_len; pos++)
+        if (nano_hip_forward(dev, &in[pos], &pos, 1, 0, NULL, &out[pos]) != NANO_HIP_OK) die_hip("seq2seq");
+    wchar_t *txt = decode_nano(ctx->tokenizer, out, max_seq_len);
+    wcscpy(output_list, txt);
+    free(txt); free(in); free(out);
+}

@@ -109,7 +109,7 @@ def test_ragged_positions_in_one_batch(model_dir):
     m1.close()
     m2 = nb.load_model_file(path, max_seq_len=16, max_batch=2)
     for p in range(3):                       # slot 1 gets a 3-token head start
-        m2.forward([int(s0[0]), int(s1[p])], [0, p], want_logits=False) if p < 3 else None
+        m2.forward([int(s0[0]), int(s1[p])], [0, p], want_logits=False)
     # now advance both: slot 0 at pos p, slot 1 at pos p+3
     # (slot 0 re-feeds pos 0 above each time: same token, same KV row -> idempotent)
     for p in range(5):
@@ -139,3 +139,30 @@ def test_sort_model_known_answer_on_gpu():
         out.append(inv[int(am[0])])
     m.close()
     assert "".join(out) == exp["output"] == "112225"
+
+
+# ---- the host C engine (reference API surface) on the GPU ------------------------------------------------
+@pytest.mark.parametrize("name", ["sample_tiny-nano_f32_rp13", "sample_tiny-nano_f32_t08p09"])
+def test_engine_sampler_ids_vs_reference_golden(model_dir, name):
+    """generate_next_token through the C engine with the reference's sampler settings: FP32 ids identical."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    path, spec = synth_model(model_dir, str(g["preset"]), str(g["quant"]), int(g["gs"]))
+    e = nb.Engine(path, max_seq_len=int(g["max_seq_len"]), rep_pen=float(g["rep_pen"]), temperature=float(g["temperature"]),
+                  top_p=float(g["top_p"]), top_k=0, seed=int(g["seed"]))
+    prompt = g["prompt"]
+    ids = e.generate(prompt, len(g["ids"]) - len(prompt))
+    e.close()
+    assert np.array_equal(ids, g["ids"])
+
+
+def test_engine_session_api_greedy(model_dir):
+    """nano_session_init_ids / nano_session_step_ids reproduce the golden greedy ids (device arg-max path)."""
+    g = np.load(os.path.join(GOLD, "e2e_tiny-nano_f32.npz"))
+    path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)
+    e = nb.Engine(path, max_seq_len=int(g["max_seq_len"]))
+    prompt = g["prompt"]
+    n_decode = len(g["ids"]) - len(prompt)
+    out, status = e.run_session(prompt, len(prompt) - 1 + n_decode)
+    e.close()
+    assert out == g["ids"][len(prompt):].tolist()
+    assert status in (12, -10)
