@@ -97,6 +97,8 @@ def cpu_baseline(path, spec, budget_s=20.0):
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()                                   # a native crash leaves a Python traceback on stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=480)
@@ -156,7 +158,9 @@ def main():
         m.forward([int(pr[p]) for pr in prompts], [p] * B, want_logits=False)
     tok = [int(pr[-1]) for pr in prompts]
     pos0 = PROMPT_LEN - 1
+    log(f"[bench] rank {rank}: prefill done")
     warm = m.decode_greedy(tok, [pos0] * B, W) if W > 0 else np.zeros((0, B), np.uint32)
+    log(f"[bench] rank {rank}: warm-up done")
     tok = [int(t) for t in warm[-1]] if W > 0 else tok
     pos0 += W
 
@@ -179,6 +183,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    log(f"[bench] rank {rank}: timed region done, {elapsed * 1e3 / K:.3f} ms/step")
     # ---- roofline of the dominant kernel (classifier GEMV), HIP events on the model's stream ----------------
     ms_cls, bytes_cls = m.time_classifier(B, 50)
     achieved = bytes_cls / (ms_cls * 1e-3) / 1e9

@@ -6,7 +6,8 @@
 // FP32 KV cache and scratch, and the HIP graphs of one decode step.  One decode step is
 //   embed -> L x [ QKV GEMV | attention | Wo GEMV(+residual) | W1/W3 GEMV(+SwiGLU) | W2 GEMV(+residual) ]
 //         -> classifier GEMV -> arg-max
-// = 5L+3 kernels, all on one stream, captured once per (batch, mode) and replayed.
+// = 5L+3 kernels, all on one stream, captured once per (batch, mode) and replayed.  Attention is split over
+// the sequence; its partials are combined in the Wo GEMV's prologue (no extra launch).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -62,9 +63,10 @@ struct NanoHipModel {
     std::vector<TensorRef> W[WCOUNT];
     // per-sequence state
     float *x = nullptr, *q = nullptr, *kraw = nullptr, *xba = nullptr, *hb = nullptr, *logits = nullptr;
+    float *attn_part = nullptr, *attn_ml = nullptr;       // split-attention partials [B][nsplit][QD], [B][n_head][nsplit][2]
     float *kcache = nullptr, *vcache = nullptr;
-    uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *step = nullptr;
-    uint32_t trace_cap = 0;
+    uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
+    uint32_t trace_cap = 0, nsplit = 1;
     // pinned host staging
     uint32_t *h_tokens = nullptr, *h_pos = nullptr, *h_amax = nullptr;
     float *h_logits = nullptr;
@@ -132,7 +134,7 @@ static void destroy(NanoHipModel *m) {
     if (m->st) (void)hipStreamSynchronize(m->st);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
-                    m->tokens, m->pos, m->amax, m->trace, m->step };
+                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -276,19 +278,22 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     const size_t B = max_batch;
     const size_t kvn = B * L * max_seq_len * KD;
     m->trace_cap = max_seq_len * max_batch;
+    m->nsplit = attention_nsplit(max_seq_len);
     bool ok = hipMalloc(&m->x, B * E * 4) == hipSuccess && hipMalloc(&m->q, B * QD * 4) == hipSuccess &&
               hipMalloc(&m->kraw, B * KD * 4) == hipSuccess && hipMalloc(&m->xba, B * QD * 4) == hipSuccess &&
               hipMalloc(&m->hb, B * H * 4) == hipSuccess && hipMalloc(&m->logits, B * V * 4) == hipSuccess &&
               hipMalloc(&m->kcache, kvn * 4) == hipSuccess && hipMalloc(&m->vcache, kvn * 4) == hipSuccess &&
               hipMalloc(&m->tokens, B * 4) == hipSuccess && hipMalloc(&m->pos, B * 4) == hipSuccess &&
               hipMalloc(&m->amax, B * 4) == hipSuccess && hipMalloc(&m->trace, (size_t)m->trace_cap * 4) == hipSuccess &&
-              hipMalloc(&m->step, 4) == hipSuccess;
+              hipMalloc(&m->pos0, B * 4) == hipSuccess &&
+              hipMalloc(&m->attn_part, B * m->nsplit * QD * 4) == hipSuccess &&
+              hipMalloc(&m->attn_ml, B * d.n_head * m->nsplit * 2 * 4) == hipSuccess;
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
     // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
     if (hipMemset(m->kcache, 0, kvn * 4) != hipSuccess || hipMemset(m->vcache, 0, kvn * 4) != hipSuccess ||
         hipMemset(m->x, 0, B * E * 4) != hipSuccess || hipMemset(m->logits, 0, B * V * 4) != hipSuccess ||
         hipMemset(m->tokens, 0, B * 4) != hipSuccess || hipMemset(m->pos, 0, B * 4) != hipSuccess ||
-        hipMemset(m->step, 0, 4) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "hipMemset failed"); }
+        hipMemset(m->pos0, 0, B * 4) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "hipMemset failed"); }
     ok = hipHostMalloc(&m->h_tokens, B * 4) == hipSuccess && hipHostMalloc(&m->h_pos, B * 4) == hipSuccess &&
          hipHostMalloc(&m->h_amax, (size_t)m->trace_cap * 4) == hipSuccess && hipHostMalloc(&m->h_logits, B * V * 4) == hipSuccess;
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipHostMalloc failed"); }
@@ -347,10 +352,10 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         }
         {   // qk-norm, rope, k-cache write, attention   reference infer.c:810-879
             AttnArgs a{};
-            a.q = m->q; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
+            a.q = m->q; a.q_out = nullptr; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
             a.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
             a.k_norm = m->k_norm ? m->k_norm + (size_t)l * m->hd : nullptr;
-            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.out = m->xba;
+            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.out = m->attn_part; a.ml = m->attn_ml; a.nsplit = m->nsplit;
             a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
@@ -360,6 +365,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[WO][l], m->x, E, E);
             a.n = QD; a.gs = d.group_size; a.nb = nb; a.xin = m->xba; a.xin_bstride = QD; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
+            a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = m->nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd;
             if ((e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
@@ -379,10 +385,9 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     if (mode == MODE_NOCLS) return hipSuccess;
     if ((e = enqueue_classifier(m, nb)) != hipSuccess) return e;      // final rmsnorm fused in the prologue (infer.c:999-1015)
     if (mode == MODE_ARGMAX || mode == MODE_LOOP) {
-        ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, nullptr, nullptr, m->step, nb };
-        if (mode == MODE_LOOP) { aa.tokens = m->tokens; aa.pos = m->pos; aa.trace = m->trace; }
+        ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, m->pos, nullptr, m->pos0, nb };
+        if (mode == MODE_LOOP) { aa.tokens = m->tokens; aa.trace = m->trace; }
         if ((e = launch_argmax(aa, nb, m->st)) != hipSuccess) return e;
-        if (mode == MODE_LOOP && (e = launch_step_inc(m->step, m->st)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -455,7 +460,7 @@ extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, c
     memcpy(m->h_tokens, tokens, batch * 4); memcpy(m->h_pos, pos, batch * 4);
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
-    HIP_TRY(hipMemsetAsync(m->step, 0, 4, m->st));
+    HIP_TRY(hipMemcpyAsync(m->pos0, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
     for (uint32_t s = 0; s < steps; s++)
         if ((rc = run_step(m, batch, 1, MODE_LOOP))) return rc;
     if (out_ids) {
@@ -534,7 +539,11 @@ extern "C" int nano_hip_read_state(NanoHipModel *m, uint32_t slot, int which, ui
     switch (which) {
     case 0: src = m->x + (size_t)slot * m->d.n_embd; cap = m->d.n_embd; break;
     case 1: src = m->q + (size_t)slot * m->QD; cap = m->QD; break;
-    case 2: src = m->xba + (size_t)slot * m->QD; cap = m->QD; break;
+    case 2:   // attention output: combine the split partials on demand
+        HIP_TRY(launch_attn_combine(m->attn_part + (size_t)slot * m->nsplit * m->QD, m->attn_ml + (size_t)slot * m->d.n_head * m->nsplit * 2,
+                                    m->xba + (size_t)slot * m->QD, m->d.n_head, m->hd, m->nsplit, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        src = m->xba + (size_t)slot * m->QD; cap = m->QD; break;
     case 3: src = m->hb + (size_t)slot * m->d.n_hidden; cap = m->d.n_hidden; break;
     case 4: src = m->logits + (size_t)slot * m->d.vocab_size; cap = m->d.vocab_size; break;
     case 5: if (layer >= m->d.n_layer || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad layer/pos"); src = m->kcache + row; cap = m->KD; break;

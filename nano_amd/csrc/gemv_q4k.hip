@@ -150,7 +150,32 @@ __device__ __forceinline__ void prologue_q4k(const GemvArgs &a, XGroup *xg, floa
             ss /= (float)n; ss += 1e-5f; ss = 1.0f / sqrtf(ss);
         }
         __syncthreads();
-        for (int i = t; i < n; i += blockDim.x) xn[i] = a.norm_w ? a.norm_w[i] * (ss * x[i]) : x[i];
+        if (a.attn_part) {      // input = combination of the split attention partials (attn.hip), as in gemv.hip
+            const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
+            float *wgt = red + 32;
+            for (uint32_t h = t; h < nh; h += blockDim.x) {
+                const float *ml = a.attn_ml + ((size_t)b * nh + h) * ns * 2;
+                float M = -INFINITY;
+                for (uint32_t s = 0; s < ns; s++) if (ml[2 * s + 1] > 0.0f) M = fmaxf(M, ml[2 * s]);
+                float L = 0.0f;
+                for (uint32_t s = 0; s < ns; s++) {
+                    const float e = (ml[2 * s + 1] > 0.0f) ? expf(ml[2 * s] - M) : 0.0f;
+                    wgt[h * ns + s] = e;
+                    L += ml[2 * s + 1] * e;
+                }
+                for (uint32_t s = 0; s < ns; s++) wgt[h * ns + s] = wgt[h * ns + s] / L;
+            }
+            __syncthreads();
+            const float *part = a.attn_part + (size_t)b * ns * n;
+            for (int i = t; i < n; i += blockDim.x) {
+                const int h = i / (int)a.attn_hd;
+                float acc = 0.0f;
+                for (uint32_t s = 0; s < ns; s++) acc += part[(size_t)s * n + i] * wgt[h * ns + s];
+                xn[i] = acc;
+            }
+        } else {
+            for (int i = t; i < n; i += blockDim.x) xn[i] = a.norm_w ? a.norm_w[i] * (ss * x[i]) : x[i];
+        }
         __syncthreads();
         for (int j = 0; j < bpl; j++) {
             const int d = (n >= (j + 1) * 256) ? 256 : (n - j * 256);

@@ -39,6 +39,11 @@ struct GemvArgs {
     const int8_t *xq_in;    // Q80 int8[n]
     const float *xs_in;     // Q80 float[n/gs]
     const uint8_t *x4_in;   // Q4K blocks[ceil(n/256)*160]
+    // input = combination of split attention partials (attn.hip) instead of xin:
+    //   x[b][i] = sum_s part[b][s][i] * w[b][head(i)][s],  w from the (max, sum) pairs in attn_ml
+    const float *attn_part; // [nb][nsplit][n] unnormalised partial outputs, or nullptr
+    const float *attn_ml;   // [nb][n_head][nsplit][2] (running max, exp-sum) per split
+    uint32_t attn_nsplit, attn_n_head, attn_hd, _pad2;
 };
 
 size_t gemv_lds_bytes(uint32_t quant, uint32_t n, uint32_t gs, int B);
@@ -47,7 +52,8 @@ hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
 
 // ---- attention ------------------------------------------------------------------------------------
 struct AttnArgs {
-    float *q;               // [nb][q_dim] raw q (normed + roped in place, head-local)
+    const float *q;         // [nb][q_dim] raw q from the QKV GEMV (normed + roped in LDS, head-local)
+    float *q_out;           // optional [nb][q_dim]: finished q written back (debug / traces), or nullptr
     const float *kraw;      // [nb][kv_dim] raw k of the current position (nullptr: k row already final in cache)
     float *kcache;          // [nb][L][S][kv_dim]
     float *vcache;
@@ -56,7 +62,10 @@ struct AttnArgs {
     const float *k_norm;
     const float *rope_cos;  // [rows][hd/2] or nullptr (no rope)
     const float *rope_sin;
-    float *out;             // [nb][q_dim]
+    float *out;             // [nb][nsplit][q_dim] UNNORMALISED partial outputs  sum_t exp(s_t - m) v_t
+    float *ml;              // [nb][n_head][nsplit][2]  (m = max score of the split, l = sum exp(s_t - m))
+    uint32_t nsplit;        // timestep blocks are dealt round-robin to `nsplit` workgroups per (head, sequence)
+    uint32_t _pad0;
     uint32_t layer, n_layer, S, hd, n_head, n_kv_head, q_dim, kv_dim;
     uint32_t rope_qwen3;    // 1: (i, i+hd/2) pairs, 0: adjacent pairs
     uint32_t is_causal;
@@ -64,6 +73,8 @@ struct AttnArgs {
     uint32_t fixed_range;          // op-test mode: attend over rows [0, fixed_range) of an externally filled cache
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
+uint32_t attention_nsplit(uint32_t S);
+hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
 
 // ---- small kernels ----------------------------------------------------------------------------------
 struct EmbedArgs {
@@ -80,7 +91,7 @@ hipError_t launch_embed(const EmbedArgs &a, uint32_t nb, hipStream_t st);
 struct ArgmaxArgs {
     const float *logits; uint32_t V, bstride;
     uint32_t *out;
-    uint32_t *tokens; uint32_t *pos; uint32_t *trace; const uint32_t *step; uint32_t nb;
+    uint32_t *tokens; uint32_t *pos; uint32_t *trace; const uint32_t *pos0; uint32_t nb;   // trace[(pos-pos0)*nb + b]
 };
 hipError_t launch_argmax(const ArgmaxArgs &a, uint32_t nb, hipStream_t st);
 
@@ -90,6 +101,5 @@ hipError_t launch_quantize_q4k(const float *x, uint32_t n, uint8_t *blocks, hipS
 hipError_t launch_swiglu(float *hb, const float *hb2, uint32_t n, hipStream_t st);
 hipError_t launch_rope(float *head, uint32_t hd, const float *fcr, const float *fci, int qwen3, hipStream_t st);
 hipError_t launch_stream_read(const void *buf, size_t bytes, float *sink, hipStream_t st);
-hipError_t launch_step_inc(uint32_t *step, hipStream_t st);
 
 }  // namespace nano

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
         if (bi == 0xffffffffu) bi = 0;
         a.out[b] = bi;
         if (a.tokens) a.tokens[b] = bi;
-        if (a.pos) a.pos[b] = a.pos[b] + 1;
-        if (a.trace) a.trace[(size_t)(*a.step) * a.nb + b] = bi;
+        if (a.trace) a.trace[(size_t)(a.pos[b] - a.pos0[b]) * a.nb + b] = bi;
+        if (a.tokens) a.pos[b] = a.pos[b] + 1;
     }
 }
 
@@ -93,11 +93,6 @@ hipError_t launch_argmax(const ArgmaxArgs &a, uint32_t nb, hipStream_t st) {
     return hipGetLastError();
 }
 
-__global__ void step_inc_kernel(uint32_t *step) { *step = *step + 1; }
-hipError_t launch_step_inc(uint32_t *step, hipStream_t st) {
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
-    return hipGetLastError();
-}
 
 // ---- stand-alone operator kernels (operator parity tests) ----------------------------------------------
 __global__ __launch_bounds__(256) void rmsnorm_kernel(float *out, const float *x, const float *w, uint32_t n) {
