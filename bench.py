@@ -59,13 +59,41 @@ def ensure_model(name, quant, gs):
     return path, spec
 
 
-def cpu_baseline(path, spec, budget_s=20.0):
-    """Reference CPU engine on the same file / prompt / greedy settings, bounded sample."""
+def usable_cores(cap=32):
+    """Host threads the CPU baseline may use: affinity mask, clipped by the cgroup CPU quota and by `cap`
+    (the reference's OpenMP loops are row/head parallel; more threads than that only add barrier cost)."""
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(path, spec, budget_s=20.0, timeout_s=150):
+    """Run the CPU baseline in a child process (own OpenMP runtime, hard time limit)."""
+    import subprocess
+    cores = usable_cores()
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+    code = ("import json, sys; sys.path.insert(0, %r); import bench; from nano_amd import modelfile as mf; "
+            "print(json.dumps(bench.cpu_baseline_worker(%r, mf.read_header(%r), %r, %d)))" % (ROOT, path, path, budget_s, cores))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode == 0 and r.stdout.strip():
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        why = f"rc={r.returncode}: {r.stderr.strip()[-300:]}"
+    except subprocess.TimeoutExpired:
+        why = f"timed out after {timeout_s}s"
+    return {"value": None, "unit": "tokens/s", "cores": cores, "kind": "reference", "sample": "CPU baseline failed: " + why}
+
+
+def cpu_baseline_worker(path, spec, budget_s, cores):
+    """Reference CPU engine on the same file / prompt / greedy settings, bounded sample."""
     from nano_amd import modelfile as mf
     from oracle import binding as ob
     lib = ob.load_ref(fast=True)

@@ -64,6 +64,7 @@ struct NanoHipModel {
     // per-sequence state
     float *x = nullptr, *q = nullptr, *kraw = nullptr, *xba = nullptr, *hb = nullptr, *logits = nullptr;
     float *attn_part = nullptr, *attn_ml = nullptr;       // split-attention partials [B][nsplit][QD], [B][n_head][nsplit][2]
+    float *tile_max = nullptr;                            // classifier per-tile (max, row) partials [B][<=V][2]
     float *kcache = nullptr, *vcache = nullptr;
     uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
     uint32_t trace_cap = 0, nsplit = 1;
@@ -134,7 +135,7 @@ static void destroy(NanoHipModel *m) {
     if (m->st) (void)hipStreamSynchronize(m->st);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
-                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml };
+                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -287,7 +288,8 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
               hipMalloc(&m->amax, B * 4) == hipSuccess && hipMalloc(&m->trace, (size_t)m->trace_cap * 4) == hipSuccess &&
               hipMalloc(&m->pos0, B * 4) == hipSuccess &&
               hipMalloc(&m->attn_part, B * m->nsplit * QD * 4) == hipSuccess &&
-              hipMalloc(&m->attn_ml, B * d.n_head * m->nsplit * 2 * 4) == hipSuccess;
+              hipMalloc(&m->attn_ml, B * d.n_head * m->nsplit * 2 * 4) == hipSuccess &&
+              hipMalloc(&m->tile_max, B * V * 2 * 4) == hipSuccess;
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
     // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
     if (hipMemset(m->kcache, 0, kvn * 4) != hipSuccess || hipMemset(m->vcache, 0, kvn * 4) != hipSuccess ||
@@ -323,11 +325,15 @@ static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     return launch_gemv(m->d.quant_type, a, max_wg, m->st);
 }
 
-static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb) {
+static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
     GemvArgs a{};
     a.nseg = 1; a.seg[0] = mkseg(m->cls, m->logits, m->d.vocab_size, m->d.vocab_size);
     a.n = m->d.n_embd; a.gs = m->d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = m->d.n_embd;
     a.epi = GEMV_EPI_STORE; a.norm_w = m->rms_final; a.pos = m->pos;
+    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K) {      // per-tile arg-max partials for the sampler
+        a.tile_max = m->tile_max;
+        *ntiles_out = gemv_tiles(m->d.quant_type, a);
+    }
     return gemv(m, a);
 }
 
@@ -383,9 +389,12 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         }
     }
     if (mode == MODE_NOCLS) return hipSuccess;
-    if ((e = enqueue_classifier(m, nb)) != hipSuccess) return e;      // final rmsnorm fused in the prologue (infer.c:999-1015)
-    if (mode == MODE_ARGMAX || mode == MODE_LOOP) {
-        ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, m->pos, nullptr, m->pos0, nb };
+    const bool sample = (mode == MODE_ARGMAX || mode == MODE_LOOP);
+    uint32_t ntiles = 0;
+    if ((e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;   // final rmsnorm fused in the prologue (infer.c:999-1015)
+    if (sample) {
+        ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, m->pos, nullptr, m->pos0, nb,
+                       ntiles ? m->tile_max : nullptr, ntiles };
         if (mode == MODE_LOOP) { aa.tokens = m->tokens; aa.trace = m->trace; }
         if ((e = launch_argmax(aa, nb, m->st)) != hipSuccess) return e;
     }

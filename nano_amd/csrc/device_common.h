@@ -15,6 +15,18 @@
 
 namespace nano {
 
+// ---- streaming (non-temporal) 16-byte loads: weights are read exactly once per step ---------------
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 ld_stream_i4(const void *p) {
+    const i32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t *>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 ld_stream_f4(const void *p) {
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ---- cross-lane --------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

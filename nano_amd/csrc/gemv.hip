@@ -6,70 +6,72 @@
 //   * matmul_q4k    (Q4K W4A4,  reference infer/tensor.c:438-471) -- see gemv_q4k.hip
 // with the surrounding elementwise work fused in:
 //   prologue : optional combine of the split attention partials (attn.hip), optional rmsnorm
-//              (infer.c:601-614) of the input vector, activation re-quantization -- recomputed by every
-//              workgroup from the (L2-resident) fp32 vector, so no extra launch and no extra sync;
-//   epilogue : plain store (q / raw k / v-cache row / logits), residual add (infer.c:906-908,963-965),
-//              or SwiGLU of the (W1,W3) row pair (infer.c:937-944).
+//              (infer.c:601-614) of the input vector, activation re-quantization -- recomputed from the
+//              (L2-resident) fp32 vector instead of costing a launch.  For <= 2 sequences every WAVE stages
+//              the activation for itself (wave-private LDS, DPP reductions, no workgroup barrier at all);
+//              for 4..8 sequences the four waves split the sequences and meet at one barrier;
+//   epilogue : plain store (q / raw k / v-cache row / logits [+ per-tile arg-max partial]), residual add
+//              (infer.c:906-908,963-965), or SwiGLU of the (W1,W3) row pair (infer.c:937-944).
 //
 // Mapping (HBM-bound byte work, 2 flop/byte: no MFMA):
-//   * a workgroup is 4 waves; a wave owns a tile of TR consecutive rows and streams them in batches
-//     of up to 8 rows x 1 KiB: lane l loads bytes [16l,16l+16) of a row chunk with one
-//     global_load_dwordx4 (fully coalesced; the row-major weight blocks stay exactly as they sit in the
-//     model file).  The next batch is issued before the current one is consumed, and the very first
-//     batch is issued BEFORE the prologue so its HBM latency overlaps the activation staging.
+//   * a workgroup is 4 independent waves; a wave owns a tile of TR consecutive rows and streams them in
+//     batches of up to 8 rows x 1 KiB: lane l loads bytes [16l,16l+16) of a row chunk with one
+//     global_load_dwordx4 (fully coalesced; the row-major weight blocks stay exactly as in the model
+//     file).  The next batch (weights + the group leaders' weight scales) is issued before the current one
+//     is consumed, and the very first batch is issued BEFORE the prologue so its HBM latency overlaps the
+//     activation staging.  TR is 1/2/4 for the small per-layer GEMVs (so that >= ~1024 waves exist) and
+//     16/8 for the classifier.
 //   * Q80: v_dot4_i32_i8 on the 16 int8 of a lane, DPP integer reduction over the gs/16 lanes of a
-//     quantization group, then through a small per-wave LDS table: (A) all 64 lanes apply
-//     ((float)ival * ws) * xs to the (row, group) entries in parallel (the weight scales of a tile are one
-//     coalesced load), (B) one lane per (row, sequence) adds the groups IN THE REFERENCE'S ORDER
+//     quantization group, the group's leader lane forms ((float)ival * ws) * xs and parks it in a small
+//     per-wave LDS table; one lane per (row, sequence) then adds the groups IN THE REFERENCE'S ORDER
 //     (infer.c:668-674) -- given identical int8 inputs the fp32 result is bit-identical to the reference.
-//     Big GEMVs (the classifier) use 64-row tiles so that all 64 lanes fold; small ones use 4-row tiles
-//     so that >=1024 waves exist.
-//   * FP32: per-lane partial sums over the lane's float4 slices, wave tree reduction (tolerance 1e-5).
+//   * FP32: per-lane partial sums over the lane's float4 slices, DPP wave reduction (tolerance 1e-5).
 #include "device_common.h"
 #include "kernels.h"
 
 namespace nano {
 
 // ------------------------------------------------------------------------------------------------
-// cross-lane integer reduction over aligned groups of W lanes (W = 2,4,8,16) using DPP only
+// DPP cross-lane helpers (no LDS traffic, unlike __shfl)
 // ------------------------------------------------------------------------------------------------
-template <int W>
+#define DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+#define DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+
+template <int W>   // sum over aligned groups of W lanes (W = 1,2,4,8,16); every lane gets the group sum
 __device__ __forceinline__ int dpp_group_sum(int v) {
-    if (W >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-    if (W >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-    if (W >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
-    if (W >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+    if (W >= 2) v += DPP_I(v, 0xB1);     // quad_perm [1,0,3,2]
+    if (W >= 4) v += DPP_I(v, 0x4E);     // quad_perm [2,3,0,1]
+    if (W >= 8) v += DPP_I(v, 0x141);    // row_half_mirror
+    if (W >= 16) v += DPP_I(v, 0x140);   // row_mirror
     return v;
+}
+template <int W>
+__device__ __forceinline__ float dpp_group_max(float v) {
+    if (W >= 2) v = fmaxf(v, DPP_F(v, 0xB1));
+    if (W >= 4) v = fmaxf(v, DPP_F(v, 0x4E));
+    if (W >= 8) v = fmaxf(v, DPP_F(v, 0x141));
+    if (W >= 16) v = fmaxf(v, DPP_F(v, 0x140));
+    if (W >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (W >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float dpp_wave_sum(float v) {
+    v += DPP_F(v, 0xB1); v += DPP_F(v, 0x4E); v += DPP_F(v, 0x141); v += DPP_F(v, 0x140);   // row (16-lane) totals
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // ------------------------------------------------------------------------------------------------
-// shared prologue pieces
+// per-wave activation staging
 // ------------------------------------------------------------------------------------------------
 
-// Input element i of sequence b: either the plain fp32 vector or the combination of the split
-// attention partials (flash-decoding style, see attn.hip): xba[i] = sum_s o_s[i] * w[h][s].
-struct InputView {
-    const float *x;          // plain vector (nullptr when combining)
-    const float *part;       // [nsplit][q_dim] partial outputs of this sequence
-    const float *wgt;        // LDS: [n_head][nsplit] combine weights
-    uint32_t nsplit, hd, q_dim;
-    __device__ __forceinline__ float4 load4(int i) const {
-        if (x) return *reinterpret_cast<const float4 *>(x + i);
-        const int h = i / (int)hd;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t s = 0; s < nsplit; s++) {
-            const float w = wgt[h * nsplit + s];
-            const float4 o = *reinterpret_cast<const float4 *>(part + (size_t)s * q_dim + i);
-            acc.x += o.x * w; acc.y += o.y * w; acc.z += o.z * w; acc.w += o.w * w;
-        }
-        return acc;
-    }
-};
-
-// combine weights of the attention splits for sequence b into LDS wgt[n_head][nsplit]
-__device__ __forceinline__ void attn_combine_weights(const GemvArgs &a, int b, float *wgt) {
+// combine weights of the attention splits (attn.hip) for sequence b: wgt[h*ns + s] = e^{m_s-M} / L, by one wave
+__device__ __forceinline__ void attn_weights_wave(const GemvArgs &a, int b, float *wgt, int lane) {
     const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
-    for (uint32_t h = threadIdx.x; h < nh; h += blockDim.x) {
+    for (uint32_t h = lane; h < nh; h += 64) {
         const float *ml = a.attn_ml + ((size_t)b * nh + h) * ns * 2;
         float M = -INFINITY;
         for (uint32_t s = 0; s < ns; s++) if (ml[2 * s + 1] > 0.0f) M = fmaxf(M, ml[2 * s]);
@@ -81,134 +83,102 @@ __device__ __forceinline__ void attn_combine_weights(const GemvArgs &a, int b, f
         }
         for (uint32_t s = 0; s < ns; s++) wgt[h * ns + s] = wgt[h * ns + s] / L;
     }
-    __syncthreads();
 }
 
-template <int B>
-__device__ __forceinline__ void block_sum_multi(float (&v)[B], float *red /* >= 16*B floats */) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int b = 0; b < B; b++) v[b] = wave_sum(v[b]);
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int b = 0; b < B; b++) red[wid * B + b] = v[b];
+// four consecutive input elements i..i+3 of sequence b (plain vector or attention combine)
+__device__ __forceinline__ float4 input4(const GemvArgs &a, int b, int i, const float *wgt) {
+    if (!a.attn_part) return *reinterpret_cast<const float4 *>(a.xin + (size_t)b * a.xin_bstride + i);
+    const uint32_t ns = a.attn_nsplit;
+    const float *part = a.attn_part + (size_t)b * ns * a.n;
+    const int h = i / (int)a.attn_hd;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t s = 0; s < ns; s++) {
+        const float w = wgt[h * ns + s];
+        const float4 o = *reinterpret_cast<const float4 *>(part + (size_t)s * a.n + i);
+        acc.x += o.x * w; acc.y += o.y * w; acc.z += o.z * w; acc.w += o.w * w;
     }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        float t = 0.0f;
-        for (int w = 0; w < nw; w++) t += red[w * B + b];
-        v[b] = t;
-    }
+    return acc;
 }
 
-// rmsnorm scale factors for all live sequences at once (one pair of barriers)
-template <int B>
-__device__ __forceinline__ void rms_scales(const GemvArgs &a, float (&ss)[B], float *red) {
-    const int tid = threadIdx.x, nthr = blockDim.x, n = (int)a.n;
-    float acc[B];
+// rmsnorm scale of sequence b computed by ONE wave (reference infer.c:603-609; tree order, tol 1e-5)
+__device__ __forceinline__ float rms_scale_wave(const GemvArgs &a, int b, int lane) {
+    const int n = (int)a.n;
+    const float *x = a.xin + (size_t)b * a.xin_bstride;
+    float acc = 0.0f;
+    for (int i = lane * 4; i < n; i += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + i);
+        acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+    }
+    float ss = dpp_wave_sum(acc);
+    ss /= (float)n;
+    ss += 1e-5f;
+    return 1.0f / sqrtf(ss);
+}
+
+// One wave quantizes sequence b (reference infer/tensor.c:21-46) into xq[n] (int8) / xs[n/GS]:
+// lane l owns elements [16l,16l+16) of every 1 KiB chunk -- exactly the slice it later multiplies.
+template <int GS>
+__device__ __forceinline__ void quantize_q80_wave(const GemvArgs &a, int b, int8_t *xq, float *xs, const float *wgt, int lane) {
+    constexpr int LPG = GS / 16;
+    const int n = (int)a.n;
+    const float ss = a.norm_w ? rms_scale_wave(a, b, lane) : 1.0f;
+    const int nchunk = (n + 1023) >> 10;
+    for (int c = 0; c < nchunk; c++) {
+        const int i0 = (c << 10) + lane * 16;
+        const bool act = i0 < n;
+        float v[16];
 #pragma unroll
-    for (int b = 0; b < B; b++) {
-        acc[b] = 0.0f;
-        if (b < (int)a.nb) {
-            const float *x = a.xin + (size_t)b * a.xin_bstride;
-            for (int i = tid * 4; i < n; i += nthr * 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(x + i);
-                acc[b] += v.x * v.x; acc[b] += v.y * v.y; acc[b] += v.z * v.z; acc[b] += v.w * v.w;
+        for (int k = 0; k < 4; k++) {
+            float4 t = act ? input4(a, b, i0 + 4 * k, wgt) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act && a.norm_w) {
+                const float4 w = *reinterpret_cast<const float4 *>(a.norm_w + i0 + 4 * k);
+                t.x = w.x * (ss * t.x); t.y = w.y * (ss * t.y); t.z = w.z * (ss * t.z); t.w = w.w * (ss * t.w);
             }
+            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        }
+        float m = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m = fmaxf(m, fabsf(v[k]));
+        m = dpp_group_max<LPG>(m);
+        const float scale = m / 127.0f;
+        if (act) {
+            uint32_t pk[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int q0 = q80_quant1(v[4 * k], scale), q1 = q80_quant1(v[4 * k + 1], scale);
+                const int q2 = q80_quant1(v[4 * k + 2], scale), q3 = q80_quant1(v[4 * k + 3], scale);
+                pk[k] = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+            }
+            *reinterpret_cast<uint4 *>(xq + i0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if ((lane % LPG) == 0) xs[i0 / GS] = scale;
         }
     }
-    block_sum_multi<B>(acc, red);
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        float s = acc[b];
-        s /= (float)n;
-        s += 1e-5f;
-        ss[b] = 1.0f / sqrtf(s);
-    }
 }
 
-// fp32 activations (optionally normalised) into LDS xf[b*n + i]
-template <int B>
-__device__ __forceinline__ void prologue_f32(const GemvArgs &a, float *xf, float *red, float *wgt) {
-    const int tid = threadIdx.x, nthr = blockDim.x, n = (int)a.n;
-    float ss[B];
-    if (a.norm_w) rms_scales<B>(a, ss, red);
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        if (b < (int)a.nb) {
-            InputView in{ a.attn_part ? nullptr : a.xin + (size_t)b * a.xin_bstride,
-                          a.attn_part ? a.attn_part + (size_t)b * a.attn_nsplit * a.n : nullptr, wgt, a.attn_nsplit, a.attn_hd, a.n };
-            if (a.attn_part) attn_combine_weights(a, b, wgt);
-            for (int i = tid * 4; i < n; i += nthr * 4) {
-                float4 v = in.load4(i);
-                if (a.norm_w) {
-                    const float4 w = *reinterpret_cast<const float4 *>(a.norm_w + i);
-                    v.x = w.x * (ss[b] * v.x); v.y = w.y * (ss[b] * v.y); v.z = w.z * (ss[b] * v.z); v.w = w.w * (ss[b] * v.w);
-                }
-                *reinterpret_cast<float4 *>(xf + (size_t)b * n + i) = v;
-            }
-            if (a.attn_part) __syncthreads();
-        }
-    }
-    __syncthreads();
+// operator-test path: caller supplied the quantized activation
+__device__ __forceinline__ void copy_q80_wave(const GemvArgs &a, int8_t *xq, float *xs, int gs, int lane) {
+    const int n = (int)a.n, ng = n / gs;
+    for (int i = lane * 16; i < n; i += 1024) *reinterpret_cast<uint4 *>(xq + i) = *reinterpret_cast<const uint4 *>(a.xq_in + i);
+    for (int i = lane; i < ng; i += 64) xs[i] = a.xs_in[i];
 }
 
-// Q80: optional rmsnorm + quantization: int8 into xq[b*n + i], group scales into xs[b*(n/gs) + g]
-template <int B, int GS>
-__device__ __forceinline__ void prologue_q80(const GemvArgs &a, int8_t *xq, float *xs, float *red, float *wgt) {
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int n = (int)a.n, ng = n / GS;
-    constexpr int tpg = GS / 4;                    // threads per quantization group (4 elements each)
-    const int iters = (n + nthr * 4 - 1) / (nthr * 4);
-    if (a.xq_in) {      // operator-test path: caller supplied the quantized activation (one sequence)
-        for (int i = tid; i < n; i += nthr) xq[i] = a.xq_in[i];
-        for (int i = tid; i < ng; i += nthr) xs[i] = a.xs_in[i];
-        __syncthreads();
-        return;
-    }
-    float ss[B];
-    if (a.norm_w) rms_scales<B>(a, ss, red);
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        if (b < (int)a.nb) {
-            InputView in{ a.attn_part ? nullptr : a.xin + (size_t)b * a.xin_bstride,
-                          a.attn_part ? a.attn_part + (size_t)b * a.attn_nsplit * a.n : nullptr, wgt, a.attn_nsplit, a.attn_hd, a.n };
-            if (a.attn_part) attn_combine_weights(a, b, wgt);
-            for (int it = 0; it < iters; it++) {
-                const int i = (it * nthr + tid) * 4;
-                const bool act = i < n;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (act) {
-                    v = in.load4(i);
-                    if (a.norm_w) {
-                        const float4 w = *reinterpret_cast<const float4 *>(a.norm_w + i);
-                        v.x = w.x * (ss[b] * v.x); v.y = w.y * (ss[b] * v.y); v.z = w.z * (ss[b] * v.z); v.w = w.w * (ss[b] * v.w);
-                    }
-                }
-                float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-                m = group_max(m, tpg);
-                const float scale = m / 127.0f;
-                if (act) {
-                    const int q0 = q80_quant1(v.x, scale), q1 = q80_quant1(v.y, scale);
-                    const int q2 = q80_quant1(v.z, scale), q3 = q80_quant1(v.w, scale);
-                    const uint32_t packed = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) |
-                                            ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-                    reinterpret_cast<uint32_t *>(xq + (size_t)b * n)[i >> 2] = packed;
-                    if ((tid % tpg) == 0) xs[(size_t)b * ng + i / GS] = scale;
-                }
-            }
-            if (a.attn_part) __syncthreads();
+// One wave stages sequence b as fp32 (optionally normalised) into xf[n]
+__device__ __forceinline__ void stage_f32_wave(const GemvArgs &a, int b, float *xf, const float *wgt, int lane) {
+    const int n = (int)a.n;
+    const float ss = a.norm_w ? rms_scale_wave(a, b, lane) : 1.0f;
+    for (int i = lane * 4; i < n; i += 256) {
+        float4 t = input4(a, b, i, wgt);
+        if (a.norm_w) {
+            const float4 w = *reinterpret_cast<const float4 *>(a.norm_w + i);
+            t.x = w.x * (ss * t.x); t.y = w.y * (ss * t.y); t.z = w.z * (ss * t.z); t.w = w.w * (ss * t.w);
         }
+        *reinterpret_cast<float4 *>(xf + i) = t;
     }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
 // tile cursor: flat iteration over (tile, pass, chunk, row batch) so that loads can run one batch ahead
 // ------------------------------------------------------------------------------------------------
-template <int TR, int RBL>
 struct Cursor {
     uint32_t tile, sidx, row0;
     int pass, c, r0;
@@ -228,7 +198,7 @@ __device__ __forceinline__ bool locate_tile(const GemvArgs &a, uint32_t tile, ui
 }
 
 template <int TR, int RBL>
-__device__ __forceinline__ void cursor_advance(const GemvArgs &a, Cursor<TR, RBL> &cu, int nchunk, int npass, uint32_t stride) {
+__device__ __forceinline__ void cursor_advance(const GemvArgs &a, Cursor &cu, int nchunk, int npass, uint32_t stride) {
     cu.r0 += RBL;
     if (cu.r0 < TR) return;
     cu.r0 = 0;
@@ -246,16 +216,13 @@ __device__ __forceinline__ float *out_ptr(const GemvArgs &a, const GemvSeg &s, i
     return s.out + off;
 }
 
-__device__ __forceinline__ void emit(const GemvArgs &a, const GemvSeg &s, int b, uint32_t row, float v, float v2) {
-    float *o = out_ptr(a, s, b) + row;
-    if (a.epi == GEMV_EPI_STORE) *o = v;
-    else if (a.epi == GEMV_EPI_RESID) *o = *o + v;             // x[i] += xb2[i]
-    else {                                                      // SwiGLU: silu(w1 x) * (w3 x)
-        float h = v;
-        h *= (1.0f / (1.0f + expf(-h)));
-        h *= v2;
-        *o = h;
-    }
+__device__ __forceinline__ float finish(const GemvArgs &a, float v, float v2, float old) {
+    if (a.epi == GEMV_EPI_STORE) return v;
+    if (a.epi == GEMV_EPI_RESID) return old + v;               // x[i] += xb2[i]
+    float h = v;                                                // SwiGLU: silu(w1 x) * (w3 x)
+    h *= (1.0f / (1.0f + expf(-h)));
+    h *= v2;
+    return h;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -267,21 +234,33 @@ __global__ __launch_bounds__(256) void gemv_q80_kernel(const GemvArgs a) {
     constexpr int RBL = (TR < 8) ? TR : 8;           // rows per load batch
     constexpr int LPG = GS / 16;                     // lanes per quantization group
     constexpr int GC = 1024 / GS;                    // groups per 1 KiB chunk
-    constexpr int PITCH = GC + 1;
+    constexpr int PITCH = GC + 4;                    // keeps every table row 16-byte aligned
     constexpr int PAIRS = TR * B;                    // (row, sequence) pairs per tile, <= 64
-    constexpr int NWS = (TR * GC + 63) / 64;         // weight-scale dwords per lane per (tile, chunk)
+    constexpr bool PRIV = (B <= 2);                  // every wave stages the activations for itself
     static_assert(PAIRS <= 64, "tile too large");
     const int n = (int)a.n, ng = n / GS;
-    // LDS carve: xq [B*n] | xs [B*ng] | red[16*B] | wgt[attn] | tab[4][PAIRS*PITCH]
-    int8_t *xq = reinterpret_cast<int8_t *>(smem);
-    const size_t xq_bytes = ((size_t)B * n + 15) & ~(size_t)15;
-    float *xs = reinterpret_cast<float *>(smem + xq_bytes);
-    float *red = xs + (((size_t)B * ng + 3) & ~(size_t)3);
-    float *wgt = red + 16 * B;
-    float *tabbase = wgt + ((a.attn_part ? a.attn_n_head * a.attn_nsplit + 3 : 0) & ~3u);
-
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    float *tab = tabbase + (size_t)wid * PAIRS * PITCH;     // ints travel as float bit patterns (one LDS type)
+
+    // LDS carve.  PRIV: per wave { xq[B*n16] | xs[B*ng4] | wgt | tab }.  shared: xq[B*n16] | xs | wgt[B] | tab[4]
+    const size_t n16 = ((size_t)n + 15) & ~(size_t)15, ng4 = ((size_t)ng + 3) & ~(size_t)3;
+    const size_t wgt_f = a.attn_part ? (((size_t)a.attn_n_head * a.attn_nsplit + 3) & ~(size_t)3) : 0;
+    const size_t tab_f = (size_t)PAIRS * PITCH;
+    const size_t x_bytes = B * n16 + B * ng4 * 4;
+    int8_t *xq; float *xs, *wgt, *tab;
+    if (PRIV) {
+        unsigned char *base = smem + (size_t)wid * (x_bytes + (wgt_f + tab_f) * 4);
+        xq = reinterpret_cast<int8_t *>(base);
+        xs = reinterpret_cast<float *>(base + B * n16);
+        wgt = xs + B * ng4;
+        tab = wgt + wgt_f;
+    } else {
+        xq = reinterpret_cast<int8_t *>(smem);
+        xs = reinterpret_cast<float *>(smem + B * n16);
+        wgt = xs + B * ng4;                           // one region per wave (each wave stages different sequences)
+        tab = wgt + 4 * wgt_f + (size_t)wid * tab_f;
+        wgt += (size_t)wid * wgt_f;
+    }
+
     const int nchunk = (n + 1023) >> 10;
     const int npass = (a.epi == GEMV_EPI_SWIGLU) ? 2 : 1;
     const uint32_t stride = gridDim.x * 4;
@@ -289,55 +268,70 @@ __global__ __launch_bounds__(256) void gemv_q80_kernel(const GemvArgs a) {
     const bool leader = (lane % LPG) == 0;
     const int nb = (int)a.nb;
 
-    using Cur = Cursor<TR, RBL>;
-    Cur cu{ blockIdx.x * 4 + wid, 0, 0, 0, 0, 0, false };
+    Cursor cu{ blockIdx.x * 4 + wid, 0, 0, 0, 0, 0, false };
     cu.valid = locate_tile<TR>(a, cu.tile, cu.sidx, cu.row0);
 
     int4 wa[RBL], wb[RBL];
-    float wsr[NWS], wsn[NWS];
-
-    auto issue = [&](const Cur &c, int4 (&w)[RBL]) {
+    float sa[RBL], sb[RBL];                          // the leaders' weight scales of the batch
+    auto issue = [&](const Cursor &c, int4 (&w)[RBL], float (&s)[RBL]) {
         const GemvSeg &sg = a.seg[c.sidx + c.pass];
         const int8_t *W = reinterpret_cast<const int8_t *>(sg.w);
         const int col = (c.c << 10) + lane * 16;
+        const int gg = c.c * GC + gl;
 #pragma unroll
         for (int r = 0; r < RBL; r++) {
             const uint32_t row = c.row0 + c.r0 + r;
-            w[r] = (col < n && row < sg.rows) ? *reinterpret_cast<const int4 *>(W + (size_t)row * n + col) : make_int4(0, 0, 0, 0);
+            const bool ok = col < n && row < sg.rows;
+            w[r] = ok ? ld_stream_i4(W + (size_t)row * n + col) : make_int4(0, 0, 0, 0);
+            s[r] = (ok && leader) ? sg.ws[(size_t)row * ng + gg] : 0.0f;
         }
     };
-    auto issue_scales = [&](const Cur &c, float (&wsr)[NWS]) {   // the tile's weight scales for chunk c.c: (r, g) = idx / GC, idx % GC
-        const GemvSeg &sg = a.seg[c.sidx + c.pass];
+    if (cu.valid) issue(cu, wa, sa);                  // in flight across the prologue
+
+    // old value of the residual stream for the first tile (RESID epilogue), also issued early
+    float oldv = 0.0f;
+    auto issue_old = [&](const Cursor &c) {
+        if (a.epi == GEMV_EPI_RESID && lane < PAIRS && (lane % B) < nb) {
+            const uint32_t row = c.row0 + lane / B;
+            if (row < a.seg[c.sidx].rows) oldv = out_ptr(a, a.seg[c.sidx], lane % B)[row];
+        }
+    };
+    if (cu.valid) issue_old(cu);
+
+    // ---- prologue: stage the activations ------------------------------------------------------------
+    if (a.xq_in) {
+        if (PRIV || wid == 0) copy_q80_wave(a, xq, xs, GS, lane);
+    } else if (PRIV) {
 #pragma unroll
-        for (int k = 0; k < NWS; k++) {
-            const int idx = k * 64 + lane;
-            const int r = idx / GC, g = idx % GC;
-            const uint32_t row = c.row0 + r;
-            const int gg = c.c * GC + g;
-            wsr[k] = (idx < TR * GC && row < sg.rows && gg < ng) ? sg.ws[(size_t)row * ng + gg] : 0.0f;
+        for (int b = 0; b < B; b++) {
+            if (b < nb) {
+                if (a.attn_part) attn_weights_wave(a, b, wgt, lane);
+                quantize_q80_wave<GS>(a, b, xq + (size_t)b * n16, xs + (size_t)b * ng4, wgt, lane);
+            }
         }
-    };
-
-    if (cu.valid) { issue(cu, wa); issue_scales(cu, wsr); }   // in flight across the prologue
-
-    prologue_q80<B, GS>(a, xq, xs, red, wgt);
+    } else {
+        for (int b = wid; b < nb; b += 4) {
+            if (a.attn_part) attn_weights_wave(a, b, wgt, lane);
+            quantize_q80_wave<GS>(a, b, xq + (size_t)b * n16, xs + (size_t)b * ng4, wgt, lane);
+        }
+    }
+    if (!PRIV) __syncthreads();
 
     float val = 0.0f, res0 = 0.0f;
     while (cu.valid) {
-        Cur nx = cu;
+        Cursor nx = cu;
         cursor_advance<TR, RBL>(a, nx, nchunk, npass, stride);
-        if (nx.valid) {
-            issue(nx, wb);
-            if (nx.r0 == 0) issue_scales(nx, wsn);     // nx opens a new (tile|pass|chunk)
-        }
+        if (nx.valid) issue(nx, wb, sb);
 
         // ---- consume batch `cu` ------------------------------------------------------------------
         const int col = (cu.c << 10) + lane * 16;
         const bool act = col < n;
+        const int gg = cu.c * GC + gl;
 #pragma unroll
         for (int b = 0; b < B; b++) {
             if (b < nb) {
-                const int4 xv = act ? *reinterpret_cast<const int4 *>(xq + (size_t)b * n + col) : make_int4(0, 0, 0, 0);
+                const int4 xv = act ? *reinterpret_cast<const int4 *>(xq + (size_t)b * n16 + col) : make_int4(0, 0, 0, 0);
+                const float xsc = (act && leader) ? xs[(size_t)b * ng4 + gg] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < RBL; r++) {
                     int iv = __builtin_amdgcn_sdot4(wa[r].x, xv.x, 0, false);
@@ -345,52 +339,53 @@ __global__ __launch_bounds__(256) void gemv_q80_kernel(const GemvArgs a) {
                     iv = __builtin_amdgcn_sdot4(wa[r].z, xv.z, iv, false);
                     iv = __builtin_amdgcn_sdot4(wa[r].w, xv.w, iv, false);
                     iv = dpp_group_sum<LPG>(iv);
-                    if (leader) tab[((cu.r0 + r) * B + b) * PITCH + gl] = __int_as_float(iv);
+                    if (leader) tab[((cu.r0 + r) * B + b) * PITCH + gl] = ((float)iv * sa[r]) * xsc;   // infer.c:672
                 }
             }
         }
 
         if (cu.r0 + RBL >= TR) {                       // last batch of this (tile, pass, chunk)
-            // (A) parallel: p = ((float)ival * ws) * xs            reference infer.c:672
-#pragma unroll
-            for (int k = 0; k < NWS; k++) {
-                const int idx = k * 64 + lane;
-                if (idx < TR * GC) {
-                    const int r = idx / GC, g = idx % GC;
-                    const int gg = cu.c * GC + g;
-#pragma unroll
-                    for (int b = 0; b < B; b++) {
-                        if (b < nb) {
-                            const int e = (r * B + b) * PITCH + g;
-                            const float xsc = (gg < ng) ? xs[(size_t)b * ng + gg] : 0.0f;
-                            tab[e] = ((float)__float_as_int(tab[e]) * wsr[k]) * xsc;
-                        }
-                    }
-                }
-            }
-            // (B) ordered: val += p[g], g ascending            reference infer.c:668-674
+            // ordered fold: val += p[g], g ascending            reference infer.c:668-674
             const int gvalid = min(GC, ng - cu.c * GC);
             if (lane < PAIRS) {
                 const float *f = tab + lane * PITCH;
-                for (int g = 0; g < gvalid; g++) val += f[g];
+                float p[GC];
+#pragma unroll
+                for (int g = 0; g < GC; g += 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(f + g);
+                    p[g] = t.x; p[g + 1] = t.y; p[g + 2] = t.z; p[g + 3] = t.w;
+                }
+#pragma unroll
+                for (int g = 0; g < GC; g++) if (g < gvalid) val += p[g];
             }
             if (cu.c + 1 == nchunk) {                   // row finished for this pass
                 if (cu.pass + 1 == npass) {
-                    if (lane < PAIRS && (lane % B) < nb) {
-                        const uint32_t row = cu.row0 + lane / B;
-                        if (row < a.seg[cu.sidx].rows)
-                            emit(a, a.seg[cu.sidx], lane % B, row, (npass == 2) ? res0 : val, val);
+                    float outv = finish(a, (npass == 2) ? res0 : val, val, oldv);
+                    const bool live = lane < PAIRS && (lane % B) < nb && (cu.row0 + lane / B) < a.seg[cu.sidx].rows;
+                    if (live) out_ptr(a, a.seg[cu.sidx], lane % B)[cu.row0 + lane / B] = outv;
+                    if (a.tile_max) {                   // per-tile arg-max partial (first maximum, lowest row on ties)
+                        if (!live) outv = -INFINITY;
+                        if (lane < PAIRS) tab[lane * PITCH] = outv;
+                        if (lane < B && lane < nb) {
+                            float best = -INFINITY; uint32_t bi = 0xffffffffu;
+                            for (int r = 0; r < TR; r++) {
+                                const float v = tab[(r * B + lane) * PITCH];
+                                const uint32_t row = cu.row0 + r;
+                                if (row < a.seg[cu.sidx].rows && (bi == 0xffffffffu || v > best)) { best = v; bi = row; }
+                            }
+                            float *tm = a.tile_max + ((size_t)lane * a.tiles + cu.tile) * 2;
+                            tm[0] = best; tm[1] = __uint_as_float(bi);
+                        }
                     }
+                    if (nx.valid) issue_old(nx);
                 } else {
                     res0 = val;
                 }
                 val = 0.0f;
             }
-#pragma unroll
-            for (int k = 0; k < NWS; k++) wsr[k] = wsn[k];
         }
 #pragma unroll
-        for (int r = 0; r < RBL; r++) wa[r] = wb[r];
+        for (int r = 0; r < RBL; r++) { wa[r] = wb[r]; sa[r] = sb[r]; }
         cu = nx;
     }
 }
@@ -402,35 +397,51 @@ template <int B, int TR>
 __global__ __launch_bounds__(256) void gemv_f32_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RBL = TR;
+    constexpr bool PRIV = (B <= 2);
     const int n = (int)a.n;
-    float *xf = reinterpret_cast<float *>(smem);
-    float *red = xf + (((size_t)B * n + 3) & ~(size_t)3);
-    float *wgt = red + 16 * B;
-
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+    const size_t wgt_f = a.attn_part ? (((size_t)a.attn_n_head * a.attn_nsplit + 3) & ~(size_t)3) : 0;
+    float *xf, *wgt;
+    if (PRIV) { xf = reinterpret_cast<float *>(smem) + (size_t)wid * (B * n4 + wgt_f); wgt = xf + B * n4; }
+    else { xf = reinterpret_cast<float *>(smem); wgt = xf + B * n4 + (size_t)wid * wgt_f; }
+
     const int nchunk = (n + 255) >> 8;
     const int npass = (a.epi == GEMV_EPI_SWIGLU) ? 2 : 1;
     const uint32_t stride = gridDim.x * 4;
     const int nb = (int)a.nb;
 
-    using Cur = Cursor<TR, RBL>;
-    Cur cu{ blockIdx.x * 4 + wid, 0, 0, 0, 0, 0, false };
+    Cursor cu{ blockIdx.x * 4 + wid, 0, 0, 0, 0, 0, false };
     cu.valid = locate_tile<TR>(a, cu.tile, cu.sidx, cu.row0);
 
     float4 wa[RBL], wb[RBL];
-    auto issue = [&](const Cur &c, float4 (&w)[RBL]) {
+    auto issue = [&](const Cursor &c, float4 (&w)[RBL]) {
         const GemvSeg &sg = a.seg[c.sidx + c.pass];
         const float *W = reinterpret_cast<const float *>(sg.w);
         const int col = (c.c << 8) + lane * 4;
 #pragma unroll
         for (int r = 0; r < RBL; r++) {
             const uint32_t row = c.row0 + r;
-            w[r] = (col < n && row < sg.rows) ? *reinterpret_cast<const float4 *>(W + (size_t)row * n + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w[r] = (col < n && row < sg.rows) ? ld_stream_f4(W + (size_t)row * n + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (cu.valid) issue(cu, wa);
 
-    prologue_f32<B>(a, xf, red, wgt);
+    if (PRIV) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (b < nb) {
+                if (a.attn_part) attn_weights_wave(a, b, wgt, lane);
+                stage_f32_wave(a, b, xf + (size_t)b * n4, wgt, lane);
+            }
+        }
+    } else {
+        for (int b = wid; b < nb; b += 4) {
+            if (a.attn_part) attn_weights_wave(a, b, wgt, lane);
+            stage_f32_wave(a, b, xf + (size_t)b * n4, wgt, lane);
+        }
+        __syncthreads();
+    }
 
     float acc[TR][B], res0[TR][B];
 #pragma unroll
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const GemvArgs a) {
         for (int b = 0; b < B; b++) { acc[r][b] = 0.0f; res0[r][b] = 0.0f; }
 
     while (cu.valid) {
-        Cur nx = cu;
+        Cursor nx = cu;
         cursor_advance<TR, RBL>(a, nx, nchunk, npass, stride);
         if (nx.valid) issue(nx, wb);
 
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const GemvArgs a) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
             if (b < nb) {
-                const float4 xv = act ? *reinterpret_cast<const float4 *>(xf + (size_t)b * n + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 xv = act ? *reinterpret_cast<const float4 *>(xf + (size_t)b * n4 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int r = 0; r < TR; r++) {
                     float t = acc[r][b];
@@ -461,14 +472,27 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const GemvArgs a) {
 #pragma unroll
             for (int r = 0; r < TR; r++)
 #pragma unroll
-                for (int b = 0; b < B; b++) acc[r][b] = wave_sum(acc[r][b]);
+                for (int b = 0; b < B; b++) acc[r][b] = dpp_wave_sum(acc[r][b]);
             if (cu.pass + 1 == npass) {
 #pragma unroll
                 for (int r = 0; r < TR; r++)
 #pragma unroll
                     for (int b = 0; b < B; b++)
-                        if (lane == r * B + b && b < nb && cu.row0 + r < a.seg[cu.sidx].rows)
-                            emit(a, a.seg[cu.sidx], b, cu.row0 + r, (npass == 2) ? res0[r][b] : acc[r][b], acc[r][b]);
+                        if (lane == r * B + b && b < nb && cu.row0 + r < a.seg[cu.sidx].rows) {
+                            float *o = out_ptr(a, a.seg[cu.sidx], b) + cu.row0 + r;
+                            const float old = (a.epi == GEMV_EPI_RESID) ? *o : 0.0f;
+                            *o = finish(a, (npass == 2) ? res0[r][b] : acc[r][b], acc[r][b], old);
+                        }
+                if (a.tile_max && lane < B && lane < nb) {
+                    float best = -INFINITY; uint32_t bi = 0xffffffffu;
+#pragma unroll
+                    for (int r = 0; r < TR; r++)
+#pragma unroll
+                        for (int b = 0; b < B; b++)
+                            if (b == lane && cu.row0 + r < a.seg[cu.sidx].rows && (bi == 0xffffffffu || acc[r][b] > best)) { best = acc[r][b]; bi = cu.row0 + r; }
+                    float *tm = a.tile_max + ((size_t)lane * a.tiles + cu.tile) * 2;
+                    tm[0] = best; tm[1] = __uint_as_float(bi);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < TR; r++)
@@ -495,8 +519,25 @@ static inline uint32_t count_tiles(const GemvArgs &a, int TR) {
     for (uint32_t s = 0; s < a.nseg; s++) t += (a.seg[s].rows + TR - 1) / TR;
     return t;
 }
-
+static inline uint32_t total_rows(const GemvArgs &a) {
+    if (a.epi == GEMV_EPI_SWIGLU) return a.seg[0].rows;
+    uint32_t r = 0;
+    for (uint32_t s = 0; s < a.nseg; s++) r += a.seg[s].rows;
+    return r;
+}
 static inline size_t attn_wgt_floats(const GemvArgs &a) { return a.attn_part ? ((size_t)a.attn_n_head * a.attn_nsplit + 3) & ~(size_t)3 : 0; }
+
+uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // fwd
+
+// tile height: small GEMVs want >= ~1024 waves, the classifier wants tall tiles
+static inline int pick_tr(const GemvArgs &a, int B) {
+    const uint32_t rows = total_rows(a);
+    const int big = (B <= 2) ? 16 : 8;
+    if (a.epi != GEMV_EPI_SWIGLU && rows / big >= 4096) return big;
+    if (rows >= 4096) return 4;
+    if (rows >= 2048) return 2;
+    return 1;
+}
 
 template <int B, int TR, int GS>
 static hipError_t launch_q80(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
@@ -504,9 +545,10 @@ static hipError_t launch_q80(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
     uint32_t wgs = (a.tiles + 3) / 4;
     if (wgs > max_wg) wgs = max_wg;
     if (!wgs) return hipSuccess;
-    const size_t xq = ((size_t)B * a.n + 15) & ~(size_t)15;
-    const size_t xs = (((size_t)B * (a.n / GS) + 3) & ~(size_t)3) * 4;
-    const size_t lds = xq + xs + (16 * B + attn_wgt_floats(a)) * 4 + (size_t)4 * TR * B * (1024 / GS + 1) * 4;
+    const size_t n16 = ((size_t)a.n + 15) & ~(size_t)15, ng4 = ((size_t)(a.n / GS) + 3) & ~(size_t)3;
+    const size_t xb = B * n16 + B * ng4 * 4;
+    const size_t tabb = (size_t)TR * B * (1024 / GS + 4) * 4;
+    const size_t lds = (B <= 2) ? 4 * (xb + attn_wgt_floats(a) * 4 + tabb) : xb + 4 * (attn_wgt_floats(a) * 4 + tabb);
     auto kern = &gemv_q80_kernel<B, TR, GS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, st, a);
@@ -515,12 +557,13 @@ static hipError_t launch_q80(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
 
 template <int B, int GS>
 static hipError_t launch_q80_tr(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
-    // big GEMVs: 64/B-row tiles (every lane folds) once that still leaves >= 2 tiles per wave slot
-    uint32_t rows = 0;
-    for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
-    constexpr int TRBIG = (B <= 2) ? 16 : 8;
-    if (a.epi != GEMV_EPI_SWIGLU && rows / TRBIG >= 4096) return launch_q80<B, TRBIG, GS>(a, max_wg, st);
-    return launch_q80<B, 4, GS>(a, max_wg, st);
+    constexpr int BIG = (B <= 2) ? 16 : 8;
+    switch (pick_tr(a, B)) {
+    case 1: return launch_q80<B, 1, GS>(a, max_wg, st);
+    case 2: return launch_q80<B, 2, GS>(a, max_wg, st);
+    case 4: return launch_q80<B, 4, GS>(a, max_wg, st);
+    default: return launch_q80<B, BIG, GS>(a, max_wg, st);
+    }
 }
 
 template <int B>
@@ -529,23 +572,30 @@ static hipError_t launch_q80_gs(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
     case 32: return launch_q80_tr<B, 32>(a, max_wg, st);
     case 64: return launch_q80_tr<B, 64>(a, max_wg, st);
     case 128: return launch_q80_tr<B, 128>(a, max_wg, st);
-    case 256: return launch_q80_tr<B, 256>(a, max_wg, st);
     default: return hipErrorInvalidValue;
     }
 }
 
-template <int B>
-static hipError_t launch_f32(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
-    constexpr int TR = (B >= 8) ? 2 : 4;
+template <int B, int TR>
+static hipError_t launch_f32_tr(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
     a.tiles = count_tiles(a, TR);
     uint32_t wgs = (a.tiles + 3) / 4;
     if (wgs > max_wg) wgs = max_wg;
     if (!wgs) return hipSuccess;
-    const size_t lds = ((((size_t)B * a.n + 3) & ~(size_t)3) + 16 * B + attn_wgt_floats(a)) * 4;
+    const size_t n4 = ((size_t)a.n + 3) & ~(size_t)3;
+    const size_t lds = ((B <= 2) ? 4 * (B * n4 + attn_wgt_floats(a)) : B * n4 + 4 * attn_wgt_floats(a)) * 4;
     auto kern = &gemv_f32_kernel<B, TR>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, st, a);
     return hipGetLastError();
+}
+
+template <int B>
+static hipError_t launch_f32(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
+    const uint32_t rows = total_rows(a);
+    if (B >= 8 || rows < 2048) return launch_f32_tr<B, (B >= 8) ? 2 : 1>(a, max_wg, st);
+    if (rows < 4096) return launch_f32_tr<B, 2>(a, max_wg, st);
+    return launch_f32_tr<B, (B >= 8) ? 2 : 4>(a, max_wg, st);
 }
 
 hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t st) {
@@ -559,6 +609,18 @@ hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t
     if (a.nb <= 2) return launch_f32<2>(a, max_wg, st);
     if (a.nb <= 4) return launch_f32<4>(a, max_wg, st);
     return launch_f32<8>(a, max_wg, st);
+}
+
+// number of tiles launch_gemv() will use for these arguments (sizes the arg-max partial buffer)
+uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a) {
+    const int B = a.nb <= 1 ? 1 : a.nb <= 2 ? 2 : a.nb <= 4 ? 4 : 8;
+    if (quant == 0x80u) return count_tiles(a, pick_tr(a, B));
+    if (quant == 0x00u) {
+        const uint32_t rows = total_rows(a);
+        const int tr = (B >= 8) ? 2 : (rows < 2048 ? 1 : rows < 4096 ? 2 : 4);
+        return count_tiles(a, tr);
+    }
+    return count_tiles(a, GEMV_RB);
 }
 
 }  // namespace nano

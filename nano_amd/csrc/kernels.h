@@ -44,9 +44,11 @@ struct GemvArgs {
     const float *attn_part; // [nb][nsplit][n] unnormalised partial outputs, or nullptr
     const float *attn_ml;   // [nb][n_head][nsplit][2] (running max, exp-sum) per split
     uint32_t attn_nsplit, attn_n_head, attn_hd, _pad2;
+    // optional per-tile arg-max partials of a STORE launch: tile_max[b][tile] = (max value, row index bits)
+    float *tile_max;
 };
 
-size_t gemv_lds_bytes(uint32_t quant, uint32_t n, uint32_t gs, int B);
+uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // tiles launch_gemv() will use (sizes tile_max)
 hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t st);
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
 
@@ -92,6 +94,7 @@ struct ArgmaxArgs {
     const float *logits; uint32_t V, bstride;
     uint32_t *out;
     uint32_t *tokens; uint32_t *pos; uint32_t *trace; const uint32_t *pos0; uint32_t nb;   // trace[(pos-pos0)*nb + b]
+    const float *tile_max; uint32_t ntiles;     // optional (max, row) partials from the classifier GEMV
 };
 hipError_t launch_argmax(const ArgmaxArgs &a, uint32_t nb, hipStream_t st);
 

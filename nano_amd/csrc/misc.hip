@@ -60,9 +60,19 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
     const float *x = a.logits + (size_t)b * a.bstride;
     float best = -INFINITY;
     uint32_t bi = 0xffffffffu;
-    for (uint32_t i = tid; i < a.V; i += blockDim.x) {
-        const float v = x[i];
-        if (bi == 0xffffffffu || v > best) { best = v; bi = i; }
+    if (a.tile_max) {
+        // the classifier GEMV already reduced every tile to (max, first row): scan ntiles pairs, not V logits
+        const float *tm = a.tile_max + (size_t)b * a.ntiles * 2;
+        for (uint32_t t = tid; t < a.ntiles; t += blockDim.x) {
+            const float v = tm[2 * t];
+            const uint32_t i = __float_as_uint(tm[2 * t + 1]);
+            if (i != 0xffffffffu && (bi == 0xffffffffu || v > best)) { best = v; bi = i; }   // tiles ascend with t
+        }
+    } else {
+        for (uint32_t i = tid; i < a.V; i += blockDim.x) {
+            const float v = x[i];
+            if (bi == 0xffffffffu || v > best) { best = v; bi = i; }
+        }
     }
     // combine: larger value wins; equal values -> smaller index (== first maximum in scan order)
 #pragma unroll
