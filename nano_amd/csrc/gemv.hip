@@ -115,53 +115,6 @@ __device__ __forceinline__ float rms_scale_wave(const GemvArgs &a, int b, int la
     return 1.0f / sqrtf(ss);
 }
 
-// One wave quantizes sequence b (reference infer/tensor.c:21-46) into xq[n] (int8) / xs[n/GS]:
-// lane l owns elements [16l,16l+16) of every 1 KiB chunk -- exactly the slice it later multiplies.
-template <int GS>
-__device__ __forceinline__ void quantize_q80_wave(const GemvArgs &a, int b, int8_t *xq, float *xs, const float *wgt, int lane) {
-    constexpr int LPG = GS / 16;
-    const int n = (int)a.n;
-    const float ss = a.norm_w ? rms_scale_wave(a, b, lane) : 1.0f;
-    const int nchunk = (n + 1023) >> 10;
-    for (int c = 0; c < nchunk; c++) {
-        const int i0 = (c << 10) + lane * 16;
-        const bool act = i0 < n;
-        float v[16];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float4 t = act ? input4(a, b, i0 + 4 * k, wgt) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act && a.norm_w) {
-                const float4 w = *reinterpret_cast<const float4 *>(a.norm_w + i0 + 4 * k);
-                t.x = w.x * (ss * t.x); t.y = w.y * (ss * t.y); t.z = w.z * (ss * t.z); t.w = w.w * (ss * t.w);
-            }
-            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
-        }
-        float m = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) m = fmaxf(m, fabsf(v[k]));
-        m = dpp_group_max<LPG>(m);
-        const float scale = m / 127.0f;
-        if (act) {
-            uint32_t pk[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int q0 = q80_quant1(v[4 * k], scale), q1 = q80_quant1(v[4 * k + 1], scale);
-                const int q2 = q80_quant1(v[4 * k + 2], scale), q3 = q80_quant1(v[4 * k + 3], scale);
-                pk[k] = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-            }
-            *reinterpret_cast<uint4 *>(xq + i0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            if ((lane % LPG) == 0) xs[i0 / GS] = scale;
-        }
-    }
-}
-
-// operator-test path: caller supplied the quantized activation
-__device__ __forceinline__ void copy_q80_wave(const GemvArgs &a, int8_t *xq, float *xs, int gs, int lane) {
-    const int n = (int)a.n, ng = n / gs;
-    for (int i = lane * 16; i < n; i += 1024) *reinterpret_cast<uint4 *>(xq + i) = *reinterpret_cast<const uint4 *>(a.xq_in + i);
-    for (int i = lane; i < ng; i += 64) xs[i] = a.xs_in[i];
-}
-
 // One wave stages sequence b as fp32 (optionally normalised) into xf[n]
 __device__ __forceinline__ void stage_f32_wave(const GemvArgs &a, int b, float *xf, const float *wgt, int lane) {
     const int n = (int)a.n;
@@ -223,171 +176,6 @@ __device__ __forceinline__ float finish(const GemvArgs &a, float v, float v2, fl
     h *= (1.0f / (1.0f + expf(-h)));
     h *= v2;
     return h;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Q80
-// ------------------------------------------------------------------------------------------------
-template <int B, int TR, int GS>
-__global__ __launch_bounds__(256) void gemv_q80_kernel(const GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RBL = (TR < 8) ? TR : 8;           // rows per load batch
-    constexpr int LPG = GS / 16;                     // lanes per quantization group
-    constexpr int GC = 1024 / GS;                    // groups per 1 KiB chunk
-    constexpr int PITCH = GC + 4;                    // keeps every table row 16-byte aligned
-    constexpr int PAIRS = TR * B;                    // (row, sequence) pairs per tile, <= 64
-    constexpr bool PRIV = (B <= 2);                  // every wave stages the activations for itself
-    static_assert(PAIRS <= 64, "tile too large");
-    const int n = (int)a.n, ng = n / GS;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-
-    // LDS carve.  PRIV: per wave { xq[B*n16] | xs[B*ng4] | wgt | tab }.  shared: xq[B*n16] | xs | wgt[B] | tab[4]
-    const size_t n16 = ((size_t)n + 15) & ~(size_t)15, ng4 = ((size_t)ng + 3) & ~(size_t)3;
-    const size_t wgt_f = a.attn_part ? (((size_t)a.attn_n_head * a.attn_nsplit + 3) & ~(size_t)3) : 0;
-    const size_t tab_f = (size_t)PAIRS * PITCH;
-    const size_t x_bytes = B * n16 + B * ng4 * 4;
-    int8_t *xq; float *xs, *wgt, *tab;
-    if (PRIV) {
-        unsigned char *base = smem + (size_t)wid * (x_bytes + (wgt_f + tab_f) * 4);
-        xq = reinterpret_cast<int8_t *>(base);
-        xs = reinterpret_cast<float *>(base + B * n16);
-        wgt = xs + B * ng4;
-        tab = wgt + wgt_f;
-    } else {
-        xq = reinterpret_cast<int8_t *>(smem);
-        xs = reinterpret_cast<float *>(smem + B * n16);
-        wgt = xs + B * ng4;                           // one region per wave (each wave stages different sequences)
-        tab = wgt + 4 * wgt_f + (size_t)wid * tab_f;
-        wgt += (size_t)wid * wgt_f;
-    }
-
-    const int nchunk = (n + 1023) >> 10;
-    const int npass = (a.epi == GEMV_EPI_SWIGLU) ? 2 : 1;
-    const uint32_t stride = gridDim.x * 4;
-    const int gl = lane / LPG;
-    const bool leader = (lane % LPG) == 0;
-    const int nb = (int)a.nb;
-
-    Cursor cu{ blockIdx.x * 4 + wid, 0, 0, 0, 0, 0, false };
-    cu.valid = locate_tile<TR>(a, cu.tile, cu.sidx, cu.row0);
-
-    int4 wa[RBL], wb[RBL];
-    float sa[RBL], sb[RBL];                          // the leaders' weight scales of the batch
-    auto issue = [&](const Cursor &c, int4 (&w)[RBL], float (&s)[RBL]) {
-        const GemvSeg &sg = a.seg[c.sidx + c.pass];
-        const int8_t *W = reinterpret_cast<const int8_t *>(sg.w);
-        const int col = (c.c << 10) + lane * 16;
-        const int gg = c.c * GC + gl;
-#pragma unroll
-        for (int r = 0; r < RBL; r++) {
-            const uint32_t row = c.row0 + c.r0 + r;
-            const bool ok = col < n && row < sg.rows;
-            w[r] = ok ? ld_stream_i4(W + (size_t)row * n + col) : make_int4(0, 0, 0, 0);
-            s[r] = (ok && leader) ? sg.ws[(size_t)row * ng + gg] : 0.0f;
-        }
-    };
-    if (cu.valid) issue(cu, wa, sa);                  // in flight across the prologue
-
-    // old value of the residual stream for the first tile (RESID epilogue), also issued early
-    float oldv = 0.0f;
-    auto issue_old = [&](const Cursor &c) {
-        if (a.epi == GEMV_EPI_RESID && lane < PAIRS && (lane % B) < nb) {
-            const uint32_t row = c.row0 + lane / B;
-            if (row < a.seg[c.sidx].rows) oldv = out_ptr(a, a.seg[c.sidx], lane % B)[row];
-        }
-    };
-    if (cu.valid) issue_old(cu);
-
-    // ---- prologue: stage the activations ------------------------------------------------------------
-    if (a.xq_in) {
-        if (PRIV || wid == 0) copy_q80_wave(a, xq, xs, GS, lane);
-    } else if (PRIV) {
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            if (b < nb) {
-                if (a.attn_part) attn_weights_wave(a, b, wgt, lane);
-                quantize_q80_wave<GS>(a, b, xq + (size_t)b * n16, xs + (size_t)b * ng4, wgt, lane);
-            }
-        }
-    } else {
-        for (int b = wid; b < nb; b += 4) {
-            if (a.attn_part) attn_weights_wave(a, b, wgt, lane);
-            quantize_q80_wave<GS>(a, b, xq + (size_t)b * n16, xs + (size_t)b * ng4, wgt, lane);
-        }
-    }
-    if (!PRIV) __syncthreads();
-
-    float val = 0.0f, res0 = 0.0f;
-    while (cu.valid) {
-        Cursor nx = cu;
-        cursor_advance<TR, RBL>(a, nx, nchunk, npass, stride);
-        if (nx.valid) issue(nx, wb, sb);
-
-        // ---- consume batch `cu` ------------------------------------------------------------------
-        const int col = (cu.c << 10) + lane * 16;
-        const bool act = col < n;
-        const int gg = cu.c * GC + gl;
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            if (b < nb) {
-                const int4 xv = act ? *reinterpret_cast<const int4 *>(xq + (size_t)b * n16 + col) : make_int4(0, 0, 0, 0);
-                const float xsc = (act && leader) ? xs[(size_t)b * ng4 + gg] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < RBL; r++) {
-                    int iv = __builtin_amdgcn_sdot4(wa[r].x, xv.x, 0, false);
-                    iv = __builtin_amdgcn_sdot4(wa[r].y, xv.y, iv, false);
-                    iv = __builtin_amdgcn_sdot4(wa[r].z, xv.z, iv, false);
-                    iv = __builtin_amdgcn_sdot4(wa[r].w, xv.w, iv, false);
-                    iv = dpp_group_sum<LPG>(iv);
-                    if (leader) tab[((cu.r0 + r) * B + b) * PITCH + gl] = ((float)iv * sa[r]) * xsc;   // infer.c:672
-                }
-            }
-        }
-
-        if (cu.r0 + RBL >= TR) {                       // last batch of this (tile, pass, chunk)
-            // ordered fold: val += p[g], g ascending            reference infer.c:668-674
-            const int gvalid = min(GC, ng - cu.c * GC);
-            if (lane < PAIRS) {
-                const float *f = tab + lane * PITCH;
-                float p[GC];
-#pragma unroll
-                for (int g = 0; g < GC; g += 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(f + g);
-                    p[g] = t.x; p[g + 1] = t.y; p[g + 2] = t.z; p[g + 3] = t.w;
-                }
-#pragma unroll
-                for (int g = 0; g < GC; g++) if (g < gvalid) val += p[g];
-            }
-            if (cu.c + 1 == nchunk) {                   // row finished for this pass
-                if (cu.pass + 1 == npass) {
-                    float outv = finish(a, (npass == 2) ? res0 : val, val, oldv);
-                    const bool live = lane < PAIRS && (lane % B) < nb && (cu.row0 + lane / B) < a.seg[cu.sidx].rows;
-                    if (live) out_ptr(a, a.seg[cu.sidx], lane % B)[cu.row0 + lane / B] = outv;
-                    if (a.tile_max) {                   // per-tile arg-max partial (first maximum, lowest row on ties)
-                        if (!live) outv = -INFINITY;
-                        if (lane < PAIRS) tab[lane * PITCH] = outv;
-                        if (lane < B && lane < nb) {
-                            float best = -INFINITY; uint32_t bi = 0xffffffffu;
-                            for (int r = 0; r < TR; r++) {
-                                const float v = tab[(r * B + lane) * PITCH];
-                                const uint32_t row = cu.row0 + r;
-                                if (row < a.seg[cu.sidx].rows && (bi == 0xffffffffu || v > best)) { best = v; bi = row; }
-                            }
-                            float *tm = a.tile_max + ((size_t)lane * a.tiles + cu.tile) * 2;
-                            tm[0] = best; tm[1] = __uint_as_float(bi);
-                        }
-                    }
-                    if (nx.valid) issue_old(nx);
-                } else {
-                    res0 = val;
-                }
-                val = 0.0f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RBL; r++) { wa[r] = wb[r]; sa[r] = sb[r]; }
-        cu = nx;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,55 +315,6 @@ static inline uint32_t total_rows(const GemvArgs &a) {
 }
 static inline size_t attn_wgt_floats(const GemvArgs &a) { return a.attn_part ? ((size_t)a.attn_n_head * a.attn_nsplit + 3) & ~(size_t)3 : 0; }
 
-uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // fwd
-
-// tile height: small GEMVs want >= ~1024 waves, the classifier wants tall tiles
-static inline int pick_tr(const GemvArgs &a, int B) {
-    const uint32_t rows = total_rows(a);
-    const int big = (B <= 2) ? 16 : 8;
-    if (a.epi != GEMV_EPI_SWIGLU && rows / big >= 4096) return big;
-    if (rows >= 4096) return 4;
-    if (rows >= 2048) return 2;
-    return 1;
-}
-
-template <int B, int TR, int GS>
-static hipError_t launch_q80(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
-    a.tiles = count_tiles(a, TR);
-    uint32_t wgs = (a.tiles + 3) / 4;
-    if (wgs > max_wg) wgs = max_wg;
-    if (!wgs) return hipSuccess;
-    const size_t n16 = ((size_t)a.n + 15) & ~(size_t)15, ng4 = ((size_t)(a.n / GS) + 3) & ~(size_t)3;
-    const size_t xb = B * n16 + B * ng4 * 4;
-    const size_t tabb = (size_t)TR * B * (1024 / GS + 4) * 4;
-    const size_t lds = (B <= 2) ? 4 * (xb + attn_wgt_floats(a) * 4 + tabb) : xb + 4 * (attn_wgt_floats(a) * 4 + tabb);
-    auto kern = &gemv_q80_kernel<B, TR, GS>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, st, a);
-    return hipGetLastError();
-}
-
-template <int B, int GS>
-static hipError_t launch_q80_tr(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
-    constexpr int BIG = (B <= 2) ? 16 : 8;
-    switch (pick_tr(a, B)) {
-    case 1: return launch_q80<B, 1, GS>(a, max_wg, st);
-    case 2: return launch_q80<B, 2, GS>(a, max_wg, st);
-    case 4: return launch_q80<B, 4, GS>(a, max_wg, st);
-    default: return launch_q80<B, BIG, GS>(a, max_wg, st);
-    }
-}
-
-template <int B>
-static hipError_t launch_q80_gs(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
-    switch (a.gs) {
-    case 32: return launch_q80_tr<B, 32>(a, max_wg, st);
-    case 64: return launch_q80_tr<B, 64>(a, max_wg, st);
-    case 128: return launch_q80_tr<B, 128>(a, max_wg, st);
-    default: return hipErrorInvalidValue;
-    }
-}
-
 template <int B, int TR>
 static hipError_t launch_f32_tr(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
     a.tiles = count_tiles(a, TR);
@@ -599,23 +338,19 @@ static hipError_t launch_f32(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
 }
 
 hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t st) {
-    if (quant == 0x80u) {
-        if (a.nb <= 1) return launch_q80_gs<1>(a, max_wg, st);
-        if (a.nb <= 2) return launch_q80_gs<2>(a, max_wg, st);
-        if (a.nb <= 4) return launch_q80_gs<4>(a, max_wg, st);
-        return launch_q80_gs<8>(a, max_wg, st);
-    }
+    if (quant == 0x80u) return launch_gemv_q80(a, st);
     if (a.nb <= 1) return launch_f32<1>(a, max_wg, st);
     if (a.nb <= 2) return launch_f32<2>(a, max_wg, st);
     if (a.nb <= 4) return launch_f32<4>(a, max_wg, st);
     return launch_f32<8>(a, max_wg, st);
 }
 
-// number of tiles launch_gemv() will use for these arguments (sizes the arg-max partial buffer)
+// number of (max, row) arg-max partials launch_gemv() will write per sequence for these arguments (sizes tile_max;
+// 0 = none written, scan the logits)
 uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a) {
-    const int B = a.nb <= 1 ? 1 : a.nb <= 2 ? 2 : a.nb <= 4 ? 4 : 8;
-    if (quant == 0x80u) return count_tiles(a, pick_tr(a, B));
+    if (quant == 0x80u) return gemv_q80_partials(a);
     if (quant == 0x00u) {
+        const int B = a.nb <= 1 ? 1 : a.nb <= 2 ? 2 : a.nb <= 4 ? 4 : 8;
         const uint32_t rows = total_rows(a);
         const int tr = (B >= 8) ? 2 : (rows < 2048 ? 1 : rows < 4096 ? 2 : 4);
         return count_tiles(a, tr);

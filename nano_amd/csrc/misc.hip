@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
         for (uint32_t t = tid; t < a.ntiles; t += blockDim.x) {
             const float v = tm[2 * t];
             const uint32_t i = __float_as_uint(tm[2 * t + 1]);
-            if (i != 0xffffffffu && (bi == 0xffffffffu || v > best)) { best = v; bi = i; }   // tiles ascend with t
+            if (i != 0xffffffffu && (bi == 0xffffffffu || v > best || (v == best && i < bi))) { best = v; bi = i; }   // partials are NOT row-ordered
         }
     } else {
         for (uint32_t i = tid; i < a.V; i += blockDim.x) {

@@ -53,6 +53,19 @@ def test_matmul_q80_bit_exact(oracle, n, d, gs):
     assert np.array_equal(bits(ref), bits(out)), float(np.abs(ref - out).max())
 
 
+@pytest.mark.parametrize("n,d,gs", [(1024, 20000, 64), (1024, 16391, 128), (512, 16384, 32), (2560, 17000, 64), (1408, 16400, 64)])
+def test_matmul_q80_tall_bit_exact(oracle, n, d, gs):
+    """rows >= 16384 take the STREAM kernel (the classifier's path): same bit-exact bar."""
+    rng = np.random.default_rng(n * 3 + d)
+    w = (0.02 * rng.standard_normal(d * n)).astype(np.float32)
+    wq, ws = mf.quantize_q80_weights(w, gs)
+    x = rng.standard_normal(n).astype(np.float32)
+    xq, xs = oracle.quantize_q80(x, gs)
+    ref = oracle.matmul_q80(xq, xs, wq, ws, n, d, gs)
+    out = nb.op_matmul_q80(xq, xs, wq, ws, n, d, gs)
+    assert np.array_equal(bits(ref), bits(out)), float(np.abs(ref - out).max())
+
+
 def test_matmul_q80_golden(oracle, gold_ops):
     xq, xs = oracle.quantize_q80(gold_ops["q80_quant_x"], 64)
     out = nb.op_matmul_q80(xq, xs, gold_ops["q80_gemv_wq"], gold_ops["q80_gemv_ws"], 1024, 96, 64)
