@@ -1,194 +1,306 @@
-// attn.hip -- single-token GQA attention over the FP32 KV cache (reference infer/infer.c:810-879),
-// split over the sequence ("flash-decoding"): nsplit workgroups per (head, sequence) each take every
-// nsplit-th block of timesteps and emit an UNNORMALISED partial  o_s = sum_t exp(s_t - m_s) v_t  with
-// its (m_s, l_s = sum_t exp(s_t - m_s)); the consumer (the Wo GEMV's prologue, gemv.hip, or
-// attn_combine_kernel below) forms  sum_s o_s e^{m_s - M} / sum_s l_s e^{m_s - M}  -- algebraically the
-// reference's softmax(q.k/sqrt(hd)) . V; rounding differs at the 1e-7 level (tolerance 1e-5).
+// attn.hip -- single-token GQA attention over the FP32 KV cache (reference infer/infer.c:810-879).
 //
-// The kernel also owns the per-head work the reference does between the QKV GEMVs and the attention
-// loop, because it is head-local:
-//   * Qwen3: rmsnorm(q_head, q_norm), rmsnorm(k_head, k_norm) (infer.c:824-835) then half-split RoPE
-//     (rope_qwen3, infer.c:692-706);  Nano/Qwen2: adjacent-pair RoPE (rope, infer.c:681-690);
-//   * the finished k row is written to cache row `pos` by split 0 of the first head of each KV group
-//     (raw k comes from the QKV GEMV through a scratch row; v goes to the cache directly); every
-//     workgroup uses its own LDS copy of that row, so nobody reads the row while it is written.
-// KV rows are read as float4 by sub-groups of hd/4 lanes (coalesced 4*hd-byte rows), 4 rows in flight
-// per sub-group.
+// One workgroup per (KV head group, sequence, split).  Like the GEMVs of a batch-1 decode step this kernel is
+// LATENCY bound (a KV head's rows are at most a few hundred KB), so it is built as ONE memory round trip:
+// at entry every thread issues the loads of q, the raw k row, the norm weights and ALL the K and V rows
+// its workgroup will ever need (buffer descriptors: rows beyond the cache are out of range and read as 0
+// without touching memory; rows beyond `range_hint`, the host's upper bound of pos+1 for this launch, are
+// skipped the same way); position-dependent work (RoPE row, causal mask, the fresh k row) is applied
+// afterwards, when pos[b] has arrived.
+//   * the q heads of a KV group share every K/V row they read (GQA: kv_mul heads per workgroup);
+//   * Qwen3 q/k rmsnorm (infer.c:824-835) and RoPE (rope_qwen3 infer.c:692-706 / rope infer.c:681-690) are
+//     head-local and done here by one wave per vector (DPP reductions, no barrier);
+//   * the finished k row is written to cache row `pos` by split 0; every workgroup uses its own LDS copy
+//     for timestep pos, so nobody reads the row while it is being written; v went to the cache directly
+//     from the QKV GEMV;
+//   * timestep blocks are dealt round-robin to `nsplit` workgroups ("flash-decoding"); with nsplit == 1 the
+//     kernel normalises and writes the final head outputs, otherwise UNNORMALISED partials
+//     o_s = sum_t exp(s_t - m_s) v_t with (m_s, l_s) which the Wo GEMV's prologue combines (gemv_q80.hip).
+// Softmax is algebraically the reference's (max-subtracted, infer.c:616-634); summation order differs
+// (tolerance 1e-5).
 #include "device_common.h"
 #include "kernels.h"
 
 namespace nano {
 
-__device__ __forceinline__ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+namespace {
 
+#define DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+
+template <int W> __device__ __forceinline__ float group_sum_t(float v) {      // aligned groups of W lanes
+    if (W >= 2) v += DPP_F(v, 0xB1);
+    if (W >= 4) v += DPP_F(v, 0x4E);
+    if (W >= 8) v += DPP_F(v, 0x141);
+    if (W >= 16) v += DPP_F(v, 0x140);
+    if (W >= 32) v += __shfl_xor(v, 16, 64);
+    if (W >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += DPP_F(v, 0xB1); v += DPP_F(v, 0x4E); v += DPP_F(v, 0x141); v += DPP_F(v, 0x140);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t OOB = 0x7ffffff0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bload_f4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ __forceinline__ float bload_f(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+
+constexpr int NP = 8;            // timestep blocks a workgroup keeps in flight per round
+
+// LPR = float4 lanes per KV row (head_dim/4 rounded up to a power of two), KVM = q heads per workgroup
+template <int LPR, int KVM>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z, tid = threadIdx.x;
-    const int nsplit = (int)a.nsplit;
-    const int hd = (int)a.hd, half = hd >> 1;
-    const int kv_mul = (int)(a.n_head / a.n_kv_head);
-    const int g = h / kv_mul;
-    const uint32_t p = a.fixed_range ? (a.fixed_range - 1) : a.pos[b];
-    const uint32_t range = a.fixed_range ? a.fixed_range : (a.is_causal ? (p + 1) : a.S);
-
-    // LDS carve (all multiples of 16 bytes): qh[hd] kh[hd] red[32] part[256*4] att[local scores]
-    const int hd4 = (hd + 3) & ~3;
-    float *qh = reinterpret_cast<float *>(smem);
-    float *kh = qh + hd4;
-    float *red = kh + hd4;
-    float *part = red + 32;
-    float *att = part + 1024;
-
-    const float *qg = a.q + (size_t)b * a.q_dim + (size_t)h * hd;
-    const size_t slot_rows = (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
-    float *kc = a.kcache + slot_rows * a.kv_dim + (size_t)g * hd;      // row t at kc + t*kv_dim
-    const float *vc = a.vcache + slot_rows * a.kv_dim + (size_t)g * hd;
+    constexpr int R = 256 / LPR;                 // timesteps per block
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t grp = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+    const uint32_t nsplit = a.nsplit;
+    const uint32_t hd = a.hd, half = hd >> 1, hd4 = (hd + 3) & ~3u;
+    const uint32_t kv_mul = a.n_head / a.n_kv_head;
+    const uint32_t h0 = (KVM == 1) ? grp : grp * KVM;          // first q head of this workgroup
+    const uint32_t g = h0 / kv_mul;                            // its KV head
     const bool fresh_k = a.kraw != nullptr;
 
-    for (int i = tid; i < hd; i += 256) {
-        qh[i] = qg[i];
-        kh[i] = fresh_k ? a.kraw[(size_t)b * a.kv_dim + (size_t)g * hd + i] : 0.0f;
-    }
-    __syncthreads();
+    // LDS: qh[KVM][hd4] kh[hd4] redm[KVM][R] redl[KVM][R] part[R][KVM][hd4]
+    float *qh = reinterpret_cast<float *>(smem);
+    float *kh = qh + KVM * hd4;
+    float *redm = kh + hd4;
+    float *redl = redm + KVM * R;
+    float *part = redl + KVM * R;
 
-    if (fresh_k) {
-        if (a.q_norm) {
-            float sq = 0.0f, sk = 0.0f;
-            for (int i = tid; i < hd; i += 256) { sq += qh[i] * qh[i]; sk += kh[i] * kh[i]; }
-            sq = block_sum(sq, red);
-            sk = block_sum(sk, red + 16);
-            sq /= (float)hd; sq += 1e-5f; sq = 1.0f / sqrtf(sq);
-            sk /= (float)hd; sk += 1e-5f; sk = 1.0f / sqrtf(sk);
-            __syncthreads();
-            for (int i = tid; i < hd; i += 256) {
-                qh[i] = a.q_norm[i] * (sq * qh[i]);
-                kh[i] = a.k_norm[i] * (sk * kh[i]);
-            }
-            __syncthreads();
+    // ---- 1. issue every load --------------------------------------------------------------------------------
+    const size_t slot_rows = (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
+    const float *kc = a.kcache + slot_rows * a.kv_dim + (size_t)g * hd;
+    const float *vc = a.vcache + slot_rows * a.kv_dim + (size_t)g * hd;
+    const uint32_t cache_bytes = a.fixed_range ? a.fixed_range * a.kv_dim * 4u : a.S * a.kv_dim * 4u;   // rows >= S: out of range
+    const __amdgpu_buffer_rsrc_t rk = mkrsrc(kc, cache_bytes - g * hd * 4u);
+    const __amdgpu_buffer_rsrc_t rv = mkrsrc(vc, cache_bytes - g * hd * 4u);
+    const uint32_t sub = (uint32_t)tid / LPR, j = (uint32_t)tid % LPR;
+    const bool jact = j * 4u < hd;
+    const uint32_t range_hint = a.fixed_range ? a.fixed_range : a.range_hint;
+
+    // the vectors this wave normalises / rotates: v = wid, wid+4, ... ; v < KVM: q head h0+v ; v == KVM: the k row
+    // a lane holds the pair(s) RoPE rotates together: Qwen3 (i, i+half), Nano/Qwen2 (2i, 2i+1); pair index pi = lane + 64*jj
+    float e0[2][2], e1[2][2], nw0[2][2], nw1[2][2];     // [vector round][jj]
+    const __amdgpu_buffer_rsrc_t rq = mkrsrc(a.q + (size_t)b * a.q_dim, a.q_dim * 4u);
+    const __amdgpu_buffer_rsrc_t rkr = mkrsrc(fresh_k ? a.kraw + (size_t)b * a.kv_dim : nullptr, fresh_k ? a.kv_dim * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rqn = mkrsrc(a.q_norm, a.q_norm ? hd * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rkn = mkrsrc(a.k_norm, a.k_norm ? hd * 4u : 0u);
+#pragma unroll
+    for (int vr = 0; vr < 2; vr++) {
+        const uint32_t v = (uint32_t)wid + 4u * vr;
+        const bool isq = v < (uint32_t)KVM, isk = v == (uint32_t)KVM;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const uint32_t pi = (uint32_t)lane + 64u * jj;
+            const uint32_t i0 = a.rope_qwen3 ? pi : 2 * pi, i1 = a.rope_qwen3 ? pi + half : 2 * pi + 1;
+            const bool ok = pi < half;
+            const uint32_t o0 = ok ? i0 * 4u : OOB, o1 = ok ? i1 * 4u : OOB;
+            const uint32_t qb = (h0 + v) * hd * 4u, kb = g * hd * 4u;
+            e0[vr][jj] = isq ? bload_f(rq, o0 + (ok ? qb : 0u)) : isk ? bload_f(rkr, o0 + (ok ? kb : 0u)) : 0.0f;
+            e1[vr][jj] = isq ? bload_f(rq, o1 + (ok ? qb : 0u)) : isk ? bload_f(rkr, o1 + (ok ? kb : 0u)) : 0.0f;
+            nw0[vr][jj] = isq ? bload_f(rqn, o0) : isk ? bload_f(rkn, o0) : 0.0f;
+            nw1[vr][jj] = isq ? bload_f(rqn, o1) : isk ? bload_f(rkn, o1) : 0.0f;
         }
-        if (a.rope_cos) {
-            const float *fcr = a.rope_cos + (size_t)p * half;
-            const float *fci = a.rope_sin + (size_t)p * half;
-            for (int i = tid; i < half; i += 256) {
-                const float c = fcr[i], s = fci[i];
-                if (a.rope_qwen3) {
-                    const float q0 = qh[i], q1 = qh[i + half];
-                    qh[i] = q0 * c - q1 * s;  qh[i + half] = q1 * c + q0 * s;
-                    const float k0 = kh[i], k1 = kh[i + half];
-                    kh[i] = k0 * c - k1 * s;  kh[i + half] = k1 * c + k0 * s;
-                } else {
-                    const float q0 = qh[2 * i], q1 = qh[2 * i + 1];
-                    qh[2 * i] = q0 * c - q1 * s;  qh[2 * i + 1] = q0 * s + q1 * c;
-                    const float k0 = kh[2 * i], k1 = kh[2 * i + 1];
-                    kh[2 * i] = k0 * c - k1 * s;  kh[2 * i + 1] = k0 * s + k1 * c;
+    }
+    float4 kreg[NP], vreg[NP];
+    auto issue_kv = [&](uint32_t round) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t t = ((round * NP + p) * nsplit + split) * R + sub;
+            const uint32_t off = (jact && t < range_hint) ? t * a.kv_dim * 4u + j * 16u : OOB;
+            kreg[p] = bload_f4(rk, off);
+            vreg[p] = bload_f4(rv, off);
+        }
+    };
+    issue_kv(0);
+
+    // ---- 2. position, RoPE row, norms ------------------------------------------------------------------------------
+    const uint32_t pos = a.fixed_range ? (a.fixed_range - 1) : a.pos[b];
+    const uint32_t range = a.fixed_range ? a.fixed_range : (a.is_causal ? (pos + 1) : a.S);
+    float rc[2], rs[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+        const uint32_t pi = (uint32_t)lane + 64u * jj;
+        const bool ok = a.rope_cos && pi < half && fresh_k;
+        rc[jj] = ok ? a.rope_cos[(size_t)pos * half + pi] : 1.0f;
+        rs[jj] = ok ? a.rope_sin[(size_t)pos * half + pi] : 0.0f;
+    }
+#pragma unroll
+    for (int vr = 0; vr < 2; vr++) {
+        const uint32_t v = (uint32_t)wid + 4u * vr;
+        if (v <= (uint32_t)KVM) {                                   // wave-uniform
+            const bool isk = v == (uint32_t)KVM;
+            float x0[2], x1[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) { x0[jj] = e0[vr][jj]; x1[jj] = e1[vr][jj]; }
+            if (fresh_k && a.q_norm) {                               // rmsnorm over the head (infer.c:601-614), tree order
+                float acc = 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) { acc += x0[jj] * x0[jj]; acc += x1[jj] * x1[jj]; }
+                float ss = wave_sum_dpp(acc);
+                ss /= (float)hd; ss += 1e-5f; ss = 1.0f / sqrtf(ss);
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) { x0[jj] = nw0[vr][jj] * (ss * x0[jj]); x1[jj] = nw1[vr][jj] * (ss * x1[jj]); }
+            }
+            float *dst = isk ? kh : qh + v * hd4;
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const uint32_t pi = (uint32_t)lane + 64u * jj;
+                if (pi < half && (!isk || fresh_k)) {
+                    const uint32_t i0 = a.rope_qwen3 ? pi : 2 * pi, i1 = a.rope_qwen3 ? pi + half : 2 * pi + 1;
+                    float y0 = x0[jj], y1 = x1[jj];
+                    if (fresh_k && a.rope_cos) {
+                        const float c = rc[jj], s = rs[jj];
+                        if (a.rope_qwen3) { y0 = x0[jj] * c - x1[jj] * s; y1 = x1[jj] * c + x0[jj] * s; }     // infer.c:700-703
+                        else { y0 = x0[jj] * c - x1[jj] * s; y1 = x0[jj] * s + x1[jj] * c; }                 // infer.c:686-687
+                    }
+                    dst[i0] = y0; dst[i1] = y1;
+                    if (isk && split == 0 && (h0 % kv_mul) == 0) { float *krow = const_cast<float *>(kc) + (size_t)pos * a.kv_dim; krow[i0] = y0; krow[i1] = y1; }
+                    if (!isk && split == 0 && a.q_out) { float *qo = a.q_out + (size_t)b * a.q_dim + (size_t)(h0 + v) * hd; qo[i0] = y0; qo[i1] = y1; }
                 }
             }
-            __syncthreads();
         }
-        if (split == 0 && (h % kv_mul) == 0)
-            for (int i = tid; i < hd; i += 256) kc[(size_t)p * a.kv_dim + i] = kh[i];
-        if (split == 0 && a.q_out)
-            for (int i = tid; i < hd; i += 256) a.q_out[(size_t)b * a.q_dim + (size_t)h * hd + i] = qh[i];
     }
+    __syncthreads();
 
-    // ---- scores of this split's timestep blocks ---------------------------------------------------
-    const int lanes = hd >> 2;                    // float4 lanes per KV row
-    const int LPR = next_pow2(lanes);             // sub-group width
-    const int nsub = 256 / LPR;                   // timesteps per block
-    const int sub = tid / LPR, j = tid % LPR;
-    const bool jact = j < lanes;
-    const float4 qv = jact ? *reinterpret_cast<const float4 *>(qh + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- 3. scores, running softmax over rounds ------------------------------------------------------------------
+    float4 qv[KVM];
+#pragma unroll
+    for (int m = 0; m < KVM; m++) qv[m] = jact ? *reinterpret_cast<const float4 *>(qh + m * hd4 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 kfresh = (jact && fresh_k) ? *reinterpret_cast<const float4 *>(kh + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float sq_hd = sqrtf((float)hd);
-    const uint32_t nblk = (range + nsub - 1) / nsub;           // timestep blocks overall
-    const uint32_t myblk = (nblk > (uint32_t)split) ? (nblk - split + nsplit - 1) / nsplit : 0;   // blocks of this split
-    const uint32_t nloc = myblk * nsub;                         // local score slots
+    float mrun[KVM], lrun[KVM];
+    float4 acc[KVM];
+#pragma unroll
+    for (int m = 0; m < KVM; m++) { mrun[m] = -INFINITY; lrun[m] = 0.0f; acc[m] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    const uint32_t per_round = NP * nsplit * R;
+    const uint32_t limit = range < range_hint ? range : range_hint;
+    const uint32_t nround = (limit + per_round - 1) / per_round;
+    for (uint32_t round = 0; round < nround; round++) {
+        if (round) issue_kv(round);
+        float sc[KVM][NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t t = ((round * NP + p) * nsplit + split) * R + sub;
+            const float4 kk = (fresh_k && t == pos) ? kfresh : kreg[p];
+#pragma unroll
+            for (int m = 0; m < KVM; m++) {
+                float d = qv[m].x * kk.x;
+                d += qv[m].y * kk.y; d += qv[m].z * kk.z; d += qv[m].w * kk.w;
+                d = group_sum_t<LPR>(d);
+                sc[m][p] = (t < range) ? d / sq_hd : -INFINITY;                                   // infer.c:858
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < KVM; m++) {
+            float mx = mrun[m];
+#pragma unroll
+            for (int p = 0; p < NP; p++) mx = fmaxf(mx, sc[m][p]);
+            const float scale = (mrun[m] == -INFINITY) ? 0.0f : expf(mrun[m] - mx);
+            float l = lrun[m] * scale;
+            float4 o = make_float4(acc[m].x * scale, acc[m].y * scale, acc[m].z * scale, acc[m].w * scale);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const float e = (sc[m][p] == -INFINITY) ? 0.0f : expf(sc[m][p] - mx);
+                l += e;
+                o.x += e * vreg[p].x; o.y += e * vreg[p].y; o.z += e * vreg[p].z; o.w += e * vreg[p].w;
+            }
+            mrun[m] = mx; lrun[m] = l; acc[m] = o;
+        }
+    }
 
-    for (uint32_t i0 = 0; i0 < myblk; i0 += 4) {
-        float4 kv[4];
+    // ---- 4. combine the R sub-groups of the workgroup ----------------------------------------------------------------
+    if (j == 0) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t t = ((i0 + u) * nsplit + split) * nsub + sub;
-            const bool ok = jact && (i0 + u) < myblk && t < range && !(fresh_k && t == p);
-            kv[u] = ok ? *reinterpret_cast<const float4 *>(kc + (size_t)t * a.kv_dim + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t t = ((i0 + u) * nsplit + split) * nsub + sub;
-            if (fresh_k && t == p && jact) kv[u] = *reinterpret_cast<const float4 *>(kh + 4 * j);
-            float acc = qv.x * kv[u].x;
-            acc += qv.y * kv[u].y; acc += qv.z * kv[u].z; acc += qv.w * kv[u].w;
-            const float d = group_sum(acc, LPR);
-            if (j == 0 && (i0 + u) < myblk) att[(i0 + u) * nsub + sub] = (t < range) ? d / sq_hd : -INFINITY;
-        }
+        for (int m = 0; m < KVM; m++) { redm[m * R + sub] = mrun[m]; redl[m * R + sub] = lrun[m]; }
     }
     __syncthreads();
-
-    // ---- local softmax numerators (reference infer.c:616-634, normalisation deferred to the combine) ----
-    float m = -INFINITY;
-    for (uint32_t i = tid; i < nloc; i += 256) m = fmaxf(m, att[i]);
-    m = block_max(m, red);
-    float sum = 0.0f;
-    for (uint32_t i = tid; i < nloc; i += 256) {
-        const float e = (att[i] == -INFINITY) ? 0.0f : expf(att[i] - m);
-        att[i] = e; sum += e;
-    }
-    sum = block_sum(sum, red + 16);
-    __syncthreads();
-
-    // ---- weighted V sum ---------------------------------------------------------------------------------
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t i0 = 0; i0 < myblk; i0 += 4) {
-        float4 vv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t t = ((i0 + u) * nsplit + split) * nsub + sub;
-            vv[u] = (jact && (i0 + u) < myblk && t < range) ? *reinterpret_cast<const float4 *>(vc + (size_t)t * a.kv_dim + 4 * j)
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const float w = ((i0 + u) < myblk) ? att[(i0 + u) * nsub + sub] : 0.0f;
-            acc.x += w * vv[u].x; acc.y += w * vv[u].y; acc.z += w * vv[u].z; acc.w += w * vv[u].w;
-        }
+    for (int m = 0; m < KVM; m++) {
+        float M = -INFINITY;
+        for (int s = 0; s < R; s++) M = fmaxf(M, redm[m * R + s]);
+        const float w = (mrun[m] == -INFINITY) ? 0.0f : expf(mrun[m] - M);
+        if (jact) *reinterpret_cast<float4 *>(part + ((size_t)sub * KVM + m) * hd4 + 4 * j) = make_float4(acc[m].x * w, acc[m].y * w, acc[m].z * w, acc[m].w * w);
     }
-    if (jact) *reinterpret_cast<float4 *>(part + (size_t)sub * hd4 + 4 * j) = acc;
     __syncthreads();
-    float *po = a.out + ((size_t)b * nsplit + split) * a.q_dim + (size_t)h * hd;
-    for (int i = tid; i < hd; i += 256) {
-        float s = 0.0f;
-        for (int sb = 0; sb < nsub; sb++) s += part[(size_t)sb * hd4 + i];
-        po[i] = s;
-    }
-    if (tid == 0) {
-        float *ml = a.ml + (((size_t)b * a.n_head + h) * nsplit + split) * 2;
-        ml[0] = m; ml[1] = sum;
+    for (uint32_t idx = tid; idx < (uint32_t)KVM * hd; idx += 256) {
+        const uint32_t m = idx / hd, i = idx - m * hd;
+        float M = -INFINITY;
+        for (int s = 0; s < R; s++) M = fmaxf(M, redm[m * R + s]);
+        float L = 0.0f, o = 0.0f;
+        for (int s = 0; s < R; s++) {
+            const float ms = redm[m * R + s];
+            L += (ms == -INFINITY) ? 0.0f : redl[m * R + s] * expf(ms - M);
+            o += part[((size_t)s * KVM + m) * hd4 + i];
+        }
+        const uint32_t h = h0 + m;
+        if (nsplit == 1) {
+            a.xba_out[(size_t)b * a.q_dim + (size_t)h * hd + i] = o / L;                              // softmax normalisation (infer.c:631-633)
+        } else {
+            a.out[((size_t)b * nsplit + split) * a.q_dim + (size_t)h * hd + i] = o;
+            if (i == 0) { float *ml = a.ml + (((size_t)b * a.n_head + h) * nsplit + split) * 2; ml[0] = M; ml[1] = L; }
+        }
     }
 }
 
-uint32_t attention_nsplit(uint32_t S) {
-    uint32_t n = S / 64;
+template <int LPR>
+static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {
+    const uint32_t kv_mul = a.n_head / a.n_kv_head;
+    const uint32_t hd4 = (a.hd + 3) & ~3u;
+    constexpr uint32_t R = 256 / LPR;
+    auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 2 * kvm * R + (size_t)R * kvm * hd4) * sizeof(float); };
+    if (kv_mul == 2) { hipLaunchKernelGGL((attention_kernel<LPR, 2>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(2), st, a); }
+    else if (kv_mul == 4) { hipLaunchKernelGGL((attention_kernel<LPR, 4>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(4), st, a); }
+    else { hipLaunchKernelGGL((attention_kernel<LPR, 1>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a); }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// timesteps one workgroup covers per round for this head size
+static uint32_t steps_per_wg(uint32_t hd) {
+    uint32_t lpr = 1; while (lpr * 4 < hd) lpr <<= 1;
+    if (lpr < 8) lpr = 8;
+    return NP * (256 / lpr);
+}
+
+// number of splits for an upper bound `range_hint` of the attended range (<= 8; the partial buffers are sized for 8)
+uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd) {
+    const uint32_t per = steps_per_wg(hd);
+    uint32_t n = (range_hint + per - 1) / per;
     if (n < 1) n = 1;
     if (n > 8) n = 8;
     return n;
 }
 
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st) {
-    const uint32_t hd4 = (a.hd + 3) & ~3u;
-    const uint32_t max_range = a.fixed_range ? a.fixed_range : a.S;
-    const uint32_t lanes = a.hd >> 2;
-    uint32_t LPR = 1; while (LPR < lanes) LPR <<= 1;
-    const uint32_t nsub = 256 / LPR;
-    const uint32_t nblk = (max_range + nsub - 1) / nsub;
-    const uint32_t nloc = ((nblk + a.nsplit - 1) / a.nsplit + 4) * nsub;
-    const size_t lds = ((size_t)2 * hd4 + 32 + 1024 + ((nloc + 3) & ~3u)) * sizeof(float);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attention_kernel, dim3(a.n_head, nb, a.nsplit), dim3(256), lds, st, a);
-    return hipGetLastError();
+    if (a.hd % 4 || a.hd > 256 || a.hd < 4 || a.nsplit == 0 || a.nsplit > 8) return hipErrorInvalidValue;
+    if (a.nsplit == 1 && !a.xba_out) return hipErrorInvalidValue;
+    uint32_t lpr = 8; while (lpr * 4 < a.hd) lpr <<= 1;
+    switch (lpr) {
+    case 8: return launch_lpr<8>(a, nb, st);
+    case 16: return launch_lpr<16>(a, nb, st);
+    case 32: return launch_lpr<32>(a, nb, st);
+    default: return launch_lpr<64>(a, nb, st);
+    }
 }
 
-// stand-alone combine (operator tests; the forward folds this into the Wo GEMV's prologue)
+// stand-alone combine (operator tests, state read-back; the forward folds this into the Wo GEMV's prologue)
 __global__ void attn_combine_kernel(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit) {
     const uint32_t h = blockIdx.x, q_dim = n_head * hd;
     const float *mlh = ml + (size_t)h * nsplit * 2;

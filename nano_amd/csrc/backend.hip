@@ -67,7 +67,7 @@ struct NanoHipModel {
     float *tile_max = nullptr;                            // classifier per-tile (max, row) partials [B][<=V][2]
     float *kcache = nullptr, *vcache = nullptr;
     uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
-    uint32_t trace_cap = 0, nsplit = 1;
+    uint32_t trace_cap = 0, nsplit = 1;                  // nsplit: of the LAST enqueued step (<= 8, buffers sized for 8)
     // pinned host staging
     uint32_t *h_tokens = nullptr, *h_pos = nullptr, *h_amax = nullptr;
     float *h_logits = nullptr;
@@ -279,7 +279,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     const size_t B = max_batch;
     const size_t kvn = B * L * max_seq_len * KD;
     m->trace_cap = max_seq_len * max_batch;
-    m->nsplit = attention_nsplit(max_seq_len);
+    m->nsplit = 8;                                       // partial buffers are sized for the maximum
     bool ok = hipMalloc(&m->x, B * E * 4) == hipSuccess && hipMalloc(&m->q, B * QD * 4) == hipSuccess &&
               hipMalloc(&m->kraw, B * KD * 4) == hipSuccess && hipMalloc(&m->xba, B * QD * 4) == hipSuccess &&
               hipMalloc(&m->hb, B * H * 4) == hipSuccess && hipMalloc(&m->logits, B * V * 4) == hipSuccess &&
@@ -337,10 +337,13 @@ static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *nti
     return gemv(m, a);
 }
 
-static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode) {
+// range_hint: host-side upper bound of the attended range of every sequence (a multiple of 64, <= S)
+static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t range_hint) {
     const NanoModelDesc &d = m->d;
     const uint32_t E = d.n_embd, H = d.n_hidden, QD = m->QD, KD = m->KD, L = d.n_layer, S = m->S;
     hipError_t e;
+    const uint32_t nsplit = attention_nsplit(range_hint, m->hd);
+    m->nsplit = nsplit;
     EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E };
     if ((e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
 
@@ -361,7 +364,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.q = m->q; a.q_out = nullptr; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
             a.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
             a.k_norm = m->k_norm ? m->k_norm + (size_t)l * m->hd : nullptr;
-            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.out = m->attn_part; a.ml = m->attn_ml; a.nsplit = m->nsplit;
+            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.out = m->attn_part; a.ml = m->attn_ml; a.xba_out = m->xba; a.nsplit = nsplit; a.range_hint = range_hint;
             a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
@@ -371,7 +374,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[WO][l], m->x, E, E);
             a.n = QD; a.gs = d.group_size; a.nb = nb; a.xin = m->xba; a.xin_bstride = QD; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
-            a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = m->nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd;
+            if (nsplit > 1) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
             if ((e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
@@ -401,15 +404,18 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     return hipSuccess;
 }
 
-static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode) {
-    if (!m->use_graph) { HIP_TRY(enqueue_step(m, nb, is_causal, mode)); return 0; }
-    const uint64_t key = ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
+// max_pos: largest position among the sequences of this step (host knowledge; the device reads the exact pos[b])
+static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t max_pos) {
+    uint32_t range_hint = is_causal ? ((max_pos + 1 + 63) / 64) * 64 : m->S;
+    if (range_hint > m->S) range_hint = m->S;
+    if (!m->use_graph) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); return 0; }
+    const uint64_t key = ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         // first use: run eagerly once (sets kernel attributes, validates launches) then capture
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
-        hipError_t e = enqueue_step(m, nb, is_causal, mode);
+        hipError_t e = enqueue_step(m, nb, is_causal, mode, range_hint);
         hipError_t e2 = hipStreamEndCapture(m->st, &g);
         if (e != hipSuccess || e2 != hipSuccess) {
             if (g) (void)hipGraphDestroy(g);
@@ -419,6 +425,7 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
         (void)hipGraphDestroy(g);
         it = m->graphs.emplace(key, ge).first;
     }
+    m->nsplit = attention_nsplit(range_hint, m->hd);
     HIP_TRY(hipGraphLaunch(it->second, m->st));
     return 0;
 }
@@ -449,7 +456,9 @@ extern "C" int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const u
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
     const uint32_t mode = argmax_out ? MODE_ARGMAX : (logits_out ? MODE_LOGITS : MODE_NOCLS);
-    if ((rc = run_step(m, batch, is_causal ? 1u : 0u, mode))) return rc;
+    uint32_t max_pos = 0;
+    for (uint32_t i = 0; i < batch; i++) if (pos[i] > max_pos) max_pos = pos[i];
+    if ((rc = run_step(m, batch, is_causal ? 1u : 0u, mode, max_pos))) return rc;
     const size_t V = m->d.vocab_size;
     if (logits_out) HIP_TRY(hipMemcpyAsync(m->h_logits, m->logits, batch * V * 4, hipMemcpyDeviceToHost, m->st));
     if (argmax_out) HIP_TRY(hipMemcpyAsync(m->h_amax, m->amax, batch * 4, hipMemcpyDeviceToHost, m->st));
@@ -470,8 +479,10 @@ extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, c
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos0, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
+    uint32_t max_pos = 0;
+    for (uint32_t i = 0; i < batch; i++) if (pos[i] > max_pos) max_pos = pos[i];
     for (uint32_t s = 0; s < steps; s++)
-        if ((rc = run_step(m, batch, 1, MODE_LOOP))) return rc;
+        if ((rc = run_step(m, batch, 1, MODE_LOOP, max_pos + s))) return rc;
     if (out_ids) {
         HIP_TRY(hipMemcpyAsync(m->h_amax, m->trace, (size_t)steps * batch * 4, hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
@@ -510,9 +521,9 @@ extern "C" int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos,
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
     int rc;
-    if ((rc = run_step(m, batch, 1, MODE_ARGMAX))) return rc;            // warm / capture
+    if ((rc = run_step(m, batch, 1, MODE_ARGMAX, pos))) return rc;       // warm / capture
     HIP_TRY(hipEventRecord(m->ev0, m->st));
-    for (uint32_t i = 0; i < iters; i++) if ((rc = run_step(m, batch, 1, MODE_ARGMAX))) return rc;
+    for (uint32_t i = 0; i < iters; i++) if ((rc = run_step(m, batch, 1, MODE_ARGMAX, pos))) return rc;
     HIP_TRY(hipEventRecord(m->ev1, m->st));
     HIP_TRY(hipEventSynchronize(m->ev1));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
@@ -548,8 +559,8 @@ extern "C" int nano_hip_read_state(NanoHipModel *m, uint32_t slot, int which, ui
     switch (which) {
     case 0: src = m->x + (size_t)slot * m->d.n_embd; cap = m->d.n_embd; break;
     case 1: src = m->q + (size_t)slot * m->QD; cap = m->QD; break;
-    case 2:   // attention output: combine the split partials on demand
-        HIP_TRY(launch_attn_combine(m->attn_part + (size_t)slot * m->nsplit * m->QD, m->attn_ml + (size_t)slot * m->d.n_head * m->nsplit * 2,
+    case 2:   // attention output: final when the last step ran unsplit, else combine the split partials on demand
+        if (m->nsplit > 1) HIP_TRY(launch_attn_combine(m->attn_part + (size_t)slot * m->nsplit * m->QD, m->attn_ml + (size_t)slot * m->d.n_head * m->nsplit * 2,
                                     m->xba + (size_t)slot * m->QD, m->d.n_head, m->hd, m->nsplit, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
         src = m->xba + (size_t)slot * m->QD; cap = m->QD; break;

@@ -66,10 +66,11 @@ struct AttnArgs {
     const float *k_norm;
     const float *rope_cos;  // [rows][hd/2] or nullptr (no rope)
     const float *rope_sin;
-    float *out;             // [nb][nsplit][q_dim] UNNORMALISED partial outputs  sum_t exp(s_t - m) v_t
-    float *ml;              // [nb][n_head][nsplit][2]  (m = max score of the split, l = sum exp(s_t - m))
-    uint32_t nsplit;        // timestep blocks are dealt round-robin to `nsplit` workgroups per (head, sequence)
-    uint32_t _pad0;
+    float *out;             // nsplit > 1: [nb][nsplit][q_dim] UNNORMALISED partial outputs  sum_t exp(s_t - m) v_t
+    float *ml;              // nsplit > 1: [nb][n_head][nsplit][2]  (m = max score of the split, l = sum exp(s_t - m))
+    float *xba_out;         // nsplit == 1: [nb][q_dim] final (normalised) head outputs
+    uint32_t nsplit;        // timestep blocks are dealt round-robin to `nsplit` workgroups per (KV group, sequence)
+    uint32_t range_hint;    // host's upper bound of the attended range (>= pos+1 of every sequence; S when not causal)
     uint32_t layer, n_layer, S, hd, n_head, n_kv_head, q_dim, kv_dim;
     uint32_t rope_qwen3;    // 1: (i, i+hd/2) pairs, 0: adjacent pairs
     uint32_t is_causal;
@@ -77,7 +78,7 @@ struct AttnArgs {
     uint32_t fixed_range;          // op-test mode: attend over rows [0, fixed_range) of an externally filled cache
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
-uint32_t attention_nsplit(uint32_t S);
+uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
 
 // ---- small kernels ----------------------------------------------------------------------------------

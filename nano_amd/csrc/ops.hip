@@ -138,7 +138,7 @@ extern "C" int nano_hip_op_attention(int device, float *out, const float *q, con
     int rc; if ((rc = begin(device))) return rc;
     if (!range || !n_kv_head || n_head % n_kv_head || head_dim % 4 || head_dim > 256) { nano_hip_set_error_("bad attention shape"); return NANO_HIP_EINVAL; }
     const size_t QD = (size_t)n_head * head_dim, KD = (size_t)n_kv_head * head_dim;
-    const uint32_t nsplit = attention_nsplit(range);
+    const uint32_t nsplit = attention_nsplit(range, head_dim);
     DevBufs B; float *dq = B.upload(q, QD), *dk = B.upload(k_cache, range * KD), *dv = B.upload(v_cache, range * KD), *dout = B.alloc<float>(QD);
     float *dpart = B.alloc<float>(nsplit * QD), *dml = B.alloc<float>((size_t)n_head * nsplit * 2);
     OP_CHECK(dq && dk && dv && dout && dpart && dml, "device alloc failed");
@@ -146,8 +146,9 @@ extern "C" int nano_hip_op_attention(int device, float *out, const float *q, con
     a.q = dq; a.q_out = nullptr; a.kraw = nullptr; a.kcache = dk; a.vcache = dv; a.pos = nullptr; a.out = dpart; a.ml = dml; a.nsplit = nsplit;
     a.layer = 0; a.n_layer = 1; a.S = range; a.hd = head_dim; a.n_head = n_head; a.n_kv_head = n_kv_head;
     a.q_dim = (uint32_t)QD; a.kv_dim = (uint32_t)KD; a.is_causal = 1; a.cache_bstride_rows = range; a.fixed_range = range;
+    a.xba_out = dout; a.range_hint = range;
     OP_HIP(launch_attention(a, 1, 0));
-    OP_HIP(launch_attn_combine(dpart, dml, dout, n_head, head_dim, nsplit, 0));
+    if (nsplit > 1) OP_HIP(launch_attn_combine(dpart, dml, dout, n_head, head_dim, nsplit, 0));
     OP_HIP(hipMemcpy(out, dout, QD * 4, hipMemcpyDeviceToHost));
     return 0;
 }
