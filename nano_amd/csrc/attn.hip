@@ -58,10 +58,12 @@ __device__ __forceinline__ float bload_f(__amdgpu_buffer_rsrc_t r, uint32_t off)
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
 
-constexpr int NP = 8;            // timestep blocks a workgroup keeps in flight per round
+constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight per round
 
-// LPR = float4 lanes per KV row (head_dim/4 rounded up to a power of two), KVM = q heads per workgroup
-template <int LPR, int KVM>
+// A KV row (head_dim floats) is shared by LPR lanes, QV float4 each (lane j owns float4 j, j+LPR, ...: every load
+// instruction reads LPR*16 contiguous bytes per row); few lanes per row keep the per-row cross-lane reduction and the
+// per-timestep exp() cheap.  KVM = q heads per workgroup.
+template <int LPR, int QV, int KVM>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = 256 / LPR;                 // timesteps per block
@@ -75,11 +77,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const uint32_t g = h0 / kv_mul;                            // its KV head
     const bool fresh_k = a.kraw != nullptr;
 
-    // LDS: qh[KVM][hd4] kh[hd4] redm[KVM][R] redl[KVM][R] part[R][KVM][hd4]
+    // LDS: qh[KVM][hd4] kh[hd4] redm[KVM][4] redl[KVM][R] part[R][KVM][hd4]
     float *qh = reinterpret_cast<float *>(smem);
     float *kh = qh + KVM * hd4;
     float *redm = kh + hd4;
-    float *redl = redm + KVM * R;
+    float *redl = redm + KVM * 4;
     float *part = redl + KVM * R;
 
     // ---- 1. issue every load --------------------------------------------------------------------------------
@@ -90,7 +92,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const __amdgpu_buffer_rsrc_t rk = mkrsrc(kc, cache_bytes - g * hd * 4u);
     const __amdgpu_buffer_rsrc_t rv = mkrsrc(vc, cache_bytes - g * hd * 4u);
     const uint32_t sub = (uint32_t)tid / LPR, j = (uint32_t)tid % LPR;
-    const bool jact = j * 4u < hd;
     const uint32_t range_hint = a.fixed_range ? a.fixed_range : a.range_hint;
 
     // the vectors this wave normalises / rotates: v = wid, wid+4, ... ; v < KVM: q head h0+v ; v == KVM: the k row
@@ -117,14 +118,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             nw1[vr][jj] = isq ? bload_f(rqn, o1) : isk ? bload_f(rkn, o1) : 0.0f;
         }
     }
-    float4 kreg[NP], vreg[NP];
+    // RoPE row of pos[b]: staged at a fixed address by the step's first kernel (no pos-dependent load)
+    float rc[2], rs[2];
+    const bool rope_staged = a.rope_cur != nullptr && fresh_k;
+    {
+        const __amdgpu_buffer_rsrc_t rr = mkrsrc(rope_staged ? a.rope_cur + (size_t)b * 2 * half : nullptr, rope_staged ? 2 * half * 4u : 0u);
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const uint32_t pi = (uint32_t)lane + 64u * jj;
+            rc[jj] = bload_f(rr, pi < half ? pi * 4u : OOB);
+            rs[jj] = bload_f(rr, pi < half ? (half + pi) * 4u : OOB);
+        }
+    }
+    float4 kreg[NP][QV], vreg[NP][QV];
     auto issue_kv = [&](uint32_t round) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const uint32_t t = ((round * NP + p) * nsplit + split) * R + sub;
-            const uint32_t off = (jact && t < range_hint) ? t * a.kv_dim * 4u + j * 16u : OOB;
-            kreg[p] = bload_f4(rk, off);
-            vreg[p] = bload_f4(rv, off);
+#pragma unroll
+            for (int q = 0; q < QV; q++) {
+                const uint32_t f = j + (uint32_t)LPR * q;                  // float4 index inside the head
+                const uint32_t off = (f * 4u < hd && t < range_hint) ? t * a.kv_dim * 4u + f * 16u : OOB;
+                kreg[p][q] = bload_f4(rk, off);
+                vreg[p][q] = bload_f4(rv, off);
+            }
         }
     };
     issue_kv(0);
@@ -132,13 +149,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     // ---- 2. position, RoPE row, norms ------------------------------------------------------------------------------
     const uint32_t pos = a.fixed_range ? (a.fixed_range - 1) : a.pos[b];
     const uint32_t range = a.fixed_range ? a.fixed_range : (a.is_causal ? (pos + 1) : a.S);
-    float rc[2], rs[2];
+    if (!rope_staged) {
 #pragma unroll
-    for (int jj = 0; jj < 2; jj++) {
-        const uint32_t pi = (uint32_t)lane + 64u * jj;
-        const bool ok = a.rope_cos && pi < half && fresh_k;
-        rc[jj] = ok ? a.rope_cos[(size_t)pos * half + pi] : 1.0f;
-        rs[jj] = ok ? a.rope_sin[(size_t)pos * half + pi] : 0.0f;
+        for (int jj = 0; jj < 2; jj++) {
+            const uint32_t pi = (uint32_t)lane + 64u * jj;
+            const bool ok = a.rope_cos && pi < half && fresh_k;
+            rc[jj] = ok ? a.rope_cos[(size_t)pos * half + pi] : 1.0f;
+            rs[jj] = ok ? a.rope_sin[(size_t)pos * half + pi] : 0.0f;
+        }
     }
 #pragma unroll
     for (int vr = 0; vr < 2; vr++) {
@@ -179,15 +197,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     __syncthreads();
 
     // ---- 3. scores, running softmax over rounds ------------------------------------------------------------------
-    float4 qv[KVM];
+    float4 qv[KVM][QV], kfresh[QV];
 #pragma unroll
-    for (int m = 0; m < KVM; m++) qv[m] = jact ? *reinterpret_cast<const float4 *>(qh + m * hd4 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 kfresh = (jact && fresh_k) ? *reinterpret_cast<const float4 *>(kh + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < QV; q++) {
+        const uint32_t f = j + (uint32_t)LPR * q;
+        const bool ok = f * 4u < hd;
+#pragma unroll
+        for (int m = 0; m < KVM; m++) qv[m][q] = ok ? *reinterpret_cast<const float4 *>(qh + m * hd4 + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        kfresh[q] = (ok && fresh_k) ? *reinterpret_cast<const float4 *>(kh + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float sq_hd = sqrtf((float)hd);
     float mrun[KVM], lrun[KVM];
-    float4 acc[KVM];
+    float4 acc[KVM][QV];
 #pragma unroll
-    for (int m = 0; m < KVM; m++) { mrun[m] = -INFINITY; lrun[m] = 0.0f; acc[m] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int m = 0; m < KVM; m++) {
+        mrun[m] = -INFINITY; lrun[m] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < QV; q++) acc[m][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const uint32_t per_round = NP * nsplit * R;
     const uint32_t limit = range < range_hint ? range : range_hint;
     const uint32_t nround = (limit + per_round - 1) / per_round;
@@ -197,11 +224,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const uint32_t t = ((round * NP + p) * nsplit + split) * R + sub;
-            const float4 kk = (fresh_k && t == pos) ? kfresh : kreg[p];
+            const bool fresh = fresh_k && t == pos;
 #pragma unroll
             for (int m = 0; m < KVM; m++) {
-                float d = qv[m].x * kk.x;
-                d += qv[m].y * kk.y; d += qv[m].z * kk.z; d += qv[m].w * kk.w;
+                float d = 0.0f;
+#pragma unroll
+                for (int q = 0; q < QV; q++) {
+                    const float4 kk = fresh ? kfresh[q] : kreg[p][q];
+                    d += qv[m][q].x * kk.x; d += qv[m][q].y * kk.y; d += qv[m][q].z * kk.z; d += qv[m][q].w * kk.w;
+                }
                 d = group_sum_t<LPR>(d);
                 sc[m][p] = (t < range) ? d / sq_hd : -INFINITY;                                   // infer.c:858
             }
@@ -213,39 +244,57 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             for (int p = 0; p < NP; p++) mx = fmaxf(mx, sc[m][p]);
             const float scale = (mrun[m] == -INFINITY) ? 0.0f : expf(mrun[m] - mx);
             float l = lrun[m] * scale;
-            float4 o = make_float4(acc[m].x * scale, acc[m].y * scale, acc[m].z * scale, acc[m].w * scale);
+#pragma unroll
+            for (int q = 0; q < QV; q++) { acc[m][q].x *= scale; acc[m][q].y *= scale; acc[m][q].z *= scale; acc[m][q].w *= scale; }
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const float e = (sc[m][p] == -INFINITY) ? 0.0f : expf(sc[m][p] - mx);
                 l += e;
-                o.x += e * vreg[p].x; o.y += e * vreg[p].y; o.z += e * vreg[p].z; o.w += e * vreg[p].w;
+#pragma unroll
+                for (int q = 0; q < QV; q++) {
+                    acc[m][q].x += e * vreg[p][q].x; acc[m][q].y += e * vreg[p][q].y; acc[m][q].z += e * vreg[p][q].z; acc[m][q].w += e * vreg[p][q].w;
+                }
             }
-            mrun[m] = mx; lrun[m] = l; acc[m] = o;
+            mrun[m] = mx; lrun[m] = l;
         }
     }
 
     // ---- 4. combine the R sub-groups of the workgroup ----------------------------------------------------------------
-    if (j == 0) {
+    // maximum: across the sub-groups of a wave by cross-lane exchange, across waves through LDS
+    constexpr int SPW = 64 / LPR;                     // sub-groups per wave
+    float Mwg[KVM];
 #pragma unroll
-        for (int m = 0; m < KVM; m++) { redm[m * R + sub] = mrun[m]; redl[m * R + sub] = lrun[m]; }
+    for (int m = 0; m < KVM; m++) {
+        float mx = mrun[m];
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) redm[m * 4 + wid] = mx;
     }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < KVM; m++) {
-        float M = -INFINITY;
-        for (int s = 0; s < R; s++) M = fmaxf(M, redm[m * R + s]);
+        const float M = fmaxf(fmaxf(redm[m * 4], redm[m * 4 + 1]), fmaxf(redm[m * 4 + 2], redm[m * 4 + 3]));
+        Mwg[m] = M;
         const float w = (mrun[m] == -INFINITY) ? 0.0f : expf(mrun[m] - M);
-        if (jact) *reinterpret_cast<float4 *>(part + ((size_t)sub * KVM + m) * hd4 + 4 * j) = make_float4(acc[m].x * w, acc[m].y * w, acc[m].z * w, acc[m].w * w);
+#pragma unroll
+        for (int q = 0; q < QV; q++) {
+            const uint32_t f = j + (uint32_t)LPR * q;
+            if (f * 4u < hd)
+                *reinterpret_cast<float4 *>(part + ((size_t)sub * KVM + m) * hd4 + 4 * f) = make_float4(acc[m][q].x * w, acc[m][q].y * w, acc[m][q].z * w, acc[m][q].w * w);
+        }
+        if (j == 0) redl[m * R + sub] = lrun[m] * w;
     }
+    (void)SPW;
     __syncthreads();
     for (uint32_t idx = tid; idx < (uint32_t)KVM * hd; idx += 256) {
         const uint32_t m = idx / hd, i = idx - m * hd;
-        float M = -INFINITY;
-        for (int s = 0; s < R; s++) M = fmaxf(M, redm[m * R + s]);
+        float M = Mwg[0];
+#pragma unroll
+        for (int q = 1; q < KVM; q++) M = (q == (int)m) ? Mwg[q] : M;
         float L = 0.0f, o = 0.0f;
+#pragma unroll 8
         for (int s = 0; s < R; s++) {
-            const float ms = redm[m * R + s];
-            L += (ms == -INFINITY) ? 0.0f : redl[m * R + s] * expf(ms - M);
+            L += redl[m * R + s];
             o += part[((size_t)s * KVM + m) * hd4 + i];
         }
         const uint32_t h = h0 + m;
@@ -258,26 +307,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
 }
 
-template <int LPR>
+template <int LPR, int QV>
 static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {
     const uint32_t kv_mul = a.n_head / a.n_kv_head;
     const uint32_t hd4 = (a.hd + 3) & ~3u;
     constexpr uint32_t R = 256 / LPR;
-    auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 2 * kvm * R + (size_t)R * kvm * hd4) * sizeof(float); };
-    if (kv_mul == 2) { hipLaunchKernelGGL((attention_kernel<LPR, 2>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(2), st, a); }
-    else if (kv_mul == 4) { hipLaunchKernelGGL((attention_kernel<LPR, 4>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(4), st, a); }
-    else { hipLaunchKernelGGL((attention_kernel<LPR, 1>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a); }
+    auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + kvm * R + (size_t)R * kvm * hd4) * sizeof(float); };
+    if (kv_mul == 2) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 2>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(2), st, a); }
+    else if (kv_mul == 4) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 4>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(4), st, a); }
+    else { hipLaunchKernelGGL((attention_kernel<LPR, QV, 1>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a); }
     return hipGetLastError();
 }
 
 }  // namespace
 
 // timesteps one workgroup covers per round for this head size
-static uint32_t steps_per_wg(uint32_t hd) {
-    uint32_t lpr = 1; while (lpr * 4 < hd) lpr <<= 1;
-    if (lpr < 8) lpr = 8;
-    return NP * (256 / lpr);
-}
+static uint32_t steps_per_wg(uint32_t hd) { return NP * (256 / (hd > 128 ? 16 : 8)); }
 
 // number of splits for an upper bound `range_hint` of the attended range (<= 8; the partial buffers are sized for 8)
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd) {
@@ -291,13 +336,10 @@ uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd) {
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st) {
     if (a.hd % 4 || a.hd > 256 || a.hd < 4 || a.nsplit == 0 || a.nsplit > 8) return hipErrorInvalidValue;
     if (a.nsplit == 1 && !a.xba_out) return hipErrorInvalidValue;
-    uint32_t lpr = 8; while (lpr * 4 < a.hd) lpr <<= 1;
-    switch (lpr) {
-    case 8: return launch_lpr<8>(a, nb, st);
-    case 16: return launch_lpr<16>(a, nb, st);
-    case 32: return launch_lpr<32>(a, nb, st);
-    default: return launch_lpr<64>(a, nb, st);
-    }
+    if (a.hd <= 32) return launch_lpr<8, 1>(a, nb, st);
+    if (a.hd <= 64) return launch_lpr<8, 2>(a, nb, st);
+    if (a.hd <= 128) return launch_lpr<8, 4>(a, nb, st);
+    return launch_lpr<16, 4>(a, nb, st);
 }
 
 // stand-alone combine (operator tests, state read-back; the forward folds this into the Wo GEMV's prologue)

@@ -64,7 +64,8 @@ struct NanoHipModel {
     // per-sequence state
     float *x = nullptr, *q = nullptr, *kraw = nullptr, *xba = nullptr, *hb = nullptr, *logits = nullptr;
     float *attn_part = nullptr, *attn_ml = nullptr;       // split-attention partials [B][nsplit][QD], [B][n_head][nsplit][2]
-    float *tile_max = nullptr;                            // classifier per-tile (max, row) partials [B][<=V][2]
+    float *tile_max = nullptr;                            // classifier arg-max partials [B][<=V][2]
+    float *rope_cur = nullptr;                            // RoPE rows of the current positions [B][2][hd/2], staged by the embed kernel
     float *kcache = nullptr, *vcache = nullptr;
     uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
     uint32_t trace_cap = 0, nsplit = 1;                  // nsplit: of the LAST enqueued step (<= 8, buffers sized for 8)
@@ -74,6 +75,7 @@ struct NanoHipModel {
     std::map<uint64_t, hipGraphExec_t> graphs;
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
+    uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -135,7 +137,7 @@ static void destroy(NanoHipModel *m) {
     if (m->st) (void)hipStreamSynchronize(m->st);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
-                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max };
+                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -289,7 +291,8 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
               hipMalloc(&m->pos0, B * 4) == hipSuccess &&
               hipMalloc(&m->attn_part, B * m->nsplit * QD * 4) == hipSuccess &&
               hipMalloc(&m->attn_ml, B * d.n_head * m->nsplit * 2 * 4) == hipSuccess &&
-              hipMalloc(&m->tile_max, B * V * 2 * 4) == hipSuccess;
+              hipMalloc(&m->tile_max, B * V * 2 * 4) == hipSuccess &&
+              hipMalloc(&m->rope_cur, B * m->hd * 4 + 64) == hipSuccess;
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
     // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
     if (hipMemset(m->kcache, 0, kvn * 4) != hipSuccess || hipMemset(m->vcache, 0, kvn * 4) != hipSuccess ||
@@ -302,6 +305,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     if (hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
         hipEventCreate(&m->ev1) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "stream/event creation failed"); }
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
+    if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
     return NANO_HIP_OK;
@@ -344,8 +348,10 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     hipError_t e;
     const uint32_t nsplit = attention_nsplit(range_hint, m->hd);
     m->nsplit = nsplit;
-    EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E };
-    if ((e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
+    EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
+                  m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0 };
+    const uint32_t skip = m->skip_mask;
+    if (!(skip & 128) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
 
     for (uint32_t l = 0; l < L; l++) {
         const size_t layer_rows = (size_t)l * S;                    // cache row offset of this layer within a slot
@@ -357,49 +363,49 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.seg[2] = mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_STORE;
             a.norm_w = m->rms_attn + (size_t)l * E; a.pos = m->pos;
-            if ((e = gemv(m, a)) != hipSuccess) return e;
+            if (!(skip & 1) && (e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // qk-norm, rope, k-cache write, attention   reference infer.c:810-879
             AttnArgs a{};
             a.q = m->q; a.q_out = nullptr; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
             a.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
             a.k_norm = m->k_norm ? m->k_norm + (size_t)l * m->hd : nullptr;
-            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.out = m->attn_part; a.ml = m->attn_ml; a.xba_out = m->xba; a.nsplit = nsplit; a.range_hint = range_hint;
+            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.rope_cur = m->rope_cos ? m->rope_cur : nullptr; a.out = m->attn_part; a.ml = m->attn_ml; a.xba_out = m->xba; a.nsplit = nsplit; a.range_hint = range_hint;
             a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
-            if ((e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
+            if (!(skip & 2) && (e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
         }
         {   // x += Wo . xba   reference infer.c:885-908
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[WO][l], m->x, E, E);
             a.n = QD; a.gs = d.group_size; a.nb = nb; a.xin = m->xba; a.xin_bstride = QD; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
             if (nsplit > 1) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
-            if ((e = gemv(m, a)) != hipSuccess) return e;
+            if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
             GemvArgs a{};
             a.nseg = 2; a.seg[0] = mkseg(m->W[W1][l], m->hb, H, H); a.seg[1] = mkseg(m->W[W3][l], m->hb, H, H);
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_SWIGLU;
             a.norm_w = m->rms_ffn + (size_t)l * E; a.pos = m->pos;
-            if ((e = gemv(m, a)) != hipSuccess) return e;
+            if (!(skip & 8) && (e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // x += W2 . hb   reference infer.c:950-965
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[W2][l], m->x, E, E);
             a.n = H; a.gs = d.group_size; a.nb = nb; a.xin = m->hb; a.xin_bstride = H; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
-            if ((e = gemv(m, a)) != hipSuccess) return e;
+            if (!(skip & 16) && (e = gemv(m, a)) != hipSuccess) return e;
         }
     }
     if (mode == MODE_NOCLS) return hipSuccess;
     const bool sample = (mode == MODE_ARGMAX || mode == MODE_LOOP);
     uint32_t ntiles = 0;
-    if ((e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;   // final rmsnorm fused in the prologue (infer.c:999-1015)
+    if (!(skip & 32) && (e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;   // final rmsnorm fused in the prologue (infer.c:999-1015)
     if (sample) {
         ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, m->pos, nullptr, m->pos0, nb,
                        ntiles ? m->tile_max : nullptr, ntiles };
         if (mode == MODE_LOOP) { aa.tokens = m->tokens; aa.trace = m->trace; }
-        if ((e = launch_argmax(aa, nb, m->st)) != hipSuccess) return e;
+        if (!(skip & 64) && (e = launch_argmax(aa, nb, m->st)) != hipSuccess) return e;
     }
     return hipSuccess;
 }

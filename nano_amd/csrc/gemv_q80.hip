@@ -109,6 +109,10 @@ template <int B, int NV>
 struct Staged {
     float4 x[B][NV];
     float4 nw[NV];
+    // split-attention combine, single sequence: every partial of this thread's items and its (max, sum) pair
+    // are fetched at kernel entry too (one round trip instead of nsplit dependent ones)
+    float4 pv[B == 1 ? NV : 1][B == 1 ? 8 : 1];
+    float ml_m, ml_l;
 };
 template <int B>
 struct Staged<B, 0> {};          // NV == 0: nothing is kept in registers, stage_finish() re-reads memory in loops
@@ -124,23 +128,43 @@ __device__ __forceinline__ void stage_issue(const Q80Dev &a, Staged<B, NV> &r) {
     for (int j = 0; j < NV; j++) {
         const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
         const uint32_t off = (i < n) ? i * 4u : OOB;
+        if (plain) {
 #pragma unroll
-        for (int b = 0; b < B; b++) r.x[b][j] = bload_f4(rx, (b < (int)a.nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
-        r.nw[j] = bload_f4(rn, off);
+            for (int b = 0; b < B; b++) r.x[b][j] = bload_f4(rx, (b < (int)a.nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
+        }
+        if (a.flags & F_NORM) r.nw[j] = bload_f4(rn, off);
+    }
+    if constexpr (B == 1) {
+      if (a.flags & F_COMBINE) {              // uniform branch: an out-of-range load is not free, do not issue 8*NV of them
+        const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
+        const __amdgpu_buffer_rsrc_t rp = mkrsrc(a.attn_part, ns * n * 4u);
+        const __amdgpu_buffer_rsrc_t rm = mkrsrc(a.attn_ml, nh * ns * 8u);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+#pragma unroll
+            for (int sp = 0; sp < 8; sp++) r.pv[j][sp] = bload_f4(rp, (i < n && (uint32_t)sp < ns) ? ((uint32_t)sp * n + i) * 4u : OOB);
+        }
+        const uint32_t sp = tid & 7u, h = tid >> 3;
+        const uint32_t mo = (h < nh && sp < ns) ? (h * ns + sp) * 8u : OOB;
+        r.ml_m = bload_f(rm, mo);
+        r.ml_l = bload_f(rm, mo == OOB ? OOB : mo + 4u);
+      }
     }
     }
 }
 
 // x[b][i] = sum_s part[b][s][i] * wgt[b][head(i)][s]  (attn.hip split partials), wgt from (max, sum) pairs
 template <int B>
-__device__ __forceinline__ void combine_weights(const Q80Dev &a, float *wgt /* LDS [B][n_head][8] */) {
+__device__ __forceinline__ void combine_weights(const Q80Dev &a, float *wgt /* LDS [B][n_head][8] */, bool preloaded, float pm, float pl) {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
     // thread (b, h, s<8): e_s = exp(m_s - M) / sum_s l_s exp(m_s - M); the 8 lanes of a head are one DPP half-row
     for (uint32_t t = tid; t < (uint32_t)B * nh * 8u; t += nthr) {
         const uint32_t s = t & 7u, h = (t >> 3) % nh, b = (t >> 3) / nh;
         float m = -INFINITY, l = 0.0f;
-        if (s < ns && b < a.nb) { const float *ml = a.attn_ml + (((size_t)b * nh + h) * ns + s) * 2; m = ml[0]; l = ml[1]; }
+        if (preloaded) { m = pm; l = pl; }
+        else if (s < ns && b < a.nb) { const float *ml = a.attn_ml + (((size_t)b * nh + h) * ns + s) * 2; m = ml[0]; l = ml[1]; }
         const bool live = l > 0.0f;
         float M = live ? m : -INFINITY;
         M = fmaxf(M, DPP_F(M, 0xB1)); M = fmaxf(M, DPP_F(M, 0x4E)); M = fmaxf(M, DPP_F(M, 0x141));
@@ -181,8 +205,8 @@ __device__ __forceinline__ void stage_finish(const Q80Dev &a, Staged<B, NV> &r, 
     }
     const bool norm = (a.flags & F_NORM) != 0, comb = (a.flags & F_COMBINE) != 0;
     float *wgt = red + B * 16;
-    if (comb) combine_weights<B>(a, wgt);
     if constexpr (NV == 0) {
+        if (comb) combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
         // generic path (large n x B): two passes over memory per sequence
         for (uint32_t b = 0; b < a.nb; b++) {
             const float *x = a.xin + (size_t)b * a.xin_bstride;
@@ -218,13 +242,31 @@ __device__ __forceinline__ void stage_finish(const Q80Dev &a, Staged<B, NV> &r, 
         __syncthreads();
     } else {
         if (comb) {
-#pragma unroll
-            for (int b = 0; b < B; b++)
+            if constexpr (B == 1) {
+                const bool pre_ml = a.attn_n_head * 8u <= nthr;       // every (head, split) pair has its own thread
+                combine_weights<B>(a, wgt, pre_ml, r.ml_m, r.ml_l);
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
                     const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
-                    r.x[b][j] = (i < n && b < (int)a.nb) ? combine4(a, b, i, wgt) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float *wg = wgt + (size_t)((i < n ? i : 0u) / a.attn_hd) * 8u;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int sp = 0; sp < 8; sp++) {          // splits >= nsplit: partial read as 0, weight 0
+                        const float w = wg[sp];
+                        acc.x += r.pv[j][sp].x * w; acc.y += r.pv[j][sp].y * w; acc.z += r.pv[j][sp].z * w; acc.w += r.pv[j][sp].w * w;
+                    }
+                    r.x[0][j] = acc;
                 }
+            } else {
+                combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+#pragma unroll
+                for (int b = 0; b < B; b++)
+#pragma unroll
+                    for (int j = 0; j < NV; j++) {
+                        const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+                        r.x[b][j] = (i < n && b < (int)a.nb) ? combine4(a, b, i, wgt) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
         }
         float ss[B];
 #pragma unroll

@@ -66,6 +66,7 @@ struct AttnArgs {
     const float *k_norm;
     const float *rope_cos;  // [rows][hd/2] or nullptr (no rope)
     const float *rope_sin;
+    const float *rope_cur;  // optional [nb][2][hd/2]: the rows of pos[b], staged by the embed kernel (else read from the tables)
     float *out;             // nsplit > 1: [nb][nsplit][q_dim] UNNORMALISED partial outputs  sum_t exp(s_t - m) v_t
     float *ml;              // nsplit > 1: [nb][n_head][nsplit][2]  (m = max score of the split, l = sum exp(s_t - m))
     float *xba_out;         // nsplit == 1: [nb][q_dim] final (normalised) head outputs
@@ -88,6 +89,9 @@ struct EmbedArgs {
     const uint32_t *tokens; // [nb]
     float *x;               // [nb][E]
     uint32_t E, gs, quant, x_bstride;
+    // the step's first kernel also stages the RoPE row of each sequence's position at a FIXED address, so that
+    // the attention kernels need no pos-dependent load: rope_cur[b] = { cos[pos[b]][0..half), sin[pos[b]][0..half) }
+    const float *rope_cos; const float *rope_sin; const uint32_t *pos; float *rope_cur; uint32_t half, _pad;
 };
 hipError_t launch_embed(const EmbedArgs &a, uint32_t nb, hipStream_t st);
 

@@ -16,6 +16,13 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     const uint32_t tok = a.tokens[b];
     float *x = a.x + (size_t)b * a.x_bstride;
     const uint32_t E = a.E;
+    if (a.rope_cur) {
+        const uint32_t p = a.pos[b];
+        for (uint32_t i = threadIdx.x; i < a.half; i += blockDim.x) {
+            a.rope_cur[(size_t)b * 2 * a.half + i] = a.rope_cos[(size_t)p * a.half + i];
+            a.rope_cur[(size_t)b * 2 * a.half + a.half + i] = a.rope_sin[(size_t)p * a.half + i];
+        }
+    }
     if (a.quant == 0x00u) {
         const float *row = reinterpret_cast<const float *>(a.tok) + (size_t)tok * E;
         for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) x[i] = row[i];
