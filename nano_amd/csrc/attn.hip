@@ -63,7 +63,10 @@ constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight 
 // A KV row (head_dim floats) is shared by LPR lanes, QV float4 each (lane j owns float4 j, j+LPR, ...: every load
 // instruction reads LPR*16 contiguous bytes per row); few lanes per row keep the per-row cross-lane reduction and the
 // per-timestep exp() cheap.  KVM = q heads per workgroup.
-template <int LPR, int QV, int KVM>
+// MODE resolves the feature flags at compile time for the decode launches (a taken branch costs ~40 cycles and every
+// instruction of the one wave per SIMD is on the critical path): 0 generic (run-time flags), 1 Qwen3 decode (q/k-norm,
+// half-split RoPE, staged RoPE row, fresh k, causal), 2 Nano/Qwen2 decode (adjacent-pair RoPE, staged row, fresh k, causal).
+template <int LPR, int QV, int KVM, int MODE>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = 256 / LPR;                 // timesteps per block
@@ -75,7 +78,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const uint32_t kv_mul = a.n_head / a.n_kv_head;
     const uint32_t h0 = (KVM == 1) ? grp : grp * KVM;          // first q head of this workgroup
     const uint32_t g = h0 / kv_mul;                            // its KV head
-    const bool fresh_k = a.kraw != nullptr;
+    constexpr bool G = MODE == 0;
+    constexpr int VR = (KVM + 1 + 3) / 4;                      // rounds of vectors per wave (q heads + the k row over 4 waves)
+    constexpr int JJ = (LPR == 16) ? 2 : 1;                    // RoPE pairs per lane (head_dim > 128 needs two)
+    const bool fresh_k = G ? a.kraw != nullptr : true;
+    const bool has_norm = G ? a.q_norm != nullptr : MODE == 1;
+    const bool rq3 = G ? a.rope_qwen3 != 0 : MODE == 1;
+    const bool has_rope = G ? a.rope_cos != nullptr : true;
+    const uint32_t fixed_range = G ? a.fixed_range : 0u;
+    const bool causal = G ? a.is_causal != 0 : true;
+    float *const q_out = G ? a.q_out : nullptr;
 
     // LDS: qh[KVM][hd4] kh[hd4] redm[KVM][4] redl[KVM][R] part[R][KVM][hd4]
     float *qh = reinterpret_cast<float *>(smem);
@@ -88,43 +100,43 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const size_t slot_rows = (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
     const float *kc = a.kcache + slot_rows * a.kv_dim + (size_t)g * hd;
     const float *vc = a.vcache + slot_rows * a.kv_dim + (size_t)g * hd;
-    const uint32_t cache_bytes = a.fixed_range ? a.fixed_range * a.kv_dim * 4u : a.S * a.kv_dim * 4u;   // rows >= S: out of range
+    const uint32_t cache_bytes = fixed_range ? fixed_range * a.kv_dim * 4u : a.S * a.kv_dim * 4u;   // rows >= S: out of range
     const __amdgpu_buffer_rsrc_t rk = mkrsrc(kc, cache_bytes - g * hd * 4u);
     const __amdgpu_buffer_rsrc_t rv = mkrsrc(vc, cache_bytes - g * hd * 4u);
     const uint32_t sub = (uint32_t)tid / LPR, j = (uint32_t)tid % LPR;
-    const uint32_t range_hint = a.fixed_range ? a.fixed_range : a.range_hint;
+    const uint32_t range_hint = fixed_range ? fixed_range : a.range_hint;
 
     // the vectors this wave normalises / rotates: v = wid, wid+4, ... ; v < KVM: q head h0+v ; v == KVM: the k row
     // a lane holds the pair(s) RoPE rotates together: Qwen3 (i, i+half), Nano/Qwen2 (2i, 2i+1); pair index pi = lane + 64*jj
-    float e0[2][2], e1[2][2], nw0[2][2], nw1[2][2];     // [vector round][jj]
+    float e0[VR][JJ], e1[VR][JJ], nw0[VR][JJ], nw1[VR][JJ];     // [vector round][jj]
     const __amdgpu_buffer_rsrc_t rq = mkrsrc(a.q + (size_t)b * a.q_dim, a.q_dim * 4u);
     const __amdgpu_buffer_rsrc_t rkr = mkrsrc(fresh_k ? a.kraw + (size_t)b * a.kv_dim : nullptr, fresh_k ? a.kv_dim * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rqn = mkrsrc(a.q_norm, a.q_norm ? hd * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rkn = mkrsrc(a.k_norm, a.k_norm ? hd * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rqn = mkrsrc(a.q_norm, has_norm ? hd * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rkn = mkrsrc(a.k_norm, has_norm ? hd * 4u : 0u);
 #pragma unroll
-    for (int vr = 0; vr < 2; vr++) {
+    for (int vr = 0; vr < VR; vr++) {
         const uint32_t v = (uint32_t)wid + 4u * vr;
         const bool isq = v < (uint32_t)KVM, isk = v == (uint32_t)KVM;
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
+        for (int jj = 0; jj < JJ; jj++) {
             const uint32_t pi = (uint32_t)lane + 64u * jj;
-            const uint32_t i0 = a.rope_qwen3 ? pi : 2 * pi, i1 = a.rope_qwen3 ? pi + half : 2 * pi + 1;
+            const uint32_t i0 = rq3 ? pi : 2 * pi, i1 = rq3 ? pi + half : 2 * pi + 1;
             const bool ok = pi < half;
             const uint32_t o0 = ok ? i0 * 4u : OOB, o1 = ok ? i1 * 4u : OOB;
             const uint32_t qb = (h0 + v) * hd * 4u, kb = g * hd * 4u;
             e0[vr][jj] = isq ? bload_f(rq, o0 + (ok ? qb : 0u)) : isk ? bload_f(rkr, o0 + (ok ? kb : 0u)) : 0.0f;
             e1[vr][jj] = isq ? bload_f(rq, o1 + (ok ? qb : 0u)) : isk ? bload_f(rkr, o1 + (ok ? kb : 0u)) : 0.0f;
-            nw0[vr][jj] = isq ? bload_f(rqn, o0) : isk ? bload_f(rkn, o0) : 0.0f;
-            nw1[vr][jj] = isq ? bload_f(rqn, o1) : isk ? bload_f(rkn, o1) : 0.0f;
+            nw0[vr][jj] = !has_norm ? 1.0f : isq ? bload_f(rqn, o0) : isk ? bload_f(rkn, o0) : 0.0f;
+            nw1[vr][jj] = !has_norm ? 1.0f : isq ? bload_f(rqn, o1) : isk ? bload_f(rkn, o1) : 0.0f;
         }
     }
     // RoPE row of pos[b]: staged at a fixed address by the step's first kernel (no pos-dependent load)
-    float rc[2], rs[2];
-    const bool rope_staged = a.rope_cur != nullptr && fresh_k;
+    float rc[JJ], rs[JJ];
+    const bool rope_staged = G ? (a.rope_cur != nullptr && fresh_k) : true;
     {
         const __amdgpu_buffer_rsrc_t rr = mkrsrc(rope_staged ? a.rope_cur + (size_t)b * 2 * half : nullptr, rope_staged ? 2 * half * 4u : 0u);
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
+        for (int jj = 0; jj < JJ; jj++) {
             const uint32_t pi = (uint32_t)lane + 64u * jj;
             rc[jj] = bload_f(rr, pi < half ? pi * 4u : OOB);
             rs[jj] = bload_f(rr, pi < half ? (half + pi) * 4u : OOB);
@@ -147,49 +159,49 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     issue_kv(0);
 
     // ---- 2. position, RoPE row, norms ------------------------------------------------------------------------------
-    const uint32_t pos = a.fixed_range ? (a.fixed_range - 1) : a.pos[b];
-    const uint32_t range = a.fixed_range ? a.fixed_range : (a.is_causal ? (pos + 1) : a.S);
+    const uint32_t pos = fixed_range ? (fixed_range - 1) : a.pos[b];
+    const uint32_t range = fixed_range ? fixed_range : (causal ? (pos + 1) : a.S);
     if (!rope_staged) {
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
+        for (int jj = 0; jj < JJ; jj++) {
             const uint32_t pi = (uint32_t)lane + 64u * jj;
-            const bool ok = a.rope_cos && pi < half && fresh_k;
+            const bool ok = has_rope && pi < half && fresh_k;
             rc[jj] = ok ? a.rope_cos[(size_t)pos * half + pi] : 1.0f;
             rs[jj] = ok ? a.rope_sin[(size_t)pos * half + pi] : 0.0f;
         }
     }
 #pragma unroll
-    for (int vr = 0; vr < 2; vr++) {
+    for (int vr = 0; vr < VR; vr++) {
         const uint32_t v = (uint32_t)wid + 4u * vr;
         if (v <= (uint32_t)KVM) {                                   // wave-uniform
             const bool isk = v == (uint32_t)KVM;
-            float x0[2], x1[2];
+            float x0[JJ], x1[JJ];
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++) { x0[jj] = e0[vr][jj]; x1[jj] = e1[vr][jj]; }
-            if (fresh_k && a.q_norm) {                               // rmsnorm over the head (infer.c:601-614), tree order
+            for (int jj = 0; jj < JJ; jj++) { x0[jj] = e0[vr][jj]; x1[jj] = e1[vr][jj]; }
+            if (fresh_k && has_norm) {                               // rmsnorm over the head (infer.c:601-614), tree order
                 float acc = 0.0f;
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++) { acc += x0[jj] * x0[jj]; acc += x1[jj] * x1[jj]; }
+                for (int jj = 0; jj < JJ; jj++) { acc += x0[jj] * x0[jj]; acc += x1[jj] * x1[jj]; }
                 float ss = wave_sum_dpp(acc);
                 ss /= (float)hd; ss += 1e-5f; ss = 1.0f / sqrtf(ss);
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++) { x0[jj] = nw0[vr][jj] * (ss * x0[jj]); x1[jj] = nw1[vr][jj] * (ss * x1[jj]); }
+                for (int jj = 0; jj < JJ; jj++) { x0[jj] = nw0[vr][jj] * (ss * x0[jj]); x1[jj] = nw1[vr][jj] * (ss * x1[jj]); }
             }
             float *dst = isk ? kh : qh + v * hd4;
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
+            for (int jj = 0; jj < JJ; jj++) {
                 const uint32_t pi = (uint32_t)lane + 64u * jj;
                 if (pi < half && (!isk || fresh_k)) {
-                    const uint32_t i0 = a.rope_qwen3 ? pi : 2 * pi, i1 = a.rope_qwen3 ? pi + half : 2 * pi + 1;
+                    const uint32_t i0 = rq3 ? pi : 2 * pi, i1 = rq3 ? pi + half : 2 * pi + 1;
                     float y0 = x0[jj], y1 = x1[jj];
-                    if (fresh_k && a.rope_cos) {
+                    if (fresh_k && has_rope) {
                         const float c = rc[jj], s = rs[jj];
-                        if (a.rope_qwen3) { y0 = x0[jj] * c - x1[jj] * s; y1 = x1[jj] * c + x0[jj] * s; }     // infer.c:700-703
+                        if (rq3) { y0 = x0[jj] * c - x1[jj] * s; y1 = x1[jj] * c + x0[jj] * s; }     // infer.c:700-703
                         else { y0 = x0[jj] * c - x1[jj] * s; y1 = x0[jj] * s + x1[jj] * c; }                 // infer.c:686-687
                     }
                     dst[i0] = y0; dst[i1] = y1;
                     if (isk && split == 0 && (h0 % kv_mul) == 0) { float *krow = const_cast<float *>(kc) + (size_t)pos * a.kv_dim; krow[i0] = y0; krow[i1] = y1; }
-                    if (!isk && split == 0 && a.q_out) { float *qo = a.q_out + (size_t)b * a.q_dim + (size_t)(h0 + v) * hd; qo[i0] = y0; qo[i1] = y1; }
+                    if (!isk && split == 0 && q_out) { float *qo = q_out + (size_t)b * a.q_dim + (size_t)(h0 + v) * hd; qo[i0] = y0; qo[i1] = y1; }
                 }
             }
         }
@@ -307,16 +319,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
 }
 
-template <int LPR, int QV>
-static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {
+template <int LPR, int QV, int MODE>
+static hipError_t launch_mode(const AttnArgs &a, uint32_t nb, hipStream_t st) {
     const uint32_t kv_mul = a.n_head / a.n_kv_head;
     const uint32_t hd4 = (a.hd + 3) & ~3u;
     constexpr uint32_t R = 256 / LPR;
     auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + kvm * R + (size_t)R * kvm * hd4) * sizeof(float); };
-    if (kv_mul == 2) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 2>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(2), st, a); }
-    else if (kv_mul == 4) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 4>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(4), st, a); }
-    else { hipLaunchKernelGGL((attention_kernel<LPR, QV, 1>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a); }
+    if (kv_mul == 2) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 2, MODE>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(2), st, a); }
+    else if (kv_mul == 4) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 4, MODE>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(4), st, a); }
+    else { hipLaunchKernelGGL((attention_kernel<LPR, QV, 1, MODE>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a); }
     return hipGetLastError();
+}
+template <int LPR, int QV>
+static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {
+    const bool decode = a.kraw && a.rope_cos && a.rope_cur && !a.fixed_range && a.is_causal && !a.q_out;
+    if (decode && a.q_norm && a.rope_qwen3) return launch_mode<LPR, QV, 1>(a, nb, st);
+    if (decode && !a.q_norm && !a.rope_qwen3) return launch_mode<LPR, QV, 2>(a, nb, st);
+    return launch_mode<LPR, QV, 0>(a, nb, st);
 }
 
 }  // namespace

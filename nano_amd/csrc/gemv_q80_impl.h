@@ -1,0 +1,769 @@
+// gemv_q80_impl.h -- body of the Q80 GEMV kernels; compiled once per group size (gemv_q80_gs*.hip define
+// NANO_Q80_GS and NANO_Q80_ENTRY and include this file) so that the instantiations build in parallel.
+// gemv_q80.hip -- Q80 (W8A8) fused decode GEMVs for gfx950 (MI355X), up to 8 sequences per launch.
+//
+// Restates for the device:
+//   * quantize      (reference infer/tensor.c:21-46)   per group: s = max|x|/127, q = (int8)round(x/s)
+//   * matmul_quant  (reference infer/infer.c:654-679)  per row, groups in ascending order:
+//                                                      val += ((float)sum_i8xi8) * ws[g] * xs[g]
+// with rmsnorm (infer.c:601-614), the split-attention combine (attn.hip), the residual adds
+// (infer.c:906-908,963-965) and SwiGLU (infer.c:937-944) fused in as prologue / epilogue.
+// Given identical int8 inputs the fp32 outputs are BIT-IDENTICAL to the reference: the integer group
+// sums are exact, every group product is formed as ((float)ival * ws) * xs and one lane adds the
+// groups of a row in ascending order (no tree, no FMA contraction).
+//
+// A batch-1 decode step is a chain of ~140 dependent kernels whose weights (2..6 MB each, except the
+// classifier) stream in well under a microsecond: every per-layer kernel is LATENCY bound, not
+// bandwidth bound.  Two kernels, built for the two regimes:
+//
+//   SLAB   (per-layer matrices).  A workgroup owns `rw` consecutive output rows x the whole row length.
+//          Its work units (4 rows x one 1 KiB column chunk, x2 matrices for SwiGLU) are dealt to its
+//          waves; every wave issues ALL of its loads right at kernel entry -- first the activation, then
+//          weights and weight scales through buffer descriptors (32-bit offsets, hardware bounds check,
+//          no exec-masked branches, no dependent scalar loads) -- so the whole kernel costs ONE memory
+//          round trip.  rmsnorm + quantization run from registers while the weights are in flight; the
+//          group products land in an LDS table and one thread per (row, sequence) folds them in order.
+//   STREAM (classifier: vocab x n_embd).  1024 persistent workgroups; a wave owns 16-row tiles,
+//          tile = wave + k * nwaves, so the chip sweeps memory linearly; the next tile's 16 KiB are in
+//          flight while the current one is consumed.  Lane l loads bytes [16l,16l+16) of each row chunk
+//          (non-temporal, fully coalesced; the row-major int8 blocks stay exactly as in the model file);
+//          DPP integer group sums; the leaders park them in a wave-private LDS table; then lane l owns
+//          (row l/4, groups 4(l%4)..+3): the scales of a whole tile arrive as ONE coalesced load, all 64
+//          lanes form products, and a 4-stage quad chain keeps the reference's group order.
+//          Measured 5.6-5.7 TB/s (cold), 95 % of what a plain read of the same bytes achieves.
+//
+// MFMA is not used: 2 flop/byte at batch <= 8, no tile forms.
+#include "device_common.h"
+#include "kernels.h"
+#include "gemv_q80_host.h"
+
+namespace nano {
+
+namespace {
+
+#define DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+#define DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+
+template <int W> __device__ __forceinline__ int dpp_group_sum(int v) {       // aligned groups of W lanes
+    if (W >= 2) v += DPP_I(v, 0xB1);      // quad_perm [1,0,3,2]
+    if (W >= 4) v += DPP_I(v, 0x4E);      // quad_perm [2,3,0,1]
+    if (W >= 8) v += DPP_I(v, 0x141);     // row_half_mirror
+    if (W >= 16) v += DPP_I(v, 0x140);    // row_mirror
+    return v;
+}
+template <int W> __device__ __forceinline__ float dpp_group_max(float v) {
+    if (W >= 2) v = fmaxf(v, DPP_F(v, 0xB1));
+    if (W >= 4) v = fmaxf(v, DPP_F(v, 0x4E));
+    if (W >= 8) v = fmaxf(v, DPP_F(v, 0x141));
+    if (W >= 16) v = fmaxf(v, DPP_F(v, 0x140));
+    if (W >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (W >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float dpp_wave_sum(float v) {
+    v += DPP_F(v, 0xB1); v += DPP_F(v, 0x4E); v += DPP_F(v, 0x141); v += DPP_F(v, 0x140);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// ---- buffer-descriptor loads: wave-uniform base, 32-bit byte offset, out-of-range -> 0 ------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t OOB = 0x7ffffff0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ int4 bload_w(__amdgpu_buffer_rsrc_t r, uint32_t off) {          // streamed once: non-temporal
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 2);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 bload_f4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ __forceinline__ float bload_f(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+
+enum : uint32_t { F_NORM = 1u, F_PRE = 2u, F_COMBINE = 4u };
+
+// Kernel roles.  A taken branch costs ~40 cycles and every instruction of the single wave a SIMD runs is on the
+// critical path of these latency-bound kernels, so the per-layer launches get kernels with their feature flags
+// resolved at compile time; R_GENERIC keeps them as run-time (wave-uniform) flags for everything else.
+enum : int { R_GENERIC = 0, R_NORM_STORE = 1, R_RESID = 2, R_RESID_COMBINE = 3, R_NORM_SWIGLU = 4 };
+struct Q80Dev;
+template <int ROLE> __device__ __forceinline__ bool has_flag(const Q80Dev &a, uint32_t f);
+template <int ROLE> __device__ __forceinline__ uint32_t role_epi(const Q80Dev &a);
+
+// Device-side argument block (one kernarg fetch, everything scalar).
+struct Q80Dev {
+    const int8_t *w[3]; const float *ws[3]; float *out[3];
+    uint32_t rows[3], out_bstride[3], out_pstride[3];
+    uint32_t n, ng, rw, log2_tiles, nchunk, magic_nchunk, units, epi, flags, nb;
+    const float *xin; const float *norm_w; const uint32_t *pos;
+    uint32_t xin_bstride, _pad0;
+    const int8_t *xq_in; const float *xs_in;
+    const float *attn_part; const float *attn_ml;
+    uint32_t attn_nsplit, attn_n_head, attn_hd, ntiles;
+    float *tile_max;
+};
+
+template <int ROLE> __device__ __forceinline__ bool has_flag(const Q80Dev &a, uint32_t f) {
+    if (ROLE == R_GENERIC) return (a.flags & f) != 0;
+    if (f == F_NORM) return ROLE == R_NORM_STORE || ROLE == R_NORM_SWIGLU;
+    if (f == F_COMBINE) return ROLE == R_RESID_COMBINE;
+    return false;       // F_PRE: generic only
+}
+template <int ROLE> __device__ __forceinline__ uint32_t role_epi(const Q80Dev &a) {
+    if (ROLE == R_GENERIC) return a.epi;
+    if (ROLE == R_NORM_STORE) return GEMV_EPI_STORE;
+    if (ROLE == R_NORM_SWIGLU) return GEMV_EPI_SWIGLU;
+    return GEMV_EPI_RESID;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Activation staging, workgroup-cooperative.  Thread t owns the float4 items t, t+nthr, ... (NV of them) of
+// every sequence; a quantization group is GS/4 consecutive threads.  stage_issue() only issues the loads
+// (call it first thing in the kernel), stage_finish() does rmsnorm + quantization from the registers into
+// LDS (xq[B][n16] int8, xs[B][ng4] float) and ends with a workgroup barrier.
+// ------------------------------------------------------------------------------------------------------------
+template <int B, int NV>
+struct Staged {
+    float4 x[B][NV];
+    float4 nw[NV];
+    // split-attention combine, single sequence: every partial of this thread's items and its (max, sum) pair
+    // are fetched at kernel entry too (one round trip instead of nsplit dependent ones)
+    float4 pv[B == 1 ? NV : 1][B == 1 ? 8 : 1];
+    float ml_m, ml_l;
+};
+template <int B>
+struct Staged<B, 0> {};          // NV == 0: nothing is kept in registers, stage_finish() re-reads memory in loops
+
+template <int ROLE, int B, int NV>
+__device__ __forceinline__ void stage_issue(const Q80Dev &a, Staged<B, NV> &r) {
+    if constexpr (NV == 0) { (void)a; (void)r; return; } else {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n;
+    const bool plain = !has_flag<ROLE>(a, F_PRE) && !has_flag<ROLE>(a, F_COMBINE);
+    const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xin, plain ? ((a.nb - 1) * a.xin_bstride + n) * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rn = mkrsrc(a.norm_w, has_flag<ROLE>(a, F_NORM) ? n * 4u : 0u);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+        const uint32_t off = (i < n) ? i * 4u : OOB;
+        if (plain) {
+#pragma unroll
+            for (int b = 0; b < B; b++) r.x[b][j] = bload_f4(rx, (b < (int)a.nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
+        }
+        if (has_flag<ROLE>(a, F_NORM)) r.nw[j] = bload_f4(rn, off);
+    }
+    if constexpr (B == 1) {
+      if (has_flag<ROLE>(a, F_COMBINE)) {     // uniform branch: an out-of-range load is not free, do not issue 8*NV of them
+        const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
+        const __amdgpu_buffer_rsrc_t rp = mkrsrc(a.attn_part, ns * n * 4u);
+        const __amdgpu_buffer_rsrc_t rm = mkrsrc(a.attn_ml, nh * ns * 8u);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+#pragma unroll
+            for (int sp = 0; sp < 8; sp++) r.pv[j][sp] = bload_f4(rp, (i < n && (uint32_t)sp < ns) ? ((uint32_t)sp * n + i) * 4u : OOB);
+        }
+        const uint32_t sp = tid & 7u, h = tid >> 3;
+        const uint32_t mo = (h < nh && sp < ns) ? (h * ns + sp) * 8u : OOB;
+        r.ml_m = bload_f(rm, mo);
+        r.ml_l = bload_f(rm, mo == OOB ? OOB : mo + 4u);
+      }
+    }
+    }
+}
+
+// x[b][i] = sum_s part[b][s][i] * wgt[b][head(i)][s]  (attn.hip split partials), wgt from (max, sum) pairs
+template <int B>
+__device__ __forceinline__ void combine_weights(const Q80Dev &a, float *wgt /* LDS [B][n_head][8] */, bool preloaded, float pm, float pl) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
+    // thread (b, h, s<8): e_s = exp(m_s - M) / sum_s l_s exp(m_s - M); the 8 lanes of a head are one DPP half-row
+    for (uint32_t t = tid; t < (uint32_t)B * nh * 8u; t += nthr) {
+        const uint32_t s = t & 7u, h = (t >> 3) % nh, b = (t >> 3) / nh;
+        float m = -INFINITY, l = 0.0f;
+        if (preloaded) { m = pm; l = pl; }
+        else if (s < ns && b < a.nb) { const float *ml = a.attn_ml + (((size_t)b * nh + h) * ns + s) * 2; m = ml[0]; l = ml[1]; }
+        const bool live = l > 0.0f;
+        float M = live ? m : -INFINITY;
+        M = fmaxf(M, DPP_F(M, 0xB1)); M = fmaxf(M, DPP_F(M, 0x4E)); M = fmaxf(M, DPP_F(M, 0x141));
+        const float e = live ? expf(m - M) : 0.0f;
+        float L = l * e;
+        L += DPP_F(L, 0xB1); L += DPP_F(L, 0x4E); L += DPP_F(L, 0x141);
+        wgt[t] = e / L;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ float4 combine4(const Q80Dev &a, uint32_t b, uint32_t i, const float *wgt) {
+    const uint32_t ns = a.attn_nsplit, n = a.n;
+    const float *part = a.attn_part + (size_t)b * ns * n + i;
+    const float *wg = wgt + ((size_t)b * a.attn_n_head + i / a.attn_hd) * 8u;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t s = 0; s < ns; s++) {
+        const float4 o = *reinterpret_cast<const float4 *>(part + (size_t)s * n);
+        const float w = wg[s];
+        acc.x += o.x * w; acc.y += o.y * w; acc.z += o.z * w; acc.w += o.w * w;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void quant_store4(float4 v, float scale, int8_t *dst) {
+    const int q0 = q80_quant1(v.x, scale), q1 = q80_quant1(v.y, scale), q2 = q80_quant1(v.z, scale), q3 = q80_quant1(v.w, scale);
+    *reinterpret_cast<uint32_t *>(dst) = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+}
+
+template <int ROLE, int GS, int B, int NV>
+__device__ __forceinline__ void stage_finish(const Q80Dev &a, Staged<B, NV> &r, int8_t *xq, float *xs, float *red, uint32_t n16, uint32_t ng4) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n, ng = a.ng;
+    const uint32_t lane = tid & 63u, wid = tid >> 6, NW = nthr >> 6;
+    if (has_flag<ROLE>(a, F_PRE)) { // operator-test path: the caller supplies the quantized activation (one sequence)
+        for (uint32_t i = tid * 16u; i < n; i += nthr * 16u) *reinterpret_cast<int4 *>(xq + i) = *reinterpret_cast<const int4 *>(a.xq_in + i);
+        for (uint32_t i = tid; i < ng; i += nthr) xs[i] = a.xs_in[i];
+        __syncthreads();
+        return;
+    }
+    const bool norm = has_flag<ROLE>(a, F_NORM), comb = has_flag<ROLE>(a, F_COMBINE);
+    float *wgt = red + B * 16;
+    if constexpr (NV == 0) {
+        if (comb) combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+        // generic path (large n x B): two passes over memory per sequence
+        for (uint32_t b = 0; b < a.nb; b++) {
+            const float *x = a.xin + (size_t)b * a.xin_bstride;
+            float ss = 1.0f;
+            if (norm) {
+                float acc = 0.0f;
+                for (uint32_t i = tid * 4u; i < n; i += nthr * 4u) {
+                    const float4 v = comb ? combine4(a, b, i, wgt) : *reinterpret_cast<const float4 *>(x + i);
+                    acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+                }
+                acc = dpp_wave_sum(acc);
+                __syncthreads();
+                if (lane == 0) red[wid] = acc;
+                __syncthreads();
+                float t = 0.0f;
+                for (uint32_t w = 0; w < NW; w++) t += red[w];
+                t /= (float)n; t += 1e-5f;
+                ss = 1.0f / sqrtf(t);
+            }
+            for (uint32_t i = tid * 4u; i < n; i += nthr * 4u) {       // n % GS == 0, 4*nthr % GS == 0: groups are whole
+                float4 v = comb ? combine4(a, b, i, wgt) : *reinterpret_cast<const float4 *>(x + i);
+                if (norm) {
+                    const float4 w = *reinterpret_cast<const float4 *>(a.norm_w + i);
+                    v.x = w.x * (ss * v.x); v.y = w.y * (ss * v.y); v.z = w.z * (ss * v.z); v.w = w.w * (ss * v.w);
+                }
+                float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+                m = dpp_group_max<GS / 4>(m);
+                const float scale = m / 127.0f;
+                quant_store4(v, scale, xq + b * n16 + i);
+                if ((tid % (GS / 4)) == 0) xs[b * ng4 + i / GS] = scale;
+            }
+        }
+        __syncthreads();
+    } else {
+        if (comb) {
+            if constexpr (B == 1) {
+                const bool pre_ml = a.attn_n_head * 8u <= nthr;       // every (head, split) pair has its own thread
+                combine_weights<B>(a, wgt, pre_ml, r.ml_m, r.ml_l);
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+                    const float *wg = wgt + (size_t)((i < n ? i : 0u) / a.attn_hd) * 8u;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int sp = 0; sp < 8; sp++) {          // splits >= nsplit: partial read as 0, weight 0
+                        const float w = wg[sp];
+                        acc.x += r.pv[j][sp].x * w; acc.y += r.pv[j][sp].y * w; acc.z += r.pv[j][sp].z * w; acc.w += r.pv[j][sp].w * w;
+                    }
+                    r.x[0][j] = acc;
+                }
+            } else {
+                combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+#pragma unroll
+                for (int b = 0; b < B; b++)
+#pragma unroll
+                    for (int j = 0; j < NV; j++) {
+                        const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+                        r.x[b][j] = (i < n && b < (int)a.nb) ? combine4(a, b, i, wgt) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
+        }
+        float ss[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) ss[b] = 1.0f;
+        if (norm) {                     // rmsnorm scale (infer.c:603-609); tree order, tolerance 1e-5
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    acc += r.x[b][j].x * r.x[b][j].x; acc += r.x[b][j].y * r.x[b][j].y;
+                    acc += r.x[b][j].z * r.x[b][j].z; acc += r.x[b][j].w * r.x[b][j].w;
+                }
+                acc = dpp_wave_sum(acc);
+                if (lane == 0) red[b * 16 + wid] = acc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                float t = 0.0f;
+                for (uint32_t w = 0; w < NW; w++) t += red[b * 16 + w];
+                t /= (float)n; t += 1e-5f;
+                ss[b] = 1.0f / sqrtf(t);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                float4 v = r.x[b][j];
+                if (norm) {
+                    v.x = r.nw[j].x * (ss[b] * v.x); v.y = r.nw[j].y * (ss[b] * v.y);
+                    v.z = r.nw[j].z * (ss[b] * v.z); v.w = r.nw[j].w * (ss[b] * v.w);
+                }
+                float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+                m = dpp_group_max<GS / 4>(m);
+                const float scale = m / 127.0f;
+                if (i < n) {
+                    quant_store4(v, scale, xq + b * n16 + i);
+                    if ((tid % (GS / 4)) == 0) xs[b * ng4 + i / GS] = scale;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float finish_epi(uint32_t epi, float v0, float v1, float old) {
+    if (epi == GEMV_EPI_STORE) return v0;
+    if (epi == GEMV_EPI_RESID) return old + v0;                 // x[i] += xb2[i]
+    float h = v0;                                               // SwiGLU: silu(w1 x) * (w3 x)
+    h *= (1.0f / (1.0f + expf(-h)));
+    h *= v1;
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// SLAB kernel
+// ------------------------------------------------------------------------------------------------------------
+template <int ROLE, int GS, int B, int NV, int UPW>
+__global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const Q80Dev a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TR = 4;
+    constexpr int LPG = GS / 16, GC = 1024 / GS;
+    constexpr int NS = (TR + LPG - 1) / LPG;               // rows a lane owns after the group reduction
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const uint32_t n = a.n, ng = a.ng;
+    const uint32_t n16 = (n + 15) & ~15u, ng4 = (ng + 3) & ~3u;
+    const uint32_t PITCH = (GC == 16) ? (((ng + 47) / 64) * 64 + 16) : (ng4 + 4);
+    const uint32_t RW = a.rw;
+    const uint32_t epi = role_epi<ROLE>(a);
+    const bool swiglu = epi == GEMV_EPI_SWIGLU;
+    const uint32_t nmat = swiglu ? 2 : 1;
+    int8_t *xq = reinterpret_cast<int8_t *>(smem);                 // [B][n16]
+    float *xs = reinterpret_cast<float *>(smem + B * n16);         // [B][ng4]
+    float *red = xs + B * ng4;                                     // [B][16] (+ combine weights [B][n_head][8])
+    float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);   // [B][nmat][RW][PITCH]
+
+    // ---- 1. activation loads (critical path) ------------------------------------------------------------
+    Staged<B, NV> sx;
+    stage_issue<ROLE, B, NV>(a, sx);
+
+    // ---- 2. all weight / scale loads of this wave; the workgroup's rows lie inside ONE segment ------------
+    const uint32_t grow0 = blockIdx.x * RW;
+    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
+    const int sel = swiglu ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
+    const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
+    const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
+    float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
+    const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
+    const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
+    const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
+    const uint32_t lrow0 = grow0 - (sel == 0 ? 0u : sel == 1 ? b0 : b1);
+    const uint32_t tmask = (1u << a.log2_tiles) - 1u;
+
+    int4 wv[UPW][TR];
+    float sv[UPW][NS];
+#pragma unroll
+    for (int k = 0; k < UPW; k++) {
+        const uint32_t u = (uint32_t)wid + (uint32_t)k * NW;
+        const uint32_t t = (u * a.magic_nchunk) >> 16;                 // u / nchunk
+        const uint32_t c = u - t * a.nchunk;
+        const uint32_t tl = t & tmask, mat = t >> a.log2_tiles;
+        const bool live = u < a.units;
+        const __amdgpu_buffer_rsrc_t rw_ = mkrsrc(mat ? a.w[1] : w0, live ? rows0 * n : 0u);
+        const __amdgpu_buffer_rsrc_t rs_ = mkrsrc(mat ? a.ws[1] : ws0, live ? rows0 * ng * 4u : 0u);
+        const uint32_t lrow = lrow0 + tl * TR;
+        const uint32_t col = (c << 10) + (uint32_t)lane * 16u;
+        const uint32_t base = (col < n) ? lrow * n + col : OOB;
+#pragma unroll
+        for (int r = 0; r < TR; r++) wv[k][r] = bload_w(rw_, base + (uint32_t)r * n);
+        const uint32_t g = c * GC + (uint32_t)lane / LPG;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const uint32_t r = ((uint32_t)lane % LPG) + s * LPG;
+            sv[k][s] = bload_f(rs_, (r < TR && g < ng) ? ((lrow + r) * ng + g) * 4u : OOB);
+        }
+    }
+    // ---- 3. the fold thread's output slot (residual: old value) -----------------------------------------------
+    const int lrw = (int)a.log2_tiles + 2;                              // log2(rows per workgroup)
+    const int fb = tid >> lrw, frl = tid & ((int)RW - 1);               // fold thread -> (sequence, local row)
+    const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
+    float *optr = out0;
+    float oldv = 0.0f;
+    if (fold_live) {
+        optr = out0 + (size_t)fb * obs + lrow0 + frl;
+        if (ops) optr += (size_t)a.pos[fb] * ops;
+        if (epi == GEMV_EPI_RESID) oldv = *optr;
+    }
+
+    // ---- 4. rmsnorm + quantization from registers (weights in flight) ----------------------------------------
+    stage_finish<ROLE, GS, B, NV>(a, sx, xq, xs, red, n16, ng4);
+
+    // ---- 5. integer dots, group products into the LDS table ----------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < UPW; k++) {
+        const uint32_t u = (uint32_t)wid + (uint32_t)k * NW;
+        if (u < a.units) {
+            const uint32_t t = (u * a.magic_nchunk) >> 16;
+            const uint32_t c = u - t * a.nchunk;
+            const uint32_t tl = t & tmask, mat = t >> a.log2_tiles;
+            const uint32_t col = (c << 10) + (uint32_t)lane * 16u;
+            const uint32_t g = c * GC + (uint32_t)lane / LPG;
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                if (b < (int)a.nb) {
+                    const int4 xv = (col < n) ? *reinterpret_cast<const int4 *>(xq + b * n16 + col) : make_int4(0, 0, 0, 0);
+                    int iv[TR];
+#pragma unroll
+                    for (int r = 0; r < TR; r++) {
+                        int d = __builtin_amdgcn_sdot4(wv[k][r].x, xv.x, 0, false);
+                        d = __builtin_amdgcn_sdot4(wv[k][r].y, xv.y, d, false);
+                        d = __builtin_amdgcn_sdot4(wv[k][r].z, xv.z, d, false);
+                        d = __builtin_amdgcn_sdot4(wv[k][r].w, xv.w, d, false);
+                        iv[r] = dpp_group_sum<LPG>(d);
+                    }
+                    const float xsc = (g < ng) ? xs[b * ng4 + g] : 0.0f;
+#pragma unroll
+                    for (int s = 0; s < NS; s++) {
+                        const uint32_t r = ((uint32_t)lane % LPG) + s * LPG;
+                        int v = iv[0];
+#pragma unroll
+                        for (int q = 1; q < TR; q++) v = (q == (int)r) ? iv[q] : v;
+                        if (r < TR && g < ng)                                                   // infer.c:672
+                            P[(((size_t)b * nmat + mat) * RW + tl * TR + r) * PITCH + g] = ((float)v * sv[k][s]) * xsc;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 6. ordered fold (infer.c:668-674) + epilogue -------------------------------------------------------------
+    if (tid < (int)(RW * B)) {
+        // all LDS reads of a 16-group batch are issued before the dependent add chain; groups beyond ng add
+        // +0.0f (exact: the running value is never -0.0f)
+        float v0 = 0.0f, v1 = 0.0f;
+        const float *p0 = P + (((size_t)fb * nmat) * RW + frl) * PITCH;
+        const float *p1 = p0 + (size_t)RW * PITCH;
+        for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
+            float4 t[4], u[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                t[q] = (g0 + 4 * q < ng4) ? *reinterpret_cast<const float4 *>(p0 + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (swiglu) u[q] = (g0 + 4 * q < ng4) ? *reinterpret_cast<const float4 *>(p1 + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t g = g0 + 4 * q;
+                v0 += (g < ng) ? t[q].x : 0.0f; v0 += (g + 1 < ng) ? t[q].y : 0.0f; v0 += (g + 2 < ng) ? t[q].z : 0.0f; v0 += (g + 3 < ng) ? t[q].w : 0.0f;
+            }
+            if (swiglu) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t g = g0 + 4 * q;
+                    v1 += (g < ng) ? u[q].x : 0.0f; v1 += (g + 1 < ng) ? u[q].y : 0.0f; v1 += (g + 2 < ng) ? u[q].z : 0.0f; v1 += (g + 3 < ng) ? u[q].w : 0.0f;
+                }
+            }
+        }
+        if (fold_live) *optr = finish_epi(epi, v0, v1, oldv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// STREAM kernel (classifier)
+// ------------------------------------------------------------------------------------------------------------
+template <int ROLE, int GS, int B, int NV>
+__global__ __launch_bounds__(256) void gemv_q80_stream_kernel(const Q80Dev a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LPG = GS / 16, GC = 1024 / GS, F = GC / 4;
+    static_assert(F >= 1, "group size too large for the stream kernel");
+    const uint32_t n = a.n, ng = a.ng;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n16 = (n + 15) & ~15u, ng4 = (ng + 3) & ~3u;
+    int8_t *xq = reinterpret_cast<int8_t *>(smem);
+    float *xs = reinterpret_cast<float *>(smem + B * n16);
+    float *red = xs + B * ng4;
+    int *tab = reinterpret_cast<int *>(red + B * 16) + wid * 16 * GC;
+
+    Staged<B, NV> sx;
+    stage_issue<ROLE, B, NV>(a, sx);
+
+    const uint32_t rows = a.rows[0];
+    const uint32_t nchunk = a.nchunk;
+    const uint32_t ntiles = (rows + 15) >> 4;
+    const uint32_t nwaves = gridDim.x * 4, wave_g = blockIdx.x * 4 + (uint32_t)wid;
+    const uint32_t nunits = (wave_g < ntiles) ? ((ntiles - wave_g + nwaves - 1) / nwaves) * nchunk : 0;
+    const __amdgpu_buffer_rsrc_t rw_ = mkrsrc(a.w[0], rows * n);
+    const __amdgpu_buffer_rsrc_t rs_ = mkrsrc(a.ws[0], rows * ng * 4u);
+
+    int4 wA[16], wB[16];
+    float sA[F], sB[F];
+    // unit u of this wave -> (tile, chunk); chunk fastest so a row's running value stays in the wave
+    uint32_t tile_i = 0, chunk_i = 0;                      // cursor of the NEXT unit to issue
+    auto issue = [&](int4 (&w)[16], float (&s)[F]) {
+        const uint32_t tile = wave_g + tile_i * nwaves;
+        const uint32_t row0 = tile << 4;
+        const uint32_t col = (chunk_i << 10) + (uint32_t)lane * 16u;
+        const uint32_t base = (col < n) ? row0 * n + col : OOB;
+#pragma unroll
+        for (int r = 0; r < 16; r++) w[r] = bload_w(rw_, base + (uint32_t)r * n);       // rows beyond `rows` are out of range -> 0
+        const uint32_t gb = chunk_i * GC + ((uint32_t)lane & 3u) * F;
+        const uint32_t so = ((row0 + ((uint32_t)lane >> 2)) * ng + gb) * 4u;
+#pragma unroll
+        for (int f = 0; f < F; f++) s[f] = bload_f(rs_, (gb + f < ng) ? so + 4u * f : OOB);
+        if (++chunk_i == nchunk) { chunk_i = 0; tile_i++; }
+    };
+    if (nunits) issue(wA, sA);
+
+    stage_finish<ROLE, GS, B, NV>(a, sx, xq, xs, red, n16, ng4);
+
+    float val[B], best[B];
+    uint32_t besti[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) { val[b] = 0.0f; best[b] = -INFINITY; besti[b] = 0xffffffffu; }
+    uint32_t ctile = 0, cchunk = 0;                        // cursor of the unit being consumed
+    auto consume = [&](int4 (&w)[16], float (&s)[F]) {
+        const uint32_t tile = wave_g + ctile * nwaves;
+        const uint32_t col = (cchunk << 10) + (uint32_t)lane * 16u;
+        const uint32_t gb = cchunk * GC + ((uint32_t)lane & 3u) * F;
+        const bool last = cchunk + 1 == nchunk;
+        const uint32_t row = (tile << 4) + ((uint32_t)lane >> 2);
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (b < (int)a.nb) {
+                const int4 xv = (col < n) ? *reinterpret_cast<const int4 *>(xq + b * n16 + col) : make_int4(0, 0, 0, 0);
+                int iv[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int d = __builtin_amdgcn_sdot4(w[r].x, xv.x, 0, false);
+                    d = __builtin_amdgcn_sdot4(w[r].y, xv.y, d, false);
+                    d = __builtin_amdgcn_sdot4(w[r].z, xv.z, d, false);
+                    d = __builtin_amdgcn_sdot4(w[r].w, xv.w, d, false);
+                    iv[r] = dpp_group_sum<LPG>(d);
+                }
+                if ((lane % LPG) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) tab[r * GC + lane / LPG] = iv[r];
+                }
+                float p[F];
+#pragma unroll
+                for (int f = 0; f < F; f++) {
+                    const int v = tab[(lane >> 2) * GC + (lane & 3) * F + f];
+                    const float xsc = (gb + f < ng) ? xs[b * ng4 + gb + f] : 0.0f;
+                    p[f] = ((float)v * s[f]) * xsc;                                          // infer.c:672
+                }
+                // ordered fold over the 4 lanes of a row: stage k adds lane k's products onto the running value
+                float cur = val[b];
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    float t = cur;
+#pragma unroll
+                    for (int f = 0; f < F; f++) t += p[f];                                   // groups beyond ng add +0.0f (exact)
+                    cur = (st == 0) ? DPP_F(t, 0x00) : (st == 1) ? DPP_F(t, 0x55) : (st == 2) ? DPP_F(t, 0xAA) : DPP_F(t, 0xFF);
+                }
+                val[b] = cur;
+                if (last) {
+                    if ((lane & 3) == 0 && row < rows) {
+                        a.out[0][(size_t)b * a.out_bstride[0] + row] = cur;
+                        if (cur > best[b] || besti[b] == 0xffffffffu) { best[b] = cur; besti[b] = row; }   // rows ascend per lane: first max kept
+                    }
+                    val[b] = 0.0f;
+                }
+            }
+        }
+        if (++cchunk == nchunk) { cchunk = 0; ctile++; }
+    };
+    for (uint32_t u = 0; u < nunits; u += 2) {
+        if (u + 1 < nunits) issue(wB, sB);
+        consume(wA, sA);
+        if (u + 1 < nunits) {
+            if (u + 2 < nunits) issue(wA, sA);
+            consume(wB, sB);
+        }
+    }
+    // per-wave arg-max partial: larger value wins, equal values -> lower row (== the reference's first maximum)
+    if (a.tile_max) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (b < (int)a.nb) {
+                float bv = best[b]; uint32_t bi = besti[b];
+#pragma unroll
+                for (int o = 32; o >= 4; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const uint32_t oi = __shfl_xor(bi, o, 64);
+                    if (oi != 0xffffffffu && (bi == 0xffffffffu || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) {
+                    float *tm = a.tile_max + ((size_t)b * a.ntiles + wave_g) * 2;
+                    tm[0] = bv; tm[1] = __uint_as_float(bi);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+static Q80Dev to_dev(const GemvArgs &a) {
+    Q80Dev d{};
+    for (int i = 0; i < 3; i++) {
+        const bool live = i < (int)a.nseg;
+        d.w[i] = live ? reinterpret_cast<const int8_t *>(a.seg[i].w) : nullptr;
+        d.ws[i] = live ? a.seg[i].ws : nullptr;
+        d.out[i] = live ? a.seg[i].out : nullptr;
+        d.rows[i] = live ? a.seg[i].rows : 0;
+        d.out_bstride[i] = live ? a.seg[i].out_bstride : 0;
+        d.out_pstride[i] = live ? a.seg[i].out_pstride : 0;
+    }
+    if (a.epi == GEMV_EPI_SWIGLU) { d.rows[1] = 0; d.rows[2] = 0; }       // segment 1 is the second matrix, not more rows
+    d.n = a.n; d.ng = a.n / a.gs;
+    d.nchunk = (a.n + 1023) / 1024;
+    d.magic_nchunk = (65536 + d.nchunk - 1) / d.nchunk;
+    d.epi = a.epi; d.nb = a.nb;
+    d.flags = (a.norm_w ? F_NORM : 0) | (a.xq_in ? F_PRE : 0) | (a.attn_part ? F_COMBINE : 0);
+    d.xin = a.xin; d.norm_w = a.norm_w; d.pos = a.pos; d.xin_bstride = a.xin_bstride;
+    d.xq_in = a.xq_in; d.xs_in = a.xs_in;
+    d.attn_part = a.attn_part; d.attn_ml = a.attn_ml; d.attn_nsplit = a.attn_nsplit; d.attn_n_head = a.attn_n_head; d.attn_hd = a.attn_hd;
+    d.tile_max = a.tile_max;
+    return d;
+}
+
+// rows per workgroup / waves per workgroup of a slab launch (tuned on Qwen3-0.6B with tools/kbench: the chain
+// time is flat within 3 % around these choices -- the kernels are latency bound)
+struct SlabPlan { uint32_t rw, nw, upw, nv; };
+static SlabPlan plan_slab(const GemvArgs &a, int B) {
+    const uint32_t nchunk = (a.n + 1023) / 1024, nmat = a.epi == GEMV_EPI_SWIGLU ? 2 : 1;
+    const uint32_t nseg = a.epi == GEMV_EPI_SWIGLU ? 1u : a.nseg;
+    uint32_t align = 0;                                   // a workgroup's rows must lie inside one segment
+    if (nseg > 1) for (uint32_t s = 0; s < nseg; s++) align |= a.seg[s].rows;
+    const uint32_t rows = total_rows(a);
+    // ~4 units (16 KiB of weights) per matrix per workgroup, >= 128 workgroups
+    uint32_t rw = 4;
+    while (rw < 32 && (align % (rw * 2)) == 0 && (rw * 2 / 4) * nchunk <= 4 && rows / (rw * 2) >= 128) rw *= 2;
+    const uint32_t units = (rw / 4) * nchunk * nmat;
+    uint32_t nw = units < 4 ? units : 4;
+    uint32_t want = (a.n * (uint32_t)(B > 2 ? B / 2 : 1) + 511) / 512;     // idle waves still help the activation prologue
+    if (want > 16) want = 16;
+    if (nw < want) nw = want;
+    if (nw * 64 < rw * (uint32_t)B) nw = (rw * (uint32_t)B + 63) / 64;      // one fold thread per (row, sequence)
+    if (nw < 2) nw = 2;
+    uint32_t upw = (units + nw - 1) / nw;
+    while (upw > 4 && nw < 16) { nw++; upw = (units + nw - 1) / nw; }
+    SlabPlan p{rw, nw, upw, (a.n + 256 * nw - 1) / (256 * nw)};
+    return p;
+}
+
+template <int ROLE, int GS, int B, int NV, int UPW>
+static hipError_t launch_slab_t(const Q80Dev &d, const SlabPlan &p, uint32_t rows, hipStream_t st) {
+    const uint32_t nmat = d.epi == GEMV_EPI_SWIGLU ? 2 : 1;
+    const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u;
+    const size_t pitch = (1024 / GS == 16) ? (((d.ng + 47) / 64) * 64 + 16) : (ng4 + 4);
+    const size_t lds = B * n16 + B * ng4 * 4 + B * 64 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 32 : 0) + (size_t)B * nmat * p.rw * pitch * 4;
+    auto kern = &gemv_q80_slab_kernel<ROLE, GS, B, NV, UPW>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(64 * p.nw), lds, st, d);
+    return hipGetLastError();
+}
+template <int ROLE, int GS, int B>
+static hipError_t launch_slab_r(const Q80Dev &d, const SlabPlan &p, uint32_t rows, hipStream_t st) {
+    if (p.upw > 4) return hipErrorInvalidValue;
+#define SLAB_GO(NV_, UPW_) do { if constexpr (B * NV_ <= 8) return launch_slab_t<ROLE, GS, B, NV_, UPW_>(d, p, rows, st); } while (0)
+    int nv = p.nv <= 1 ? 1 : p.nv <= 2 ? 2 : p.nv <= 4 ? 4 : 0;
+    const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
+    if (B * nv > 8) nv = 0;          // too many staged registers: loop path
+    if (nv == 1) { if (upw == 1) SLAB_GO(1, 1); if (upw == 2) SLAB_GO(1, 2); SLAB_GO(1, 4); }
+    if (nv == 2) { if (upw == 1) SLAB_GO(2, 1); if (upw == 2) SLAB_GO(2, 2); SLAB_GO(2, 4); }
+    if (nv == 4) { if (upw == 1) SLAB_GO(4, 1); if (upw == 2) SLAB_GO(4, 2); SLAB_GO(4, 4); }
+    if (upw == 1) SLAB_GO(0, 1);
+    if (upw == 2) SLAB_GO(0, 2);
+    SLAB_GO(0, 4);
+    return hipErrorInvalidValue;
+#undef SLAB_GO
+}
+template <int GS, int B>
+static hipError_t launch_slab_b(Q80Dev &d, const GemvArgs &a, hipStream_t st) {
+    const SlabPlan p = plan_slab(a, B);
+    d.rw = p.rw;
+    uint32_t l2 = 0; while ((1u << l2) < p.rw / 4) l2++;
+    d.log2_tiles = l2;
+    d.units = (p.rw / 4) * d.nchunk * (d.epi == GEMV_EPI_SWIGLU ? 2 : 1);
+    const uint32_t rows = total_rows(a);
+    if constexpr (B == 1) {         // the per-layer launches of a batch-1 step: flags resolved at compile time
+        const uint32_t f = d.flags;
+        if (f == F_NORM && d.epi == GEMV_EPI_STORE) return launch_slab_r<R_NORM_STORE, GS, B>(d, p, rows, st);
+        if (f == 0 && d.epi == GEMV_EPI_RESID) return launch_slab_r<R_RESID, GS, B>(d, p, rows, st);
+        if (f == F_COMBINE && d.epi == GEMV_EPI_RESID) return launch_slab_r<R_RESID_COMBINE, GS, B>(d, p, rows, st);
+        if (f == F_NORM && d.epi == GEMV_EPI_SWIGLU) return launch_slab_r<R_NORM_SWIGLU, GS, B>(d, p, rows, st);
+    }
+    return launch_slab_r<R_GENERIC, GS, B>(d, p, rows, st);
+}
+
+template <int ROLE, int GS, int B>
+static hipError_t launch_stream_r(Q80Dev &d, hipStream_t st) {
+    d.ntiles = STREAM_WGS * 4;
+    const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u;
+    const size_t lds = B * n16 + B * ng4 * 4 + B * 64 + 4 * 16 * (1024 / GS) * 4;
+    const uint32_t nv = (d.n + 1023) / 1024;
+    bool done = false;
+    if (nv <= 1) { hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, 1>), dim3(STREAM_WGS), dim3(256), lds, st, d); done = true; }
+    if constexpr (B <= 4) { if (!done && nv <= 2) { hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, 2>), dim3(STREAM_WGS), dim3(256), lds, st, d); done = true; } }
+    if constexpr (B <= 2) { if (!done && nv <= 4) { hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, 4>), dim3(STREAM_WGS), dim3(256), lds, st, d); done = true; } }
+    if (!done) { hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, 0>), dim3(STREAM_WGS), dim3(256), lds, st, d); }
+    return hipGetLastError();
+}
+template <int GS, int B>
+static hipError_t launch_stream_b(Q80Dev &d, hipStream_t st) {
+    if (d.flags == F_NORM) return launch_stream_r<R_NORM_STORE, GS, B>(d, st);      // the classifier
+    return launch_stream_r<R_GENERIC, GS, B>(d, st);
+}
+
+template <int GS, int B>
+static hipError_t launch_b(const GemvArgs &a, hipStream_t st) {
+    Q80Dev d = to_dev(a);
+    if (use_stream(a)) return launch_stream_b<GS, B>(d, st);
+    d.tile_max = nullptr;
+    return launch_slab_b<GS, B>(d, a, st);
+}
+template <int GS>
+static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
+    if (a.nb <= 1) return launch_b<GS, 1>(a, st);
+    if (a.nb <= 2) return launch_b<GS, 2>(a, st);
+    if (a.nb <= 4) return launch_b<GS, 4>(a, st);
+    return launch_b<GS, 8>(a, st);
+}
+
+}  // namespace
+
+hipError_t NANO_Q80_ENTRY(const GemvArgs &a, hipStream_t st) { return launch_gs<NANO_Q80_GS>(a, st); }
+
+}  // namespace nano

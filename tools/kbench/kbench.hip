@@ -25,6 +25,25 @@ __global__ void fill_f32(float *p, size_t n, uint32_t seed, float lo, float hi) 
         p[i] = lo + (hi - lo) * (float)(hash32((uint32_t)i * 2246822519u + seed) >> 8) * (1.0f / 16777216.0f);
 }
 __global__ void empty_kernel(float *p) { if (p && threadIdx.x == 9999) p[0] = 1.0f; }
+template <int N, bool UNROLL>
+__global__ void alu_chain_kernel(const float *in, float *out) {     // N dependent fp32 adds per thread, straight-line vs loop
+    float v = in[threadIdx.x];
+    if (UNROLL) {
+#pragma unroll
+        for (int i = 0; i < N; i++) v = v * 1.0001f + (float)i;
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < N; i++) v = v * 1.0001f + (float)i;
+    }
+    if (blockIdx.x == 0) out[threadIdx.x] = v;
+}
+struct BigArgs { const float *p[12]; uint32_t v[40]; float *out; };
+__global__ void bigarg_kernel(const BigArgs a) { if (a.v[39] == 12345u && threadIdx.x == 0) a.out[0] = a.p[11][0]; }
+__global__ void bigarg_lds_kernel(const BigArgs a) { extern __shared__ float sm[]; if (a.v[39] == 12345u && threadIdx.x == 0) { sm[0] = 1.0f; a.out[0] = a.p[11][0] + sm[0]; } }
+__global__ void load_store_kernel(const float *in, float *out) {   // minimal dependent chain: read what the previous kernel wrote, write for the next
+    const float4 v = *reinterpret_cast<const float4 *>(in + threadIdx.x * 4);
+    if (blockIdx.x == 0) *reinterpret_cast<float4 *>(out + threadIdx.x * 4) = make_float4(v.x + 1.0f, v.y, v.z, v.w);
+}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void stream_read_kernel(const u32x4 *buf, size_t n16, float *sink) {
@@ -158,9 +177,18 @@ static Slab to_slab(const Args &a, uint32_t rw) {
     s.xin = a.xin; s.norm_w = a.norm_w; s.xin_bstride = a.n; s.xq_in = a.xq_in; s.xs_in = a.xs_in; s.dbg = a.dbg;
     return s;
 }
+static int g_abl = 0;
 template <int NV, int UPW>
 static void launch_slab3_t(const Slab &s, uint32_t total_rows, uint32_t nw, bool ts) {
     const size_t lds = slab3_lds(s.n, 64, s.rw, s.epi == EPI_SWIGLU ? 2 : 1, 1);
+#define ABLGO(A) case A: hipLaunchKernelGGL((q80_slab3<64, 1, NV, UPW, false, A>), dim3(total_rows / s.rw), dim3(64 * nw), lds, st, s); return
+    if (g_abl == 100) { const int role = s.epi == EPI_SWIGLU ? 3 : s.epi == EPI_RESID ? 2 : 1;
+        if (role == 1) hipLaunchKernelGGL((q80_slab3<64, 1, NV, UPW, false, 0, 1>), dim3(total_rows / s.rw), dim3(64 * nw), lds, st, s);
+        else if (role == 2) hipLaunchKernelGGL((q80_slab3<64, 1, NV, UPW, false, 0, 2>), dim3(total_rows / s.rw), dim3(64 * nw), lds, st, s);
+        else hipLaunchKernelGGL((q80_slab3<64, 1, NV, UPW, false, 0, 3>), dim3(total_rows / s.rw), dim3(64 * nw), lds, st, s);
+        return; }
+    switch (g_abl) { case 0: break; ABLGO(1); ABLGO(2); ABLGO(4); ABLGO(8); ABLGO(16); ABLGO(24); ABLGO(31); ABLGO(7); }
+#undef ABLGO
     if (ts) hipLaunchKernelGGL((q80_slab3<64, 1, NV, UPW, true>), dim3(total_rows / s.rw), dim3(64 * nw), lds, st, s);
     else hipLaunchKernelGGL((q80_slab3<64, 1, NV, UPW, false>), dim3(total_rows / s.rw), dim3(64 * nw), lds, st, s);
 }
@@ -199,6 +227,34 @@ int main(int argc, char **argv) {
         }
         float us = time_loop(200, [&](int) { empty_kernel<<<256, 256, 0, st>>>(sink); });
         printf("floor: eager empty kernel back-to-back: %.3f us per kernel\n", us);
+        float *bufa, *bufb; CK(hipMalloc(&bufa, 8192)); CK(hipMalloc(&bufb, 8192)); CK(hipMemset(bufa, 0, 8192)); CK(hipMemset(bufb, 0, 8192));
+        BigArgs ba{}; ba.out = sink; for (int i = 0; i < 12; i++) ba.p[i] = bufa;
+        for (int variant = 0; variant < 13; variant++) {
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            for (int i = 0; i < 140; i++) {
+                switch (variant) {
+                case 0: empty_kernel<<<256, 256, 0, st>>>(sink); break;
+                case 1: empty_kernel<<<1024, 256, 0, st>>>(sink); break;
+                case 2: bigarg_kernel<<<256, 256, 0, st>>>(ba); break;
+                case 3: bigarg_lds_kernel<<<256, 256, 16384, st>>>(ba); break;
+                case 4: bigarg_lds_kernel<<<1024, 256, 16384, st>>>(ba); break;
+                case 5: load_store_kernel<<<256, 256, 0, st>>>((i & 1) ? bufb : bufa, (i & 1) ? bufa : bufb); break;
+                case 6: empty_kernel<<<64, 256, 0, st>>>(sink); break;
+                case 7: alu_chain_kernel<256, true><<<256, 256, 0, st>>>(bufa, bufb); break;
+                case 8: alu_chain_kernel<256, false><<<256, 256, 0, st>>>(bufa, bufb); break;
+                case 9: alu_chain_kernel<1024, true><<<256, 256, 0, st>>>(bufa, bufb); break;
+                case 10: alu_chain_kernel<1024, false><<<256, 256, 0, st>>>(bufa, bufb); break;
+                case 11: alu_chain_kernel<4096, true><<<256, 256, 0, st>>>(bufa, bufb); break;
+                case 12: alu_chain_kernel<4096, false><<<256, 256, 0, st>>>(bufa, bufb); break;
+                }
+            }
+            CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            float t = 1e30f; for (int r = 0; r < 5; r++) t = std::min(t, time_loop(30, [&](int) { CK(hipGraphLaunch(ge, st)); }));
+            const char *nm[13] = {"empty 256 WGs", "empty 1024 WGs", "250-byte kernarg read, 256 WGs", "kernarg + 16 KB LDS, 256 WGs", "kernarg + 16 KB LDS, 1024 WGs", "load prev kernel's 4 KB + store 4 KB, 256 WGs", "empty 64 WGs",
+                                   "256 dependent fma, straight-line", "256 dependent fma, loop", "1024 dependent fma, straight-line", "1024 dependent fma, loop", "4096 dependent fma, straight-line", "4096 dependent fma, loop"};
+            printf("floor: chain of 140 [%s]: %.3f us per kernel\n", nm[variant], t / 140);
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        }
     }
 
     // activation vectors
@@ -393,6 +449,10 @@ int main(int argc, char **argv) {
             };
             const Cfg bq{16, 4}, bo{8, 4}, b13{16, 4}, b2{4, 6};
             printf("chain base: %.2f us/layer (4 kernels)\n", chain(bq, bo, b13, b2));
+            for (int abl : {1, 2, 4, 8, 16, 24, 7, 31}) { g_abl = abl; printf("ablation %2d (1 quant math, 2 dots, 4 fold, 8 weight loads, 16 x loads): %.2f us/layer; qkv %.2f wo %.2f w13 %.2f w2 %.2f\n", abl,
+                chain(bq, bo, b13, b2), chain(bq, bo, b13, b2, 1), chain(bq, bo, b13, b2, 2), chain(bq, bo, b13, b2, 4), chain(bq, bo, b13, b2, 8)); }
+            g_abl = 100; printf("role-specialised: %.2f us/layer; qkv %.2f wo %.2f w13 %.2f w2 %.2f\n", chain(bq, bo, b13, b2), chain(bq, bo, b13, b2, 1), chain(bq, bo, b13, b2, 2), chain(bq, bo, b13, b2, 4), chain(bq, bo, b13, b2, 8));
+            g_abl = 0;
             printf("chain only qkv: %.2f  only wo: %.2f  only w13: %.2f  only w2: %.2f us/kernel\n", chain(bq, bo, b13, b2, 1), chain(bq, bo, b13, b2, 2), chain(bq, bo, b13, b2, 4), chain(bq, bo, b13, b2, 8));
             for (Cfg c : std::vector<Cfg>{{4, 1}, {4, 2}, {8, 2}, {8, 4}, {16, 4}, {16, 8}, {32, 8}, {32, 4}}) printf("chain qkv RW=%2u NW=%2u: %.2f us/layer\n", c.rw, c.nw, chain(c, bo, b13, b2));
             for (Cfg c : std::vector<Cfg>{{4, 2}, {4, 4}, {4, 8}, {8, 4}, {8, 8}, {16, 8}, {16, 4}}) printf("chain wo  RW=%2u NW=%2u: %.2f us/layer\n", c.rw, c.nw, chain(bq, c, b13, b2));

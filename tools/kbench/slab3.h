@@ -36,7 +36,8 @@ __device__ __forceinline__ float bload4f(__amdgpu_buffer_rsrc_t r, uint32_t off)
 
 constexpr uint32_t OOB = 0x7ffffff0u;
 
-template <int GS, int B, int NV, int UPW, bool TS>
+// ABL (ablation, measurement only): 1 no quantization math, 2 no dots, 4 no ordered fold, 8 no weight loads, 16 no activation loads, 32 no prologue barrier work at all
+template <int GS, int B, int NV, int UPW, bool TS, int ABL = 0, int ROLE = 0>
 __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TR = 4;
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
     const uint32_t n16 = (n + 15) & ~15u, ng4 = (ng + 3) & ~3u;
     const uint32_t PITCH = (GC == 16) ? (((ng + 47) / 64) * 64 + 16) : (ng4 + 4);
     const uint32_t RW = a.rw;
-    const bool swiglu = a.epi == EPI_SWIGLU;
+    const uint32_t epi = ROLE == 0 ? a.epi : ROLE == 1 ? (uint32_t)EPI_STORE : ROLE == 2 ? (uint32_t)EPI_RESID : (uint32_t)EPI_SWIGLU;
+    const bool swiglu = epi == EPI_SWIGLU;
     const uint32_t nmat = swiglu ? 2 : 1;
     int8_t *xq = reinterpret_cast<int8_t *>(smem);                 // [B][n16]
     float *xs = reinterpret_cast<float *>(smem + B * n16);         // [B][ng4]
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
 
     // ---- activation loads first ---------------------------------------------------------------------------
     float4 xv[B][NV], nwv[NV];
-    const bool pre = (a.flags & F_PRE) != 0, norm = (a.flags & F_NORM) != 0;
+    const bool pre = ROLE == 0 ? (a.flags & F_PRE) != 0 : false, norm = ROLE == 0 ? (a.flags & F_NORM) != 0 : (ROLE == 1 || ROLE == 3);
     {
         const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xin, pre ? 0u : ((a.nb - 1) * a.xin_bstride + n) * 4u);
         const __amdgpu_buffer_rsrc_t rn = mkrsrc(a.norm_w, norm ? n * 4u : 0u);
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
             const uint32_t i = (uint32_t)(tid + j * nthr) * 4u;
             const uint32_t off = (i < n) ? i * 4u : OOB;
 #pragma unroll
-            for (int b = 0; b < B; b++) xv[b][j] = bload16f(rx, (b < (int)a.nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
-            nwv[j] = bload16f(rn, off);
+            for (int b = 0; b < B; b++) xv[b][j] = (ABL & 16) ? make_float4(1.f, 2.f, 3.f, (float)tid) : bload16f(rx, (b < (int)a.nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
+            nwv[j] = (ABL & 16) ? make_float4(1.f, 1.f, 1.f, 1.f) : bload16f(rn, off);
         }
     }
 
@@ -100,19 +102,19 @@ __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
         const uint32_t col = (c << 10) + (uint32_t)lane * 16u;
         const uint32_t base = (col < n) ? lrow * n + col : OOB;
 #pragma unroll
-        for (int r = 0; r < TR; r++) wv[k][r] = bload16(rw_, base + (uint32_t)r * n, true);
+        for (int r = 0; r < TR; r++) wv[k][r] = (ABL & 8) ? make_int4(r, lane, 3, 4) : bload16(rw_, base + (uint32_t)r * n, true);
         const uint32_t g = c * GC + (uint32_t)lane / LPG;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const uint32_t r = ((uint32_t)lane % LPG) + s * LPG;
-            sv[k][s] = bload4f(rs_, (r < TR && g < ng) ? ((lrow + r) * ng + g) * 4u : OOB);
+            sv[k][s] = (ABL & 8) ? 1.0f : bload4f(rs_, (r < TR && g < ng) ? ((lrow + r) * ng + g) * 4u : OOB);
         }
     }
     const int lrw = (int)a.log2_tiles + 2;                          // log2(rows per workgroup)
     const int fb = tid >> lrw, frl = tid & ((int)RW - 1);           // fold thread -> (sequence, local row)
     const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
     float oldv = 0.0f;
-    if (a.epi == EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];
+    if (epi == EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];
     TS3(1);
 
     // ---- rmsnorm + Q80 quantization from registers ---------------------------------------------------------
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
                 m = dpp_group_max<GS / 4>(m);
                 const float scale = m / 127.0f;
                 if (i < n) {
-                    const int q0 = q80_quant1(v.x, scale), q1 = q80_quant1(v.y, scale), q2 = q80_quant1(v.z, scale), q3 = q80_quant1(v.w, scale);
+                    const int q0 = (ABL & 1) ? (int)v.x : q80_quant1(v.x, scale), q1 = (ABL & 1) ? (int)v.y : q80_quant1(v.y, scale), q2 = (ABL & 1) ? (int)v.z : q80_quant1(v.z, scale), q3 = (ABL & 1) ? (int)v.w : q80_quant1(v.w, scale);
                     *reinterpret_cast<uint32_t *>(xq + b * n16 + i) = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
                     if ((tid % (GS / 4)) == 0) xs[b * ng4 + i / GS] = scale;
                 }
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
                 int iv[TR];
 #pragma unroll
                 for (int r = 0; r < TR; r++) {
+                    if (ABL & 2) { iv[r] = wv[k][r].x + xvq.x; continue; }
                     int t2 = __builtin_amdgcn_sdot4(wv[k][r].x, xvq.x, 0, false);
                     t2 = __builtin_amdgcn_sdot4(wv[k][r].y, xvq.y, t2, false);
                     t2 = __builtin_amdgcn_sdot4(wv[k][r].z, xvq.z, t2, false);
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
         float v0 = 0.0f, v1 = 0.0f;
         const float *p0 = P + (((size_t)b * nmat) * RW + rl) * PITCH;
         const float *p1 = p0 + (size_t)RW * PITCH;
-        for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
+        for (uint32_t g0 = 0; g0 < ((ABL & 4) ? 1u : ng); g0 += 16) {
             float4 t[4], u[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(1024) void q80_slab3(const Slab a) {
         if (fold_live) {
             float o = v0;
             if (swiglu) { float h = v0; h *= (1.0f / (1.0f + expf(-h))); h *= v1; o = h; }
-            else if (a.epi == EPI_RESID) o = oldv + v0;
+            else if (epi == EPI_RESID) o = oldv + v0;
             out0[(size_t)b * obs + lrow0 + rl] = o;
         }
     }
