@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 PROMPT_LEN = 16
 SEQ_LEN = 512
+# HBM bytes per classifier launch from the rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE corrected as
+# MI355X_MICROARCH.md prescribes), keyed by (model, quant, group size); None = not collected
+TRAFFIC_BYTES = {("qwen3-0.6b", "q80", 64): 165498395}    # profiles/r01_pmc_fetch_size.txt: FETCH_SIZE 80809.76 KB x 1024 x 2
 
 
 def log(*a):
@@ -213,7 +216,9 @@ def main():
 
     log(f"[bench] rank {rank}: timed region done, {elapsed * 1e3 / K:.3f} ms/step")
     # ---- roofline of the dominant kernel (classifier GEMV), HIP events on the model's stream ----------------
-    ms_cls, bytes_cls = m.time_classifier(B, 50)
+    # measured where it runs: inside whole decode steps of the same workload (cold weights), HIP events on the model's stream
+    ms_cls, bytes_cls, ms_pair = m.time_classifier_in_step(B, min(pos0 + K // 2, SEQ_LEN - 1), 60)
+    ms_b2b, _ = m.time_classifier(B, 50)                    # back-to-back launches (the 256 MB Infinity Cache helps here): reported, not used
     achieved = bytes_cls / (ms_cls * 1e-3) / 1e9
     step_bytes = m.weight_bytes_per_step
     m.close()
@@ -238,9 +243,12 @@ def main():
                    "weight_bytes_per_step": step_bytes, "kv_bytes_per_seq_mid_run": kv_mid,
                    "end_to_end_weight_GBps_per_gpu": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                    "end_to_end_frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-        "roofline": {"bound": "hbm", "kernel": "classifier GEMV (gemv_%s_kernel, %d x %d)" % (args.quant, spec.vocab_size, spec.n_embd),
+        "roofline": {"bound": "hbm", "kernel": "classifier GEMV (%s, %d x %d)" % ({"q80": "gemv_q80_stream_kernel", "q4k": "gemv_q4k_kernel", "f32": "gemv_f32_kernel"}[args.quant], spec.vocab_size, spec.n_embd),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                     "traffic": None, "bytes_per_launch": bytes_cls, "us_per_launch": round(ms_cls * 1e3, 2)},
+                     "traffic": TRAFFIC_BYTES.get((args.model, args.quant, spec.group_size)), "bytes_per_launch": bytes_cls, "us_per_launch": round(ms_cls * 1e3, 2),
+                     "how": "HIP events right before / after the launch inside 60 whole decode steps (eager launches, weights cold); raw span, nothing subtracted",
+                     "empty_event_pair_us": round(ms_pair * 1e3, 2),
+                     "us_per_launch_back_to_back": round(ms_b2b * 1e3, 2)},
     }
     if not args.no_cpu_baseline and n_gpus == 1:
         try:

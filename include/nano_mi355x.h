@@ -115,6 +115,13 @@ int nano_hip_sync(NanoHipModel *m);
  * back on the model's stream between two HIP events and returns the average milliseconds per
  * launch and the algorithmic bytes one launch streams. */
 int nano_hip_time_classifier(NanoHipModel *m, uint32_t batch, uint32_t iters, float *ms_per_launch, uint64_t *bytes_per_launch);
+/* The same launch timed where it runs: inside `iters` whole decode steps at position `pos` (eager launches, HIP
+ * events on the model's stream right before / after the classifier launch).  Its weights are cold there -- the
+ * layers' bytes went through the caches since the previous step -- which back-to-back launches of
+ * nano_hip_time_classifier() do not guarantee.  *ms_per_launch is the raw event span, *ms_empty_pair (optional)
+ * the span of an empty event pair recorded right after it (event overhead, reported, not subtracted). */
+int nano_hip_time_classifier_in_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_launch,
+                                     uint64_t *bytes_per_launch, float *ms_empty_pair);
 /* Same for one whole decode step (graph replay), `iters` replays between two events. */
 int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_step);
 /* Device read-bandwidth microbenchmark: streams `bytes` of device memory `iters` times; GB/s out. */

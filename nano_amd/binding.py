@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
     fn("nano_hip_decode_greedy", C.c_int, [vp, u32p, u32p, C.c_uint32, C.c_uint32, vp])
     fn("nano_hip_sync", C.c_int, [vp])
     fn("nano_hip_time_classifier", C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64)])
+    fn("nano_hip_time_classifier_in_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_float)])
     fn("nano_hip_time_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)])
     fn("nano_hip_membw", C.c_int, [C.c_int, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)])
     fn("nano_hip_read_state", C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, f32p, C.c_size_t])
@@ -160,6 +161,13 @@ class DeviceModel:
         ms, nbytes = C.c_float(0), C.c_uint64(0)
         check(lib().nano_hip_time_classifier(self.h, batch, iters, C.byref(ms), C.byref(nbytes)))
         return float(ms.value), int(nbytes.value)
+
+    def time_classifier_in_step(self, batch: int = 1, pos: int = 0, iters: int = 20):
+        """(ms per classifier launch measured inside whole decode steps [raw event span], algorithmic bytes per launch,
+        ms of an empty event pair)"""
+        ms, nbytes, empty = C.c_float(0), C.c_uint64(0), C.c_float(0)
+        check(lib().nano_hip_time_classifier_in_step(self.h, batch, pos, iters, C.byref(ms), C.byref(nbytes), C.byref(empty)))
+        return float(ms.value), int(nbytes.value), float(empty.value)
 
     def time_step(self, batch: int = 1, pos: int = 0, iters: int = 20) -> float:
         ms = C.c_float(0)

@@ -16,8 +16,8 @@
 //   * timestep blocks are dealt round-robin to `nsplit` workgroups ("flash-decoding"); with nsplit == 1 the
 //     kernel normalises and writes the final head outputs, otherwise UNNORMALISED partials
 //     o_s = sum_t exp(s_t - m_s) v_t with (m_s, l_s) which the Wo GEMV's prologue combines (gemv_q80.hip).
-// Softmax is algebraically the reference's (max-subtracted, infer.c:616-634); summation order differs
-// (tolerance 1e-5).
+// Softmax is algebraically the reference's (max-subtracted, infer.c:616-634); summation order differs and the
+// q.k / weighted-V accumulations use fused multiply-adds (tolerance 1e-5).
 #include "device_common.h"
 #include "kernels.h"
 
@@ -106,13 +106,43 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const uint32_t sub = (uint32_t)tid / LPR, j = (uint32_t)tid % LPR;
     const uint32_t range_hint = fixed_range ? fixed_range : a.range_hint;
 
-    // the vectors this wave normalises / rotates: v = wid, wid+4, ... ; v < KVM: q head h0+v ; v == KVM: the k row
-    // a lane holds the pair(s) RoPE rotates together: Qwen3 (i, i+half), Nano/Qwen2 (2i, 2i+1); pair index pi = lane + 64*jj
-    float e0[VR][JJ], e1[VR][JJ], nw0[VR][JJ], nw1[VR][JJ];     // [vector round][jj]
+    // ---- q heads and the raw k row ------------------------------------------------------------------------------------
+    // Decode modes keep them in REGISTERS: the LPR lanes of a sub-group own the whole head (float4 j, j+LPR, ...), the
+    // RoPE partner of float4 f (f + head_dim/8 for the half-split style, the same float4 for adjacent pairs) lives in
+    // the same lane, so rmsnorm + RoPE need one DPP reduction and no LDS / barrier; every sub-group does it redundantly.
+    constexpr bool REGQK = MODE != 0;
+    float4 qv[KVM][QV], kfresh[QV];
+    float4 qnw[QV], knw[QV], rcs[QV], rsn[QV];
     const __amdgpu_buffer_rsrc_t rq = mkrsrc(a.q + (size_t)b * a.q_dim, a.q_dim * 4u);
     const __amdgpu_buffer_rsrc_t rkr = mkrsrc(fresh_k ? a.kraw + (size_t)b * a.kv_dim : nullptr, fresh_k ? a.kv_dim * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rqn = mkrsrc(a.q_norm, has_norm ? hd * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rkn = mkrsrc(a.k_norm, has_norm ? hd * 4u : 0u);
+    float e0[VR][JJ], e1[VR][JJ], nw0[VR][JJ], nw1[VR][JJ];     // generic path: [vector round][jj]
+    float rc[JJ], rs[JJ];
+    const bool rope_staged = G ? (a.rope_cur != nullptr && fresh_k) : true;
+    if constexpr (REGQK) {
+        const __amdgpu_buffer_rsrc_t rr = mkrsrc(a.rope_cur + (size_t)b * 2 * half, 2 * half * 4u);
+#pragma unroll
+        for (int q = 0; q < QV; q++) {
+            const uint32_t f = j + (uint32_t)LPR * q;
+            const uint32_t fo = (f * 4u < hd) ? f * 16u : OOB;
+#pragma unroll
+            for (int m = 0; m < KVM; m++) qv[m][q] = bload_f4(rq, fo == OOB ? OOB : (h0 + m) * hd * 4u + fo);
+            kfresh[q] = bload_f4(rkr, fo == OOB ? OOB : g * hd * 4u + fo);
+            if (MODE == 1) {
+                qnw[q] = bload_f4(rqn, fo); knw[q] = bload_f4(rkn, fo);
+                const uint32_t fr = f % (half / 4u);                 // cos/sin of element i and i+half are those of pair i
+                rcs[q] = bload_f4(rr, fo == OOB ? OOB : fr * 16u);
+                rsn[q] = bload_f4(rr, fo == OOB ? OOB : (half + fr * 4u) * 4u);
+            } else {                                                  // adjacent pairs (2p, 2p+1), p = 2f, 2f+1: .xy = cos, .zw = sin
+                const float c0 = bload_f(rr, fo == OOB ? OOB : (2u * f) * 4u), c1 = bload_f(rr, fo == OOB ? OOB : (2u * f + 1u) * 4u);
+                const float s0 = bload_f(rr, fo == OOB ? OOB : (half + 2u * f) * 4u), s1 = bload_f(rr, fo == OOB ? OOB : (half + 2u * f + 1u) * 4u);
+                rcs[q] = make_float4(c0, c1, 0.f, 0.f); rsn[q] = make_float4(s0, s1, 0.f, 0.f);
+            }
+        }
+    } else {
+    // the vectors this wave normalises / rotates: v = wid, wid+4, ... ; v < KVM: q head h0+v ; v == KVM: the k row
+    // a lane holds the pair(s) RoPE rotates together: Qwen3 (i, i+half), Nano/Qwen2 (2i, 2i+1); pair index pi = lane + 64*jj
 #pragma unroll
     for (int vr = 0; vr < VR; vr++) {
         const uint32_t v = (uint32_t)wid + 4u * vr;
@@ -131,8 +161,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
     }
     // RoPE row of pos[b]: staged at a fixed address by the step's first kernel (no pos-dependent load)
-    float rc[JJ], rs[JJ];
-    const bool rope_staged = G ? (a.rope_cur != nullptr && fresh_k) : true;
     {
         const __amdgpu_buffer_rsrc_t rr = mkrsrc(rope_staged ? a.rope_cur + (size_t)b * 2 * half : nullptr, rope_staged ? 2 * half * 4u : 0u);
 #pragma unroll
@@ -142,6 +170,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             rs[jj] = bload_f(rr, pi < half ? (half + pi) * 4u : OOB);
         }
     }
+    }
     float4 kreg[NP][QV], vreg[NP][QV];
     auto issue_kv = [&](uint32_t round) {
 #pragma unroll
@@ -150,7 +179,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int q = 0; q < QV; q++) {
                 const uint32_t f = j + (uint32_t)LPR * q;                  // float4 index inside the head
-                const uint32_t off = (f * 4u < hd && t < range_hint) ? t * a.kv_dim * 4u + f * 16u : OOB;
+                const uint32_t off = (f * 4u < hd && t < range_hint && !(a.dbg & 1u)) ? t * a.kv_dim * 4u + f * 16u : OOB;
                 kreg[p][q] = bload_f4(rk, off);
                 vreg[p][q] = bload_f4(rv, off);
             }
@@ -161,6 +190,64 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     // ---- 2. position, RoPE row, norms ------------------------------------------------------------------------------
     const uint32_t pos = fixed_range ? (fixed_range - 1) : a.pos[b];
     const uint32_t range = fixed_range ? fixed_range : (causal ? (pos + 1) : a.S);
+    if (a.dbg & 8u) return;
+    if constexpr (REGQK) {
+        if (MODE == 1 && !(a.dbg & 4u)) {                         // rmsnorm over the head (infer.c:601-614, 824-835), tree order
+            float sk = 0.0f, sq[KVM];
+#pragma unroll
+            for (int m = 0; m < KVM; m++) sq[m] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < QV; q++) {
+                sk += kfresh[q].x * kfresh[q].x; sk += kfresh[q].y * kfresh[q].y; sk += kfresh[q].z * kfresh[q].z; sk += kfresh[q].w * kfresh[q].w;
+#pragma unroll
+                for (int m = 0; m < KVM; m++) { sq[m] += qv[m][q].x * qv[m][q].x; sq[m] += qv[m][q].y * qv[m][q].y; sq[m] += qv[m][q].z * qv[m][q].z; sq[m] += qv[m][q].w * qv[m][q].w; }
+            }
+            sk = group_sum_t<LPR>(sk); sk /= (float)hd; sk += 1e-5f; sk = 1.0f / sqrtf(sk);
+#pragma unroll
+            for (int m = 0; m < KVM; m++) { sq[m] = group_sum_t<LPR>(sq[m]); sq[m] /= (float)hd; sq[m] += 1e-5f; sq[m] = 1.0f / sqrtf(sq[m]); }
+#pragma unroll
+            for (int q = 0; q < QV; q++) {
+                kfresh[q].x = knw[q].x * (sk * kfresh[q].x); kfresh[q].y = knw[q].y * (sk * kfresh[q].y); kfresh[q].z = knw[q].z * (sk * kfresh[q].z); kfresh[q].w = knw[q].w * (sk * kfresh[q].w);
+#pragma unroll
+                for (int m = 0; m < KVM; m++) {
+                    qv[m][q].x = qnw[q].x * (sq[m] * qv[m][q].x); qv[m][q].y = qnw[q].y * (sq[m] * qv[m][q].y);
+                    qv[m][q].z = qnw[q].z * (sq[m] * qv[m][q].z); qv[m][q].w = qnw[q].w * (sq[m] * qv[m][q].w);
+                }
+            }
+            // half-split RoPE (rope_qwen3, infer.c:692-706): float4 q pairs with float4 q + QV/2
+            auto rot = [&](float4 &lo, float4 &hi, const float4 &c, const float4 &sn) {
+                const float4 l = lo, h = hi;
+                lo.x = l.x * c.x - h.x * sn.x; hi.x = h.x * c.x + l.x * sn.x;
+                lo.y = l.y * c.y - h.y * sn.y; hi.y = h.y * c.y + l.y * sn.y;
+                lo.z = l.z * c.z - h.z * sn.z; hi.z = h.z * c.z + l.z * sn.z;
+                lo.w = l.w * c.w - h.w * sn.w; hi.w = h.w * c.w + l.w * sn.w;
+            };
+#pragma unroll
+            for (int q = 0; q < QV / 2; q++) {
+                rot(kfresh[q], kfresh[q + QV / 2], rcs[q], rsn[q]);
+#pragma unroll
+                for (int m = 0; m < KVM; m++) rot(qv[m][q], qv[m][q + QV / 2], rcs[q], rsn[q]);
+            }
+        } else {
+            // adjacent-pair RoPE (rope, infer.c:681-690): (x,y) with (cos0,sin0), (z,w) with (cos1,sin1)
+            auto rot = [&](float4 &v, const float4 &c, const float4 &sn) {
+                const float4 t = v;
+                v.x = t.x * c.x - t.y * sn.x; v.y = t.x * sn.x + t.y * c.x;
+                v.z = t.z * c.y - t.w * sn.y; v.w = t.z * sn.y + t.w * c.y;
+            };
+#pragma unroll
+            for (int q = 0; q < QV; q++) {
+                rot(kfresh[q], rcs[q], rsn[q]);
+#pragma unroll
+                for (int m = 0; m < KVM; m++) rot(qv[m][q], rcs[q], rsn[q]);
+            }
+        }
+        if (split == 0 && sub == 0 && (h0 % kv_mul) == 0) {      // the finished k row -> cache row pos
+            float *krow = const_cast<float *>(kc) + (size_t)pos * a.kv_dim;
+#pragma unroll
+            for (int q = 0; q < QV; q++) { const uint32_t f = j + (uint32_t)LPR * q; if (f * 4u < hd) *reinterpret_cast<float4 *>(krow + 4 * f) = kfresh[q]; }
+        }
+    } else {
     if (!rope_staged) {
 #pragma unroll
         for (int jj = 0; jj < JJ; jj++) {
@@ -209,7 +296,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     __syncthreads();
 
     // ---- 3. scores, running softmax over rounds ------------------------------------------------------------------
-    float4 qv[KVM][QV], kfresh[QV];
 #pragma unroll
     for (int q = 0; q < QV; q++) {
         const uint32_t f = j + (uint32_t)LPR * q;
@@ -217,6 +303,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
         for (int m = 0; m < KVM; m++) qv[m][q] = ok ? *reinterpret_cast<const float4 *>(qh + m * hd4 + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
         kfresh[q] = (ok && fresh_k) ? *reinterpret_cast<const float4 *>(kh + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     }
     const float sq_hd = sqrtf((float)hd);
     float mrun[KVM], lrun[KVM];
@@ -229,7 +316,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
     const uint32_t per_round = NP * nsplit * R;
     const uint32_t limit = range < range_hint ? range : range_hint;
-    const uint32_t nround = (limit + per_round - 1) / per_round;
+    const uint32_t nround = (a.dbg & 2u) ? 0u : (limit + per_round - 1) / per_round;
     for (uint32_t round = 0; round < nround; round++) {
         if (round) issue_kv(round);
         float sc[KVM][NP];
@@ -243,7 +330,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
                 for (int q = 0; q < QV; q++) {
                     const float4 kk = fresh ? kfresh[q] : kreg[p][q];
-                    d += qv[m][q].x * kk.x; d += qv[m][q].y * kk.y; d += qv[m][q].z * kk.z; d += qv[m][q].w * kk.w;
+                    d = __builtin_fmaf(qv[m][q].x, kk.x, d); d = __builtin_fmaf(qv[m][q].y, kk.y, d); d = __builtin_fmaf(qv[m][q].z, kk.z, d); d = __builtin_fmaf(qv[m][q].w, kk.w, d);
                 }
                 d = group_sum_t<LPR>(d);
                 sc[m][p] = (t < range) ? d / sq_hd : -INFINITY;                                   // infer.c:858
@@ -264,7 +351,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                 l += e;
 #pragma unroll
                 for (int q = 0; q < QV; q++) {
-                    acc[m][q].x += e * vreg[p][q].x; acc[m][q].y += e * vreg[p][q].y; acc[m][q].z += e * vreg[p][q].z; acc[m][q].w += e * vreg[p][q].w;
+                    acc[m][q].x = __builtin_fmaf(e, vreg[p][q].x, acc[m][q].x); acc[m][q].y = __builtin_fmaf(e, vreg[p][q].y, acc[m][q].y);
+                    acc[m][q].z = __builtin_fmaf(e, vreg[p][q].z, acc[m][q].z); acc[m][q].w = __builtin_fmaf(e, vreg[p][q].w, acc[m][q].w);
                 }
             }
             mrun[m] = mx; lrun[m] = l;
@@ -333,7 +421,7 @@ static hipError_t launch_mode(const AttnArgs &a, uint32_t nb, hipStream_t st) {
 template <int LPR, int QV>
 static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {
     const bool decode = a.kraw && a.rope_cos && a.rope_cur && !a.fixed_range && a.is_causal && !a.q_out;
-    if (decode && a.q_norm && a.rope_qwen3) return launch_mode<LPR, QV, 1>(a, nb, st);
+    if (decode && a.q_norm && a.rope_qwen3 && a.hd % 64 == 0) return launch_mode<LPR, QV, 1>(a, nb, st);
     if (decode && !a.q_norm && !a.rope_qwen3) return launch_mode<LPR, QV, 2>(a, nb, st);
     return launch_mode<LPR, QV, 0>(a, nb, st);
 }

@@ -54,7 +54,8 @@ struct NanoHipModel {
     int device = 0, cus = 0;
     uint32_t S = 0, maxB = 0, hd = 0, QD = 0, KD = 0;
     hipStream_t st = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    bool probe_cls = false;                               // record ev0 / ev1 / ev2 around the classifier launch of the next eager step
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
     const float *rms_attn = nullptr, *rms_ffn = nullptr, *rms_final = nullptr;
@@ -143,6 +144,7 @@ static void destroy(NanoHipModel *m) {
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->ev2) (void)hipEventDestroy(m->ev2);
     if (m->st) (void)hipStreamDestroy(m->st);
     delete m;
 }
@@ -303,7 +305,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
          hipHostMalloc(&m->h_amax, (size_t)m->trace_cap * 4) == hipSuccess && hipHostMalloc(&m->h_logits, B * V * 4) == hipSuccess;
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipHostMalloc failed"); }
     if (hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
-        hipEventCreate(&m->ev1) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "stream/event creation failed"); }
+        hipEventCreate(&m->ev1) != hipSuccess || hipEventCreate(&m->ev2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "stream/event creation failed"); }
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
     HIP_TRY(hipDeviceSynchronize());
@@ -374,6 +376,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
+            { static const char *dbg = getenv("NANO_ATTN_DBG"); a.dbg = dbg ? (uint32_t)atoi(dbg) : 0u; }
             if (!(skip & 2) && (e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
         }
         {   // x += Wo . xba   reference infer.c:885-908
@@ -400,7 +403,11 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     if (mode == MODE_NOCLS) return hipSuccess;
     const bool sample = (mode == MODE_ARGMAX || mode == MODE_LOOP);
     uint32_t ntiles = 0;
-    if (!(skip & 32) && (e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;   // final rmsnorm fused in the prologue (infer.c:999-1015)
+    if (m->probe_cls && (e = hipEventRecord(m->ev0, m->st)) != hipSuccess) return e;
+    if (!(skip & 32) && (e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;
+    if (m->probe_cls) {      // ev0..ev1 brackets the classifier, ev1..ev2 an empty span (the event overhead to subtract)
+        if ((e = hipEventRecord(m->ev1, m->st)) != hipSuccess || (e = hipEventRecord(m->ev2, m->st)) != hipSuccess) return e;
+    }   // final rmsnorm fused in the prologue (infer.c:999-1015)
     if (sample) {
         ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, m->pos, nullptr, m->pos0, nb,
                        ntiles ? m->tile_max : nullptr, ntiles };
@@ -517,6 +524,42 @@ extern "C" int nano_hip_time_classifier(NanoHipModel *m, uint32_t batch, uint32_
         *bytes_per_launch = (m->d.quant_type == NANO_QUANT_F32) ? 4 * VE
                           : (m->d.quant_type == NANO_QUANT_Q80) ? VE + 4 * (VE / m->d.group_size) : VE * 160 / 256;
     }
+    return 0;
+}
+
+static uint64_t classifier_bytes(const NanoHipModel *m) {
+    const uint64_t VE = (uint64_t)m->d.vocab_size * m->d.n_embd;
+    return (m->d.quant_type == NANO_QUANT_F32) ? 4 * VE : (m->d.quant_type == NANO_QUANT_Q80) ? VE + 4 * (VE / m->d.group_size) : VE * 160 / 256;
+}
+
+// The classifier launch timed INSIDE whole decode steps (its weights are cold: the layers' 468 MB went through the
+// caches since the previous step), HIP events on the model's stream, eager launches.  *ms_per_launch is the raw
+// event span (end of the previous kernel -> end of the classifier); *ms_empty_pair the span of an empty event pair.
+extern "C" int nano_hip_time_classifier_in_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_launch,
+                                                uint64_t *bytes_per_launch, float *ms_empty_pair) {
+    if (!m || !iters || batch == 0 || batch > 8 || batch > m->maxB || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    for (uint32_t i = 0; i < batch; i++) { m->h_tokens[i] = 1 % m->d.vocab_size; m->h_pos[i] = pos; }
+    HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
+    uint32_t range_hint = ((pos + 1 + 63) / 64) * 64;
+    if (range_hint > m->S) range_hint = m->S;
+    double cls = 0.0, empty = 0.0;
+    for (uint32_t i = 0; i < iters + 1; i++) {
+        m->probe_cls = true;
+        hipError_t e = enqueue_step(m, batch, 1, MODE_ARGMAX, range_hint);
+        m->probe_cls = false;
+        HIP_TRY(e);
+        HIP_TRY(hipEventSynchronize(m->ev2));
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, m->ev0, m->ev1));
+        HIP_TRY(hipEventElapsedTime(&b, m->ev1, m->ev2));
+        if (i) { cls += a; empty += b; }            // iteration 0 warms up
+    }
+    HIP_TRY(hipStreamSynchronize(m->st));
+    if (ms_per_launch) *ms_per_launch = (float)(cls / iters);          // raw span: includes the launch latency
+    if (ms_empty_pair) *ms_empty_pair = (float)(empty / iters);
+    if (bytes_per_launch) *bytes_per_launch = classifier_bytes(m);
     return 0;
 }
 
