@@ -52,6 +52,7 @@ uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // tiles launch_gemv()
 hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t st);
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
 hipError_t launch_gemv_q80(const GemvArgs &a, hipStream_t st);      // gemv_q80.hip
+hipError_t launch_gemv_f32(const GemvArgs &a, hipStream_t st);      // gemv_f32.hip
 uint32_t gemv_q80_partials(const GemvArgs &a);
 
 // ---- attention ------------------------------------------------------------------------------------
