@@ -19,8 +19,7 @@
 // applied to a weight dword yields), the dequantized 6-bit scale/bias floats and the nibble sum.
 #include <float.h>
 
-#include "device_common.h"
-#include "kernels.h"
+#include "gemv_common.h"
 
 namespace nano {
 
@@ -109,227 +108,393 @@ hipError_t launch_quantize_q4k(const float *x, uint32_t n, uint8_t *blocks, hipS
     return hipGetLastError();
 }
 
-// ---- fused GEMV ---------------------------------------------------------------------------------------
-template <int B>
-__device__ __forceinline__ void prologue_q4k(const GemvArgs &a, XGroup *xg, float *xn, float *red) {
-    const int t = threadIdx.x;
-    const int n = (int)a.n;
-    const int bpl = (n + 255) / 256, GT = bpl * 8;
-    uint8_t *xgb = reinterpret_cast<uint8_t *>(xg);
-    if (a.x4_in) {          // operator-test path: unpack caller-supplied blocks (one sequence)
-        for (int gg = t; gg < GT; gg += blockDim.x) {
-            const uint8_t *blk = a.x4_in + (size_t)(gg >> 3) * 160;
-            const int g = gg & 7;
-            const float s_scale = *reinterpret_cast<const float *>(blk + 12), s_bias = *reinterpret_cast<const float *>(blk + 16);
-            uint32_t s6, b6;
-            q4k_unpack6(*reinterpret_cast<const uint32_t *>(blk + 20), *reinterpret_cast<const uint32_t *>(blk + 24),
-                        *reinterpret_cast<const uint32_t *>(blk + 28), g, s6, b6);
-            XGroup o; int sum = 0;
-            for (int m = 0; m < 4; m++) {
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(blk + 32 + g * 16 + m * 4);
-                o.lo[m] = w & 0x0f0f0f0fu; o.hi[m] = (w >> 4) & 0x0f0f0f0fu;
-                sum += (int)__builtin_amdgcn_udot4(o.lo[m], 0x01010101u, 0u, false) + (int)__builtin_amdgcn_udot4(o.hi[m], 0x01010101u, 0u, false);
-            }
-            o.sq = (float)s6 * s_scale; o.bq = (float)b6 * s_bias; o.sumq = sum; o._pad = 0;
-            xg[gg] = o;
-        }
-        __syncthreads();
-        return;
-    }
-    for (int b = 0; b < B; b++) {
-        if (b >= (int)a.nb) break;
-        const float *x = a.xin + (size_t)b * a.xin_bstride;
-        float ss = 1.0f;
-        if (a.norm_w) {
-            float acc = 0.0f;
-            for (int i = t * 4; i < n; i += blockDim.x * 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(x + i);
-                acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
-            }
-            ss = block_sum(acc, red);
-            ss /= (float)n; ss += 1e-5f; ss = 1.0f / sqrtf(ss);
-        }
-        __syncthreads();
-        if (a.attn_part) {      // input = combination of the split attention partials (attn.hip), as in gemv.hip
-            const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
-            float *wgt = red + 32;
-            for (uint32_t h = t; h < nh; h += blockDim.x) {
-                const float *ml = a.attn_ml + ((size_t)b * nh + h) * ns * 2;
-                float M = -INFINITY;
-                for (uint32_t s = 0; s < ns; s++) if (ml[2 * s + 1] > 0.0f) M = fmaxf(M, ml[2 * s]);
-                float L = 0.0f;
-                for (uint32_t s = 0; s < ns; s++) {
-                    const float e = (ml[2 * s + 1] > 0.0f) ? expf(ml[2 * s] - M) : 0.0f;
-                    wgt[h * ns + s] = e;
-                    L += ml[2 * s + 1] * e;
-                }
-                for (uint32_t s = 0; s < ns; s++) wgt[h * ns + s] = wgt[h * ns + s] / L;
-            }
-            __syncthreads();
-            const float *part = a.attn_part + (size_t)b * ns * n;
-            for (int i = t; i < n; i += blockDim.x) {
-                const int h = i / (int)a.attn_hd;
+// ---- fused GEMV (SLAB structure, see gemv_q80_impl.h) -------------------------------------------------------------
+// A workgroup owns `rw` consecutive rows; its items (row, 32-weight group) are dealt to its threads, every thread issues
+// the activation loads and then ALL its weight loads (16 nibble bytes + the 32-byte block header, buffer descriptors)
+// at kernel entry; the activation is normalised from registers into LDS, block-quantized by the whole workgroup in two
+// barrier-separated phases (group min/max + nibbles, then the 6-bit scale/bias quantization against the block maxima),
+// and the per-group results land in an LDS table that one thread per (row, sequence) folds in the reference's order.
+namespace {
+
+template <int ROLE, int B, int NV>
+__device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, float *xn, float *red, uint32_t n4) {
+    // rmsnorm / split-attention combine of the activation into xn[B][n4] (same code path as the FP32 GEMV's staging)
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n;
+    const uint32_t lane = tid & 63u, wid = tid >> 6, NW = nthr >> 6;
+    const bool norm = has_flag<ROLE>(a, F_NORM), comb = has_flag<ROLE>(a, F_COMBINE);
+    float *wgt = red + B * 16;
+    if constexpr (NV == 0) {
+        if (comb) combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+        for (uint32_t b = 0; b < a.nb; b++) {
+            const float *x = a.xin + (size_t)b * a.xin_bstride;
+            float ss = 1.0f;
+            if (norm) {
                 float acc = 0.0f;
-                for (uint32_t s = 0; s < ns; s++) acc += part[(size_t)s * n + i] * wgt[h * ns + s];
-                xn[i] = acc;
+                for (uint32_t i = tid * 4u; i < n; i += nthr * 4u) {
+                    const float4 v = comb ? combine4(a, b, i, wgt) : *reinterpret_cast<const float4 *>(x + i);
+                    acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+                }
+                acc = dpp_wave_sum(acc);
+                __syncthreads();
+                if (lane == 0) red[wid] = acc;
+                __syncthreads();
+                float t = 0.0f;
+                for (uint32_t w = 0; w < NW; w++) t += red[w];
+                t /= (float)n; t += 1e-5f;
+                ss = 1.0f / sqrtf(t);
             }
-        } else {
-            for (int i = t; i < n; i += blockDim.x) xn[i] = a.norm_w ? a.norm_w[i] * (ss * x[i]) : x[i];
+            for (uint32_t i = tid * 4u; i < n; i += nthr * 4u) {
+                float4 v = comb ? combine4(a, b, i, wgt) : *reinterpret_cast<const float4 *>(x + i);
+                if (norm) {
+                    const float4 w = *reinterpret_cast<const float4 *>(a.norm_w + i);
+                    v.x = w.x * (ss * v.x); v.y = w.y * (ss * v.y); v.z = w.z * (ss * v.z); v.w = w.w * (ss * v.w);
+                }
+                *reinterpret_cast<float4 *>(xn + b * n4 + i) = v;
+            }
         }
         __syncthreads();
-        for (int j = 0; j < bpl; j++) {
-            const int d = (n >= (j + 1) * 256) ? 256 : (n - j * 256);
-            const bool valid = t < d;
-            const float v = valid ? xn[(size_t)j * d + t] : 0.0f;       // sic: j*d
-            Q4kBlockHdr hdr; float sq, bq;
-            const uint32_t nib = q4k_quantize_block_coop(v, valid, red, hdr, sq, bq);
-            const int g = t >> 5, e = t & 31;
-            XGroup *o = xg + (size_t)b * GT + j * 8 + g;
-            // byte lane of element e inside the split-nibble dwords
-            uint8_t *ob = reinterpret_cast<uint8_t *>(o);
-            ob[((e & 1) ? 16 : 0) + (e >> 3) * 4 + ((e & 7) >> 1)] = (uint8_t)nib;
-            const int sum = group_sum_i((int)nib, 32);
-            if (e == 0) { o->sq = sq; o->bq = bq; o->sumq = sum; o->_pad = 0; }
-            __syncthreads();
+    } else {
+        if (comb) {
+            if constexpr (B == 1) {
+                const bool pre_ml = a.attn_n_head * 8u <= nthr;
+                combine_weights<B>(a, wgt, pre_ml, r.ml_m, r.ml_l);
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+                    const float *wg = wgt + (size_t)((i < n ? i : 0u) / a.attn_hd) * 8u;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int sp = 0; sp < 8; sp++) {
+                        const float w = wg[sp];
+                        acc.x += r.pv[j][sp].x * w; acc.y += r.pv[j][sp].y * w; acc.z += r.pv[j][sp].z * w; acc.w += r.pv[j][sp].w * w;
+                    }
+                    r.x[0][j] = acc;
+                }
+            } else {
+                combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+#pragma unroll
+                for (int b = 0; b < B; b++)
+#pragma unroll
+                    for (int j = 0; j < NV; j++) {
+                        const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+                        r.x[b][j] = (i < n && b < (int)a.nb) ? combine4(a, b, i, wgt) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
         }
+        float ss[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) ss[b] = 1.0f;
+        if (norm) {
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    acc += r.x[b][j].x * r.x[b][j].x; acc += r.x[b][j].y * r.x[b][j].y;
+                    acc += r.x[b][j].z * r.x[b][j].z; acc += r.x[b][j].w * r.x[b][j].w;
+                }
+                acc = dpp_wave_sum(acc);
+                if (lane == 0) red[b * 16 + wid] = acc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                float t = 0.0f;
+                for (uint32_t w = 0; w < NW; w++) t += red[b * 16 + w];
+                t /= (float)n; t += 1e-5f;
+                ss[b] = 1.0f / sqrtf(t);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                float4 v = r.x[b][j];
+                if (norm) {
+                    v.x = r.nw[j].x * (ss[b] * v.x); v.y = r.nw[j].y * (ss[b] * v.y);
+                    v.z = r.nw[j].z * (ss[b] * v.z); v.w = r.nw[j].w * (ss[b] * v.w);
+                }
+                if (i < n) *reinterpret_cast<float4 *>(xn + b * n4 + i) = v;
+            }
+        }
+        __syncthreads();
     }
-    (void)xgb;
+}
+
+// Block-quantize xn[B][n4] into the staged groups xg[B][GT] (reference quantize_tensor_q4k_in_situ on a 1-D tensor,
+// tensor.c:281-310 + 144-242), all blocks at once: phase 1 = one thread per element, phase 2 = one thread per group.
+// tmp: [B][bpl][16] floats (group scales, group biases).  Ends with a barrier.
+__device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *xn, XGroup *xg, float *tmp, uint32_t n4, int nbq) {
+    const int n = (int)a.n, tid = threadIdx.x, nthr = blockDim.x;
+    const int bpl = (n + 255) / 256, GT = bpl * 8;
+    for (int idx = tid; idx < nbq * bpl * 256; idx += nthr) {          // nthr % 64 == 0: a 32-element group = one half wave
+        const int t = idx & 255, j = (idx >> 8) % bpl, b = (idx >> 8) / bpl;
+        const int d = (n >= (j + 1) * 256) ? 256 : (n - j * 256);
+        const bool valid = t < d;
+        const float v = valid ? xn[(size_t)b * n4 + (size_t)j * d + t] : 0.0f;       // sic: j*d (reference tensor.c:307)
+        // reference: min starts at FLT_MAX, max at FLT_TRUE_MIN, strict comparisons (NaN ignored)
+        float lo = valid ? v : FLT_MAX, hi = valid ? v : FLT_TRUE_MIN;
+        lo = (lo < FLT_MAX) ? lo : FLT_MAX;
+        hi = (hi > FLT_TRUE_MIN) ? hi : FLT_TRUE_MIN;
+        for (int o = 16; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+        const float gsc = (lo <= 0.0f) ? ((hi - lo) / 15.0f) : (hi / 15.0f);
+        const float gbi = (lo <= 0.0f) ? (-lo) : 0.0f;
+        uint32_t nib = 0;
+        if (valid && gsc != 0.0f) nib = (uint32_t)(nearest_int_magic((v + gbi) / gsc) & 0x0f);
+        const int g = t >> 5, e = t & 31;
+        XGroup *o = xg + (size_t)b * GT + j * 8 + g;
+        reinterpret_cast<uint8_t *>(o)[((e & 1) ? 16 : 0) + (e >> 3) * 4 + ((e & 7) >> 1)] = (uint8_t)nib;   // split-nibble byte lane of element e
+        const int sum = group_sum_i((int)nib, 32);
+        if (e == 0) { o->sumq = sum; o->_pad = 0; float *tp = tmp + ((size_t)b * bpl + j) * 16; tp[g] = gsc; tp[8 + g] = gbi; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nbq * GT; idx += nthr) {
+        const int gg = idx % GT, b = idx / GT, j = gg >> 3, g = gg & 7;
+        const float *tp = tmp + ((size_t)b * bpl + j) * 16;
+        float smax = FLT_TRUE_MIN, bmax = FLT_TRUE_MIN;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (tp[k] > smax) smax = tp[k]; if (tp[8 + k] > bmax) bmax = tp[8 + k]; }
+        const float s_scale = smax / 63.0f, s_bias = bmax / 63.0f;
+        const uint32_t s6 = (s_scale == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(tp[g] / s_scale) & 0x3f);
+        const uint32_t b6 = (s_bias == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(tp[8 + g] / s_bias) & 0x3f);
+        XGroup *o = xg + (size_t)b * GT + gg;
+        o->sq = (float)s6 * s_scale;       // what get_group_scale_and_bias() reads back (tensor.c:137-140)
+        o->bq = (float)b6 * s_bias;
+    }
     __syncthreads();
 }
 
-template <int B, int RB>
-__global__ __launch_bounds__(256) void gemv_q4k_kernel(const GemvArgs a) {
+// operator-test path: unpack caller-supplied activation blocks (one sequence) into the staged groups
+__device__ __forceinline__ void unpack_q4k_wg(const GemvDev &a, XGroup *xg) {
+    const int n = (int)a.n, GT = ((n + 255) / 256) * 8;
+    const uint8_t *x4 = reinterpret_cast<const uint8_t *>(a.xq_in);
+    for (int gg = threadIdx.x; gg < GT; gg += blockDim.x) {
+        const uint8_t *blk = x4 + (size_t)(gg >> 3) * 160;
+        const int g = gg & 7;
+        const float s_scale = *reinterpret_cast<const float *>(blk + 12), s_bias = *reinterpret_cast<const float *>(blk + 16);
+        uint32_t s6, b6;
+        q4k_unpack6(*reinterpret_cast<const uint32_t *>(blk + 20), *reinterpret_cast<const uint32_t *>(blk + 24),
+                    *reinterpret_cast<const uint32_t *>(blk + 28), g, s6, b6);
+        XGroup o; int sum = 0;
+        for (int m = 0; m < 4; m++) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(blk + 32 + g * 16 + m * 4);
+            o.lo[m] = w & 0x0f0f0f0fu; o.hi[m] = (w >> 4) & 0x0f0f0f0fu;
+            sum += (int)__builtin_amdgcn_udot4(o.lo[m], 0x01010101u, 0u, false) + (int)__builtin_amdgcn_udot4(o.hi[m], 0x01010101u, 0u, false);
+        }
+        o.sq = (float)s6 * s_scale; o.bq = (float)b6 * s_bias; o.sumq = sum; o._pad = 0;
+        xg[gg] = o;
+    }
+    __syncthreads();
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 bload_u4(__amdgpu_buffer_rsrc_t r, uint32_t off, bool nt) {
+    const i32x4 v = nt ? __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+}
+
+template <int ROLE, int B, int NV, int IPT>
+__global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n = (int)a.n;
-    const int bpl = (n + 255) / 256, GT = bpl * 8;
-    const int pitch = GT + 1;
-    // LDS carve: XGroup[B*GT] | xn[n] | red[32] | fold[4][RB*B*pitch]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t n = a.n, n4 = (n + 3) & ~3u;
+    const uint32_t bpl = (n + 255) / 256, GT = bpl * 8, GTP = GT + 1;
+    const uint32_t RW = a.rw;
+    const uint32_t epi = role_epi<ROLE>(a);
+    const bool swiglu = epi == GEMV_EPI_SWIGLU;
+    const uint32_t nmat = swiglu ? 2 : 1;
+    // LDS: xg[B][GT] | xn[B][n4] | tmp[B][bpl][16] | red[B*16 (+ combine weights)] | P[B][nmat][RW][GTP]
     XGroup *xg = reinterpret_cast<XGroup *>(smem);
     float *xn = reinterpret_cast<float *>(smem + (size_t)B * GT * sizeof(XGroup));
-    float *red = xn + ((n + 3) & ~3);
-    float *foldbase = red + 32;
+    float *tmp = xn + B * n4;
+    float *red = tmp + B * bpl * 16;
+    float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);
 
-    prologue_q4k<B>(a, xg, xn, red);
+    Staged<B, NV> sx;
+    stage_issue<ROLE, B, NV>(a, sx);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    float *fold = foldbase + (size_t)wid * (RB * B) * pitch;
-    const int nb = (int)a.nb;
-    const int items = RB * GT;
-    const int pr = lane / B, pb = lane % B;
+    const uint32_t grow0 = blockIdx.x * RW;
+    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
+    const int sel = swiglu ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
+    const uint8_t *w0 = reinterpret_cast<const uint8_t *>(sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2]);
+    float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
+    const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
+    const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
+    const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
+    const uint32_t lrow0 = grow0 - (sel == 0 ? 0u : sel == 1 ? b0 : b1);
+    const __amdgpu_buffer_rsrc_t rw0 = mkrsrc(w0, rows0 * bpl * 160u);
+    const __amdgpu_buffer_rsrc_t rw1 = mkrsrc(swiglu ? a.w[1] : nullptr, swiglu ? rows0 * bpl * 160u : 0u);
 
-    for (uint32_t tile = blockIdx.x * 4 + wid; tile < a.tiles; tile += gridDim.x * 4) {
-        uint32_t sidx, row0;
-        if (a.epi == GEMV_EPI_SWIGLU) { sidx = 0; row0 = tile * RB; if (row0 >= a.seg[0].rows) continue; }
-        else {
-            uint32_t tt = tile; bool found = false;
-            for (uint32_t s = 0; s < a.nseg; s++) {
-                const uint32_t cnt = (a.seg[s].rows + RB - 1) / RB;
-                if (tt < cnt) { sidx = s; row0 = tt * RB; found = true; break; }
-                tt -= cnt;
+    // item it -> (matrix, local row, group); group fastest so that consecutive lanes read consecutive nibble runs
+    const uint32_t items = RW * GT * nmat;
+    uint4 nibv[IPT], h0v[IPT], h1v[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+        const uint32_t it = (uint32_t)tid + (uint32_t)k * nthr;
+        const uint32_t gg = it % GT, rr = it / GT;                    // rr = mat * RW + local row
+        const uint32_t mat = rr >= RW ? 1u : 0u, rl = rr - mat * RW;
+        const uint32_t boff = (it < items) ? ((lrow0 + rl) * bpl + (gg >> 3)) * 160u : OOB;   // rows beyond the segment: out of range -> 0
+        const bool m1 = mat != 0;
+        nibv[k] = m1 ? bload_u4(rw1, boff == OOB ? OOB : boff + 32u + (gg & 7u) * 16u, true) : bload_u4(rw0, boff == OOB ? OOB : boff + 32u + (gg & 7u) * 16u, true);
+        h0v[k] = m1 ? bload_u4(rw1, boff, false) : bload_u4(rw0, boff, false);
+        h1v[k] = m1 ? bload_u4(rw1, boff == OOB ? OOB : boff + 16u, false) : bload_u4(rw0, boff == OOB ? OOB : boff + 16u, false);
+    }
+    uint32_t lrw = 0; while ((1u << lrw) < RW) lrw++;
+    const int fb = tid >> lrw, frl = tid & ((int)RW - 1);
+    const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
+    float *optr = out0;
+    float oldv = 0.0f;
+    if (fold_live) {
+        optr = out0 + (size_t)fb * obs + lrow0 + frl;
+        if (ops) optr += (size_t)a.pos[fb] * ops;
+        if (epi == GEMV_EPI_RESID) oldv = *optr;
+    }
+
+    if (has_flag<ROLE>(a, F_PRE)) unpack_q4k_wg(a, xg);
+    else {
+        stage_xn<ROLE, B, NV>(a, sx, xn, red, n4);
+        quantize_q4k_wg(a, xn, xg, tmp, n4, (int)a.nb);
+    }
+
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+        const uint32_t it = (uint32_t)tid + (uint32_t)k * nthr;
+        if (it < items) {
+            const uint32_t gg = it % GT, rr = it / GT, g = gg & 7u;
+            const uint4 nib = nibv[k];
+            const float s_scale = __uint_as_float(h0v[k].w);
+            const int len = (int)h0v[k].y;
+            uint32_t s6, b6;
+            q4k_unpack6(h1v[k].y, h1v[k].z, h1v[k].w, (int)g, s6, b6);
+            const float sp = (float)s6 * s_scale, bp = (float)b6 * __uint_as_float(h1v[k].x);
+            const int glen = (len >= (int)(g + 1) * 32) ? 32 : (len - 32 * (int)g);
+            const uint32_t wl[4] = { nib.x & 0x0f0f0f0fu, nib.y & 0x0f0f0f0fu, nib.z & 0x0f0f0f0fu, nib.w & 0x0f0f0f0fu };
+            const uint32_t wh[4] = { (nib.x >> 4) & 0x0f0f0f0fu, (nib.y >> 4) & 0x0f0f0f0fu, (nib.z >> 4) & 0x0f0f0f0fu, (nib.w >> 4) & 0x0f0f0f0fu };
+            uint32_t sump = 0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                sump = __builtin_amdgcn_udot4(wl[m], 0x01010101u, sump, false);
+                sump = __builtin_amdgcn_udot4(wh[m], 0x01010101u, sump, false);
             }
-            if (!found) continue;
-        }
-        float res[2] = {0.0f, 0.0f};
-        const int npass = (a.epi == GEMV_EPI_SWIGLU) ? 2 : 1;
-        for (int pass = 0; pass < npass; pass++) {
-            const GemvSeg &sg = a.seg[sidx + pass];
-            const uint8_t *W = reinterpret_cast<const uint8_t *>(sg.w);
-            for (int it = lane; it < items; it += 64) {
-                const int r = it / GT, gg = it % GT, blk = gg >> 3, g = gg & 7;
-                const uint32_t row = row0 + r;
-                if (row < sg.rows) {
-                    const uint8_t *wb = W + ((size_t)row * bpl + blk) * 160;
-                    const uint4 nib = *reinterpret_cast<const uint4 *>(wb + 32 + g * 16);
-                    const uint4 hq = *reinterpret_cast<const uint4 *>(wb + 16);        // s_bias, sb[0..11]
-                    const float s_scale = *reinterpret_cast<const float *>(wb + 12);
-                    const int len = *reinterpret_cast<const int *>(wb + 4);
-                    uint32_t s6, b6;
-                    q4k_unpack6(hq.y, hq.z, hq.w, g, s6, b6);
-                    const float sp = (float)s6 * s_scale, bp = (float)b6 * __uint_as_float(hq.x);
-                    const int glen = (len >= (g + 1) * 32) ? 32 : (len - 32 * g);
-                    const uint32_t wl[4] = { nib.x & 0x0f0f0f0fu, nib.y & 0x0f0f0f0fu, nib.z & 0x0f0f0f0fu, nib.w & 0x0f0f0f0fu };
-                    const uint32_t wh[4] = { (nib.x >> 4) & 0x0f0f0f0fu, (nib.y >> 4) & 0x0f0f0f0fu,
-                                             (nib.z >> 4) & 0x0f0f0f0fu, (nib.w >> 4) & 0x0f0f0f0fu };
-                    uint32_t sump = 0;
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                if (b < (int)a.nb) {
+                    const XGroup &xq = xg[(size_t)b * GT + gg];
+                    uint32_t spq = 0;
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
-                        sump = __builtin_amdgcn_udot4(wl[m], 0x01010101u, sump, false);
-                        sump = __builtin_amdgcn_udot4(wh[m], 0x01010101u, sump, false);
+                        spq = __builtin_amdgcn_udot4(wl[m], xq.lo[m], spq, false);
+                        spq = __builtin_amdgcn_udot4(wh[m], xq.hi[m], spq, false);
                     }
-#pragma unroll
-                    for (int b = 0; b < B; b++) {
-                        if (b < nb) {
-                            const XGroup &xq = xg[(size_t)b * GT + gg];
-                            uint32_t spq = 0;
-#pragma unroll
-                            for (int m = 0; m < 4; m++) {
-                                spq = __builtin_amdgcn_udot4(wl[m], xq.lo[m], spq, false);
-                                spq = __builtin_amdgcn_udot4(wh[m], xq.hi[m], spq, false);
-                            }
-                            const float sq = xq.sq, bq = xq.bq;
-                            // reference tensor.c:425-428, same association
-                            const float grp = sp * sq * (float)(int)spq - sp * bq * (float)(int)sump - sq * bp * (float)xq.sumq + glen * bp * bq;
-                            fold[(r * B + b) * pitch + gg] = grp;
-                        }
-                    }
+                    const float sq = xq.sq, bq = xq.bq;
+                    // reference tensor.c:425-428, same association
+                    const float grp = sp * sq * (float)(int)spq - sp * bq * (float)(int)sump - sq * bp * (float)xq.sumq + glen * bp * bq;
+                    P[((size_t)b * nmat * RW + rr) * GTP + gg] = grp;
                 }
-            }
-            // ordered fold (groups inside a block, then blocks along the row)
-            float line = 0.0f;
-            if (lane < RB * B && pb < nb) {
-                const float *f = fold + lane * pitch;
-                for (int blk = 0; blk < bpl; blk++) {
-                    const int d = (n >= (blk + 1) * 256) ? 256 : (n - blk * 256);
-                    const int gv = (d + 31) >> 5;
-                    float ds = 0.0f;
-                    for (int g = 0; g < gv; g++) ds += f[blk * 8 + g];
-                    line += ds;
-                }
-            }
-            res[pass] = line;
-        }
-        if (lane < RB * B && pb < nb) {
-            const uint32_t row = row0 + pr;
-            if (row < a.seg[sidx].rows) {
-                const GemvSeg &s = a.seg[sidx];
-                size_t off = (size_t)pb * s.out_bstride;
-                if (s.out_pstride) off += (size_t)a.pos[pb] * s.out_pstride;
-                float *o = s.out + off + row;
-                if (a.epi == GEMV_EPI_STORE) *o = res[0];
-                else if (a.epi == GEMV_EPI_RESID) *o = *o + res[0];
-                else { float h = res[0]; h *= (1.0f / (1.0f + expf(-h))); h *= res[1]; *o = h; }
             }
         }
     }
+    __syncthreads();
+
+    // ordered fold (groups inside a block, then blocks along the row; reference tensor.c:359-434, 438-471)
+    if (tid < (int)(RW * B)) {
+        float res[2] = {0.0f, 0.0f};
+        for (uint32_t mat = 0; mat < nmat; mat++) {
+            const float *f = P + ((size_t)fb * nmat * RW + mat * RW + frl) * GTP;
+            float line = 0.0f;
+            for (uint32_t blk = 0; blk < bpl; blk++) {
+                const int d = ((int)n >= (int)(blk + 1) * 256) ? 256 : ((int)n - (int)blk * 256);
+                const int gv = (d + 31) >> 5;
+                float ds = 0.0f;
+                for (int g = 0; g < gv; g++) ds += f[blk * 8 + g];
+                line += ds;
+            }
+            res[mat] = line;
+        }
+        if (fold_live) *optr = finish_epi(epi, res[0], res[1], oldv);
+    }
 }
 
-static size_t q4k_lds_bytes(uint32_t n, int B, int RB) {
-    const size_t bpl = (n + 255) / 256, GT = bpl * 8;
-    return (size_t)B * GT * sizeof(XGroup) + (((size_t)n + 3) & ~(size_t)3) * 4 + 32 * 4 + (size_t)4 * RB * B * (GT + 1) * 4;
+struct Q4kPlan { uint32_t rw, nthr, ipt, nv; };
+static Q4kPlan plan_q4k(const GemvArgs &a, int B) {
+    const uint32_t GT = ((a.n + 255) / 256) * 8, nmat = a.epi == GEMV_EPI_SWIGLU ? 2 : 1;
+    const uint32_t nseg = a.epi == GEMV_EPI_SWIGLU ? 1u : a.nseg;
+    uint32_t align = 0;
+    if (nseg > 1) for (uint32_t s = 0; s < nseg; s++) align |= a.seg[s].rows;
+    uint32_t rows = 0;
+    if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
+    // ~512 items (8 KB of nibbles) per workgroup, >= 128 workgroups; tall matrices: up to 2048 items
+    uint32_t rw = 4;
+    const uint32_t cap = rows >= 16384 ? 2048u : 512u;
+    while (rw < 64 && (align % (rw * 2)) == 0 && (rw * 2) * GT * nmat <= cap && rows / (rw * 2) >= 128) rw *= 2;
+    const uint32_t items = rw * GT * nmat;
+    uint32_t nthr = ((items + 63) / 64) * 64;
+    if (nthr > 512) nthr = 512;
+    if (nthr < 256) nthr = 256;
+    if (nthr < rw * (uint32_t)B) nthr = ((rw * (uint32_t)B + 63) / 64) * 64;
+    const uint32_t ipt = (items + nthr - 1) / nthr;
+    return Q4kPlan{rw, nthr, ipt, (a.n + 4 * nthr - 1) / (4 * nthr)};
 }
 
-template <int B>
-static hipError_t launch_q4k_b(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
-    constexpr int RB = GEMV_RB;
-    uint32_t tiles = 0;
-    if (a.epi == GEMV_EPI_SWIGLU) tiles = (a.seg[0].rows + RB - 1) / RB;
-    else for (uint32_t s = 0; s < a.nseg; s++) tiles += (a.seg[s].rows + RB - 1) / RB;
-    a.tiles = tiles;
-    uint32_t wgs = (tiles + 3) / 4;
-    if (wgs > max_wg) wgs = max_wg;
-    if (!wgs) return hipSuccess;
-    const size_t lds = q4k_lds_bytes(a.n, B, RB);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemv_q4k_kernel<B, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gemv_q4k_kernel<B, RB>), dim3(wgs), dim3(256), lds, st, a);
+template <int ROLE, int B, int NV, int IPT>
+static hipError_t launch_q4k_t(const GemvDev &d, const Q4kPlan &p, uint32_t rows, hipStream_t st) {
+    const uint32_t nmat = d.epi == GEMV_EPI_SWIGLU ? 2 : 1;
+    const size_t n4 = (d.n + 3) & ~3u, bpl = (d.n + 255) / 256, GT = bpl * 8;
+    const size_t lds = (size_t)B * GT * sizeof(XGroup) + (B * n4 + B * bpl * 16 + B * 16 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 8 : 0) +
+                                                           (size_t)B * nmat * p.rw * (GT + 1)) * 4;
+    auto kern = &gemv_q4k_slab_kernel<ROLE, B, NV, IPT>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(p.nthr), lds, st, d);
     return hipGetLastError();
 }
+template <int ROLE, int B>
+static hipError_t launch_q4k_r(const GemvDev &d, const Q4kPlan &p, uint32_t rows, hipStream_t st) {
+    if (p.ipt > 4) return hipErrorInvalidValue;
+#define Q4K_GO(NV_, IPT_) do { if constexpr (B * NV_ <= 8) return launch_q4k_t<ROLE, B, NV_, IPT_>(d, p, rows, st); } while (0)
+    int nv = p.nv <= 1 ? 1 : p.nv <= 2 ? 2 : p.nv <= 4 ? 4 : 0;
+    const int ipt = p.ipt <= 1 ? 1 : p.ipt <= 2 ? 2 : 4;
+    if (B * nv > 8) nv = 0;
+    if (nv == 1) { if (ipt == 1) Q4K_GO(1, 1); if (ipt == 2) Q4K_GO(1, 2); Q4K_GO(1, 4); }
+    if (nv == 2) { if (ipt == 1) Q4K_GO(2, 1); if (ipt == 2) Q4K_GO(2, 2); Q4K_GO(2, 4); }
+    if (nv == 4) { if (ipt == 1) Q4K_GO(4, 1); if (ipt == 2) Q4K_GO(4, 2); Q4K_GO(4, 4); }
+    if (ipt == 1) Q4K_GO(0, 1);
+    if (ipt == 2) Q4K_GO(0, 2);
+    Q4K_GO(0, 4);
+    return hipErrorInvalidValue;
+#undef Q4K_GO
+}
+template <int B>
+static hipError_t launch_q4k_b(const GemvArgs &a, hipStream_t st) {
+    GemvDev d = to_dev(a);
+    d.tile_max = nullptr;
+    if (a.x4_in) { d.flags |= F_PRE; d.xq_in = reinterpret_cast<const int8_t *>(a.x4_in); }
+    const Q4kPlan p = plan_q4k(a, B);
+    d.rw = p.rw;
+    uint32_t rows = 0;
+    if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
+    if constexpr (B == 1) {
+        const uint32_t f = d.flags;
+        if (f == F_NORM && d.epi == GEMV_EPI_STORE) return launch_q4k_r<R_NORM_STORE, B>(d, p, rows, st);
+        if (f == 0 && d.epi == GEMV_EPI_RESID) return launch_q4k_r<R_RESID, B>(d, p, rows, st);
+        if (f == F_COMBINE && d.epi == GEMV_EPI_RESID) return launch_q4k_r<R_RESID_COMBINE, B>(d, p, rows, st);
+        if (f == F_NORM && d.epi == GEMV_EPI_SWIGLU) return launch_q4k_r<R_NORM_SWIGLU, B>(d, p, rows, st);
+    }
+    return launch_q4k_r<R_GENERIC, B>(d, p, rows, st);
+}
+
+}  // namespace
 
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
-    if (a.nb <= 1) return launch_q4k_b<1>(a, max_wg, st);
-    if (a.nb <= 2) return launch_q4k_b<2>(a, max_wg, st);
-    if (a.nb <= 4) return launch_q4k_b<4>(a, max_wg, st);
-    return launch_q4k_b<8>(a, max_wg, st);
+    (void)max_wg;
+    if (a.nb == 0 || a.nb > 8 || a.n % 4 || a.nseg == 0 || a.nseg > 3) return hipErrorInvalidValue;
+    if (a.attn_part && (a.norm_w || a.attn_nsplit > 8 || a.attn_hd % 4)) return hipErrorInvalidValue;
+    if (a.epi != GEMV_EPI_SWIGLU && a.nseg > 1)
+        for (uint32_t s = 0; s < a.nseg; s++) if (a.seg[s].rows % 4) return hipErrorInvalidValue;
+    if (a.nb <= 1) return launch_q4k_b<1>(a, st);
+    if (a.nb <= 2) return launch_q4k_b<2>(a, st);
+    if (a.nb <= 4) return launch_q4k_b<4>(a, st);
+    return launch_q4k_b<8>(a, st);
 }
 
 }  // namespace nano
