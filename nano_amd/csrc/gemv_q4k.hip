@@ -237,7 +237,12 @@ __device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *x
         float lo = valid ? v : FLT_MAX, hi = valid ? v : FLT_TRUE_MIN;
         lo = (lo < FLT_MAX) ? lo : FLT_MAX;
         hi = (hi > FLT_TRUE_MIN) ? hi : FLT_TRUE_MIN;
-        for (int o = 16; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+        // min / max over the 32 lanes of the group: DPP inside 16-lane rows, one cross-row exchange
+        lo = fminf(lo, DPP_F(lo, 0xB1)); hi = fmaxf(hi, DPP_F(hi, 0xB1));
+        lo = fminf(lo, DPP_F(lo, 0x4E)); hi = fmaxf(hi, DPP_F(hi, 0x4E));
+        lo = fminf(lo, DPP_F(lo, 0x141)); hi = fmaxf(hi, DPP_F(hi, 0x141));
+        lo = fminf(lo, DPP_F(lo, 0x140)); hi = fmaxf(hi, DPP_F(hi, 0x140));
+        lo = fminf(lo, __shfl_xor(lo, 16, 64)); hi = fmaxf(hi, __shfl_xor(hi, 16, 64));
         const float gsc = (lo <= 0.0f) ? ((hi - lo) / 15.0f) : (hi / 15.0f);
         const float gbi = (lo <= 0.0f) ? (-lo) : 0.0f;
         uint32_t nib = 0;
@@ -245,7 +250,8 @@ __device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *x
         const int g = t >> 5, e = t & 31;
         XGroup *o = xg + (size_t)b * GT + j * 8 + g;
         reinterpret_cast<uint8_t *>(o)[((e & 1) ? 16 : 0) + (e >> 3) * 4 + ((e & 7) >> 1)] = (uint8_t)nib;   // split-nibble byte lane of element e
-        const int sum = group_sum_i((int)nib, 32);
+        int sum = dpp_group_sum<16>((int)nib);
+        sum += __shfl_xor(sum, 16, 64);
         if (e == 0) { o->sumq = sum; o->_pad = 0; float *tp = tmp + ((size_t)b * bpl + j) * 16; tp[g] = gsc; tp[8 + g] = gbi; }
     }
     __syncthreads();
@@ -432,6 +438,9 @@ static Q4kPlan plan_q4k(const GemvArgs &a, int B) {
     uint32_t nthr = ((items + 63) / 64) * 64;
     if (nthr > 512) nthr = 512;
     if (nthr < 256) nthr = 256;
+    uint32_t want = ((a.n / 4 + 63) / 64) * 64;            // the block quantizer is one thread per element: ~4 elements per thread
+    if (want > 1024) want = 1024;
+    if (nthr < want) nthr = want;
     if (nthr < rw * (uint32_t)B) nthr = ((rw * (uint32_t)B + 63) / 64) * 64;
     const uint32_t ipt = (items + nthr - 1) / nthr;
     return Q4kPlan{rw, nthr, ipt, (a.n + 4 * nthr - 1) / (4 * nthr)};

@@ -24,31 +24,35 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
         }
     }
     if (a.quant == 0x00u) {
-        const float *row = reinterpret_cast<const float *>(a.tok) + (size_t)tok * E;
-        for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) x[i] = row[i];
+        const float4 *row = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(a.tok) + (size_t)tok * E);
+        for (uint32_t i = threadIdx.x; i < E / 4; i += blockDim.x) reinterpret_cast<float4 *>(x)[i] = row[i];
     } else if (a.quant == 0x80u) {
-        const int8_t *row = reinterpret_cast<const int8_t *>(a.tok) + (size_t)tok * E;
+        const int8_t *row = reinterpret_cast<const int8_t *>(a.tok) + (size_t)tok * E;      // E % 4 == 0, gs % 4 == 0
         const float *s = a.tok_s + ((size_t)tok * E) / a.gs;
-        for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) x[i] = (float)row[i] * s[i / a.gs];
+        for (uint32_t i = threadIdx.x * 4; i < E; i += blockDim.x * 4) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(row + i);
+            const float sc = s[i / a.gs];
+            reinterpret_cast<float4 *>(x + i)[0] = make_float4((float)(int8_t)(w & 0xff) * sc, (float)(int8_t)((w >> 8) & 0xff) * sc,
+                                                               (float)(int8_t)((w >> 16) & 0xff) * sc, (float)(int8_t)(w >> 24) * sc);
+        }
     } else {
         const uint32_t bpl = (E + 255) / 256;
         const uint8_t *blocks = reinterpret_cast<const uint8_t *>(a.tok) + (size_t)tok * bpl * 160;
-        for (uint32_t j = 0; j < bpl; j++) {
+        for (uint32_t it = threadIdx.x; it < bpl * 256; it += blockDim.x) {       // all blocks in flight at once
+            const uint32_t j = it >> 8, k = it & 255;
             const uint8_t *blk = blocks + (size_t)j * 160;
             const uint32_t d = (E >= (j + 1) * 256) ? 256 : (E - j * 256);
             const uint32_t len = *reinterpret_cast<const uint32_t *>(blk + 4);
-            const float s_scale = *reinterpret_cast<const float *>(blk + 12);
-            const float s_bias = *reinterpret_cast<const float *>(blk + 16);
-            const uint32_t sb0 = *reinterpret_cast<const uint32_t *>(blk + 20);
-            const uint32_t sb1 = *reinterpret_cast<const uint32_t *>(blk + 24);
-            const uint32_t sb2 = *reinterpret_cast<const uint32_t *>(blk + 28);
-            for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) {
+            if (k < len) {
+                const float s_scale = *reinterpret_cast<const float *>(blk + 12);
+                const float s_bias = *reinterpret_cast<const float *>(blk + 16);
                 uint32_t s6, b6;
-                q4k_unpack6(sb0, sb1, sb2, (int)(k >> 5), s6, b6);
-                const float s = (float)s6 * s_scale, bb = (float)b6 * s_bias;
+                q4k_unpack6(*reinterpret_cast<const uint32_t *>(blk + 20), *reinterpret_cast<const uint32_t *>(blk + 24),
+                            *reinterpret_cast<const uint32_t *>(blk + 28), (int)(k >> 5), s6, b6);
+                const float sc = (float)s6 * s_scale, bb = (float)b6 * s_bias;
                 const uint8_t byte = blk[32 + (k >> 1)];
                 const uint32_t nib = (k & 1) ? (uint32_t)(byte >> 4) : (uint32_t)(byte & 0x0f);
-                x[(size_t)j * d + k] = (float)nib * s - bb;     // j*d destination offset as tensor.c:339
+                x[(size_t)j * d + k] = (float)nib * sc - bb;        // j*d destination offset as tensor.c:339
             }
         }
     }
@@ -76,10 +80,24 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
             if (i != 0xffffffffu && (bi == 0xffffffffu || v > best || (v == best && i < bi))) { best = v; bi = i; }   // partials are NOT row-ordered
         }
     } else {
-        for (uint32_t i = tid; i < a.V; i += blockDim.x) {
-            const float v = x[i];
-            if (bi == 0xffffffffu || v > best) { best = v; bi = i; }
+        // thread t scans float4 t, t+1024, ...: ascending indices per thread, 4 loads in flight
+        const uint32_t V4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? a.V / 4 : 0;
+        auto upd = [&](float v, uint32_t i) { if (bi == 0xffffffffu || v > best) { best = v; bi = i; } };
+        uint32_t i = tid;
+        for (; i + 3 * blockDim.x < V4; i += 4 * blockDim.x) {
+            const float4 v0 = reinterpret_cast<const float4 *>(x)[i], v1 = reinterpret_cast<const float4 *>(x)[i + blockDim.x];
+            const float4 v2 = reinterpret_cast<const float4 *>(x)[i + 2 * blockDim.x], v3 = reinterpret_cast<const float4 *>(x)[i + 3 * blockDim.x];
+            upd(v0.x, 4 * i); upd(v0.y, 4 * i + 1); upd(v0.z, 4 * i + 2); upd(v0.w, 4 * i + 3);
+            const uint32_t i1 = i + blockDim.x, i2 = i + 2 * blockDim.x, i3 = i + 3 * blockDim.x;
+            upd(v1.x, 4 * i1); upd(v1.y, 4 * i1 + 1); upd(v1.z, 4 * i1 + 2); upd(v1.w, 4 * i1 + 3);
+            upd(v2.x, 4 * i2); upd(v2.y, 4 * i2 + 1); upd(v2.z, 4 * i2 + 2); upd(v2.w, 4 * i2 + 3);
+            upd(v3.x, 4 * i3); upd(v3.y, 4 * i3 + 1); upd(v3.z, 4 * i3 + 2); upd(v3.w, 4 * i3 + 3);
         }
+        for (; i < V4; i += blockDim.x) {
+            const float4 v0 = reinterpret_cast<const float4 *>(x)[i];
+            upd(v0.x, 4 * i); upd(v0.y, 4 * i + 1); upd(v0.z, 4 * i + 2); upd(v0.w, 4 * i + 3);
+        }
+        for (uint32_t k = V4 * 4 + tid; k < a.V; k += blockDim.x) upd(x[k], k);
     }
     // combine: larger value wins; equal values -> smaller index (== first maximum in scan order)
 #pragma unroll

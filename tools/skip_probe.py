@@ -9,8 +9,9 @@ NAMES = {0: "full", 1: "qkv", 2: "attn", 4: "wo", 8: "w13", 16: "w2", 32: "cls",
 def child(mask, poss):
     from nano_amd import binding as nb
     from nano_amd import modelfile as mf
-    spec = mf.preset("qwen3-0.6b", "q80", group_size=64, block_size=1024)
-    path = "/tmp/qwen3-0.6b-q80-64.bin"
+    quant = os.environ.get("SKIP_QUANT", "q80"); model = os.environ.get("SKIP_MODEL", "qwen3-0.6b")
+    spec = mf.preset(model, quant, group_size=64 if quant == "q80" else 0, block_size=1024)
+    path = f"/tmp/{model}-{quant}-64.bin"
     if not os.path.exists(path):
         mf.write_model(path, spec, seed=39)
     m = nb.load_model_file(path, max_seq_len=512, max_batch=1)
@@ -36,5 +37,6 @@ if __name__ == "__main__":
             print(mask, "failed", r.stderr[-300:]); continue
         if mask == 0:
             base = res
-        line = f"{NAMES[mask]:>11}: " + "  ".join(f"pos {p}: {res[p]:7.1f} us" + (f" (-{base[p] - res[p]:6.1f}, {(base[p] - res[p]) / 28:5.2f}/layer)" if mask else "") for p in res)
+        nl = {"qwen3-0.6b": 28, "nano-168m": 24, "nano-56m": 16, "qwen3-4b": 36}.get(os.environ.get("SKIP_MODEL", "qwen3-0.6b"), 28)
+        line = f"{NAMES[mask]:>11}: " + "  ".join(f"pos {p}: {res[p]:7.1f} us" + (f" (-{base[p] - res[p]:6.1f}, {(base[p] - res[p]) / nl:5.2f}/layer)" if mask else "") for p in res)
         print(line, flush=True)
