@@ -343,12 +343,20 @@ static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *nti
     return gemv(m, a);
 }
 
+// attention splits of a step: batches bring their own parallelism (nb x KV groups workgroups per split) and every
+// split costs the Wo prologue nb x nsplit partial reads, so larger batches split less
+static uint32_t step_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_hint) {
+    uint32_t ns = attention_nsplit(range_hint, m->hd);
+    if (nb >= 4) { const uint32_t div = nb / 2; ns = (ns + div - 1) / div; }
+    return ns ? ns : 1;
+}
+
 // range_hint: host-side upper bound of the attended range of every sequence (a multiple of 64, <= S)
 static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t range_hint) {
     const NanoModelDesc &d = m->d;
     const uint32_t E = d.n_embd, H = d.n_hidden, QD = m->QD, KD = m->KD, L = d.n_layer, S = m->S;
     hipError_t e;
-    const uint32_t nsplit = attention_nsplit(range_hint, m->hd);
+    const uint32_t nsplit = step_nsplit(m, nb, range_hint);
     m->nsplit = nsplit;
     EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
                   m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0 };
@@ -438,7 +446,7 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
         (void)hipGraphDestroy(g);
         it = m->graphs.emplace(key, ge).first;
     }
-    m->nsplit = attention_nsplit(range_hint, m->hd);
+    m->nsplit = step_nsplit(m, nb, range_hint);
     HIP_TRY(hipGraphLaunch(it->second, m->st));
     return 0;
 }

@@ -171,11 +171,14 @@ __device__ __forceinline__ float4 combine4(const GemvDev &a, uint32_t b, uint32_
     const uint32_t ns = a.attn_nsplit, n = a.n;
     const float *part = a.attn_part + (size_t)b * ns * n + i;
     const float *wg = wgt + ((size_t)b * a.attn_n_head + i / a.attn_hd) * 8u;
+    float4 o[8];                        // all splits in flight at once (one round trip), then the ordered accumulation
+#pragma unroll
+    for (int s = 0; s < 8; s++) o[s] = ((uint32_t)s < ns) ? *reinterpret_cast<const float4 *>(part + (size_t)s * n) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t s = 0; s < ns; s++) {
-        const float4 o = *reinterpret_cast<const float4 *>(part + (size_t)s * n);
-        const float w = wg[s];
-        acc.x += o.x * w; acc.y += o.y * w; acc.z += o.z * w; acc.w += o.w * w;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const float w = wg[s];          // splits >= nsplit carry weight 0
+        acc.x += o[s].x * w; acc.y += o[s].y * w; acc.z += o[s].z * w; acc.w += o[s].w * w;
     }
     return acc;
 }

@@ -95,6 +95,9 @@ def preset(name: str, quant: str = "f32", group_size: int = 0, block_size: Optio
         "tiny-nano":  (ARCH_NANO, 64, 512, 2, 128, 4, 2, 384, 0),
         "tiny-nano-odd": (ARCH_NANO, 64, 512, 2, 192, 4, 2, 352, 0),   # head_dim 48, hidden%256!=0
         "tiny-qwen3": (ARCH_QWEN3, 128, 1024, 2, 256, 4, 2, 768, 64),
+        # one layer with Qwen3-4B's row lengths (2560 / 4096 / 9728: partial 1 KiB chunks, many chunks per row,
+        # 4 q heads per KV head) and a vocabulary tall enough for the classifier's STREAM kernel
+        "wide-qwen3": (ARCH_QWEN3, 128, 20000, 1, 2560, 32, 8, 9728, 128),
     }
     a, bs, V, L, E, nh, nkv, H, hd = table[name]
     if block_size is not None:

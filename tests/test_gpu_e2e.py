@@ -56,7 +56,10 @@ def test_greedy_ids_identical_fp32(model_dir, preset, quant, gs):
     assert np.array_equal(out[:, 0], g["ids"][len(prompt):])
 
 
-@pytest.mark.parametrize("preset,quant,gs", CASES)
+WIDE_CASES = [("wide-qwen3", "q80", 64), ("wide-qwen3", "q80", 128), ("wide-qwen3", "q4k", 0)]
+
+
+@pytest.mark.parametrize("preset,quant,gs", CASES + WIDE_CASES)
 def test_first_forward_state_vs_oracle(oracle, model_dir, preset, quant, gs):
     """pos 0: no history, identical inputs -> compare logits and the layer-0 KV rows."""
     path, spec = synth_model(model_dir, preset, quant, gs)
