@@ -172,13 +172,12 @@ __global__ __launch_bounds__(1024) void gemv_f32_slab_kernel(const GemvDev a) {
     const int lrw = (int)a.log2_tiles + 2;
     const int fb = tid >> lrw, frl = tid & ((int)RW - 1);
     const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
-    float *optr = out0;
+    // the position of a pos-indexed output (v-cache row) is fetched now and used only by the final store: no wait
+    // here (a wait on it would also wait for every weight load issued above -- vmcnt counts in order)
+    uint32_t opos = 0;
+    if (ops && fold_live) opos = a.pos[fb];
     float oldv = 0.0f;
-    if (fold_live) {
-        optr = out0 + (size_t)fb * obs + lrow0 + frl;
-        if (ops) optr += (size_t)a.pos[fb] * ops;
-        if (epi == GEMV_EPI_RESID) oldv = *optr;
-    }
+    if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];      // residual stream: never pos-indexed
 
     stage_finish_f32<ROLE, B, NV>(a, sx, xf, red, n4);
 
@@ -212,7 +211,7 @@ __global__ __launch_bounds__(1024) void gemv_f32_slab_kernel(const GemvDev a) {
         const float *p0 = P + (((size_t)fb * nmat) * RW + frl) * PC;
         const float *p1 = p0 + (size_t)RW * PC;
         for (uint32_t c = 0; c < nchunk; c++) { v0 += p0[c]; if (swiglu) v1 += p1[c]; }
-        if (fold_live) *optr = finish_epi(epi, v0, v1, oldv);
+        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, v0, v1, oldv);
     }
 }
 

@@ -349,13 +349,12 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     uint32_t lrw = 0; while ((1u << lrw) < RW) lrw++;
     const int fb = tid >> lrw, frl = tid & ((int)RW - 1);
     const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
-    float *optr = out0;
+    // the position of a pos-indexed output (v-cache row) is fetched now and used only by the final store: no wait
+    // here (a wait on it would also wait for every weight load issued above -- vmcnt counts in order)
+    uint32_t opos = 0;
+    if (ops && fold_live) opos = a.pos[fb];
     float oldv = 0.0f;
-    if (fold_live) {
-        optr = out0 + (size_t)fb * obs + lrow0 + frl;
-        if (ops) optr += (size_t)a.pos[fb] * ops;
-        if (epi == GEMV_EPI_RESID) oldv = *optr;
-    }
+    if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];      // residual stream: never pos-indexed
 
     if (has_flag<ROLE>(a, F_PRE)) unpack_q4k_wg(a, xg);
     else {
@@ -418,7 +417,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
             }
             res[mat] = line;
         }
-        if (fold_live) *optr = finish_epi(epi, res[0], res[1], oldv);
+        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, res[0], res[1], oldv);
     }
 }
 

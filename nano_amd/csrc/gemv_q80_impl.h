@@ -237,13 +237,12 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     const int lrw = (int)a.log2_tiles + 2;                              // log2(rows per workgroup)
     const int fb = tid >> lrw, frl = tid & ((int)RW - 1);               // fold thread -> (sequence, local row)
     const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
-    float *optr = out0;
+    // the position of a pos-indexed output (v-cache row) is fetched now and used only by the final store: no wait
+    // here (a wait on it would also wait for every weight load issued above -- vmcnt counts in order)
+    uint32_t opos = 0;
+    if (ops && fold_live) opos = a.pos[fb];
     float oldv = 0.0f;
-    if (fold_live) {
-        optr = out0 + (size_t)fb * obs + lrow0 + frl;
-        if (ops) optr += (size_t)a.pos[fb] * ops;
-        if (epi == GEMV_EPI_RESID) oldv = *optr;
-    }
+    if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];      // residual stream: never pos-indexed
 
     // ---- 4. rmsnorm + quantization from registers (weights in flight) ----------------------------------------
     stage_finish<ROLE, GS, B, NV>(a, sx, xq, xs, red, n16, ng4);
@@ -294,27 +293,41 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         float v0 = 0.0f, v1 = 0.0f;
         const float *p0 = P + (((size_t)fb * nmat) * RW + frl) * PITCH;
         const float *p1 = p0 + (size_t)RW * PITCH;
+        if ((ng & 15u) == 0) {              // whole 16-group batches (every BASELINE shape): no per-element selects
+            for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
+                float4 t[4], u[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { t[q] = *reinterpret_cast<const float4 *>(p0 + g0 + 4 * q); if (swiglu) u[q] = *reinterpret_cast<const float4 *>(p1 + g0 + 4 * q); }
+#pragma unroll
+                for (int q = 0; q < 4; q++) { v0 += t[q].x; v0 += t[q].y; v0 += t[q].z; v0 += t[q].w; }
+                if (swiglu) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { v1 += u[q].x; v1 += u[q].y; v1 += u[q].z; v1 += u[q].w; }
+                }
+            }
+        } else {
         for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
-            float4 t[4], u[4];
+                float4 t[4], u[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                t[q] = (g0 + 4 * q < ng4) ? *reinterpret_cast<const float4 *>(p0 + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (swiglu) u[q] = (g0 + 4 * q < ng4) ? *reinterpret_cast<const float4 *>(p1 + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t g = g0 + 4 * q;
-                v0 += (g < ng) ? t[q].x : 0.0f; v0 += (g + 1 < ng) ? t[q].y : 0.0f; v0 += (g + 2 < ng) ? t[q].z : 0.0f; v0 += (g + 3 < ng) ? t[q].w : 0.0f;
-            }
-            if (swiglu) {
+                for (int q = 0; q < 4; q++) {
+                    t[q] = (g0 + 4 * q < ng4) ? *reinterpret_cast<const float4 *>(p0 + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (swiglu) u[q] = (g0 + 4 * q < ng4) ? *reinterpret_cast<const float4 *>(p1 + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint32_t g = g0 + 4 * q;
-                    v1 += (g < ng) ? u[q].x : 0.0f; v1 += (g + 1 < ng) ? u[q].y : 0.0f; v1 += (g + 2 < ng) ? u[q].z : 0.0f; v1 += (g + 3 < ng) ? u[q].w : 0.0f;
+                    v0 += (g < ng) ? t[q].x : 0.0f; v0 += (g + 1 < ng) ? t[q].y : 0.0f; v0 += (g + 2 < ng) ? t[q].z : 0.0f; v0 += (g + 3 < ng) ? t[q].w : 0.0f;
+                }
+                if (swiglu) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t g = g0 + 4 * q;
+                        v1 += (g < ng) ? u[q].x : 0.0f; v1 += (g + 1 < ng) ? u[q].y : 0.0f; v1 += (g + 2 < ng) ? u[q].z : 0.0f; v1 += (g + 3 < ng) ? u[q].w : 0.0f;
+                    }
                 }
             }
         }
-        if (fold_live) *optr = finish_epi(epi, v0, v1, oldv);
+        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, v0, v1, oldv);
     }
 }
 
