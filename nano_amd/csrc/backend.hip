@@ -66,6 +66,7 @@ struct NanoHipModel {
     float *x = nullptr, *q = nullptr, *kraw = nullptr, *xba = nullptr, *hb = nullptr, *logits = nullptr;
     float *attn_part = nullptr, *attn_ml = nullptr;       // split-attention partials [B][nsplit][QD], [B][n_head][nsplit][2]
     float *tile_max = nullptr;                            // classifier arg-max partials [B][<=V][2]
+    int8_t *gq = nullptr; float *gxs = nullptr;           // MFMA GEMM path (batch > 8, Q80): quantized activations of all sequences
     float *rope_cur = nullptr;                            // RoPE rows of the current positions [B][2][hd/2], staged by the embed kernel
     float *kcache = nullptr, *vcache = nullptr;
     uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
@@ -138,7 +139,7 @@ static void destroy(NanoHipModel *m) {
     if (m->st) (void)hipStreamSynchronize(m->st);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
-                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur };
+                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -295,6 +296,10 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
               hipMalloc(&m->attn_ml, B * d.n_head * m->nsplit * 2 * 4) == hipSuccess &&
               hipMalloc(&m->tile_max, B * V * 2 * 4) == hipSuccess &&
               hipMalloc(&m->rope_cur, B * m->hd * 4 + 64) == hipSuccess;
+    if (ok && B > 8 && d.quant_type == NANO_QUANT_Q80) {
+        size_t nmax = E > QD ? E : QD; if (H > nmax) nmax = H;
+        ok = hipMalloc(&m->gq, B * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, B * (nmax / d.group_size) * 4) == hipSuccess;
+    }
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
     // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
     if (hipMemset(m->kcache, 0, kvn * 4) != hipSuccess || hipMemset(m->vcache, 0, kvn * 4) != hipSuccess ||
@@ -328,6 +333,14 @@ static GemvSeg mkseg(const TensorRef &t, float *out, uint32_t rows, uint32_t bst
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     const uint32_t max_wg = (uint32_t)m->cus * 8;
     if (m->d.quant_type == NANO_QUANT_Q4K) return launch_gemv_q4k(a, max_wg, m->st);
+    if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 8) {
+        // 9..64 sequences: quantize every sequence's activation once, then the int8 MFMA GEMM (gemm_q80.hip)
+        if (a.attn_part || !m->gq || !m->gxs) return hipErrorInvalidValue;
+        hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
+        if (e != hipSuccess) return e;
+        a.xq_in = m->gq; a.xs_in = m->gxs;
+        return launch_gemm_q80(a, m->st);
+    }
     return launch_gemv(m->d.quant_type, a, max_wg, m->st);
 }
 
@@ -348,6 +361,7 @@ static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *nti
 static uint32_t step_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_hint) {
     uint32_t ns = attention_nsplit(range_hint, m->hd);
     if (nb >= 4) { const uint32_t div = nb / 2; ns = (ns + div - 1) / div; }
+    if (nb > 8) ns = 1;                 // the MFMA GEMM path takes plain activations only
     return ns ? ns : 1;
 }
 
@@ -460,7 +474,8 @@ extern "C" int nano_hip_sync(NanoHipModel *m) {
 
 static int check_batch(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, uint32_t extra_steps) {
     if (!m || !tokens || !pos) FAIL(NANO_HIP_EINVAL, "null argument");
-    if (batch == 0 || batch > m->maxB || batch > 8) FAIL(NANO_HIP_EINVAL, "batch %u out of range (max %u, kernel capacity 8)", batch, m->maxB);
+    const uint32_t cap = m->d.quant_type == NANO_QUANT_Q80 ? NANO_MAX_BATCH : 8u;      // > 8 sequences: Q80 MFMA GEMM path only
+    if (batch == 0 || batch > m->maxB || batch > cap) FAIL(NANO_HIP_EINVAL, "batch %u out of range (max %u, kernel capacity %u)", batch, m->maxB, cap);
     for (uint32_t i = 0; i < batch; i++) {
         if (tokens[i] >= m->d.vocab_size) FAIL(NANO_HIP_EINVAL, "token %u out of vocabulary", tokens[i]);
         if ((uint64_t)pos[i] + (extra_steps ? extra_steps - 1 : 0) >= (uint64_t)m->S) FAIL(NANO_HIP_EINVAL, "position %u (+%u steps) exceeds max_seq_len %u", pos[i], extra_steps, m->S);
@@ -518,7 +533,7 @@ extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, c
 // measurement
 // ------------------------------------------------------------------------------------------------
 extern "C" int nano_hip_time_classifier(NanoHipModel *m, uint32_t batch, uint32_t iters, float *ms_per_launch, uint64_t *bytes_per_launch) {
-    if (!m || !iters || batch == 0 || batch > 8 || batch > m->maxB) FAIL(NANO_HIP_EINVAL, "bad argument");
+    if (!m || !iters || batch == 0 || batch > m->maxB || (batch > 8 && m->d.quant_type != NANO_QUANT_Q80)) FAIL(NANO_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(enqueue_classifier(m, batch));                               // warm
     HIP_TRY(hipEventRecord(m->ev0, m->st));
@@ -545,7 +560,7 @@ static uint64_t classifier_bytes(const NanoHipModel *m) {
 // event span (end of the previous kernel -> end of the classifier); *ms_empty_pair the span of an empty event pair.
 extern "C" int nano_hip_time_classifier_in_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_launch,
                                                 uint64_t *bytes_per_launch, float *ms_empty_pair) {
-    if (!m || !iters || batch == 0 || batch > 8 || batch > m->maxB || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
+    if (!m || !iters || batch == 0 || batch > m->maxB || (batch > 8 && m->d.quant_type != NANO_QUANT_Q80) || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     for (uint32_t i = 0; i < batch; i++) { m->h_tokens[i] = 1 % m->d.vocab_size; m->h_pos[i] = pos; }
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
@@ -572,7 +587,7 @@ extern "C" int nano_hip_time_classifier_in_step(NanoHipModel *m, uint32_t batch,
 }
 
 extern "C" int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_step) {
-    if (!m || !iters || batch == 0 || batch > 8 || batch > m->maxB || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
+    if (!m || !iters || batch == 0 || batch > m->maxB || (batch > 8 && m->d.quant_type != NANO_QUANT_Q80) || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     for (uint32_t i = 0; i < batch; i++) { m->h_tokens[i] = 1 % m->d.vocab_size; m->h_pos[i] = pos; }
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));

@@ -14,7 +14,7 @@ static inline uint32_t total_rows(const GemvArgs &a) {
     return r;
 }
 static inline bool use_stream(const GemvArgs &a) {
-    return a.nseg == 1 && a.epi == GEMV_EPI_STORE && a.seg[0].rows >= STREAM_MIN_ROWS && a.seg[0].out_pstride == 0 && !a.attn_part;
+    return a.nseg == 1 && a.epi == GEMV_EPI_STORE && a.seg[0].rows >= STREAM_MIN_ROWS && a.seg[0].out_pstride == 0 && !a.attn_part && a.nb <= 8;
 }
 
 

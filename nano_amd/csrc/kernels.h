@@ -53,6 +53,10 @@ hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
 hipError_t launch_gemv_q80(const GemvArgs &a, hipStream_t st);      // gemv_q80.hip
 hipError_t launch_gemv_f32(const GemvArgs &a, hipStream_t st);      // gemv_f32.hip
+// 9..64 tokens per weight read on the int8 matrix cores (gemm_q80.hip); a.xq_in / a.xs_in = quantized activations of all tokens
+hipError_t launch_gemm_q80(const GemvArgs &a, hipStream_t st);
+hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
+                             int8_t *xq, float *xs, hipStream_t st);
 uint32_t gemv_q80_partials(const GemvArgs &a);
 
 // ---- attention ------------------------------------------------------------------------------------

@@ -99,6 +99,34 @@ def test_batch_slots_are_independent(oracle, model_dir):
     m1.close()
 
 
+@pytest.mark.parametrize("B", [16, 21, 64])
+def test_large_batch_mfma_gemm_path(model_dir, B):
+    """More than 8 sequences per step take the int8 MFMA GEMM (gemm_q80.hip): same logits as one-by-one decoding.
+    The GEMM is bit-exact like the GEMVs; the per-token rmsnorm sums may associate differently from the GEMV prologue
+    on some shapes, so the bar here is the Q80 end-to-end tolerance, and exact equality is reported."""
+    path, spec = synth_model(model_dir, "tiny-qwen3", "q80", 64)
+    from nano_amd import modelfile as mf
+    T = 8
+    seqs = [mf.prompt_ids(300 + b, T, spec.vocab_size) for b in range(B)]
+    mb = nb.load_model_file(path, max_seq_len=16, max_batch=B)
+    batched = []
+    for pos in range(T):
+        lg, am = mb.forward([int(s[pos]) for s in seqs], [pos] * B, want_logits=True, want_argmax=True)
+        assert np.array_equal(am, np.argmax(lg, axis=1))
+        batched.append(lg)
+    mb.close()
+    m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    worst, exact = 0.0, True
+    for b in range(B):
+        for pos in range(T):
+            lg, _ = m1.forward([int(seqs[b][pos])], [pos])
+            worst = max(worst, rel_err(batched[pos][b], lg[0]))
+            exact = exact and np.array_equal(lg[0], batched[pos][b])
+    m1.close()
+    print(f"batch {B} (MFMA GEMM) vs batch 1 (GEMV): worst rel err {worst:.3e}, bit-identical: {exact}")
+    assert worst < TOL["q80"]
+
+
 def test_ragged_positions_in_one_batch(model_dir):
     """Slots at different positions in the same step (pos is per slot)."""
     path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)
