@@ -59,45 +59,49 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const float *x, uint32_
 struct GemmDev {
     const int8_t *w[3]; const float *ws[3]; float *out[3];
     uint32_t rows[3], out_bstride[3], out_pstride[3];
-    uint32_t n, ng, epi, nb, ttiles, n16;
+    uint32_t n, ng, epi, nb, ttiles, n16, magic_ng, _pad;
     const int8_t *xq; const float *xs; const uint32_t *pos;
 };
 
-// integer group sums of a 16x16 tile for one quantization group: GS/64 MFMAs of K = 64 (GS = 32: one of K = 32)
+// One quantization group of a 16x16 tile needs GS bytes of K per weight row and per token: FR = fragment registers
+// (one per MFMA) per group.  GS >= 64: FR = GS/64 MFMAs of K = 64, a lane holds 16 bytes per fragment; GS = 32: one
+// MFMA of K = 32, 8 bytes per lane.
+template <int GS> struct Frag { i32x4 v; };
+template <> struct Frag<32> { long v; };
+
 template <int GS>
-__device__ __forceinline__ v4i group_mma(__amdgpu_buffer_rsrc_t rw, uint32_t woff, __amdgpu_buffer_rsrc_t rx, uint32_t xoff, uint32_t kq) {
-    v4i c = {0, 0, 0, 0};
+__device__ __forceinline__ Frag<GS> load_frag(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t kq, int ks) {
+    Frag<GS> f;
     if constexpr (GS == 32) {
-        // K = 32: lane holds 8 bytes, k = 8*kq .. +7
-        const uint32_t wo = woff == OOB ? OOB : woff + kq * 8u, xo = xoff == OOB ? OOB : xoff + kq * 8u;
-        const uint32_t a0 = __builtin_amdgcn_raw_buffer_load_b32(rw, (int)wo, 0, 0), a1 = __builtin_amdgcn_raw_buffer_load_b32(rw, (int)(wo == OOB ? OOB : wo + 4u), 0, 0);
-        const uint32_t b0 = __builtin_amdgcn_raw_buffer_load_b32(rx, (int)xo, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(xo == OOB ? OOB : xo + 4u), 0, 0);
-        const long a = (long)(((unsigned long)a1 << 32) | a0), b = (long)(((unsigned long)b1 << 32) | b0);
-        c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, c, 0, 0, 0);
+        const uint32_t o = off == OOB ? OOB : off + kq * 8u;
+        const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(r, (int)o, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b32(r, (int)(o == OOB ? OOB : o + 4u), 0, 0);
+        f.v = (long)(((unsigned long)hi << 32) | lo);
     } else {
-#pragma unroll
-        for (int ks = 0; ks < GS / 64; ks++) {
-            const uint32_t wo = woff == OOB ? OOB : woff + ks * 64u + kq * 16u, xo = xoff == OOB ? OOB : xoff + ks * 64u + kq * 16u;
-            const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)wo, 0, 0);
-            const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xo, 0, 0);
-            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
-        }
+        f.v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off == OOB ? OOB : off + (uint32_t)ks * 64u + kq * 16u), 0, 0);
     }
-    return c;
+    return f;
+}
+template <int GS>
+__device__ __forceinline__ v4i mma(const Frag<GS> &a, const Frag<GS> &b, v4i c) {
+    if constexpr (GS == 32) return __builtin_amdgcn_mfma_i32_16x16x32_i8(a.v, b.v, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_i32_16x16x64_i8(a.v, b.v, c, 0, 0, 0);
 }
 
 template <int GS>
 __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int FR = GS >= 64 ? GS / 64 : 1;                  // fragments per group
+    constexpr int GB = 16 / FR;                                 // groups per batch: 16 fragment loads per operand in flight
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t n = a.n, ng = a.ng;
+    const uint32_t n = a.n, ng = a.ng, ngp = ng | 1u;            // odd LDS pitch: conflict-free row-strided reads
     const bool swiglu = a.epi == GEMV_EPI_SWIGLU;
     // (row tile, token tile) pair of this wave; token tile fastest: the waves of a workgroup share their rows
     const uint32_t pair = blockIdx.x * 4u + (uint32_t)wid;
     const uint32_t tt = pair % a.ttiles, rt = pair / a.ttiles;
     const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1], total = swiglu ? a.rows[0] : b1 + a.rows[2];
     const uint32_t grow0 = rt * 16u;
-    if (grow0 >= total) return;                                  // wave-uniform
+    if (grow0 >= total) return;                                  // wave-uniform; no workgroup barrier below
     const int sel = swiglu ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
     const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
     const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
@@ -114,24 +118,72 @@ __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
     const uint32_t wrow = (lrow0 + m) * n;                        // A operand: weight row lrow0 + m  (rows beyond the segment: out of range -> 0)
     const uint32_t tok = tt * 16u + m;                           // B operand / result column: token
     const uint32_t xrow = tok < a.nb ? tok * a.n16 : OOB;
-    const uint32_t srow = (lrow0 + kq * 4u) * ng * 4u;            // result rows 4*kq + i: their weight scales
-    const uint32_t xsrow = tok < a.nb ? tok * ng * 4u : OOB;
+
+    // ---- fragment loads of the first group batch go out first; the scales of the tile follow ------------------------
+    auto issue = [&](uint32_t g0, Frag<GS> (&fa)[GB][FR], Frag<GS> (&fb)[GB][FR], Frag<GS> (&fa1)[GB][FR]) {
+#pragma unroll
+        for (int gi = 0; gi < GB; gi++) {
+            const uint32_t g = g0 + gi;
+            const uint32_t wo = g < ng ? wrow + g * GS : OOB, xo = (g < ng && xrow != OOB) ? xrow + g * GS : OOB;
+#pragma unroll
+            for (int ks = 0; ks < FR; ks++) {
+                fa[gi][ks] = load_frag<GS>(rw0, wo, kq, ks);
+                fb[gi][ks] = load_frag<GS>(rx, xo, kq, ks);
+                if (swiglu) fa1[gi][ks] = load_frag<GS>(rw1, wo, kq, ks);
+            }
+        }
+    };
+    Frag<GS> fa[GB][FR], fb[GB][FR], fa1[GB][FR];
+    issue(0, fa, fb, fa1);
+
+    // scales into wave-private LDS: ws[16 rows][ng] and xs[16 tokens][ng] of a tile are contiguous blocks of 16*ng
+    // floats; all loads of a pass are issued before the first LDS write (one round trip per 3 x 64 float4)
+    float *wsl0 = smem_f + (size_t)wid * (swiglu ? 3u : 2u) * 16u * ngp, *xsl = wsl0 + 16u * ngp, *wsl1 = xsl + 16u * ngp;
+    const uint32_t nf4 = 4u * ng;                                  // float4 items per block (ng % 4 == 0 checked by the launcher)
+    for (uint32_t base = 0; base < nf4; base += 192u) {
+        float4 tw[3], tx[3], tw1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t i4 = base + (uint32_t)k * 64u + (uint32_t)lane;
+            const uint32_t off = i4 < nf4 ? i4 * 16u : OOB;
+            tw[k] = bload_f4(rs0, off == OOB ? OOB : lrow0 * ng * 4u + off);
+            tx[k] = bload_f4(rxs, off == OOB ? OOB : tt * 16u * ng * 4u + off);     // tokens >= nb: out of range -> 0
+            if (swiglu) tw1[k] = bload_f4(rs1, off == OOB ? OOB : lrow0 * ng * 4u + off);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t i4 = base + (uint32_t)k * 64u + (uint32_t)lane;
+            if (i4 < nf4) {
+                const uint32_t e = i4 * 4u, r = (e * a.magic_ng) >> 20, g = e - r * ng;      // e / ng, e < 16 * ng
+                float *dw = wsl0 + r * ngp + g, *dx = xsl + r * ngp + g;
+                dw[0] = tw[k].x; dw[1] = tw[k].y; dw[2] = tw[k].z; dw[3] = tw[k].w;
+                dx[0] = tx[k].x; dx[1] = tx[k].y; dx[2] = tx[k].z; dx[3] = tx[k].w;
+                if (swiglu) { float *d1 = wsl1 + r * ngp + g; d1[0] = tw1[k].x; d1[1] = tw1[k].y; d1[2] = tw1[k].z; d1[3] = tw1[k].w; }
+            }
+        }
+    }
 
     float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (uint32_t g = 0; g < ng; g++) {                           // ascending groups: the reference's order (infer.c:668-674)
-        const uint32_t koff = g * GS;
-        const v4i c0 = group_mma<GS>(rw0, wrow + koff, rx, xrow == OOB ? OOB : xrow + koff, kq);
-        const float xsc = bload_f(rxs, xsrow == OOB ? OOB : xsrow + g * 4u);
-        float wsc[4];
+    for (uint32_t g0 = 0; g0 < ng; g0 += GB) {                    // ascending groups: the reference's order (infer.c:668-674)
+        if (g0) issue(g0, fa, fb, fa1);
 #pragma unroll
-        for (int i = 0; i < 4; i++) wsc[i] = bload_f(rs0, srow + ((uint32_t)i * ng + g) * 4u);
+        for (int gi = 0; gi < GB; gi++) {
+            const uint32_t g = g0 + gi;
+            if (g < ng) {
+                v4i c0 = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc0[i] += ((float)c0[i] * wsc[i]) * xsc;                   // infer.c:672
-        if (swiglu) {
-            const v4i c1 = group_mma<GS>(rw1, wrow + koff, rx, xrow == OOB ? OOB : xrow + koff, kq);
+                for (int ks = 0; ks < FR; ks++) c0 = mma<GS>(fa[gi][ks], fb[gi][ks], c0);
+                const float xsc = xsl[m * ngp + g];
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc1[i] += ((float)c1[i] * bload_f(rs1, srow + ((uint32_t)i * ng + g) * 4u)) * xsc;
+                for (int i = 0; i < 4; i++) acc0[i] += ((float)c0[i] * wsl0[(kq * 4u + i) * ngp + g]) * xsc;      // infer.c:672
+                if (swiglu) {
+                    v4i c1 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < FR; ks++) c1 = mma<GS>(fa1[gi][ks], fb[gi][ks], c1);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc1[i] += ((float)c1[i] * wsl1[(kq * 4u + i) * ngp + g]) * xsc;
+                }
+            }
         }
     }
     if (tok < a.nb) {
@@ -159,10 +211,16 @@ static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
     if (a.epi == GEMV_EPI_SWIGLU) { d.rows[1] = 0; d.rows[2] = 0; }
     d.n = a.n; d.ng = a.n / a.gs; d.epi = a.epi; d.nb = a.nb; d.ttiles = (a.nb + 15) / 16; d.n16 = (a.n + 15) & ~15u;
     d.xq = a.xq_in; d.xs = a.xs_in; d.pos = a.pos;
+    d.magic_ng = ((1u << 20) + d.ng - 1) / d.ng;               // e / ng == (e * magic) >> 20 for e < 16 * ng (checked below)
+    for (uint32_t e = 0; e < 16 * d.ng; e += 4) if (((e * d.magic_ng) >> 20) != e / d.ng) return hipErrorInvalidValue;
+    if (d.ng % 4) return hipErrorInvalidValue;                 // TODO: scalar staging for ng % 4 != 0 (no BASELINE shape)
     uint32_t rows = 0;
     if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
     const uint32_t pairs = ((rows + 15) / 16) * d.ttiles;
-    hipLaunchKernelGGL((gemm_q80_mfma_kernel<GS>), dim3((pairs + 3) / 4), dim3(256), 0, st, d);
+    const size_t lds = (size_t)4 * (a.epi == GEMV_EPI_SWIGLU ? 3 : 2) * 16 * (d.ng | 1u) * sizeof(float);
+    auto kern = &gemm_q80_mfma_kernel<GS>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((pairs + 3) / 4), dim3(256), lds, st, d);
     return hipGetLastError();
 }
 
