@@ -107,6 +107,12 @@ int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const uint32_t *po
 int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
                            uint32_t steps, uint32_t *out_ids);
 
+/* Batched prefill: feed `count` prompt tokens at positions pos0 .. pos0+count-1 of sequence `slot`, up
+ * to 64 (Q80) / 8 tokens per weight read instead of one forward per token; no logits are produced (the reference
+ * computes and discards them for prompt positions, infer.c:1146-1149, 1258-1260).  KV rows and all later outputs equal
+ * those of `count` nano_hip_forward() calls.  Replaces the prompt loop around llm_forward (infer.c:1258-1260). */
+int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *tokens, uint32_t pos0, uint32_t count);
+
 /* Blocks until all work queued on the model's stream has finished. */
 int nano_hip_sync(NanoHipModel *m);
 

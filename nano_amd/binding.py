@@ -60,6 +60,7 @@ def lib() -> C.CDLL:
     fn("nano_hip_weight_bytes_per_step", C.c_uint64, [vp])
     fn("nano_hip_forward", C.c_int, [vp, u32p, u32p, C.c_uint32, C.c_uint32, vp, vp])
     fn("nano_hip_decode_greedy", C.c_int, [vp, u32p, u32p, C.c_uint32, C.c_uint32, vp])
+    fn("nano_hip_prefill", C.c_int, [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32])
     fn("nano_hip_sync", C.c_int, [vp])
     fn("nano_hip_time_classifier", C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64)])
     fn("nano_hip_time_classifier_in_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_float)])
@@ -153,6 +154,11 @@ class DeviceModel:
         out = np.empty((steps, t.size), np.uint32) if fetch else None
         check(lib().nano_hip_decode_greedy(self.h, t, p, t.size, steps, out.ctypes.data if fetch else None))
         return out
+
+    def prefill(self, tokens: Sequence[int], pos0: int = 0, slot: int = 0):
+        """Batched prefill of one sequence: tokens at positions pos0.. (no logits)."""
+        t = np.ascontiguousarray(tokens, np.uint32).reshape(-1)
+        check(lib().nano_hip_prefill(self.h, slot, t, pos0, t.size))
 
     def sync(self):
         check(lib().nano_hip_sync(self.h))

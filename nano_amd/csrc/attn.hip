@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int q = 0; q < QV; q++) { const uint32_t f = j + (uint32_t)LPR * q; if (f * 4u < hd) *reinterpret_cast<float4 *>(krow + 4 * f) = kfresh[q]; }
         }
+        if (a.prep_only) return;                                  // batched prefill, pass 1: the k row is all that was wanted
     } else {
     if (!rope_staged) {
 #pragma unroll
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
     }
     __syncthreads();
+    if (a.prep_only) return;                                      // batched prefill, pass 1 (generic path)
 
     // ---- 3. scores, running softmax over rounds ------------------------------------------------------------------
 #pragma unroll

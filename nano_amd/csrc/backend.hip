@@ -53,6 +53,8 @@ struct NanoHipModel {
     NanoModelDesc d{};
     int device = 0, cus = 0;
     uint32_t S = 0, maxB = 0, hd = 0, QD = 0, KD = 0;
+    uint32_t Bs = 0;                                      // rows of the per-token scratch (>= maxB: a prefill chunk processes Bs prompt tokens of ONE sequence)
+    uint32_t pf_slot = 0; bool pf = false;                // prefill in progress: every token of the step lives in KV slot pf_slot
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     bool probe_cls = false;                               // record ev0 / ev1 / ev2 around the classifier launch of the next eager step
@@ -282,31 +284,35 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
 
     // ---- state ---------------------------------------------------------------------------------------
     const size_t B = max_batch;
+    // per-token scratch also serves batched prefill: up to 64 (Q80: int8 MFMA GEMM) / 8 prompt tokens per pass
+    const size_t PF = d.quant_type == NANO_QUANT_Q80 ? 64 : 8;
+    const size_t Bs = B > PF ? B : PF;
+    m->Bs = (uint32_t)Bs;
     const size_t kvn = B * L * max_seq_len * KD;
     m->trace_cap = max_seq_len * max_batch;
     m->nsplit = 8;                                       // partial buffers are sized for the maximum
-    bool ok = hipMalloc(&m->x, B * E * 4) == hipSuccess && hipMalloc(&m->q, B * QD * 4) == hipSuccess &&
-              hipMalloc(&m->kraw, B * KD * 4) == hipSuccess && hipMalloc(&m->xba, B * QD * 4) == hipSuccess &&
-              hipMalloc(&m->hb, B * H * 4) == hipSuccess && hipMalloc(&m->logits, B * V * 4) == hipSuccess &&
+    bool ok = hipMalloc(&m->x, Bs * E * 4) == hipSuccess && hipMalloc(&m->q, Bs * QD * 4) == hipSuccess &&
+              hipMalloc(&m->kraw, Bs * KD * 4) == hipSuccess && hipMalloc(&m->xba, Bs * QD * 4) == hipSuccess &&
+              hipMalloc(&m->hb, Bs * H * 4) == hipSuccess && hipMalloc(&m->logits, B * V * 4) == hipSuccess &&
               hipMalloc(&m->kcache, kvn * 4) == hipSuccess && hipMalloc(&m->vcache, kvn * 4) == hipSuccess &&
-              hipMalloc(&m->tokens, B * 4) == hipSuccess && hipMalloc(&m->pos, B * 4) == hipSuccess &&
+              hipMalloc(&m->tokens, Bs * 4) == hipSuccess && hipMalloc(&m->pos, Bs * 4) == hipSuccess &&
               hipMalloc(&m->amax, B * 4) == hipSuccess && hipMalloc(&m->trace, (size_t)m->trace_cap * 4) == hipSuccess &&
               hipMalloc(&m->pos0, B * 4) == hipSuccess &&
-              hipMalloc(&m->attn_part, B * m->nsplit * QD * 4) == hipSuccess &&
-              hipMalloc(&m->attn_ml, B * d.n_head * m->nsplit * 2 * 4) == hipSuccess &&
+              hipMalloc(&m->attn_part, Bs * m->nsplit * QD * 4) == hipSuccess &&
+              hipMalloc(&m->attn_ml, Bs * d.n_head * m->nsplit * 2 * 4) == hipSuccess &&
               hipMalloc(&m->tile_max, B * V * 2 * 4) == hipSuccess &&
-              hipMalloc(&m->rope_cur, B * m->hd * 4 + 64) == hipSuccess;
-    if (ok && B > 8 && d.quant_type == NANO_QUANT_Q80) {
+              hipMalloc(&m->rope_cur, Bs * m->hd * 4 + 64) == hipSuccess;
+    if (ok && Bs > 8 && d.quant_type == NANO_QUANT_Q80) {
         size_t nmax = E > QD ? E : QD; if (H > nmax) nmax = H;
-        ok = hipMalloc(&m->gq, B * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, B * (nmax / d.group_size) * 4) == hipSuccess;
+        ok = hipMalloc(&m->gq, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, Bs * (nmax / d.group_size) * 4) == hipSuccess;
     }
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
     // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
     if (hipMemset(m->kcache, 0, kvn * 4) != hipSuccess || hipMemset(m->vcache, 0, kvn * 4) != hipSuccess ||
-        hipMemset(m->x, 0, B * E * 4) != hipSuccess || hipMemset(m->logits, 0, B * V * 4) != hipSuccess ||
-        hipMemset(m->tokens, 0, B * 4) != hipSuccess || hipMemset(m->pos, 0, B * 4) != hipSuccess ||
+        hipMemset(m->x, 0, Bs * E * 4) != hipSuccess || hipMemset(m->logits, 0, B * V * 4) != hipSuccess ||
+        hipMemset(m->tokens, 0, Bs * 4) != hipSuccess || hipMemset(m->pos, 0, Bs * 4) != hipSuccess ||
         hipMemset(m->pos0, 0, B * 4) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "hipMemset failed"); }
-    ok = hipHostMalloc(&m->h_tokens, B * 4) == hipSuccess && hipHostMalloc(&m->h_pos, B * 4) == hipSuccess &&
+    ok = hipHostMalloc(&m->h_tokens, Bs * 4) == hipSuccess && hipHostMalloc(&m->h_pos, Bs * 4) == hipSuccess &&
          hipHostMalloc(&m->h_amax, (size_t)m->trace_cap * 4) == hipSuccess && hipHostMalloc(&m->h_logits, B * V * 4) == hipSuccess;
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipHostMalloc failed"); }
     if (hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
@@ -384,7 +390,9 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.nseg = 3;
             a.seg[0] = mkseg(m->W[WQ][l], m->q, QD, QD);
             a.seg[1] = mkseg(m->W[WK][l], m->kraw, KD, KD);
-            a.seg[2] = mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
+            // v goes straight to its cache row; prefill: every token of the step is a position of KV slot pf_slot
+            a.seg[2] = m->pf ? mkseg(m->W[WV][l], m->vcache + ((size_t)m->pf_slot * L * S + layer_rows) * KD, KD, 0, KD)
+                             : mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_STORE;
             a.norm_w = m->rms_attn + (size_t)l * E; a.pos = m->pos;
             if (!(skip & 1) && (e = gemv(m, a)) != hipSuccess) return e;
@@ -399,6 +407,16 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
             { static const char *dbg = getenv("NANO_ATTN_DBG"); a.dbg = dbg ? (uint32_t)atoi(dbg) : 0u; }
+            if (m->pf) {
+                // batched prefill: the nb tokens are consecutive positions of ONE sequence.  Pass 1 finishes every k row
+                // (norm + RoPE + cache write, nothing else) so that pass 2 finds the rows of the earlier tokens of the
+                // chunk in the cache; pass 2 is the ordinary decode attention per token (it recomputes its own k row).
+                a.kcache = m->kcache + (size_t)m->pf_slot * L * S * KD; a.vcache = m->vcache + (size_t)m->pf_slot * L * S * KD;
+                a.cache_bstride_rows = 0;
+                a.prep_only = 1;
+                if ((e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
+                a.prep_only = 0;
+            }
             if (!(skip & 2) && (e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
         }
         {   // x += Wo . xba   reference infer.c:885-908
@@ -501,6 +519,34 @@ extern "C" int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const u
     HIP_TRY(hipStreamSynchronize(m->st));
     if (logits_out) memcpy(logits_out, m->h_logits, batch * V * 4);
     if (argmax_out) memcpy(argmax_out, m->h_amax, batch * 4);
+    return 0;
+}
+
+// Batched prefill: feeds `count` prompt tokens at positions pos0 .. pos0+count-1 of sequence `slot` in
+// passes of up to 64 (Q80, int8 MFMA GEMM) / 8 tokens per weight read instead of one decode step per token; no
+// logits (the reference computes and discards them for prompt positions, infer.c:1146-1149).  The KV rows and every
+// later logit are the ones token-by-token feeding produces (same kernels per token).
+extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *tokens, uint32_t pos0, uint32_t count) {
+    if (!m || !tokens) FAIL(NANO_HIP_EINVAL, "null argument");
+    if (slot >= m->maxB) FAIL(NANO_HIP_EINVAL, "slot %u out of range (max_batch %u)", slot, m->maxB);
+    if ((uint64_t)pos0 + count > m->S) FAIL(NANO_HIP_EINVAL, "positions %u..%u exceed max_seq_len %u", pos0, pos0 + count, m->S);
+    for (uint32_t i = 0; i < count; i++) if (tokens[i] >= m->d.vocab_size) FAIL(NANO_HIP_EINVAL, "token %u out of vocabulary", tokens[i]);
+    HIP_TRY(hipSetDevice(m->device));
+    const uint32_t chunk_max = m->d.quant_type == NANO_QUANT_Q80 ? 64u : 8u;
+    for (uint32_t done = 0; done < count;) {
+        const uint32_t nb = (count - done < chunk_max) ? count - done : chunk_max;
+        for (uint32_t i = 0; i < nb; i++) { m->h_tokens[i] = tokens[done + i]; m->h_pos[i] = pos0 + done + i; }
+        HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, nb * 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, nb * 4, hipMemcpyHostToDevice, m->st));
+        uint32_t range_hint = ((pos0 + done + nb + 63) / 64) * 64;
+        if (range_hint > m->S) range_hint = m->S;
+        m->pf = true; m->pf_slot = slot;
+        hipError_t e = enqueue_step(m, nb, 1, MODE_NOCLS, range_hint);      // eager: one pass per chunk
+        m->pf = false;
+        HIP_TRY(e);
+        HIP_TRY(hipStreamSynchronize(m->st));                              // h_tokens / h_pos are reused by the next chunk
+        done += nb;
+    }
     return 0;
 }
 

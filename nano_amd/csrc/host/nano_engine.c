@@ -330,6 +330,9 @@ Sampler *build_sampler(int vocab_size, float repetition_penalty, float temperatu
 }
 void free_sampler(Sampler *s) { if (s) { free(s->probindex); free(s); } }
 
+/* set by step_core while it calls generate_next_token for a prompt position its batched prefill already covered */
+static int g_position_prefilled = 0;
+
 /* reference infer/infer.c:1135-1193 */
 uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t pos, int is_prefilling) {
     LLM *llm = ctx->llm;
@@ -340,9 +343,10 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
 
     if (is_prefilling == 1) {
         /* the reference computes the logits of prompt positions and discards them (infer.c:1146-1149):
-         * skip the classifier, the KV rows written are the same */
+         * skip the classifier, the KV rows written are the same.  Inside a session step the whole prompt may
+         * already have been fed by one batched prefill (step_core): nothing left to do for this position. */
         observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
-        if (nano_hip_forward(dev, &token, &pos, 1, 1, NULL, NULL) != NANO_HIP_OK) die_hip("generate_next_token");
+        if (!g_position_prefilled && nano_hip_forward(dev, &token, &pos, 1, 1, NULL, NULL) != NANO_HIP_OK) die_hip("generate_next_token");
         return output_ids[pos + 1];
     }
 
@@ -417,7 +421,23 @@ static int32_t step_core(Nano_Context *ctx, Nano_Session *s, int with_text) {
     if (s->pos >= s->max_seq_len) return LLM_STOPPED_WITH_ERROR;
     if (s->output_text) { free(s->output_text); s->output_text = NULL; }
     s->is_prefilling = (s->pos < s->num_prompt_tokens - 1) ? 1 : 0;
+    /* Batched prefill: at the first step of a session the prompt positions 0 .. n-2 are fed in one
+     * call (<= 64 / 8 tokens per weight read) instead of one forward per step; the per-step protocol (status codes,
+     * callbacks, output_text) is unchanged, the following prefilling steps just find their position done.
+     * NANO_NO_BATCHED_PREFILL=1 restores one forward per prompt token. */
+    static const Nano_Session *pf_session = NULL;
+    static uint32_t pf_upto = 0;
+    if (s->pos == 0) {
+        pf_session = NULL;
+        NanoHipModel *dev = reg_get(ctx->llm);
+        if (dev && s->num_prompt_tokens > 2 && s->num_prompt_tokens - 1 <= s->max_seq_len && !getenv("NANO_NO_BATCHED_PREFILL")) {
+            if (nano_hip_prefill(dev, 0, s->output_ids, 0, s->num_prompt_tokens - 1) != NANO_HIP_OK) die_hip("llm_session_step (prefill)");
+            pf_session = s; pf_upto = s->num_prompt_tokens - 1;
+        }
+    }
+    g_position_prefilled = (pf_session == s && s->is_prefilling == 1 && s->pos < pf_upto) ? 1 : 0;
     s->next_token = generate_next_token(ctx, s->output_ids, s->pos, s->is_prefilling);
+    g_position_prefilled = 0;
     const uint32_t arch = ctx->llm->arch;
     if (arch != LLM_ARCH_NANO && arch != LLM_ARCH_QWEN2 && arch != LLM_ARCH_QWEN3) { printf("Error: unknown LLM arch.\n"); return LLM_STOPPED_WITH_ERROR; }
     uint32_t *text_ids; uint32_t text_n;

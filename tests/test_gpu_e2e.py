@@ -127,6 +127,36 @@ def test_large_batch_mfma_gemm_path(model_dir, B):
     assert worst < TOL["q80"]
 
 
+@pytest.mark.parametrize("preset,quant,gs,T", [("tiny-qwen3", "q80", 64, 5), ("tiny-qwen3", "q80", 64, 23), ("tiny-qwen3", "q80", 64, 70),
+                                               ("tiny-nano", "f32", 0, 11), ("tiny-nano-odd", "q4k", 0, 13), ("tiny-qwen3", "f32", 0, 9)])
+def test_batched_prefill_equals_token_by_token(model_dir, preset, quant, gs, T):
+    """nano_hip_prefill (<= 64 / 8 prompt tokens per weight read) leaves the KV cache and the next logits exactly as
+    feeding the prompt one token at a time does (same kernels per token; Q80 chunks > 8 take the MFMA GEMM)."""
+    path, spec = synth_model(model_dir, preset, quant, gs)
+    from nano_amd import modelfile as mf
+    S = 96
+    ids = mf.prompt_ids(500 + T, T + 3, spec.vocab_size)
+    ma = nb.load_model_file(path, max_seq_len=S, max_batch=2)
+    for p in range(T):
+        ma.forward([int(ids[p])], [p], want_logits=False)
+    ref = [ma.forward([int(ids[T + i])], [T + i])[0][0] for i in range(3)]
+    kv_dim = spec.kv_dim
+    ref_k = ma.read_state("k", kv_dim, layer=spec.n_layer - 1, pos=T - 1); ref_v = ma.read_state("v", kv_dim, layer=0, pos=T // 2)
+    ma.close()
+    mb = nb.load_model_file(path, max_seq_len=S, max_batch=2)
+    mb.prefill(ids[:T], pos0=0, slot=1)                      # a non-zero slot: the KV aliasing must honour it
+    got_k = mb.read_state("k", kv_dim, slot=1, layer=spec.n_layer - 1, pos=T - 1); got_v = mb.read_state("v", kv_dim, slot=1, layer=0, pos=T // 2)
+    got = []
+    for i in range(3):
+        lg, _ = mb.forward([0, int(ids[T + i])], [0, T + i])           # slot 0 idles at pos 0, slot 1 continues the prompt
+        got.append(lg[1])
+    mb.close()
+    worst = max(rel_err(g, r) for g, r in zip(got, ref))
+    exact = all(np.array_equal(g, r) for g, r in zip(got, ref)) and np.array_equal(got_k, ref_k) and np.array_equal(got_v, ref_v)
+    print(f"prefill {preset}/{quant} T={T}: worst rel err of the next 3 logits {worst:.3e}, bit-identical (logits + KV rows): {exact}")
+    assert worst < TOL[quant] * 1e-2 and rel_err(got_k, ref_k) < 1e-6 and rel_err(got_v, ref_v) < 1e-6
+
+
 def test_ragged_positions_in_one_batch(model_dir):
     """Slots at different positions in the same step (pos is per slot)."""
     path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)
