@@ -347,6 +347,18 @@ static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
         a.xq_in = m->gq; a.xs_in = m->gxs;
         return launch_gemm_q80(a, m->st);
     }
+    if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 1 && !a.attn_part && m->gq && m->gxs) {
+        // every workgroup of a GEMV launch re-quantizes the nb x n activations; when that redundant work outweighs a
+        // launch (~3 us) the activations are quantized once (quant_rows_kernel) and the GEMV reads them back
+        uint32_t rows = 0;
+        if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
+        const uint64_t redundant = (uint64_t)(rows / 16) * a.nb * a.n;          // ~ workgroups x elements
+        if (redundant > (4u << 20)) {
+            hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
+            if (e != hipSuccess) return e;
+            a.xq_in = m->gq; a.xs_in = m->gxs; a.norm_w = nullptr;
+        }
+    }
     return launch_gemv(m->d.quant_type, a, max_wg, m->st);
 }
 
@@ -368,6 +380,7 @@ static uint32_t step_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_h
     uint32_t ns = attention_nsplit(range_hint, m->hd);
     if (nb >= 4) { const uint32_t div = nb / 2; ns = (ns + div - 1) / div; }
     if (nb > 8) ns = 1;                 // the MFMA GEMM path takes plain activations only
+    if (nb > 1 && (uint64_t)(m->d.n_embd / 16) * nb * m->QD > (4u << 20)) ns = 1;   // ditto the quantize-once GEMV path (see gemv())
     return ns ? ns : 1;
 }
 

@@ -50,9 +50,12 @@ template <int ROLE, int GS, int B, int NV>
 __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r, int8_t *xq, float *xs, float *red, uint32_t n16, uint32_t ng4) {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n, ng = a.ng;
     const uint32_t lane = tid & 63u, wid = tid >> 6, NW = nthr >> 6;
-    if (has_flag<ROLE>(a, F_PRE)) { // operator-test path: the caller supplies the quantized activation (one sequence)
-        for (uint32_t i = tid * 16u; i < n; i += nthr * 16u) *reinterpret_cast<int4 *>(xq + i) = *reinterpret_cast<const int4 *>(a.xq_in + i);
-        for (uint32_t i = tid; i < ng; i += nthr) xs[i] = a.xs_in[i];
+    if (has_flag<ROLE>(a, F_PRE)) { // the activations arrive quantized: xq_in[nb][n16], xs_in[nb][ng] (operator tests; large
+                                    // batch x row-length products, where quant_rows_kernel quantizes ONCE instead of once per workgroup)
+        for (uint32_t b = 0; b < a.nb; b++) {
+            for (uint32_t i = tid * 16u; i < n; i += nthr * 16u) *reinterpret_cast<int4 *>(xq + b * n16 + i) = *reinterpret_cast<const int4 *>(a.xq_in + (size_t)b * n16 + i);
+            for (uint32_t i = tid; i < ng; i += nthr) xs[b * ng4 + i] = a.xs_in[(size_t)b * ng + i];
+        }
         __syncthreads();
         return;
     }
@@ -478,9 +481,17 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     uint32_t align = 0;                                   // a workgroup's rows must lie inside one segment
     if (nseg > 1) for (uint32_t s = 0; s < nseg; s++) align |= a.seg[s].rows;
     const uint32_t rows = total_rows(a);
-    // ~4 units (16 KiB of weights) per matrix per workgroup, >= 128 workgroups
+    // Every workgroup re-stages the activations (B x n elements), so the row slab grows until one wave of workgroups
+    // covers the chip: the largest power of two with >= 256 workgroups (small matrices: ~4 units = 16 KiB of weights per
+    // matrix and >= 128 workgroups, the tuned batch-1 optimum), bounded by the LDS product table.
     uint32_t rw = 4;
     while (rw < 32 && (align % (rw * 2)) == 0 && (rw * 2 / 4) * nchunk <= 4 && rows / (rw * 2) >= 128) rw *= 2;
+    while (rw < 64 && (align % (rw * 2)) == 0 && rows / (rw * 2) >= 256) rw *= 2;
+    {
+        const uint32_t ng = a.n / a.gs, pitch = ((ng + 47) / 64) * 64 + 16;
+        while (rw > 4 && (size_t)B * nmat * rw * pitch * 4 > 64 * 1024) rw /= 2;
+        while (rw > 4 && (rw / 4) * nchunk * nmat > 64) rw /= 2;          // <= 16 waves x 4 units
+    }
     const uint32_t units = (rw / 4) * nchunk * nmat;
     uint32_t nw = units < 4 ? units : 4;
     uint32_t want = (a.n * (uint32_t)(B > 2 ? B / 2 : 1) + 511) / 512;     // idle waves still help the activation prologue
