@@ -5,9 +5,9 @@
 // group product ((float)ival * ws[r][g]) * xs[t][g] is applied on the VALU and accumulated per (row, token) in
 // ascending group order, exactly like the GEMV kernels.
 //
-// Mapping: a wave owns one (16-row tile, 16-token tile) pair and walks all groups of the row in order; the waves of a
-// workgroup are the token tiles of the same rows, so the weight bytes come from HBM once and from the CU's L1 for
-// the other token tiles.  MFMA operand layout (verified on gfx950, tools/kbench/mfma_probe.hip): lane l holds
+// Mapping: a workgroup owns a 16-row tile and stages its weights in LDS with coalesced 1 KiB loads; wave w owns token
+// tile w and walks all groups of the row in order, so the weight bytes are read from HBM once for up to 64 tokens.
+// MFMA operand layout (verified on gfx950, tools/kbench/mfma_probe.hip): lane l holds
 // A[m = l%16][k = 16*(l/16) .. +15], B[k = same][n = l%16]; result c[i] = C[m = 4*(l/16) + i][n = l%16].
 // The activations of all tokens are quantized once per GEMM by quant_rows_kernel (rmsnorm + quantize, reference
 // infer/tensor.c:21-46, infer.c:601-614) into a global scratch the GEMM reads through L2.
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const float *x, uint32_
 struct GemmDev {
     const int8_t *w[3]; const float *ws[3]; float *out[3];
     uint32_t rows[3], out_bstride[3], out_pstride[3];
-    uint32_t n, ng, epi, nb, ttiles, n16, magic_ng, _pad;
+    uint32_t n, ng, epi, nb, ttiles, n16, magic_ng, kc;
     const int8_t *xq; const float *xs; const uint32_t *pos;
 };
 
@@ -87,21 +87,33 @@ __device__ __forceinline__ v4i mma(const Frag<GS> &a, const Frag<GS> &b, v4i c) 
     else return __builtin_amdgcn_mfma_i32_16x16x64_i8(a.v, b.v, c, 0, 0, 0);
 }
 
+// LDS fragment read of a staged weight row (row pitch KP bytes)
+template <int GS>
+__device__ __forceinline__ Frag<GS> lds_frag(const int8_t *row, uint32_t koff, uint32_t kq, int ks) {
+    Frag<GS> f;
+    if constexpr (GS == 32) f.v = *reinterpret_cast<const long *>(row + koff + kq * 8u);
+    else f.v = *reinterpret_cast<const i32x4 *>(row + koff + (uint32_t)ks * 64u + kq * 16u);
+    return f;
+}
+
+// One workgroup = one 16-row tile (both matrices for SwiGLU); wave w = token tile w.  The tile's weights are staged in
+// LDS with fully coalesced loads (each wave streams 4 rows, 1 KiB per load instruction), up to KC bytes of row length
+// per pass, all loads of a pass issued before the first LDS write; the MFMA A fragments are then ds_read_b128 at
+// row pitch KC+16 (conflict-free: consecutive rows are 4 banks apart).  B fragments (this wave's 16 tokens) come
+// straight from the quantized-activation scratch through L2, 16 in flight per batch.
 template <int GS>
 __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    constexpr int FR = GS >= 64 ? GS / 64 : 1;                  // fragments per group
-    constexpr int GB = 16 / FR;                                 // groups per batch: 16 fragment loads per operand in flight
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int FR = GS >= 64 ? GS / 64 : 1;                  // MFMA fragments per group
+    constexpr int GB = 16 / FR;                                 // groups per B-fragment batch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t n = a.n, ng = a.ng, ngp = ng | 1u;            // odd LDS pitch: conflict-free row-strided reads
+    const uint32_t n = a.n, ng = a.ng, ngp = ng | 1u;            // odd LDS pitch for the scale tables
     const bool swiglu = a.epi == GEMV_EPI_SWIGLU;
-    // (row tile, token tile) pair of this wave; token tile fastest: the waves of a workgroup share their rows
-    const uint32_t pair = blockIdx.x * 4u + (uint32_t)wid;
-    const uint32_t tt = pair % a.ttiles, rt = pair / a.ttiles;
-    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1], total = swiglu ? a.rows[0] : b1 + a.rows[2];
-    const uint32_t grow0 = rt * 16u;
-    if (grow0 >= total) return;                                  // wave-uniform; no workgroup barrier below
+    const uint32_t nmat = swiglu ? 2u : 1u;
+    const uint32_t KC = a.kc, KP = KC + 16u;                     // row bytes staged per pass, LDS row pitch
+    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
+    const uint32_t grow0 = blockIdx.x * 16u;
     const int sel = swiglu ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
     const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
     const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
@@ -111,82 +123,118 @@ __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
     const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
     const uint32_t lrow0 = grow0 - (sel == 0 ? 0u : sel == 1 ? b0 : b1);
 
+    // LDS: wt[nmat][16][KP] int8 | wsl[nmat][16][ngp] | xsl[4 waves][16][ngp]
+    int8_t *wt = reinterpret_cast<int8_t *>(smem);
+    float *wsl = reinterpret_cast<float *>(smem + (size_t)nmat * 16u * KP);
+    float *xsl = wsl + (size_t)nmat * 16u * ngp + (size_t)wid * 16u * ngp;
+
     const uint32_t m = (uint32_t)lane & 15u, kq = (uint32_t)lane >> 4;
     const __amdgpu_buffer_rsrc_t rw0 = mkrsrc(w0, rows0 * n), rw1 = mkrsrc(swiglu ? a.w[1] : nullptr, swiglu ? rows0 * n : 0u);
     const __amdgpu_buffer_rsrc_t rs0 = mkrsrc(ws0, rows0 * ng * 4u), rs1 = mkrsrc(swiglu ? a.ws[1] : nullptr, swiglu ? rows0 * ng * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xq, a.nb * a.n16), rxs = mkrsrc(a.xs, a.nb * ng * 4u);
-    const uint32_t wrow = (lrow0 + m) * n;                        // A operand: weight row lrow0 + m  (rows beyond the segment: out of range -> 0)
-    const uint32_t tok = tt * 16u + m;                           // B operand / result column: token
-    const uint32_t xrow = tok < a.nb ? tok * a.n16 : OOB;
+    const bool has_tile = (uint32_t)wid < a.ttiles;               // waves beyond the token tiles only help staging
+    const uint32_t tok = (uint32_t)wid * 16u + m;
+    const uint32_t xrow = (has_tile && tok < a.nb) ? tok * a.n16 : OOB;
 
-    // ---- fragment loads of the first group batch go out first; the scales of the tile follow ------------------------
-    auto issue = [&](uint32_t g0, Frag<GS> (&fa)[GB][FR], Frag<GS> (&fb)[GB][FR], Frag<GS> (&fa1)[GB][FR]) {
+    // ---- pass 0 loads first: this wave's 4 weight rows (per matrix), 4 x 1 KiB each, then the first B fragments ----
+    int4 stg[2][4][4];                                            // [matrix][row of this wave][1 KiB column chunk]
+    auto issue_w = [&](uint32_t c0) {
 #pragma unroll
-        for (int gi = 0; gi < GB; gi++) {
-            const uint32_t g = g0 + gi;
-            const uint32_t wo = g < ng ? wrow + g * GS : OOB, xo = (g < ng && xrow != OOB) ? xrow + g * GS : OOB;
+        for (int mt = 0; mt < 2; mt++) {
+            if (mt < (int)nmat) {
 #pragma unroll
-            for (int ks = 0; ks < FR; ks++) {
-                fa[gi][ks] = load_frag<GS>(rw0, wo, kq, ks);
-                fb[gi][ks] = load_frag<GS>(rx, xo, kq, ks);
-                if (swiglu) fa1[gi][ks] = load_frag<GS>(rw1, wo, kq, ks);
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t row = lrow0 + (uint32_t)wid * 4u + r;
+#pragma unroll
+                    for (int jc = 0; jc < 4; jc++) {
+                        const uint32_t col = (uint32_t)jc * 1024u + (uint32_t)lane * 16u;       // inside the pass
+                        if ((uint32_t)jc * 1024u < KC) {                                         // uniform: an out-of-range load is not free
+                            const uint32_t off = (c0 + col < n) ? row * n + c0 + col : OOB;
+                            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mt ? rw1 : rw0, (int)off, 0, 2);
+                            stg[mt][r][jc] = make_int4(v.x, v.y, v.z, v.w);
+                        }
+                    }
+                }
             }
         }
     };
-    Frag<GS> fa[GB][FR], fb[GB][FR], fa1[GB][FR];
-    issue(0, fa, fb, fa1);
-
-    // scales into wave-private LDS: ws[16 rows][ng] and xs[16 tokens][ng] of a tile are contiguous blocks of 16*ng
-    // floats; all loads of a pass are issued before the first LDS write (one round trip per 3 x 64 float4)
-    float *wsl0 = smem_f + (size_t)wid * (swiglu ? 3u : 2u) * 16u * ngp, *xsl = wsl0 + 16u * ngp, *wsl1 = xsl + 16u * ngp;
-    const uint32_t nf4 = 4u * ng;                                  // float4 items per block (ng % 4 == 0 checked by the launcher)
-    for (uint32_t base = 0; base < nf4; base += 192u) {
-        float4 tw[3], tx[3], tw1[3];
+    Frag<GS> fb[GB][FR];
+    auto issue_b = [&](uint32_t g0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t i4 = base + (uint32_t)k * 64u + (uint32_t)lane;
-            const uint32_t off = i4 < nf4 ? i4 * 16u : OOB;
-            tw[k] = bload_f4(rs0, off == OOB ? OOB : lrow0 * ng * 4u + off);
-            tx[k] = bload_f4(rxs, off == OOB ? OOB : tt * 16u * ng * 4u + off);     // tokens >= nb: out of range -> 0
-            if (swiglu) tw1[k] = bload_f4(rs1, off == OOB ? OOB : lrow0 * ng * 4u + off);
+        for (int gi = 0; gi < GB; gi++) {
+            const uint32_t g = g0 + gi;
+            const uint32_t xo = (g < ng && xrow != OOB) ? xrow + g * GS : OOB;
+#pragma unroll
+            for (int ks = 0; ks < FR; ks++) fb[gi][ks] = load_frag<GS>(rx, xo, kq, ks);
         }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t i4 = base + (uint32_t)k * 64u + (uint32_t)lane;
-            if (i4 < nf4) {
-                const uint32_t e = i4 * 4u, r = (e * a.magic_ng) >> 20, g = e - r * ng;      // e / ng, e < 16 * ng
-                float *dw = wsl0 + r * ngp + g, *dx = xsl + r * ngp + g;
-                dw[0] = tw[k].x; dw[1] = tw[k].y; dw[2] = tw[k].z; dw[3] = tw[k].w;
-                dx[0] = tx[k].x; dx[1] = tx[k].y; dx[2] = tx[k].z; dx[3] = tx[k].w;
-                if (swiglu) { float *d1 = wsl1 + r * ngp + g; d1[0] = tw1[k].x; d1[1] = tw1[k].y; d1[2] = tw1[k].z; d1[3] = tw1[k].w; }
+    };
+    issue_w(0);
+    if (has_tile) issue_b(0);
+
+    // scales: ws tile (shared by the waves) and this wave's xs tile -> LDS, all loads of a pass before the first write
+    const uint32_t nf4 = 4u * ng;                                  // float4 items per 16 x ng block (ng % 4 == 0)
+    for (uint32_t base = 0; base < nf4; base += 64u) {
+        const uint32_t i4 = base + (uint32_t)lane;
+        const uint32_t off = i4 < nf4 ? i4 * 16u : OOB;
+        float4 tw = make_float4(0.f, 0.f, 0.f, 0.f), tw1 = tw;
+        // the four waves split the weight-scale block; every wave loads its own activation-scale block
+        const bool mine = ((base >> 6) & 3u) == (uint32_t)wid;
+        if (mine) { tw = bload_f4(rs0, off == OOB ? OOB : lrow0 * ng * 4u + off); if (swiglu) tw1 = bload_f4(rs1, off == OOB ? OOB : lrow0 * ng * 4u + off); }
+        const float4 tx = bload_f4(rxs, (off == OOB || !has_tile) ? OOB : (uint32_t)wid * 16u * ng * 4u + off);
+        if (i4 < nf4) {
+            const uint32_t e = i4 * 4u, r = (e * a.magic_ng) >> 20, g = e - r * ng;      // e / ng, e < 16 * ng
+            if (mine) {
+                float *dw = wsl + r * ngp + g; dw[0] = tw.x; dw[1] = tw.y; dw[2] = tw.z; dw[3] = tw.w;
+                if (swiglu) { float *d1 = wsl + 16u * ngp + r * ngp + g; d1[0] = tw1.x; d1[1] = tw1.y; d1[2] = tw1.z; d1[3] = tw1.w; }
             }
+            float *dx = xsl + r * ngp + g; dx[0] = tx.x; dx[1] = tx.y; dx[2] = tx.z; dx[3] = tx.w;
         }
     }
 
     float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t g0 = 0; g0 < ng; g0 += GB) {                    // ascending groups: the reference's order (infer.c:668-674)
-        if (g0) issue(g0, fa, fb, fa1);
+    for (uint32_t c0 = 0; c0 < n; c0 += KC) {                     // passes over the row length (one for n <= KC)
+        if (c0) { __syncthreads(); issue_w(c0); }                  // everybody is done reading the previous pass
 #pragma unroll
-        for (int gi = 0; gi < GB; gi++) {
-            const uint32_t g = g0 + gi;
-            if (g < ng) {
-                v4i c0 = {0, 0, 0, 0};
+        for (int mt = 0; mt < 2; mt++) {
+            if (mt < (int)nmat) {
 #pragma unroll
-                for (int ks = 0; ks < FR; ks++) c0 = mma<GS>(fa[gi][ks], fb[gi][ks], c0);
-                const float xsc = xsl[m * ngp + g];
+                for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc0[i] += ((float)c0[i] * wsl0[(kq * 4u + i) * ngp + g]) * xsc;      // infer.c:672
-                if (swiglu) {
-                    v4i c1 = {0, 0, 0, 0};
+                    for (int jc = 0; jc < 4; jc++) {
+                        const uint32_t col = (uint32_t)jc * 1024u + (uint32_t)lane * 16u;
+                        if (col < KC) *reinterpret_cast<int4 *>(wt + ((size_t)mt * 16u + (uint32_t)wid * 4u + r) * KP + col) = stg[mt][r][jc];
+                    }
+            }
+        }
+        __syncthreads();
+        if (has_tile) {
+            const uint32_t gbeg = c0 / GS, gend = min(ng, (c0 + KC) / GS);
+            for (uint32_t g0 = gbeg; g0 < gend; g0 += GB) {       // ascending groups: the reference's order (infer.c:668-674)
+                if (g0) issue_b(g0);
 #pragma unroll
-                    for (int ks = 0; ks < FR; ks++) c1 = mma<GS>(fa1[gi][ks], fb[gi][ks], c1);
+                for (int gi = 0; gi < GB; gi++) {
+                    const uint32_t g = g0 + gi;
+                    if (g < gend) {
+                        const uint32_t koff = g * GS - c0;
+                        v4i c0v = {0, 0, 0, 0};
 #pragma unroll
-                    for (int i = 0; i < 4; i++) acc1[i] += ((float)c1[i] * wsl1[(kq * 4u + i) * ngp + g]) * xsc;
+                        for (int ks = 0; ks < FR; ks++) c0v = mma<GS>(lds_frag<GS>(wt + (size_t)m * KP, koff, kq, ks), fb[gi][ks], c0v);
+                        const float xsc = xsl[m * ngp + g];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) acc0[i] += ((float)c0v[i] * wsl[(kq * 4u + i) * ngp + g]) * xsc;          // infer.c:672
+                        if (swiglu) {
+                            v4i c1v = {0, 0, 0, 0};
+#pragma unroll
+                            for (int ks = 0; ks < FR; ks++) c1v = mma<GS>(lds_frag<GS>(wt + ((size_t)16u + m) * KP, koff, kq, ks), fb[gi][ks], c1v);
+#pragma unroll
+                            for (int i = 0; i < 4; i++) acc1[i] += ((float)c1v[i] * wsl[16u * ngp + (kq * 4u + i) * ngp + g]) * xsc;
+                        }
+                    }
                 }
             }
         }
     }
-    if (tok < a.nb) {
+    if (has_tile && tok < a.nb) {
         float *o = out0 + (size_t)tok * obs + (ops ? (size_t)a.pos[tok] * ops : 0);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -216,11 +264,16 @@ static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
     if (d.ng % 4) return hipErrorInvalidValue;                 // TODO: scalar staging for ng % 4 != 0 (no BASELINE shape)
     uint32_t rows = 0;
     if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
-    const uint32_t pairs = ((rows + 15) / 16) * d.ttiles;
-    const size_t lds = (size_t)4 * (a.epi == GEMV_EPI_SWIGLU ? 3 : 2) * 16 * (d.ng | 1u) * sizeof(float);
+    if (d.ttiles > 4) return hipErrorInvalidValue;
+    const uint32_t nmat = a.epi == GEMV_EPI_SWIGLU ? 2 : 1;
+    d.kc = nmat == 2 ? 2048u : 4096u;                            // row bytes staged per pass (<= 66 KB of LDS for the weights)
+    const uint32_t n1k = (d.n + 1023) & ~1023u;
+    if (d.kc > n1k) d.kc = n1k;
+    const uint32_t ngp = d.ng | 1u;
+    const size_t lds = (size_t)nmat * 16 * (d.kc + 16) + ((size_t)nmat * 16 * ngp + (size_t)4 * 16 * ngp) * sizeof(float);
     auto kern = &gemm_q80_mfma_kernel<GS>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((pairs + 3) / 4), dim3(256), lds, st, d);
+    hipLaunchKernelGGL(kern, dim3((rows + 15) / 16), dim3(256), lds, st, d);
     return hipGetLastError();
 }
 
