@@ -101,7 +101,7 @@ __device__ __forceinline__ Frag<GS> lds_frag(const int8_t *row, uint32_t koff, u
 // per pass, all loads of a pass issued before the first LDS write; the MFMA A fragments are then ds_read_b128 at
 // row pitch KC+16 (conflict-free: consecutive rows are 4 banks apart).  B fragments (this wave's 16 tokens) come
 // straight from the quantized-activation scratch through L2, 16 in flight per batch.
-template <int GS>
+template <int GS, bool SW>
 __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int FR = GS >= 64 ? GS / 64 : 1;                  // MFMA fragments per group
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n = a.n, ng = a.ng, ngp = ng | 1u;            // odd LDS pitch for the scale tables
-    const bool swiglu = a.epi == GEMV_EPI_SWIGLU;
-    const uint32_t nmat = swiglu ? 2u : 1u;
+    constexpr bool swiglu = SW;                                  // compile-time: no per-group branches
+    constexpr uint32_t nmat = SW ? 2u : 1u;
     const uint32_t KC = a.kc, KP = KC + 16u;                     // row bytes staged per pass, LDS row pitch
     const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
     const uint32_t grow0 = blockIdx.x * 16u;
@@ -137,11 +137,11 @@ __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
     const uint32_t xrow = (has_tile && tok < a.nb) ? tok * a.n16 : OOB;
 
     // ---- pass 0 loads first: this wave's 4 weight rows (per matrix), 4 x 1 KiB each, then the first B fragments ----
-    int4 stg[2][4][4];                                            // [matrix][row of this wave][1 KiB column chunk]
+    int4 stg[SW ? 2 : 1][4][4];                                   // [matrix][row of this wave][1 KiB column chunk]
     auto issue_w = [&](uint32_t c0) {
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            if (mt < (int)nmat) {
+        for (int mt = 0; mt < (int)nmat; mt++) {
+            {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const uint32_t row = lrow0 + (uint32_t)wid * 4u + r;
@@ -173,21 +173,28 @@ __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
 
     // scales: ws tile (shared by the waves) and this wave's xs tile -> LDS, all loads of a pass before the first write
     const uint32_t nf4 = 4u * ng;                                  // float4 items per 16 x ng block (ng % 4 == 0)
-    for (uint32_t base = 0; base < nf4; base += 64u) {
-        const uint32_t i4 = base + (uint32_t)lane;
-        const uint32_t off = i4 < nf4 ? i4 * 16u : OOB;
-        float4 tw = make_float4(0.f, 0.f, 0.f, 0.f), tw1 = tw;
-        // the four waves split the weight-scale block; every wave loads its own activation-scale block
-        const bool mine = ((base >> 6) & 3u) == (uint32_t)wid;
-        if (mine) { tw = bload_f4(rs0, off == OOB ? OOB : lrow0 * ng * 4u + off); if (swiglu) tw1 = bload_f4(rs1, off == OOB ? OOB : lrow0 * ng * 4u + off); }
-        const float4 tx = bload_f4(rxs, (off == OOB || !has_tile) ? OOB : (uint32_t)wid * 16u * ng * 4u + off);
-        if (i4 < nf4) {
-            const uint32_t e = i4 * 4u, r = (e * a.magic_ng) >> 20, g = e - r * ng;      // e / ng, e < 16 * ng
-            if (mine) {
-                float *dw = wsl + r * ngp + g; dw[0] = tw.x; dw[1] = tw.y; dw[2] = tw.z; dw[3] = tw.w;
-                if (swiglu) { float *d1 = wsl + 16u * ngp + r * ngp + g; d1[0] = tw1.x; d1[1] = tw1.y; d1[2] = tw1.z; d1[3] = tw1.w; }
+    for (uint32_t base = 0; base < nf4; base += 256u) {           // 4 x 64 items per pass: one round trip for ng <= 64
+        float4 tw[4], tw1[4], tx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i4 = base + (uint32_t)k * 64u + (uint32_t)lane;
+            const uint32_t off = i4 < nf4 ? i4 * 16u : OOB;
+            const bool mine = (uint32_t)k == (uint32_t)wid;       // the four waves split the weight-scale block
+            tw[k] = tw1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mine) { tw[k] = bload_f4(rs0, off == OOB ? OOB : lrow0 * ng * 4u + off); if (swiglu) tw1[k] = bload_f4(rs1, off == OOB ? OOB : lrow0 * ng * 4u + off); }
+            tx[k] = bload_f4(rxs, (off == OOB || !has_tile) ? OOB : (uint32_t)wid * 16u * ng * 4u + off);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i4 = base + (uint32_t)k * 64u + (uint32_t)lane;
+            if (i4 < nf4) {
+                const uint32_t e = i4 * 4u, r = (e * a.magic_ng) >> 20, g = e - r * ng;      // e / ng, e < 16 * ng
+                if ((uint32_t)k == (uint32_t)wid) {
+                    float *dw = wsl + r * ngp + g; dw[0] = tw[k].x; dw[1] = tw[k].y; dw[2] = tw[k].z; dw[3] = tw[k].w;
+                    if (swiglu) { float *d1 = wsl + 16u * ngp + r * ngp + g; d1[0] = tw1[k].x; d1[1] = tw1[k].y; d1[2] = tw1[k].z; d1[3] = tw1[k].w; }
+                }
+                float *dx = xsl + r * ngp + g; dx[0] = tx[k].x; dx[1] = tx[k].y; dx[2] = tx[k].z; dx[3] = tx[k].w;
             }
-            float *dx = xsl + r * ngp + g; dx[0] = tx.x; dx[1] = tx.y; dx[2] = tx.z; dx[3] = tx.w;
         }
     }
 
@@ -195,8 +202,8 @@ __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
     for (uint32_t c0 = 0; c0 < n; c0 += KC) {                     // passes over the row length (one for n <= KC)
         if (c0) { __syncthreads(); issue_w(c0); }                  // everybody is done reading the previous pass
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            if (mt < (int)nmat) {
+        for (int mt = 0; mt < (int)nmat; mt++) {
+            {
 #pragma unroll
                 for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -271,9 +278,15 @@ static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
     if (d.kc > n1k) d.kc = n1k;
     const uint32_t ngp = d.ng | 1u;
     const size_t lds = (size_t)nmat * 16 * (d.kc + 16) + ((size_t)nmat * 16 * ngp + (size_t)4 * 16 * ngp) * sizeof(float);
-    auto kern = &gemm_q80_mfma_kernel<GS>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((rows + 15) / 16), dim3(256), lds, st, d);
+    if (nmat == 2) {
+        auto kern = &gemm_q80_mfma_kernel<GS, true>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((rows + 15) / 16), dim3(256), lds, st, d);
+    } else {
+        auto kern = &gemm_q80_mfma_kernel<GS, false>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((rows + 15) / 16), dim3(256), lds, st, d);
+    }
     return hipGetLastError();
 }
 
