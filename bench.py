@@ -37,7 +37,7 @@ PROMPT_LEN = 16
 SEQ_LEN = 512
 # HBM bytes per classifier launch from the rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE corrected as
 # MI355X_MICROARCH.md prescribes), keyed by (model, quant, group size); None = not collected
-TRAFFIC_BYTES = {("qwen3-0.6b", "q80", 64): 165498395}    # profiles/r01_pmc_fetch_size.txt: FETCH_SIZE 80809.76 KB x 1024 x 2
+TRAFFIC_BYTES = {("qwen3-0.6b", "q80", 64): 165500014}    # profiles/r01_pmc_fetch_size.txt: FETCH_SIZE 80810.55 KB x 1024 x 2
 
 
 def log(*a):
@@ -246,7 +246,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "classifier GEMV (%s, %d x %d)" % ({"q80": "gemv_q80_stream_kernel", "q4k": "gemv_q4k_kernel", "f32": "gemv_f32_kernel"}[args.quant], spec.vocab_size, spec.n_embd),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": TRAFFIC_BYTES.get((args.model, args.quant, spec.group_size)), "bytes_per_launch": bytes_cls, "us_per_launch": round(ms_cls * 1e3, 2),
-                     "how": "HIP events right before / after the launch inside 60 whole decode steps (eager launches, weights cold); raw span, nothing subtracted",
+                     "how": ("kernel start/stop HIP events of the launch itself (hipExtLaunchKernelGGL) inside 60 whole decode steps, eager launches, weights cold"
+                             if ms_pair == 0.0 else "HIP events recorded right before / after the launch inside 60 whole decode steps (raw span; an empty event pair costs empty_event_pair_us)"),
                      "empty_event_pair_us": round(ms_pair * 1e3, 2),
                      "us_per_launch_back_to_back": round(ms_b2b * 1e3, 2)},
     }

@@ -4,6 +4,8 @@
 
 namespace nano {
 
+hipEvent_t g_q80_probe_start = nullptr, g_q80_probe_stop = nullptr;
+
 hipError_t launch_gemv_q80_gs32(const GemvArgs &a, hipStream_t st);
 hipError_t launch_gemv_q80_gs64(const GemvArgs &a, hipStream_t st);
 hipError_t launch_gemv_q80_gs128(const GemvArgs &a, hipStream_t st);

@@ -1,11 +1,19 @@
 // gemv_q80_host.h -- host-side routing shared by the Q80 GEMV translation units.
 #pragma once
 #include "kernels.h"
+#include <hip/hip_ext.h>
+#include <stdlib.h>
 
 namespace nano {
 
 constexpr uint32_t STREAM_MIN_ROWS = 16384;     // taller matrices go to the stream kernel
-constexpr uint32_t STREAM_WGS = 1024;
+// workgroups of a STREAM launch: 1024 = two resident rounds of 512 (2 per CU at the kernel's register footprint);
+// NANO_STREAM_WGS overrides for experiments
+static inline uint32_t stream_wgs() {
+    static const uint32_t v = [] { const char *e = getenv("NANO_STREAM_WGS"); const uint32_t x = e ? (uint32_t)atoi(e) : 0u; return x ? x : 1024u; }();
+    return v;
+}
+#define STREAM_WGS (::nano::stream_wgs())
 
 static inline uint32_t total_rows(const GemvArgs &a) {
     if (a.epi == GEMV_EPI_SWIGLU) return a.seg[0].rows;
@@ -17,5 +25,9 @@ static inline bool use_stream(const GemvArgs &a) {
     return a.nseg == 1 && a.epi == GEMV_EPI_STORE && a.seg[0].rows >= STREAM_MIN_ROWS && a.seg[0].out_pstride == 0 && !a.attn_part && a.nb <= 8;
 }
 
+
+// measurement hook: when both are set, the next STREAM (classifier) launch is issued with hipExtLaunchKernelGGL so that the
+// two events carry the kernel's own start / stop timestamps (what rocprofv3 reports), then the hook clears itself
+extern hipEvent_t g_q80_probe_start, g_q80_probe_stop;
 
 }  // namespace nano

@@ -556,11 +556,16 @@ static hipError_t launch_stream_r(GemvDev &d, hipStream_t st) {
     const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u;
     const size_t lds = B * n16 + B * ng4 * 4 + B * 64 + 4 * 16 * (1024 / GS) * 4;
     const uint32_t nv = (d.n + 1023) / 1024;
+    hipEvent_t e0 = g_q80_probe_start, e1 = g_q80_probe_stop;
+    g_q80_probe_start = g_q80_probe_stop = nullptr;
+#define STREAM_GO(NV_) do { if (e0 && e1) hipExtLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, NV_>), dim3(STREAM_WGS), dim3(256), (uint32_t)lds, st, e0, e1, 0, d); \
+                            else hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, NV_>), dim3(STREAM_WGS), dim3(256), lds, st, d); } while (0)
     bool done = false;
-    if (nv <= 1) { hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, 1>), dim3(STREAM_WGS), dim3(256), lds, st, d); done = true; }
-    if constexpr (B <= 4) { if (!done && nv <= 2) { hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, 2>), dim3(STREAM_WGS), dim3(256), lds, st, d); done = true; } }
-    if constexpr (B <= 2) { if (!done && nv <= 4) { hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, 4>), dim3(STREAM_WGS), dim3(256), lds, st, d); done = true; } }
-    if (!done) { hipLaunchKernelGGL((gemv_q80_stream_kernel<ROLE, GS, B, 0>), dim3(STREAM_WGS), dim3(256), lds, st, d); }
+    if (nv <= 1) { STREAM_GO(1); done = true; }
+    if constexpr (B <= 4) { if (!done && nv <= 2) { STREAM_GO(2); done = true; } }
+    if constexpr (B <= 2) { if (!done && nv <= 4) { STREAM_GO(4); done = true; } }
+    if (!done) { STREAM_GO(0); }
+#undef STREAM_GO
     return hipGetLastError();
 }
 template <int GS, int B>
