@@ -298,6 +298,17 @@ int main(int argc, char **argv) {
                 });
                 printf("cls: q80_stream nt=%d %4d WGs: %.2f us -> %.0f GB/s (%.1f%% of 8 TB/s)\n", nt, wg, us, bytes / us * 1e-3, bytes / us * 1e-3 / 80.0);
             }
+        CK(hipMemsetAsync(out, 0xff, (size_t)V * 4, st));
+        hipLaunchKernelGGL((q80_stream_sb<64, true>), dim3(777), dim3(256), stream_lds(E, GS), st, a);
+        CK(hipStreamSynchronize(st));
+        cmp(out, out_ref, V, "stream_sb (fused norm+quant)");
+        for (int wg : {1024, 1536, 2048, 3072, 4096}) {
+            float us = time_loop(20, [&](int i) {
+                Args b = a; b.seg[0].w = cls[i % NB].w; b.seg[0].ws = cls[i % NB].ws;
+                hipLaunchKernelGGL((q80_stream_sb<64, true>), dim3(wg), dim3(256), stream_lds(E, GS), st, b);
+            });
+            printf("cls: q80_stream_sb (single buffer) %4d WGs: %.2f us -> %.0f GB/s (%.1f%% of 8 TB/s)\n", wg, us, bytes / us * 1e-3, bytes / us * 1e-3 / 80.0);
+        }
         for (int i = 0; i < NB; i++) { CK(hipFree(cls[i].w)); CK(hipFree(cls[i].ws)); }
     }
 

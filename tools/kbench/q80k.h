@@ -206,6 +206,96 @@ __global__ __launch_bounds__(256) void q80_stream(const Args a) {
     }
 }
 
+template <int GS, bool NT>
+__global__ __launch_bounds__(256) void q80_stream_sb(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LPG = GS / 16, GC = 1024 / GS, F = GC / 4;
+    static_assert(F >= 1, "GS too large");
+    const int n = (int)a.n, ng = n / GS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n16 = (n + 15) & ~15;
+    int8_t *xq = reinterpret_cast<int8_t *>(smem);
+    float *xs = reinterpret_cast<float *>(smem + n16);
+    float *red = xs + ((ng + 3) & ~3);
+    int *tab = reinterpret_cast<int *>(red + 8) + wid * 16 * GC;
+
+    const Seg sg = a.seg[0];
+    const uint32_t rows = sg.rows;
+    const int nchunk = (n + 1023) >> 10;
+    const uint32_t ntiles = (rows + 15) >> 4;
+    const uint32_t nwaves = gridDim.x * 4, wave_g = blockIdx.x * 4 + wid;
+    const uint32_t nunits = (wave_g < ntiles) ? ((ntiles - wave_g + nwaves - 1) / nwaves) * nchunk : 0;
+
+    int4 wA[16];
+    float sA[F];
+    auto issue = [&](uint32_t u, int4 (&w)[16], float (&s)[F]) {
+        const uint32_t tile = wave_g + (u / nchunk) * nwaves;
+        const int c = (int)(u % nchunk);
+        const uint32_t row0 = tile << 4;
+        const int col = (c << 10) + lane * 16;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t row = min(row0 + r, rows - 1);
+            w[r] = (col < n) ? ld16<NT>(sg.w + (size_t)row * n + col) : make_int4(0, 0, 0, 0);
+        }
+        const uint32_t rr = min(row0 + (lane >> 2), rows - 1);
+        const int gb = c * GC + (lane & 3) * F;
+#pragma unroll
+        for (int f = 0; f < F; f++) s[f] = (gb + f < ng) ? sg.ws[(size_t)rr * ng + gb + f] : 0.0f;
+    };
+    if (nunits) issue(0, wA, sA);
+
+    stage_q80_wg<GS>(a, xq, xs, red);
+
+    float val = 0.0f;
+    auto consume = [&](uint32_t u, int4 (&w)[16], float (&s)[F]) {
+        const uint32_t tile = wave_g + (u / nchunk) * nwaves;
+        const int c = (int)(u % nchunk);
+        const int col = (c << 10) + lane * 16;
+        const int4 xv = (col < n) ? *reinterpret_cast<const int4 *>(xq + col) : make_int4(0, 0, 0, 0);
+        int iv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int t = __builtin_amdgcn_sdot4(w[r].x, xv.x, 0, false);
+            t = __builtin_amdgcn_sdot4(w[r].y, xv.y, t, false);
+            t = __builtin_amdgcn_sdot4(w[r].z, xv.z, t, false);
+            t = __builtin_amdgcn_sdot4(w[r].w, xv.w, t, false);
+            iv[r] = dpp_group_sum<LPG>(t);
+        }
+        if ((lane % LPG) == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) tab[r * GC + lane / LPG] = iv[r];
+        }
+        const int gb = c * GC + (lane & 3) * F;
+        float p[F];
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            const int v = tab[(lane >> 2) * GC + (lane & 3) * F + f];
+            const float xsc = (gb + f < ng) ? xs[gb + f] : 0.0f;
+            p[f] = ((float)v * s[f]) * xsc;
+        }
+        // ordered fold over the 4 lanes of a row: stage k adds lane k's products onto the running value
+        float cur = val;
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            float t = cur;
+#pragma unroll
+            for (int f = 0; f < F; f++) t += p[f];      // groups beyond ng contribute +0.0f exactly
+            cur = (st == 0) ? DPP_F(t, 0x00) : (st == 1) ? DPP_F(t, 0x55) : (st == 2) ? DPP_F(t, 0xAA) : DPP_F(t, 0xFF);
+        }
+        val = cur;
+        if (c + 1 == nchunk) {
+            const uint32_t row = (tile << 4) + (lane >> 2);
+            if ((lane & 3) == 0 && row < rows) sg.out[row] = val;
+            val = 0.0f;
+        }
+    };
+    for (uint32_t u = 0; u < nunits; u++) {          // single buffer: occupancy (4+ waves per SIMD) hides the latency
+        if (u) issue(u, wA, sA);
+        consume(u, wA, sA);
+    }
+}
+
 static inline size_t stream_lds(uint32_t n, uint32_t gs) {
     const size_t n16 = (n + 15) & ~15u, ng4 = ((n / gs) + 3) & ~3u;
     return n16 + ng4 * 4 + 32 + 4 * 16 * (1024 / gs) * 4;
