@@ -15,6 +15,11 @@ if ROOT not in sys.path:
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
+# The CPU oracle is OpenMP code run on tiny models: on a many-core GPU host the default thread count makes every
+# parallel region a spin-wait festival (seconds per forward).  Results do not depend on the thread count.
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) and the built HIP library")

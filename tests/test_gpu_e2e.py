@@ -157,6 +157,31 @@ def test_batched_prefill_equals_token_by_token(model_dir, preset, quant, gs, T):
     assert worst < TOL[quant] * 1e-2 and rel_err(got_k, ref_k) < 1e-6 and rel_err(got_v, ref_v) < 1e-6
 
 
+@pytest.mark.parametrize("preset,quant,gs", [("tiny-qwen3", "q80", 64), ("tiny-nano-odd", "f32", 0)])
+def test_position_buckets_and_odd_seq_len(oracle, model_dir, preset, quant, gs):
+    """max_seq_len that is not a multiple of the 64-position attention bucket; a graph-replayed greedy decode that crosses
+    a bucket boundary (new graph, more attention splits) equals step-by-step forwards, and the logits stay on the oracle."""
+    path, spec = synth_model(model_dir, preset, quant, gs)
+    S = 100
+    m = nb.load_model_file(path, max_seq_len=S, max_batch=1)
+    o = ob.OracleCtx(oracle, path, max_seq_len=S)
+    tok, ids_fwd, worst = 5, [], 0.0
+    for pos in range(S - 1):
+        lg, am = m.forward([tok], [pos], want_logits=True, want_argmax=True)
+        ref = o.forward(tok, pos)                     # the oracle must see every position (its KV cache)
+        if pos % 7 == 0 or pos >= S - 3 or 60 <= pos <= 68:
+            worst = max(worst, rel_err(lg[0], ref))
+        tok = int(am[0]); ids_fwd.append(tok)
+        assert tok == int(np.argmax(lg[0]))
+    m.close(); o.close()
+    m = nb.load_model_file(path, max_seq_len=S, max_batch=1)
+    ids_loop = m.decode_greedy([5], [0], S - 1)[:, 0].tolist()
+    m.close()
+    print(f"{preset}/{quant}: {S - 1} teacher-free steps, worst max|dlogit|/max|logit| vs oracle {worst:.3e}")
+    assert ids_loop == ids_fwd
+    assert worst < TOL[quant]
+
+
 def test_ragged_positions_in_one_batch(model_dir):
     """Slots at different positions in the same step (pos is per slot)."""
     path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)
