@@ -15,27 +15,10 @@
 
 namespace nano {
 
-// ---- streaming (non-temporal) 16-byte loads: weights are read exactly once per step ---------------
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int4 ld_stream_i4(const void *p) {
-    const i32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t *>(p));
-    return make_int4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float4 ld_stream_f4(const void *p) {
-    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
 // ---- cross-lane --------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 // sum over aligned sub-groups of `width` lanes (width power of two <= 64)
@@ -45,10 +28,6 @@ __device__ __forceinline__ float group_sum(float v, int width) {
 }
 __device__ __forceinline__ float group_max(float v, int width) {
     for (int o = width >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ int group_sum_i(int v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
@@ -62,16 +41,6 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     __syncthreads();
     float t = 0.0f;
     for (int i = 0; i < nw; i++) t += red[i];
-    return t;
-}
-__device__ __forceinline__ float block_max(float v, float *red) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    v = wave_max(v);
-    __syncthreads();
-    if (lane == 0) red[wid] = v;
-    __syncthreads();
-    float t = red[0];
-    for (int i = 1; i < nw; i++) t = fmaxf(t, red[i]);
     return t;
 }
 

@@ -7,8 +7,6 @@
 
 namespace nano {
 
-constexpr int GEMV_RB = 4;          // rows per wave tile
-
 enum : uint32_t { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_SWIGLU = 2 };
 
 // One weight tensor (or a run of them sharing the input vector) of a fused GEMV launch.
