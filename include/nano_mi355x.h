@@ -113,6 +113,13 @@ int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, const uint32
  * those of `count` nano_hip_forward() calls.  Replaces the prompt loop around llm_forward (infer.c:1258-1260). */
 int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *tokens, uint32_t pos0, uint32_t count);
 
+/* LoRA side branches of the Nano architecture (reference infer.c:434-498 loader, 792-808 / 898-903 forward).
+ * `params` = the floats that follow the 256-byte header of a LoRA module file, in file order; rank / alpha = header words
+ * 6 / 7.  Attaching enables the module; nano_hip_lora_enable(m, 0/1) is the reference's per-call `lora != NULL`.
+ * Replaces: load_lora / parse_lora_file's device side and the use_lora branches of transformer_block_forward. */
+int nano_hip_lora_attach(NanoHipModel *m, uint32_t rank, uint32_t alpha, const float *params, size_t n_floats);
+int nano_hip_lora_enable(NanoHipModel *m, int on);
+
 /* Blocks until all work queued on the model's stream has finished. */
 int nano_hip_sync(NanoHipModel *m);
 

@@ -61,6 +61,8 @@ def lib() -> C.CDLL:
     fn("nano_hip_forward", C.c_int, [vp, u32p, u32p, C.c_uint32, C.c_uint32, vp, vp])
     fn("nano_hip_decode_greedy", C.c_int, [vp, u32p, u32p, C.c_uint32, C.c_uint32, vp])
     fn("nano_hip_prefill", C.c_int, [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32])
+    fn("nano_hip_lora_attach", C.c_int, [vp, C.c_uint32, C.c_uint32, f32p, C.c_size_t])
+    fn("nano_hip_lora_enable", C.c_int, [vp, C.c_int])
     fn("nano_hip_sync", C.c_int, [vp])
     fn("nano_hip_time_classifier", C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64)])
     fn("nano_hip_time_classifier_in_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_float)])
@@ -159,6 +161,16 @@ class DeviceModel:
         """Batched prefill of one sequence: tokens at positions pos0.. (no logits)."""
         t = np.ascontiguousarray(tokens, np.uint32).reshape(-1)
         check(lib().nano_hip_prefill(self.h, slot, t, pos0, t.size))
+
+    def lora_attach_file(self, path: str):
+        """Attach a LoRA module file (reference format: 256-byte header, rank / alpha = words 6 / 7, then FP32 tensors)."""
+        raw = np.fromfile(path, dtype=np.uint8)
+        hdr = raw[:256].view(np.uint32)
+        params = np.ascontiguousarray(raw[256:].view(np.float32))
+        check(lib().nano_hip_lora_attach(self.h, int(hdr[6]), int(hdr[7]), params, params.size))
+
+    def lora_enable(self, on: bool):
+        check(lib().nano_hip_lora_enable(self.h, 1 if on else 0))
 
     def sync(self):
         check(lib().nano_hip_sync(self.h))
@@ -270,7 +282,8 @@ class Engine:
     the host C code of this library; ids in, ids out (no tokenizer linked in the stand-alone library)."""
 
     def __init__(self, path: str, max_seq_len: int = 512, rep_pen: float = 1.0, temperature: float = 0.0,
-                 top_p: float = 1.0, top_k: int = 0, seed: int = 39, device: int = 0, max_batch: int = 1):
+                 top_p: float = 1.0, top_k: int = 0, seed: int = 39, device: int = 0, max_batch: int = 1,
+                 lora_path: Optional[str] = None):
         L = lib()
         vp = C.c_void_p
         L.nano_set_device.argtypes = [C.c_int]; L.nano_set_max_batch.argtypes = [C.c_uint32]
@@ -289,7 +302,7 @@ class Engine:
         L.nano_set_device(device)
         L.nano_set_max_batch(max_batch)
         self.L = L
-        self.ctx = L.llm_context_init(path.encode(), None, max_seq_len, rep_pen, temperature, top_p, top_k, seed)
+        self.ctx = L.llm_context_init(path.encode(), lora_path.encode() if lora_path else None, max_seq_len, rep_pen, temperature, top_p, top_k, seed)
         self.max_seq_len = max_seq_len
 
     def close(self):

@@ -70,6 +70,10 @@ struct NanoHipModel {
     float *x = nullptr, *q = nullptr, *kraw = nullptr, *xba = nullptr, *hb = nullptr, *logits = nullptr;
     float *attn_part = nullptr, *attn_ml = nullptr;       // split-attention partials [B][nsplit][QD], [B][n_head][nsplit][2]
     float *tile_max = nullptr;                            // classifier arg-max partials [B][<=V][2]
+    // LoRA module (Nano architecture, reference infer.c:434-498): 8 FP32 tensors in one device buffer + o1 scratch
+    float *lora_buf = nullptr, *lora_o1 = nullptr;
+    const float *lora_t[8] = {nullptr};                   // qa qb ka kb va vb oa ob, each [L][...]
+    uint32_t lora_rank = 0, lora_alpha = 0; bool lora_on = false;
     int8_t *gq = nullptr; float *gxs = nullptr;           // MFMA GEMM path (batch > 8, Q80): quantized activations of all sequences
     float *rope_cur = nullptr;                            // RoPE rows of the current positions [B][2][hd/2], staged by the embed kernel
     float *kcache = nullptr, *vcache = nullptr;
@@ -143,7 +147,7 @@ static void destroy(NanoHipModel *m) {
     if (m->st) (void)hipStreamSynchronize(m->st);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
-                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs };
+                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1 };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -343,7 +347,7 @@ static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     if (m->d.quant_type == NANO_QUANT_Q4K) return launch_gemv_q4k(a, max_wg, m->st);
     if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 8) {
         // 9..64 sequences: quantize every sequence's activation once, then the int8 MFMA GEMM (gemm_q80.hip)
-        if (a.attn_part || !m->gq || !m->gxs) return hipErrorInvalidValue;
+        if (a.attn_part || a.resid_add || !m->gq || !m->gxs) return hipErrorInvalidValue;
         hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
         if (e != hipSuccess) return e;
         a.xq_in = m->gq; a.xs_in = m->gxs;
@@ -382,6 +386,7 @@ static uint32_t step_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_h
     uint32_t ns = attention_nsplit(range_hint, m->hd);
     if (nb >= 4) { const uint32_t div = nb / 2; ns = (ns + div - 1) / div; }
     if (nb > 8) ns = 1;                 // the MFMA GEMM path takes plain activations only
+    if (m->lora_on) ns = 1;             // the LoRA o-branch reads the combined attention output
     if (nb > 1 && (uint64_t)(m->d.n_embd / 16) * nb * m->QD > (4u << 20)) ns = 1;   // ditto the quantize-once GEMV path (see gemv())
     return ns ? ns : 1;
 }
@@ -411,6 +416,18 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_STORE;
             a.norm_w = m->rms_attn + (size_t)l * E; a.pos = m->pos;
             if (!(skip & 1) && (e = gemv(m, a)) != hipSuccess) return e;
+            if (m->lora_on) {       // q / k / v += (alpha/rank) B (A xb)   reference infer.c:792-808
+                const size_t la = (size_t)l * m->lora_rank * E, lbq = (size_t)l * E * m->lora_rank, lbk = (size_t)l * KD * m->lora_rank;
+                LoraArgs la_{};
+                la_.x = m->x; la_.norm_w = m->rms_attn + (size_t)l * E;
+                la_.qa = m->lora_t[0] + la; la_.qb = m->lora_t[1] + lbq; la_.ka = m->lora_t[2] + la; la_.kb = m->lora_t[3] + lbk;
+                la_.va = m->lora_t[4] + la; la_.vb = m->lora_t[5] + lbk;
+                la_.q = m->q; la_.kraw = m->kraw;
+                la_.v = m->pf ? m->vcache + ((size_t)m->pf_slot * L * S + layer_rows) * KD : m->vcache + layer_rows * KD;
+                la_.v_bstride = m->pf ? 0u : (uint32_t)((size_t)L * S * KD);
+                la_.pos = m->pos; la_.E = E; la_.KD = KD; la_.rank = m->lora_rank; la_.alpha = m->lora_alpha;
+                if ((e = launch_lora_qkv(la_, nb, m->st)) != hipSuccess) return e;
+            }
         }
         {   // qk-norm, rope, k-cache write, attention   reference infer.c:810-879
             AttnArgs a{};
@@ -438,6 +455,13 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[WO][l], m->x, E, E);
             a.n = QD; a.gs = d.group_size; a.nb = nb; a.xin = m->xba; a.xin_bstride = QD; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
+            if (m->lora_on) {       // o1 = (alpha/rank) B_o (A_o xba), added by the Wo epilogue: x += (Wo xba + o1)   infer.c:898-908
+                LoraArgs la_{};
+                la_.x = m->xba; la_.qa = m->lora_t[6] + (size_t)l * m->lora_rank * E; la_.qb = m->lora_t[7] + (size_t)l * E * m->lora_rank;
+                la_.q = m->lora_o1; la_.E = E; la_.KD = KD; la_.rank = m->lora_rank; la_.alpha = m->lora_alpha;
+                if ((e = launch_lora_o(la_, nb, m->st)) != hipSuccess) return e;
+                a.resid_add = m->lora_o1; a.resid_add_bstride = E;
+            }
             if (nsplit > 1) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
             if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
         }
@@ -484,7 +508,7 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
     uint32_t range_hint = is_causal ? ((max_pos + 1 + 63) / 64) * 64 : m->S;
     if (range_hint > m->S) range_hint = m->S;
     if (!m->use_graph) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); return 0; }
-    const uint64_t key = ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
+    const uint64_t key = ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         // first use: run eagerly once (sets kernel attributes, validates launches) then capture
@@ -541,6 +565,34 @@ extern "C" int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const u
     HIP_TRY(hipStreamSynchronize(m->st));
     if (logits_out) memcpy(logits_out, m->h_logits, batch * V * 4);
     if (argmax_out) memcpy(argmax_out, m->h_amax, batch * 4);
+    return 0;
+}
+
+// ---- LoRA ---------------------------------------------------------------------------------------------
+// `params` = the floats of a LoRA module file after its 256-byte header, in file order (reference infer.c:476-497):
+// wq_a[L][r][E] wq_b[L][E][r] wk_a[L][r][E] wk_b[L][KD][r] wv_a[L][r][E] wv_b[L][KD][r] wo_a[L][r][E] wo_b[L][E][r].
+extern "C" int nano_hip_lora_attach(NanoHipModel *m, uint32_t rank, uint32_t alpha, const float *params, size_t n_floats) {
+    if (!m || !params || !rank) FAIL(NANO_HIP_EINVAL, "bad argument");
+    if (m->d.arch != NANO_ARCH_NANO) FAIL(NANO_HIP_EINVAL, "LoRA side branches exist for the Nano architecture only (reference infer.c:792)");
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t L = m->d.n_layer, E = m->d.n_embd, KD = m->KD, r = rank;
+    const size_t len[8] = { L * r * E, L * E * r, L * r * E, L * KD * r, L * r * E, L * KD * r, L * r * E, L * E * r };
+    size_t total = 0; for (size_t v : len) total += v;
+    if (n_floats < total) FAIL(NANO_HIP_EINVAL, "LoRA parameter block too small: %zu floats, need %zu", n_floats, total);
+    HIP_TRY(hipStreamSynchronize(m->st));
+    if (m->lora_buf) { (void)hipFree(m->lora_buf); m->lora_buf = nullptr; }
+    if (!m->lora_o1) HIP_TRY(hipMalloc(&m->lora_o1, (size_t)m->Bs * E * 4));
+    HIP_TRY(hipMalloc(&m->lora_buf, total * 4));
+    HIP_TRY(hipMemcpy(m->lora_buf, params, total * 4, hipMemcpyHostToDevice));
+    size_t off = 0; for (int i = 0; i < 8; i++) { m->lora_t[i] = m->lora_buf + off; off += len[i]; }
+    m->lora_rank = rank; m->lora_alpha = alpha; m->lora_on = true;
+    return 0;
+}
+// use_lora of the reference's forward (lora != NULL): switch the attached module on / off per call
+extern "C" int nano_hip_lora_enable(NanoHipModel *m, int on) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    if (on && !m->lora_buf) FAIL(NANO_HIP_EINVAL, "no LoRA module attached");
+    m->lora_on = on != 0;
     return 0;
 }
 

@@ -76,6 +76,7 @@ struct GemvDev {
     const float *attn_part; const float *attn_ml;
     uint32_t attn_nsplit, attn_n_head, attn_hd, ntiles;
     float *tile_max;
+    const float *resid_add; uint32_t resid_add_bstride, _pad1;
 };
 
 template <int ROLE> __device__ __forceinline__ bool has_flag(const GemvDev &a, uint32_t f) {
@@ -214,6 +215,7 @@ static GemvDev to_dev(const GemvArgs &a) {
     d.xq_in = a.xq_in; d.xs_in = a.xs_in;
     d.attn_part = a.attn_part; d.attn_ml = a.attn_ml; d.attn_nsplit = a.attn_nsplit; d.attn_n_head = a.attn_n_head; d.attn_hd = a.attn_hd;
     d.tile_max = a.tile_max;
+    d.resid_add = a.resid_add; d.resid_add_bstride = a.resid_add_bstride;
     return d;
 }
 

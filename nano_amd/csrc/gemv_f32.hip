@@ -178,6 +178,9 @@ __global__ __launch_bounds__(1024) void gemv_f32_slab_kernel(const GemvDev a) {
     if (ops && fold_live) opos = a.pos[fb];
     float oldv = 0.0f;
     if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];      // residual stream: never pos-indexed
+    float addv = 0.0f;                                              // LoRA o-branch: x += (W.act + addv), reference order
+    const bool has_add = epi == GEMV_EPI_RESID && a.resid_add != nullptr;
+    if (has_add && fold_live) addv = a.resid_add[(size_t)fb * a.resid_add_bstride + lrow0 + frl];
 
     stage_finish_f32<ROLE, B, NV>(a, sx, xf, red, n4);
 
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(1024) void gemv_f32_slab_kernel(const GemvDev a) {
         const float *p0 = P + (((size_t)fb * nmat) * RW + frl) * PC;
         const float *p1 = p0 + (size_t)RW * PC;
         for (uint32_t c = 0; c < nchunk; c++) { v0 += p0[c]; if (swiglu) v1 += p1[c]; }
-        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, v0, v1, oldv);
+        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
     }
 }
 

@@ -355,6 +355,9 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     if (ops && fold_live) opos = a.pos[fb];
     float oldv = 0.0f;
     if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];      // residual stream: never pos-indexed
+    float addv = 0.0f;                                              // LoRA o-branch: x += (W.act + addv), reference order
+    const bool has_add = epi == GEMV_EPI_RESID && a.resid_add != nullptr;
+    if (has_add && fold_live) addv = a.resid_add[(size_t)fb * a.resid_add_bstride + lrow0 + frl];
 
     if (has_flag<ROLE>(a, F_PRE)) unpack_q4k_wg(a, xg);
     else {
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
             }
             res[mat] = line;
         }
-        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, res[0], res[1], oldv);
+        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, has_add ? res[0] + addv : res[0], res[1], oldv);
     }
 }
 

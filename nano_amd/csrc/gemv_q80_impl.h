@@ -246,6 +246,9 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     if (ops && fold_live) opos = a.pos[fb];
     float oldv = 0.0f;
     if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];      // residual stream: never pos-indexed
+    float addv = 0.0f;                                              // LoRA o-branch: x += (W.act + addv), reference order
+    const bool has_add = epi == GEMV_EPI_RESID && a.resid_add != nullptr;
+    if (has_add && fold_live) addv = a.resid_add[(size_t)fb * a.resid_add_bstride + lrow0 + frl];
 
     // ---- 4. rmsnorm + quantization from registers (weights in flight) ----------------------------------------
     stage_finish<ROLE, GS, B, NV>(a, sx, xq, xs, red, n16, ng4);
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
                 }
             }
         }
-        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, v0, v1, oldv);
+        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
     }
 }
 

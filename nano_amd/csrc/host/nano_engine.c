@@ -191,15 +191,56 @@ void free_llm(LLM *llm, Tokenizer *tk) {
     free(llm);
 }
 
-/* LoRA side branches (reference infer/infer.c:408-545,792-808,898-903) are SURVEY 8f-4 "next": not on
- * the device yet.  Loading is refused loudly instead of silently running without the adapter. */
-LoRA *load_lora_from_buffer(LLM *llm, uint8_t *buffer) {
-    (void)llm; (void)buffer;
-    fprintf(stderr, "Error: LoRA modules are not supported by the MI355X backend yet.\n");
-    exit(EXIT_FAILURE);
+/* LoRA modules (reference infer/infer.c:434-498 parse_lora_file, 500-527 loaders).  File = 256-byte header of LE u32
+ * (words 6..13: rank, alpha, n_layer, n_embd, n_head, n_kv_head, n_hidden, lora_config) followed by the eight FP32
+ * tensors in the order of LoRA_Param.  The tensors go to the device (nano_hip_lora_attach); the host pointers in
+ * LoRA_Param keep pointing into the caller's / the loader's buffer like in the reference. */
+static LoRA *lora_from_buffer(LLM *llm, uint8_t *buffer, int owns) {
+    NanoHipModel *dev = reg_get(llm);
+    if (!dev) { fprintf(stderr, "load_lora: model is not resident on a device\n"); exit(EXIT_FAILURE); }
+    if (llm->arch != LLM_ARCH_NANO) { fprintf(stderr, "Error: LoRA modules apply to the Nano architecture only.\n"); exit(EXIT_FAILURE); }
+    const uint32_t *h = (const uint32_t *)buffer;
+    LoRA *p = (LoRA *)calloc(1, sizeof(LoRA));
+    if (!p) { fprintf(stderr, "mem alloc failed!\n"); exit(EXIT_FAILURE); }
+    LoRA_Config *c = &p->config;
+    c->lora_rank = h[6]; c->lora_alpha = h[7]; c->n_layer = h[8]; c->n_embd = h[9];
+    c->n_head = h[10]; c->n_kv_head = h[11]; c->n_hidden = h[12]; c->lora_config = h[13];
+    const LLM_Config *m = &llm->config;
+    if (m->n_layer != c->n_layer || m->n_embd != c->n_embd || m->n_head != c->n_head || m->n_kv_head != c->n_kv_head || m->n_hidden != c->n_hidden) {
+        fprintf(stderr, "Error: LoRA module does not fit the base model.\n");      /* reference infer.c:470 */
+        exit(EXIT_FAILURE);
+    }
+    const size_t L = m->n_layer, E = m->n_embd, r = c->lora_rank, KD = (size_t)(E / m->n_head) * m->n_kv_head;
+    float *f = (float *)(buffer + 256);
+    p->data = owns ? (float *)buffer : NULL;                 /* what free_lora releases */
+    p->params.wq_lora_a = f; f += L * r * E;  p->params.wq_lora_b = f; f += L * E * r;
+    p->params.wk_lora_a = f; f += L * r * E;  p->params.wk_lora_b = f; f += L * KD * r;
+    p->params.wv_lora_a = f; f += L * r * E;  p->params.wv_lora_b = f; f += L * KD * r;
+    p->params.wo_lora_a = f; f += L * r * E;  p->params.wo_lora_b = f; f += L * E * r;
+    const size_t n_floats = (size_t)(f - (float *)(buffer + 256));
+    if (nano_hip_lora_attach(dev, c->lora_rank, c->lora_alpha, (const float *)(buffer + 256), n_floats) != NANO_HIP_OK) die_hip("load_lora");
+    return p;
 }
-LoRA *load_lora(LLM *llm, char *lora_path) { (void)lora_path; return load_lora_from_buffer(llm, NULL); }
-void free_lora(LLM *llm, LoRA *lora) { (void)llm; (void)lora; }
+LoRA *load_lora_from_buffer(LLM *llm, uint8_t *buffer) { return lora_from_buffer(llm, buffer, 0); }
+LoRA *load_lora(LLM *llm, char *lora_path) {
+    FILE *file = fopen(lora_path, "rb");
+    if (!file) { fprintf(stderr, "Couldn't open LoRA module file %s\n", lora_path); exit(EXIT_FAILURE); }
+    fseek(file, 0, SEEK_END);
+    const long file_size = ftell(file);
+    rewind(file);
+    uint8_t *buf = (uint8_t *)calloc((size_t)file_size + 1, 1);
+    if (!buf) { fprintf(stderr, "mem alloc failed.\n"); exit(EXIT_FAILURE); }
+    if (file_size < 256 || fread(buf, 1, (size_t)file_size, file) != (size_t)file_size) { fprintf(stderr, "Couldn't read LoRA module file %s\n", lora_path); exit(EXIT_FAILURE); }
+    fclose(file);
+    return lora_from_buffer(llm, buf, 1);
+}
+void free_lora(LLM *llm, LoRA *lora) {
+    if (!lora) return;
+    NanoHipModel *dev = llm ? reg_get(llm) : NULL;
+    if (dev) (void)nano_hip_lora_enable(dev, 0);
+    free(lora->data);                                        /* the loader's buffer (NULL for _from_buffer) */
+    free(lora);
+}
 
 /* =====================================================================================================
  * context (reference infer/infer.c:552-581)
@@ -251,10 +292,18 @@ static inline void observe(Nano_Context *ctx, int32_t layer, int32_t phase) {
     }
 }
 
+/* the reference's use_lora = (lora != NULL) of each forward call (infer.c:721) */
+static void lora_select(NanoHipModel *dev, const LoRA *lora) {
+    static const NanoHipModel *last_dev = NULL; static int last_on = -1;
+    const int on = lora != NULL;
+    if (dev != last_dev || on != last_on) { if (nano_hip_lora_enable(dev, on) != NANO_HIP_OK && on) die_hip("lora"); last_dev = dev; last_on = on; }
+}
+
 float *llm_forward(Nano_Context *ctx, uint32_t token, uint32_t pos, uint32_t max_seq_len, uint32_t is_causal, LLM *llm, LoRA *lora) {
-    (void)max_seq_len; (void)lora;
+    (void)max_seq_len;
     NanoHipModel *dev = reg_get(llm);
     if (!dev) { fprintf(stderr, "llm_forward: model is not resident on a device\n"); exit(EXIT_FAILURE); }
+    lora_select(dev, lora);
     /* The fused device forward has no per-layer host boundary: phase hooks fire at token granularity. */
     observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
     if (nano_hip_forward(dev, &token, &pos, 1, is_causal, llm->state.logits, NULL) != NANO_HIP_OK) die_hip("llm_forward");
@@ -266,6 +315,7 @@ float *llm_forward(Nano_Context *ctx, uint32_t token, uint32_t pos, uint32_t max
 int nano_forward_batch(Nano_Context *ctx, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, float *logits, uint32_t *argmax) {
     NanoHipModel *dev = reg_get(ctx->llm);
     if (!dev) return NANO_HIP_EINVAL;
+    lora_select(dev, ctx->lora);
     return nano_hip_forward(dev, tokens, pos, batch, 1, logits, argmax);
 }
 
@@ -340,6 +390,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
     NanoHipModel *dev = reg_get(llm);
     if (!dev) { fprintf(stderr, "generate_next_token: model is not resident on a device\n"); exit(EXIT_FAILURE); }
     uint32_t token = output_ids[pos];
+    lora_select(dev, ctx->lora);
 
     if (is_prefilling == 1) {
         /* the reference computes the logits of prompt positions and discards them (infer.c:1146-1149):
@@ -431,6 +482,7 @@ static int32_t step_core(Nano_Context *ctx, Nano_Session *s, int with_text) {
         pf_session = NULL;
         NanoHipModel *dev = reg_get(ctx->llm);
         if (dev && s->num_prompt_tokens > 2 && s->num_prompt_tokens - 1 <= s->max_seq_len && !getenv("NANO_NO_BATCHED_PREFILL")) {
+            lora_select(dev, ctx->lora);
             if (nano_hip_prefill(dev, 0, s->output_ids, 0, s->num_prompt_tokens - 1) != NANO_HIP_OK) die_hip("llm_session_step (prefill)");
             pf_session = s; pf_upto = s->num_prompt_tokens - 1;
         }

@@ -42,6 +42,9 @@ struct GemvArgs {
     const float *attn_part; // [nb][nsplit][n] unnormalised partial outputs, or nullptr
     const float *attn_ml;   // [nb][n_head][nsplit][2] (running max, exp-sum) per split
     uint32_t attn_nsplit, attn_n_head, attn_hd, _pad2;
+    // residual epilogue only: an extra vector added to the GEMV result BEFORE the residual add, x += (W.act + resid_add)
+    // (the LoRA o-branch, reference infer.c:898-908); [nb][resid_add_bstride] or nullptr
+    const float *resid_add; uint32_t resid_add_bstride, _pad3;
     // optional per-tile arg-max partials of a STORE launch: tile_max[b][tile] = (max value, row index bits)
     float *tile_max;
 };
@@ -86,6 +89,18 @@ struct AttnArgs {
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
+
+// ---- LoRA side branches (lora.hip) -------------------------------------------------------------------
+struct LoraArgs {
+    const float *x;         // qkv: residual stream x [nb][E]; o: attention output xba [nb][E]
+    const float *norm_w;    // qkv: rms_attn weight of the layer
+    const float *qa, *qb, *ka, *kb, *va, *vb;      // this layer's pairs; o: qa / qb = the o pair
+    float *q, *kraw, *v;    // qkv: in-place targets (v = cache base of slot 0 / of the prefill slot); o: q = o1 out
+    const uint32_t *pos;
+    uint32_t E, KD, rank, alpha, v_bstride, _pad;
+};
+hipError_t launch_lora_qkv(const LoraArgs &a, uint32_t nb, hipStream_t st);
+hipError_t launch_lora_o(const LoraArgs &a, uint32_t nb, hipStream_t st);
 
 // ---- small kernels ----------------------------------------------------------------------------------
 struct EmbedArgs {

@@ -413,3 +413,20 @@ def prompt_ids(seed: int, n: int, vocab: int) -> np.ndarray:
         out[i] = ((s * 0x2545F4914F6CDD1D) & M) >> 32
         out[i] %= vocab
     return out
+
+
+def write_lora(path: str, spec: ModelSpec, rank: int = 8, alpha: int = 16, seed: int = 7, std: float = 0.05) -> None:
+    """Synthetic LoRA module in the reference's file format (infer/infer.c:434-498): 256-byte LE u32 header
+    (words 6..13 = rank, alpha, n_layer, n_embd, n_head, n_kv_head, n_hidden, lora_config) + eight FP32 tensors
+    wq_a[L][r][E] wq_b[L][E][r] wk_a wk_b[L][KD][r] wv_a wv_b wo_a wo_b.  Nano architecture only."""
+    assert spec.arch == ARCH_NANO
+    rng = np.random.default_rng(seed)
+    L, E, KD = spec.n_layer, spec.n_embd, spec.kv_dim
+    hdr = np.zeros(64, np.uint32)
+    hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5] = 0x42443453, 0x41524F4C, 1, 0, 0, 32
+    hdr[6:14] = [rank, alpha, L, E, spec.n_head, spec.n_kv_head, spec.n_hidden, 0]
+    shapes = [(L, rank, E), (L, E, rank), (L, rank, E), (L, KD, rank), (L, rank, E), (L, KD, rank), (L, rank, E), (L, E, rank)]
+    with open(path, "wb") as f:
+        f.write(hdr.tobytes())
+        for shp in shapes:          # unlike real adapters the B matrices are non-zero: the branch must show up in the logits
+            f.write((std * rng.standard_normal(int(np.prod(shp)))).astype(np.float32).tobytes())

@@ -60,6 +60,7 @@ class OracleLib:
         self.trace_end = fn("trace_end", None, [vp, vp])
         if prefix == "ref":
             self.seq2seq = fn("seq2seq", None, [vp, u32p, C.c_uint32, u32p, C.c_uint32])
+            self.ctx_load_lora = fn("ctx_load_lora", None, [vp, C.c_char_p])
         else:
             self.seq2seq_ids = fn("seq2seq_ids", None, [vp, u32p, u32p, C.c_uint32])
         self.op_rmsnorm = fn("op_rmsnorm", None, [f32p, f32p, f32p, C.c_int32])
@@ -137,6 +138,10 @@ class OracleCtx:
     def close(self):
         if self.h:
             self.lib.ctx_close(self.h); self.h = None
+
+    def load_lora(self, path: str):
+        """Attach a LoRA module file (compiled reference only): later forwards run with it."""
+        self.lib.ctx_load_lora(self.h, path.encode())
 
     def forward(self, token: int, pos: int, is_causal: int = 1) -> np.ndarray:
         p = self.lib.forward(self.h, token, pos, is_causal)

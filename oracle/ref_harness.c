@@ -116,6 +116,12 @@ void *ref_ctx_open_buffer(uint8_t *buffer, uint32_t max_seq_len, float rep_pen, 
 
 /* NOTE: llm_context_free() of the reference munmaps/closes; for _from_buffer contexts llm->fd is
  * 0 and llm->buffer NULL, so we do not call it for those (leak on purpose in the test process). */
+/* attach a LoRA module file to the context (reference load_lora, infer/infer.c:500): later forwards use it */
+void ref_ctx_load_lora(void *vctx, const char *path) {
+    Nano_Context *ctx = (Nano_Context *)vctx;
+    ctx->lora = load_lora(ctx->llm, (char *)path);
+}
+
 void ref_ctx_close(void *vctx) {
     Nano_Context *ctx = (Nano_Context *)vctx;
     if (ctx->llm->buffer) llm_context_free(ctx);

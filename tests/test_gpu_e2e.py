@@ -182,6 +182,51 @@ def test_position_buckets_and_odd_seq_len(oracle, model_dir, preset, quant, gs):
     assert worst < TOL[quant]
 
 
+@pytest.mark.parametrize("preset,quant,gs", [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano-odd", "f32", 0)])
+def test_lora_logits_vs_reference_golden(model_dir, preset, quant, gs):
+    """LoRA side branches: teacher-forced logits with a synthetic module attached vs the compiled
+    reference (tests/golden/lora_*.npz, tools/make_golden.py); switching the module off restores the base model;
+    batched prefill with the module equals token-by-token."""
+    from nano_amd import modelfile as mf
+    g = np.load(os.path.join(GOLD, f"lora_{preset}_{quant}.npz"))
+    path, spec = synth_model(model_dir, preset, quant, gs)
+    lpath = os.path.join(model_dir, f"{preset}-lora.bin")
+    mf.write_lora(lpath, spec, rank=int(g["rank"]), alpha=int(g["alpha"]), seed=int(g["lora_seed"]))
+    ids, gl = g["ids"], g["logits"]
+    m = nb.load_model_file(path, max_seq_len=32, max_batch=1)
+    base0 = m.forward([int(ids[0])], [0])[0][0].copy()
+    m.lora_attach_file(lpath)
+    worst, got = 0.0, []
+    for p in range(len(ids)):
+        lg = m.forward([int(ids[p])], [p])[0][0]
+        got.append(lg.copy()); worst = max(worst, rel_err(lg, gl[p]))
+    assert rel_err(got[0], base0) > 0.05                      # the module visibly changes the logits ...
+    m.lora_enable(False)
+    assert np.array_equal(m.forward([int(ids[0])], [0])[0][0], base0)   # ... and switching it off restores the base model
+    m.lora_enable(True)
+    m.prefill(ids[:8], pos0=0)                                # batched prefill with the module == token by token
+    pf = m.forward([int(ids[8])], [8])[0][0]
+    m.close()
+    print(f"LoRA {preset}/{quant}: worst max|dlogit|/max|logit| vs the reference over {len(ids)} steps = {worst:.3e}; prefill diff {rel_err(pf, got[8]):.1e}")
+    assert worst < TOL[quant]
+    assert rel_err(pf, got[8]) < 1e-6
+
+
+def test_engine_lora_path(model_dir):
+    """The engine API route: llm_context_init(model, lora_path) -> greedy ids equal the reference's arg-max ids."""
+    from nano_amd import modelfile as mf
+    g = np.load(os.path.join(GOLD, "lora_tiny-nano_f32.npz"))
+    path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)
+    lpath = os.path.join(model_dir, "tiny-nano-lora.bin")
+    mf.write_lora(lpath, spec, rank=int(g["rank"]), alpha=int(g["alpha"]), seed=int(g["lora_seed"]))
+    e = nb.Engine(path, max_seq_len=32, lora_path=lpath)
+    ids = np.zeros(33, np.uint32); ids[:len(g["ids"])] = g["ids"]
+    for p in range(len(g["ids"])):
+        tok = e.L.generate_next_token(e.ctx, ids, p, 0)
+        assert int(tok) == int(np.argmax(g["logits"][p])), p
+    e.close()
+
+
 def test_ragged_positions_in_one_batch(model_dir):
     """Slots at different positions in the same step (pos is per slot)."""
     path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)

@@ -109,6 +109,37 @@ def make_e2e(tmpdir):
         print("sample", name, quant, tag, "ids", ids[n_prompt:].tolist())
 
 
+LORA_CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano-odd", "f32", 0)]
+
+
+def make_lora(tmpdir):
+    """Teacher-forced logits of the compiled reference with a synthetic LoRA module attached (rank 8, alpha 16)."""
+    ref = ob.load_ref()
+    for (name, quant, gs) in LORA_CASES:
+        spec = mf.preset(name, quant, group_size=gs)
+        path = os.path.join(tmpdir, f"{name}-{quant}.bin")
+        lpath = os.path.join(tmpdir, f"{name}-lora.bin")
+        mf.write_model(path, spec, seed=39)
+        mf.write_lora(lpath, spec, rank=8, alpha=16, seed=7)
+        ctx = ob.OracleCtx(ref, path, max_seq_len=32)
+        base = ctx.forward(17, 0).copy()
+        ctx.close()
+        ctx = ob.OracleCtx(ref, path, max_seq_len=32)
+        ctx.load_lora(lpath)
+        ids = mf.prompt_ids(77, 12, spec.vocab_size)
+        logits = np.stack([ctx.forward(int(ids[p]), p).copy() for p in range(len(ids))])
+        first = ctx.forward  # noqa: F841
+        ctx.close()
+        ctx = ob.OracleCtx(ref, path, max_seq_len=32)
+        ctx.load_lora(lpath)
+        with_lora = ctx.forward(17, 0).copy()
+        ctx.close()
+        np.savez_compressed(os.path.join(GOLD, f"lora_{name}_{quant}.npz"), preset=name, quant=quant, gs=spec.group_size, seed=39,
+                            lora_seed=7, rank=8, alpha=16, ids=ids, logits=logits, model_sha256=sha256(path), lora_sha256=sha256(lpath))
+        print("lora", name, quant, "max|logit|", float(np.abs(logits).max()), "effect of the module on pos-0 logits:",
+              float(np.abs(with_lora - base).max()))
+
+
 def make_ops():
     ref = ob.load_ref()
     rng = np.random.default_rng(1234)
@@ -180,4 +211,5 @@ if __name__ == "__main__":
     assert ob.load_ref() is not None, "build oracle/_ref first: make -C oracle ref"
     extract_sort_model()
     make_e2e(tmp)
+    make_lora(tmp)
     make_ops()
