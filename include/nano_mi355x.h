@@ -120,6 +120,35 @@ int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *tokens, uin
 int nano_hip_lora_attach(NanoHipModel *m, uint32_t rank, uint32_t alpha, const float *params, size_t n_floats);
 int nano_hip_lora_enable(NanoHipModel *m, int on);
 
+/* ---- device-side sampling ------------------------------------------------------------------
+ * One decode step of sequence slot 0 followed by the reference's sampler, run on the device: repetition penalty over
+ * `history[0..n_history)` (the reference marks output_ids[0..pos), infer.c:1158-1166), temperature, softmax, top-p
+ * nucleus, one draw with `coin` (the caller's xorshift64* float, infer/utils.c:959-970).  temperature == 0 gives the
+ * penalised arg-max (infer.c:1169-1171).  The sampled token is the one the host code returns for the same logits
+ * (expf, the index-order float sum, the stable sort and the cut are evaluated in the reference's order).
+ * status NANO_SAMPLE_FALLBACK: the nucleus does not fit the device's sorter (more than NANO_SAMPLE_MAX_CANDIDATES tokens
+ * down to the power of two below the cut: near-uniform distributions); `token` is not valid and the caller samples on the host from the logits of this step
+ * (nano_hip_read_state(m, 0, 4, ...)); nothing else has to be redone.
+ * Replaces: the D2H copy of V logits plus the host loops of generate_next_token (infer.c:1156-1189). */
+#define NANO_SAMPLE_OK        0u
+#define NANO_SAMPLE_FALLBACK  1u
+#define NANO_SAMPLE_MAX_CANDIDATES 8192u
+typedef struct NanoHipSample {
+    uint32_t token;            /* sampled token id */
+    uint32_t status;           /* NANO_SAMPLE_* */
+    uint32_t n_candidates;     /* tokens with p >= (1-top_p)/(V-1) */
+    uint32_t n_sorted;         /* of those, how many the device sorted (a superset of the nucleus) */
+    uint32_t nucleus;          /* tokens kept by the top-p cut */
+    uint32_t top[6];           /* the six most probable tokens (the reference's sampling observation, infer.c:1085-1094) */
+    uint32_t sum_bits;         /* bits of the softmax denominator */
+    uint32_t walked_chunks;    /* diagnostic: 256-element chunks the denominator was added element by element */
+} NanoHipSample;
+int nano_hip_forward_sample(NanoHipModel *m, uint32_t token, uint32_t pos, const uint32_t *history, uint32_t n_history,
+                            float repetition_penalty, float temperature, float top_p, float coin, NanoHipSample *out);
+/* The sampler alone on caller-provided logits (host pointer, V floats): operator parity tests. */
+int nano_hip_op_sample(NanoHipModel *m, const float *logits, const uint32_t *history, uint32_t n_history,
+                       float repetition_penalty, float temperature, float top_p, float coin, NanoHipSample *out);
+
 /* Blocks until all work queued on the model's stream has finished. */
 int nano_hip_sync(NanoHipModel *m);
 

@@ -63,6 +63,8 @@ def lib() -> C.CDLL:
     fn("nano_hip_prefill", C.c_int, [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32])
     fn("nano_hip_lora_attach", C.c_int, [vp, C.c_uint32, C.c_uint32, f32p, C.c_size_t])
     fn("nano_hip_lora_enable", C.c_int, [vp, C.c_int])
+    fn("nano_hip_forward_sample", C.c_int, [vp, C.c_uint32, C.c_uint32, u32p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NanoHipSample)])
+    fn("nano_hip_op_sample", C.c_int, [vp, f32p, u32p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NanoHipSample)])
     fn("nano_hip_sync", C.c_int, [vp])
     fn("nano_hip_time_classifier", C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64)])
     fn("nano_hip_time_classifier_in_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_float)])
@@ -108,6 +110,12 @@ def membw(device: int = 0, nbytes: int = 1 << 30, iters: int = 10) -> float:
 
 
 STATE_IDS = {"x": 0, "q": 1, "xba": 2, "hb": 3, "logits": 4, "k": 5, "v": 6}
+
+
+class NanoHipSample(C.Structure):
+    """Result of the device-side sampler (include/nano_mi355x.h NanoHipSample)."""
+    _fields_ = [("token", C.c_uint32), ("status", C.c_uint32), ("n_candidates", C.c_uint32), ("n_sorted", C.c_uint32), ("nucleus", C.c_uint32),
+                ("top", C.c_uint32 * 6), ("sum_bits", C.c_uint32), ("walked_chunks", C.c_uint32)]
 
 
 class DeviceModel:
@@ -161,6 +169,24 @@ class DeviceModel:
         """Batched prefill of one sequence: tokens at positions pos0.. (no logits)."""
         t = np.ascontiguousarray(tokens, np.uint32).reshape(-1)
         check(lib().nano_hip_prefill(self.h, slot, t, pos0, t.size))
+
+    def forward_sample(self, token: int, pos: int, history: Sequence[int], repetition_penalty: float, temperature: float,
+                       top_p: float, coin: float) -> NanoHipSample:
+        """One decode step of slot 0 + the reference's sampler on the device (infer.c:1156-1189)."""
+        h = np.ascontiguousarray(history, np.uint32).reshape(-1)
+        r = NanoHipSample()
+        check(lib().nano_hip_forward_sample(self.h, token, pos, h, h.size, repetition_penalty, temperature, top_p, coin, C.byref(r)))
+        return r
+
+    def op_sample(self, logits: np.ndarray, history: Sequence[int], repetition_penalty: float, temperature: float,
+                  top_p: float, coin: float) -> NanoHipSample:
+        """The device sampler alone, on host-provided logits (V floats)."""
+        l = np.ascontiguousarray(logits, np.float32).reshape(-1)
+        assert l.size == self.vocab
+        h = np.ascontiguousarray(history, np.uint32).reshape(-1)
+        r = NanoHipSample()
+        check(lib().nano_hip_op_sample(self.h, l, h, h.size, repetition_penalty, temperature, top_p, coin, C.byref(r)))
+        return r
 
     def lora_attach_file(self, path: str):
         """Attach a LoRA module file (reference format: 256-byte header, rank / alpha = words 6 / 7, then FP32 tensors)."""

@@ -51,6 +51,16 @@ enum { WQ = 0, WK, WV, WO, W1, W2, W3, WCOUNT };
 
 struct TensorRef { const void *w = nullptr; const float *s = nullptr; };
 
+// device-side sampler (sampler.hip): one device block + pinned staging + the host's record of the `seen` set
+struct SamplerState {
+    uint8_t *block = nullptr;
+    SampleArgs a{};
+    uint8_t *seen = nullptr;
+    uint32_t *hist = nullptr, hist_cap = 0;
+    uint32_t *h_hist = nullptr; NanoHipSample *h_res = nullptr;
+    std::vector<uint32_t> applied;                        // ids already marked in `seen`, in history order
+};
+
 struct NanoHipModel {
     NanoModelDesc d{};
     int device = 0, cus = 0;
@@ -85,6 +95,7 @@ struct NanoHipModel {
     std::map<uint64_t, hipGraphExec_t> graphs;
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
+    struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
 };
 
@@ -151,6 +162,12 @@ static void destroy(NanoHipModel *m) {
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
+    if (m->smp) {
+        if (m->smp->block) (void)hipFree(m->smp->block);
+        if (m->smp->h_hist) (void)hipHostFree(m->smp->h_hist);
+        if (m->smp->h_res) (void)hipHostFree(m->smp->h_res);
+        delete m->smp;
+    }
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->ev2) (void)hipEventDestroy(m->ev2);
@@ -566,6 +583,109 @@ extern "C" int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const u
     if (logits_out) memcpy(logits_out, m->h_logits, batch * V * 4);
     if (argmax_out) memcpy(argmax_out, m->h_amax, batch * 4);
     return 0;
+}
+
+// ---- device-side sampling (reference infer.c:1156-1189) ------------------------------------------------
+static int sampler_init(NanoHipModel *m) {
+    if (m->smp) return 0;
+    const uint32_t V = m->d.vocab_size;
+    const uint32_t nch = (((V + SAMPLE_CHUNK - 1) / SAMPLE_CHUNK) + 3u) & ~3u;
+    if (nch > SAMPLE_MAX_CHUNKS) FAIL(NANO_HIP_EINVAL, "vocabulary %u too large for the device sampler (max %u)", V, SAMPLE_MAX_CHUNKS * SAMPLE_CHUNK);
+    SamplerState *sp = new SamplerState();
+    const size_t npad = (size_t)nch * SAMPLE_CHUNK;
+    sp->hist_cap = m->S + 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_y = take(npad * 4), o_e = take(npad * 4), o_seen = take(npad), o_approx = take(nch * 4), o_spec = take(nch * 4),
+                 o_fn = take(nch * 8), o_cells = take(256), o_bins = take(SAMPLE_BINS * 12), o_cand = take((size_t)SAMPLE_MAX_CANDIDATES * 8), o_res = take(sizeof(NanoHipSample)),
+                 o_hist = take((size_t)sp->hist_cap * 4);
+    if (hipMalloc(&sp->block, off) != hipSuccess || hipMemset(sp->block, 0, off) != hipSuccess ||
+        hipHostMalloc(&sp->h_hist, (size_t)sp->hist_cap * 4) != hipSuccess || hipHostMalloc(&sp->h_res, sizeof(NanoHipSample)) != hipSuccess) {
+        if (sp->block) (void)hipFree(sp->block);
+        if (sp->h_hist) (void)hipHostFree(sp->h_hist);
+        delete sp;
+        FAIL(NANO_HIP_ENOMEM, "device sampler scratch allocation failed");
+    }
+    uint8_t *b = sp->block;
+    SampleArgs &a = sp->a;
+    a.V = V; a.nch = nch;
+    a.y = (float *)(b + o_y); a.e = (float *)(b + o_e); sp->seen = b + o_seen;
+    a.approx = (float *)(b + o_approx); a.spec = (uint32_t *)(b + o_spec); a.fn = (uint2 *)(b + o_fn);
+    a.maxcell = (uint32_t *)(b + o_cells); a.ncand = a.maxcell + 1; a.sum = (float *)(a.maxcell + 2);
+    a.ndrop = a.maxcell + 3; a.dropmax = a.maxcell + 4; a.bstar = a.maxcell + 5;
+    a.bin_mass = (unsigned long long *)(b + o_bins); a.bin_cnt = (uint32_t *)(b + o_bins + SAMPLE_BINS * 8);
+    a.cand = (unsigned long long *)(b + o_cand); a.cap = SAMPLE_MAX_CANDIDATES; a.res = (NanoHipSample *)(b + o_res);
+    sp->hist = (uint32_t *)(b + o_hist);
+    m->smp = sp;
+    return 0;
+}
+
+// queue the sampler behind whatever produced `logits` (device pointer) on the model's stream, wait, fill *out
+static int sample_run(NanoHipModel *m, const float *logits, const uint32_t *history, uint32_t n_history,
+                      float penalty, float temperature, float top_p, float coin, NanoHipSample *out) {
+    SamplerState *sp = m->smp;
+    SampleArgs a = sp->a;
+    a.logits = logits; a.penalty = penalty; a.temperature = temperature; a.top_p = top_p; a.coin = coin;
+    a.cutoff = (1.0f - top_p) / (float)((int)a.V - 1);                     // (1.0f - top_p) / (n - 1), infer.c:1064
+    a.seen = nullptr;
+    if (penalty != 1.0f) {                                                 // x / 1.0f is exact: no set needed
+        if (n_history > sp->hist_cap) FAIL(NANO_HIP_EINVAL, "history of %u ids exceeds max_seq_len + 1", n_history);
+        for (uint32_t i = 0; i < n_history; i++) if (history[i] >= a.V) FAIL(NANO_HIP_EINVAL, "history id %u out of vocabulary", history[i]);
+        std::vector<uint32_t> &ap = sp->applied;
+        if (ap.size() > n_history || memcmp(ap.data(), history, ap.size() * 4) != 0) {     // another sequence: start the set over
+            HIP_TRY(hipMemsetAsync(sp->seen, 0, (size_t)a.nch * SAMPLE_CHUNK, m->st));
+            ap.clear();
+        }
+        const uint32_t n_new = n_history - (uint32_t)ap.size();
+        if (n_new) {
+            memcpy(sp->h_hist, history + ap.size(), (size_t)n_new * 4);
+            HIP_TRY(hipMemcpyAsync(sp->hist, sp->h_hist, (size_t)n_new * 4, hipMemcpyHostToDevice, m->st));
+            HIP_TRY(launch_seen_set(sp->hist, n_new, sp->seen, m->st));
+            ap.insert(ap.end(), history + ap.size(), history + n_history);
+        }
+        a.seen = sp->seen;
+    }
+    if (temperature == 0.0f) {                                             // penalised arg-max (infer.c:1169-1171)
+        HIP_TRY(launch_sample_prep(a, m->st));
+        ArgmaxArgs aa{ a.y, a.V, a.V, m->amax, nullptr, m->pos, nullptr, m->pos0, 1, nullptr, 0 };
+        HIP_TRY(launch_argmax(aa, 1, m->st));
+        HIP_TRY(hipMemcpyAsync(m->h_amax, m->amax, 4, hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        memset(out, 0, sizeof *out);
+        out->token = m->h_amax[0]; out->status = NANO_SAMPLE_OK;
+        return 0;
+    }
+    HIP_TRY(launch_sample(a, m->st));
+    HIP_TRY(hipMemcpyAsync(sp->h_res, a.res, sizeof(NanoHipSample), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    *out = *sp->h_res;
+    return 0;
+}
+
+extern "C" int nano_hip_forward_sample(NanoHipModel *m, uint32_t token, uint32_t pos, const uint32_t *history, uint32_t n_history,
+                                       float repetition_penalty, float temperature, float top_p, float coin, NanoHipSample *out) {
+    int rc;
+    if (!out || (n_history && !history)) FAIL(NANO_HIP_EINVAL, "null argument");
+    if ((rc = check_batch(m, &token, &pos, 1, 0))) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = sampler_init(m))) return rc;
+    m->h_tokens[0] = token; m->h_pos[0] = pos;
+    HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, 4, hipMemcpyHostToDevice, m->st));
+    if ((rc = run_step(m, 1, 1u, MODE_LOGITS, pos))) return rc;
+    return sample_run(m, m->logits, history, n_history, repetition_penalty, temperature, top_p, coin, out);
+}
+
+extern "C" int nano_hip_op_sample(NanoHipModel *m, const float *logits, const uint32_t *history, uint32_t n_history,
+                                  float repetition_penalty, float temperature, float top_p, float coin, NanoHipSample *out) {
+    int rc;
+    if (!m || !logits || !out || (n_history && !history)) FAIL(NANO_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = sampler_init(m))) return rc;
+    const size_t V = m->d.vocab_size;
+    memcpy(m->h_logits, logits, V * 4);
+    HIP_TRY(hipMemcpyAsync(m->logits, m->h_logits, V * 4, hipMemcpyHostToDevice, m->st));
+    return sample_run(m, m->logits, history, n_history, repetition_penalty, temperature, top_p, coin, out);
 }
 
 // ---- LoRA ---------------------------------------------------------------------------------------------

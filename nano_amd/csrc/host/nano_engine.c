@@ -382,6 +382,8 @@ void free_sampler(Sampler *s) { if (s) { free(s->probindex); free(s); } }
 
 /* set by step_core while it calls generate_next_token for a prompt position its batched prefill already covered */
 static int g_position_prefilled = 0;
+/* NANO_HOST_SAMPLER=1: copy the logits back and run the sampler loops on the host (A/B checks) */
+static int g_host_sampler = -1;
 
 /* reference infer/infer.c:1135-1193 */
 uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t pos, int is_prefilling) {
@@ -391,6 +393,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
     if (!dev) { fprintf(stderr, "generate_next_token: model is not resident on a device\n"); exit(EXIT_FAILURE); }
     uint32_t token = output_ids[pos];
     lora_select(dev, ctx->lora);
+    if (g_host_sampler < 0) { const char *e = getenv("NANO_HOST_SAMPLER"); g_host_sampler = (e && *e && *e != '0') ? 1 : 0; }
 
     if (is_prefilling == 1) {
         /* the reference computes the logits of prompt positions and discards them (infer.c:1146-1149):
@@ -409,9 +412,34 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
         return best;
     }
 
-    float *logits = llm_forward(ctx, token, pos, ctx->max_seq_len, 1, llm, ctx->lora);
-    observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
+    /* Sampling with a penalty and/or a temperature.  The coin is drawn exactly when the reference draws it
+     * (only on the softmax branch, infer.c:1180); nothing else consumes the generator. */
+    const float coin = sp->temperature != 0.0f ? xorshift_f32(&sp->rng_state) : 0.0f;
     const int V = sp->vocab_size;
+    float *logits = NULL;
+    if (!g_host_sampler) {
+        /* the sampler runs on the device behind the forward: one 52-byte result comes back */
+        NanoHipSample r;
+        observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
+        if (nano_hip_forward_sample(dev, token, pos, output_ids, pos, sp->repetition_penalty, sp->temperature, sp->top_p, coin, &r) != NANO_HIP_OK)
+            die_hip("generate_next_token");
+        observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
+        if (r.status == NANO_SAMPLE_OK) {
+            if (sp->temperature != 0.0f && ctx->observation) {
+                Nano_Observation o; memset(&o, 0, sizeof o);
+                o.layer = -1; o.phase = NANO_LLM_PHASE_SAMPLE;
+                o.token_0 = r.top[0]; o.token_1 = r.top[1]; o.token_2 = r.top[2]; o.token_3 = r.top[3]; o.token_4 = r.top[4]; o.token_5 = r.top[5];
+                ctx->observation(o, ctx->observation_env);
+            }
+            return r.token;
+        }
+        /* more candidates than the device nucleus holds (near-uniform distribution): same logits, host loops */
+        logits = llm->state.logits;
+        if (nano_hip_read_state(dev, 0, 4, 0, 0, logits, (size_t)V) != NANO_HIP_OK) die_hip("generate_next_token");
+    } else {
+        logits = llm_forward(ctx, token, pos, ctx->max_seq_len, 1, llm, ctx->lora);
+        observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
+    }
     uint32_t *seen = (uint32_t *)calloc((size_t)V, sizeof(uint32_t));
     if (seen) {
         for (uint32_t i = 0; i < pos; i++) seen[output_ids[i]] = 1;
@@ -421,7 +449,6 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
     if (sp->temperature == 0.0f) return (uint32_t)argmax_first(logits, V);
     for (int i = 0; i < V; i++) logits[i] /= sp->temperature;
     softmax_inplace(logits, V);
-    float coin = xorshift_f32(&sp->rng_state);
     return (uint32_t)nucleus(ctx, logits, V, sp->top_p, sp->probindex, coin);   /* top-p always (infer.c:1183) */
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include "../../include/nano_mi355x.h"
 
 namespace nano {
 
@@ -131,5 +132,27 @@ hipError_t launch_quantize_q4k(const float *x, uint32_t n, uint8_t *blocks, hipS
 hipError_t launch_swiglu(float *hb, const float *hb2, uint32_t n, hipStream_t st);
 hipError_t launch_rope(float *head, uint32_t hd, const float *fcr, const float *fci, int qwen3, hipStream_t st);
 hipError_t launch_stream_read(const void *buf, size_t bytes, float *sink, hipStream_t st);
+
+// ---- device-side sampler (sampler.hip) ----
+constexpr uint32_t SAMPLE_CHUNK = 256;            // softmax numerators per chunk function (one wave x float4)
+constexpr uint32_t SAMPLE_MAX_CHUNKS = 1024;      // vocabularies up to 262144
+constexpr uint32_t SAMPLE_MAX_CANDIDATES = NANO_SAMPLE_MAX_CANDIDATES;
+constexpr uint32_t SAMPLE_BINS = 256;             // histogram of the softmax numerators: 8 bins per binade, 2^0 .. 2^-31
+struct SampleArgs {
+    const float *logits; uint32_t V;
+    uint32_t nch;                                 // chunks, rounded up to a multiple of 4; y/e hold nch*256 floats
+    float *y, *e;                                 // penalised+tempered logits, softmax numerators
+    const uint8_t *seen;                          // null when the penalty is 1
+    float penalty, temperature, top_p, cutoff, coin;
+    uint32_t *maxcell, *ncand, *ndrop, *dropmax, *bstar;  // accumulators, left at 0 by the last kernel (bstar: set by propagate)
+    uint32_t *bin_cnt; unsigned long long *bin_mass;      // [SAMPLE_BINS], likewise
+    float *approx; uint32_t *spec; uint2 *fn;     // per chunk: approximate sum, guessed exponent field, chunk function
+    float *sum;
+    unsigned long long *cand; uint32_t cap;
+    NanoHipSample *res;
+};
+hipError_t launch_seen_set(const uint32_t *ids, uint32_t n, uint8_t *seen, hipStream_t st);
+hipError_t launch_sample_prep(const SampleArgs &a, hipStream_t st);   // penalty (and temperature) only
+hipError_t launch_sample(const SampleArgs &a, hipStream_t st);
 
 }  // namespace nano

@@ -1,0 +1,295 @@
+// sampler.hip — the reference's sampler on the device, token-for-token identical to the host code.
+//
+// Reference: generate_next_token / softmax / sample_top_p (infer/infer.c:1026-1109, 1156-1189): repetition penalty
+// (divide the logits of every token seen so far), divide by the temperature, softmax (first-max, libm expf, index-order
+// float sum, divide), keep p >= (1-top_p)/(V-1), qsort by probability (glibc's merge sort: stable, so equal
+// probabilities stay in index order), cut where the running sum passes top_p, draw with one xorshift64* coin.
+//
+// Every step whose result depends on evaluation order is evaluated in the reference's order:
+//   * expf        exact_expf_nonpos (exact_math.h): the same double-precision operation sequence as the pinned libm;
+//   * the sum     chunk functions (exact_math.h): integer mantissa increments per 256-element chunk, folded as a tree,
+//                 then one wave walks the 594 chunk functions (Qwen3 vocabulary) and adds element by element only where
+//                 the running sum changes binade (about ten chunks);
+//   * the sort    a total order (probability desc, index asc) in LDS, so any network gives the stable result; only a
+//                 superset of the nucleus is sorted when the candidates are many: a 32-bin histogram of the numerators'
+//                 exponents gives a lower bound of the mass above each power of two, tokens below the first bound that
+//                 exceeds top_p are dropped, and the cut is accepted only if it fell strictly above every dropped token;
+//   * the cut and the draw   one thread, sequential, over the sorted nucleus.
+// Six dependent kernels, ~V*4 B each way through L2; nothing but a 52-byte result crosses PCIe.
+#include "kernels.h"
+#include "exact_math.h"
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace nano {
+using namespace nano_exact;
+
+static constexpr int CH = SAMPLE_CHUNK;           // elements per chunk = one wave x float4
+static_assert(SAMPLE_BINS == 256, "the histogram is zeroed / flushed by 256-thread workgroups and scanned 4 bins per lane");
+
+__device__ __forceinline__ uint32_t ord_of(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+// histogram bin of a softmax numerator e in [0, 1]: 8 bins per binade, bin 7 = {1.0}, larger e -> smaller bin,
+// everything below 2^-31 (and 0) in the last bin
+__device__ __forceinline__ uint32_t exp_bin(float e) {
+    const uint32_t u = __float_as_uint(e), f = u >> 23;
+    const uint32_t b = (127u - f) * 8u + (7u - ((u >> 20) & 7u));
+    return f > 127u ? 0u : (b > SAMPLE_BINS - 1 ? SAMPLE_BINS - 1 : b);
+}
+__device__ __forceinline__ float ord_to(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+__global__ __launch_bounds__(256) void seen_set_kernel(const uint32_t *ids, uint32_t n, uint8_t *seen) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) seen[ids[i]] = 1;
+}
+
+// K1: y = (seen ? l / penalty : l) / temperature over the padded range (padding = -inf -> numerator 0), running max
+__global__ __launch_bounds__(256) void samp_prep_kernel(const SampleArgs a) {
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    float v[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k;
+        float l = -INFINITY;
+        if (i < a.V) {
+            l = a.logits[i];
+            if (a.seen && a.seen[i]) l /= a.penalty;
+            if (a.temperature != 0.0f) l /= a.temperature;
+        }
+        v[k] = l; mx = fmaxf(mx, l);
+    }
+    *reinterpret_cast<float4 *>(a.y + i0) = make_float4(v[0], v[1], v[2], v[3]);
+    if (a.temperature == 0.0f) return;            // penalised arg-max only: no softmax
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(a.maxcell, ord_of(mx));
+}
+
+// K2: numerators e = expf(y - max) and one approximate float sum per chunk (used only to guess each chunk's binade)
+__global__ __launch_bounds__(256) void samp_exp_kernel(const SampleArgs a) {
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= a.nch) return;
+    const float m = ord_to(*a.maxcell);
+    const float4 y = reinterpret_cast<const float4 *>(a.y)[c * 64 + lane];
+    float4 e;
+    e.x = exact_expf_nonpos(y.x - m, kExp2Tab); e.y = exact_expf_nonpos(y.y - m, kExp2Tab);
+    e.z = exact_expf_nonpos(y.z - m, kExp2Tab); e.w = exact_expf_nonpos(y.w - m, kExp2Tab);
+    reinterpret_cast<float4 *>(a.e)[c * 64 + lane] = e;
+    float s = (e.x + e.y) + (e.z + e.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) a.approx[c] = s;
+    // per-bin count and mass of the numerators; the mass in 2^-40 fixed point so that the totals do not depend on the
+    // order of the atomics (truncation < 2^-40 per token: 1.4e-7 over the whole vocabulary)
+    __shared__ uint32_t hcnt[SAMPLE_BINS];
+    __shared__ unsigned long long hmass[SAMPLE_BINS];
+    hcnt[threadIdx.x] = 0; hmass[threadIdx.x] = 0;
+    __syncthreads();
+    const float ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (ev[k] != 0.0f) {
+            const uint32_t b = exp_bin(ev[k]);
+            atomicAdd(&hcnt[b], 1u);
+            atomicAdd(&hmass[b], (unsigned long long)((double)ev[k] * 0x1p40));
+        }
+    __syncthreads();
+    if (hcnt[threadIdx.x]) { atomicAdd(&a.bin_cnt[threadIdx.x], hcnt[threadIdx.x]); atomicAdd(&a.bin_mass[threadIdx.x], hmass[threadIdx.x]); }
+}
+
+// K3: the chunk function of every chunk, for the binade its approximate prefix falls in
+__global__ __launch_bounds__(256) void samp_chunkfn_kernel(const SampleArgs a) {
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= a.nch) return;
+    float pre = 0.0f;
+    for (uint32_t j = lane; j < c; j += 64) pre += a.approx[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+    const uint32_t Es = sum_exp(__float_as_uint(pre));
+    const float4 e = reinterpret_cast<const float4 *>(a.e)[c * 64 + lane];
+    ChunkFn f{0u, 0u};
+    chunk_push(f, __float_as_uint(e.x), Es); chunk_push(f, __float_as_uint(e.y), Es);
+    chunk_push(f, __float_as_uint(e.z), Es); chunk_push(f, __float_as_uint(e.w), Es);
+#pragma unroll
+    for (int st = 1; st < 64; st <<= 1) {
+        ChunkFn g;
+        g.dE = __shfl_down(f.dE, st, 64); g.dO = __shfl_down(f.dO, st, 64);
+        if ((lane & (2 * st - 1)) == 0) f = chunk_then(f, g);
+    }
+    if (lane == 0) { a.fn[c] = make_uint2(f.dE, f.dO); a.spec[c] = Es; }
+}
+
+// K4: one wave carries the exact running sum through the chunk functions; where one does not apply (the sum is in
+// another binade than guessed, or leaves it inside the chunk) the chunk's 256 numerators are added one by one.
+__global__ __launch_bounds__(64) void samp_propagate_kernel(const SampleArgs a) {
+    __shared__ uint32_t s_dE[SAMPLE_MAX_CHUNKS], s_dO[SAMPLE_MAX_CHUNKS], s_spec[SAMPLE_MAX_CHUNKS];
+    __shared__ float4 s_buf[64];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t c = lane; c < a.nch; c += 64) { const uint2 f = a.fn[c]; s_dE[c] = f.x; s_dO[c] = f.y; s_spec[c] = a.spec[c]; }
+    __syncthreads();
+    uint32_t sb = 0, walks = 0;
+    for (uint32_t c = 0; c < a.nch; c++) {
+        const ChunkFn f{s_dE[c], s_dO[c]};
+        if (!chunk_apply(sb, f, s_spec[c])) {                       // wave-uniform
+            s_buf[lane] = reinterpret_cast<const float4 *>(a.e)[c * 64 + lane];
+            __syncthreads();
+            float s = __uint_as_float(sb);
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) { const float4 w = s_buf[k]; s += w.x; s += w.y; s += w.z; s += w.w; }
+            sb = __float_as_uint(s);
+            walks++;
+            __syncthreads();
+        }
+    }
+    const float sum = __uint_as_float(sb);
+    // Which tokens have to be sorted?  All candidates if they fit; otherwise the bins down to the first one at which
+    // the mass of the numerators passes top_p (with head-room for the rounding of the float running sum) — the cut then
+    // falls inside them.  Lane l owns bins 4l..4l+3; cumulative counts / masses by a wave scan.
+    uint32_t c[4]; unsigned long long ms[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { c[k] = a.bin_cnt[lane * 4 + k]; ms[k] = a.bin_mass[lane * 4 + k]; }
+#pragma unroll
+    for (int k = 1; k < 4; k++) { c[k] += c[k - 1]; ms[k] += ms[k - 1]; }
+    uint32_t ct = c[3]; unsigned long long mt = ms[3];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t oc = __shfl_up(ct, o, 64); const unsigned long long om = __shfl_up(mt, o, 64);
+        if (lane >= (uint32_t)o) { ct += oc; mt += om; }
+    }
+    const uint32_t cbase = ct - c[3]; const unsigned long long mbase = mt - ms[3];
+    const double need = (double)a.top_p * 1.002 * (double)sum * 0x1p40;
+    uint32_t bm = SAMPLE_BINS - 1, b6 = SAMPLE_BINS - 1;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        if ((double)(mbase + ms[k]) > need) bm = lane * 4 + k;
+        if (cbase + c[k] >= 6u) b6 = lane * 4 + k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { bm = min(bm, (uint32_t)__shfl_xor(bm, o, 64)); b6 = min(b6, (uint32_t)__shfl_xor(b6, o, 64)); }
+    const uint32_t bc = exp_bin(a.cutoff * sum * 0.999f);            // every candidate (p >= cutoff) lies in bins <= bc
+    uint32_t cc = bc % 4 == 0 ? c[0] : bc % 4 == 1 ? c[1] : bc % 4 == 2 ? c[2] : c[3];
+    cc = __shfl(cbase + cc, bc / 4, 64);
+    if (lane == 0) {
+        a.sum[0] = sum; a.res->sum_bits = sb; a.res->walked_chunks = walks;
+        *a.bstar = cc <= a.cap ? SAMPLE_BINS - 1 : max(bm, b6);
+    }
+}
+
+// K5: p = e / sum; candidates p >= cutoff appended as keys (probability bits, ~index): one u64 compare = the
+// reference's order (probability descending, then index ascending — glibc's qsort is a stable merge sort).
+// Candidates in bins after `bstar` (chosen by the propagate kernel) are only counted, and their largest probability
+// recorded for the check in the pick kernel.
+__global__ __launch_bounds__(256) void samp_filter_kernel(const SampleArgs a) {
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4, lane = threadIdx.x & 63;
+    const float sum = a.sum[0];
+    const uint32_t bstar = *a.bstar;
+    const float4 e = reinterpret_cast<const float4 *>(a.e)[i0 / 4];
+    const float ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k;
+        const float p = ev[k] / sum;
+        const bool cand = i < a.V && p >= a.cutoff;
+        const bool keep = cand && exp_bin(ev[k]) <= bstar;
+        const bool drop = cand && !keep;
+        const unsigned long long mask = __ballot(keep), dmask = __ballot(drop);
+        if (dmask != 0) {
+            float pm = drop ? p : 0.0f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o, 64));
+            if (lane == 0) { atomicAdd(a.ndrop, (uint32_t)__popcll(dmask)); atomicMax(a.dropmax, __float_as_uint(pm)); }
+        }
+        if (mask == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.ncand, (uint32_t)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (keep && slot < a.cap) a.cand[slot] = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned long long)(0xffffffffu - i);
+    }
+}
+
+// K6: sort the candidates, cut the nucleus, draw.  Also re-arms the two cells the next call's K1/K5 accumulate into.
+__global__ __launch_bounds__(1024) void samp_pick_kernel(const SampleArgs a) {
+    __shared__ unsigned long long key[SAMPLE_MAX_CANDIDATES];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n0 = *a.ncand, ndrop = *a.ndrop;
+    const float dropmax = __uint_as_float(*a.dropmax);
+    __syncthreads();
+    if (tid == 0) { *a.ncand = 0; *a.maxcell = 0; *a.ndrop = 0; *a.dropmax = 0; a.res->n_candidates = n0 + ndrop; a.res->n_sorted = n0; }
+    if (tid < SAMPLE_BINS) { a.bin_cnt[tid] = 0; a.bin_mass[tid] = 0; }
+    if (n0 == 0 || n0 > a.cap || (ndrop && n0 < 6)) { if (tid == 0) { a.res->status = NANO_SAMPLE_FALLBACK; a.res->token = 0; } return; }
+    uint32_t n = 2;
+    while (n < n0) n <<= 1;
+    for (uint32_t i = tid; i < n; i += 1024) key[i] = i < n0 ? a.cand[i] : 0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= n; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < n / 2; t += 1024) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                const unsigned long long x = key[i], y = key[p];
+                const bool desc = (i & k) == 0;
+                if (desc ? (x < y) : (x > y)) { key[i] = y; key[p] = x; }
+            }
+            __syncthreads();
+        }
+    if (tid != 0) return;
+    // the two sequential loops of sample_top_p.  Probabilities are >= 0, so the running sums never decrease: eight
+    // additions at a time, one test per block.
+    const uint32_t *kw = reinterpret_cast<const uint32_t *>(key);      // probability bits = high word of key i
+    auto prob = [&](uint32_t i) { return __uint_as_float(kw[2 * i + 1]); };
+    auto first_above = [&](float thr, uint32_t n, float &run, uint32_t &where) {     // first i < n whose running sum > thr
+        uint32_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            float cs[8];
+            cs[0] = run + prob(i);
+#pragma unroll
+            for (int k = 1; k < 8; k++) cs[k] = cs[k - 1] + prob(i + k);
+            if (cs[7] > thr) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (cs[k] > thr) { run = cs[k]; where = i + k; return true; }
+            }
+            run = cs[7];
+        }
+        for (; i < n; i++) { run += prob(i); if (run > thr) { where = i; return true; } }
+        return false;
+    };
+    float cum = 0.0f;
+    uint32_t last = n0 - 1;
+    const bool cut = first_above(a.top_p, n0, cum, last);        // cumulative_prob > top_p (infer.c:1078-1084)
+    // tokens were dropped: the sorted list is the reference's only down to the largest dropped probability
+    // (and so are the six most probable tokens reported to the observation hook)
+    const uint32_t deepest = last > 5 ? last : 5;             // n0 >= 6 whenever ndrop != 0
+    if (ndrop && !(cut && prob(deepest) > dropmax)) { a.res->status = NANO_SAMPLE_FALLBACK; a.res->token = 0; return; }
+    const float r = a.coin * cum;
+    float cdf = 0.0f;
+    uint32_t pick = last;
+    (void)first_above(r, last + 1, cdf, pick);                   // r < cdf (infer.c:1100-1106); else probindex[last_idx]
+    a.res->token = 0xffffffffu - (uint32_t)key[pick];
+    a.res->status = NANO_SAMPLE_OK;
+    a.res->nucleus = last + 1;
+    for (uint32_t i = 0; i < 6; i++) a.res->top[i] = i < n0 ? 0xffffffffu - (uint32_t)key[i] : 0u;
+}
+
+hipError_t launch_seen_set(const uint32_t *ids, uint32_t n, uint8_t *seen, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(seen_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, seen);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_prep(const SampleArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(samp_prep_kernel, dim3(a.nch * CH / 1024), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample(const SampleArgs &a, hipStream_t st) {
+    const uint32_t wgs = a.nch * CH / 1024;       // nch is a multiple of 4
+    hipLaunchKernelGGL(samp_prep_kernel, dim3(wgs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(samp_exp_kernel, dim3(a.nch / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(samp_chunkfn_kernel, dim3(a.nch / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(samp_propagate_kernel, dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(samp_filter_kernel, dim3(wgs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(samp_pick_kernel, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace nano

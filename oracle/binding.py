@@ -75,10 +75,24 @@ class OracleLib:
         self.op_quantize_q4k = fn("op_quantize_q4k", None, [f32p, C.c_uint32, u32p, u8p])
         self.op_dequantize_q4k = fn("op_dequantize_q4k", None, [u8p, f32p])
         self.op_matmul_q4k = fn("op_matmul_q4k", None, [f32p, u8p, u8p, C.c_uint32])
+        sargs = [f32p, C.c_int32, u32p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint32)]
+        self._sample_logits = fn("sample_logits", C.c_uint32, ([vp] if prefix == "ref" else []) + sargs)
+        if prefix == "orc":
+            self.softmax_denominator = fn("softmax_denominator", C.c_float, [f32p, C.c_int32])
         self.random_u32 = fn("random_u32", C.c_uint32, [C.POINTER(C.c_uint64)])
         self.random_f32 = fn("random_f32", C.c_float, [C.POINTER(C.c_uint64)])
 
     # ---- numpy conveniences --------------------------------------------------------------
+    def sample_logits(self, logits, history, rep_pen, temperature, top_p, coin, ctx=None):
+        """The sampler of generate_next_token on a logits vector -> (token, candidates above the top-p cutoff).
+        The compiled reference needs a context handle for its observation hook (any model)."""
+        l = np.array(logits, np.float32).reshape(-1)          # copy: overwritten like llm->state.logits
+        h = np.ascontiguousarray(history, np.uint32).reshape(-1)
+        n = C.c_uint32(0)
+        pre = [ctx] if self.prefix == "ref" else []
+        tok = self._sample_logits(*pre, l, l.size, h, h.size, rep_pen, temperature, top_p, coin, C.byref(n))
+        return int(tok), int(n.value)
+
     def rmsnorm(self, x, w):
         x = np.ascontiguousarray(x, np.float32); o = np.empty_like(x)
         self.op_rmsnorm(o, x, np.ascontiguousarray(w, np.float32), x.size); return o

@@ -807,12 +807,12 @@ static int cmp_prob_desc(const void *a, const void *b) {
     return 0;
 }
 
-static int pick_top_p(OrcCtx *ctx, const float *p, int n, float top_p, float coin) {
-    struct ProbIdx *pi = ctx->probindex;
+static int pick_top_p(struct ProbIdx *pi, const float *p, int n, float top_p, float coin, uint32_t *n_cand) {
     int n0 = 0;
     const float cutoff = (1.0f - top_p) / (n - 1);
     for (int i = 0; i < n; i++) if (p[i] >= cutoff) { pi[n0].index = i; pi[n0].prob = p[i]; n0++; }
     qsort(pi, (size_t)n0, sizeof(struct ProbIdx), cmp_prob_desc);
+    if (n_cand) *n_cand = (uint32_t)n0;
     float cum = 0.0f;
     int last = n0 - 1;
     for (int i = 0; i < n0; i++) { cum += pi[i].prob; if (cum > top_p) { last = i; break; } }
@@ -821,22 +821,43 @@ static int pick_top_p(OrcCtx *ctx, const float *p, int n, float top_p, float coi
     return pi[last].index;
 }
 
+/* the denominator of the reference's softmax (infer/infer.c:1026-1040: first max, expf, float sum in index order) */
+float orc_softmax_denominator(const float *x, int32_t n) {
+    float m = x[0];
+    for (int i = 1; i < n; i++) if (x[i] > m) m = x[i];
+    float sum = 0.0f;
+    for (int i = 0; i < n; i++) sum += expf(x[i] - m);
+    return sum;
+}
+
+/* The sampler of generate_next_token (reference infer/infer.c:1156-1189) on a caller-owned logits vector, which it
+ * overwrites exactly as the reference overwrites llm->state.logits.  `history` = output_ids[0..pos).  The coin is
+ * passed in (reference: random_f32(&sampler->rng_state), drawn only on the temperature != 0 branch). */
+uint32_t orc_sample_logits(float *logits, int32_t V, const uint32_t *history, uint32_t n_history, float rep_pen,
+                           float temperature, float top_p, float coin, uint32_t *n_cand) {
+    uint32_t *seen = (uint32_t *)calloc((size_t)V, sizeof(uint32_t));
+    if (seen) {
+        for (uint32_t i = 0; i < n_history; i++) seen[history[i]] = 1;
+        for (int id = 0; id < V; id++) if (seen[id] == 1) logits[id] /= rep_pen;
+        free(seen);
+    }
+    if (n_cand) *n_cand = 0;
+    if (temperature == 0.0f) return (uint32_t)pick_argmax(logits, V);
+    for (int i = 0; i < V; i++) logits[i] /= temperature;
+    orc_op_softmax(logits, V);
+    struct ProbIdx *pi = (struct ProbIdx *)calloc((size_t)V, sizeof(struct ProbIdx));
+    /* the reference's guard `top_p > 0 || top_p < 1` is always true (infer.c:1183): always top-p */
+    const uint32_t tok = (uint32_t)pick_top_p(pi, logits, V, top_p, coin, n_cand);
+    free(pi);
+    return tok;
+}
+
 uint32_t orc_next_token(OrcCtx *ctx, uint32_t *ids, uint32_t pos, int32_t is_prefilling) {
     int V = (int)ctx->c.vocab;
     float *logits = orc_forward(ctx, ids[pos], pos, 1);
     if (is_prefilling == 1) return ids[pos + 1];
-    uint32_t *seen = (uint32_t *)calloc((size_t)V, sizeof(uint32_t));
-    if (seen) {
-        for (uint32_t i = 0; i < pos; i++) seen[ids[i]] = 1;
-        for (int id = 0; id < V; id++) if (seen[id] == 1) logits[id] /= ctx->rep_pen;
-        free(seen);
-    }
-    if (ctx->temperature == 0.0f) return (uint32_t)pick_argmax(logits, V);
-    for (int i = 0; i < V; i++) logits[i] /= ctx->temperature;
-    orc_op_softmax(logits, V);
-    float coin = orc_random_f32(&ctx->rng);
-    /* the reference's guard `top_p > 0 || top_p < 1` is always true (infer.c:1183): always top-p */
-    return (uint32_t)pick_top_p(ctx, logits, V, ctx->top_p, coin);
+    const float coin = ctx->temperature != 0.0f ? orc_random_f32(&ctx->rng) : 0.0f;
+    return orc_sample_logits(logits, V, ids, pos, ctx->rep_pen, ctx->temperature, ctx->top_p, coin, NULL);
 }
 
 double orc_generate_ids(OrcCtx *ctx, uint32_t *ids, uint32_t n_prompt, uint32_t n_decode, float *logits_out) {

@@ -34,6 +34,9 @@ void orc_ctx_config(OrcCtx *ctx, uint32_t *out13);
 /* forward + sampling (llm_forward infer/infer.c:971, generate_next_token infer/infer.c:1135) */
 float *orc_forward(OrcCtx *ctx, uint32_t token, uint32_t pos, uint32_t is_causal);
 uint32_t orc_next_token(OrcCtx *ctx, uint32_t *ids, uint32_t pos, int32_t is_prefilling);
+float orc_softmax_denominator(const float *x, int32_t n);
+uint32_t orc_sample_logits(float *logits, int32_t V, const uint32_t *history, uint32_t n_history, float rep_pen,
+                           float temperature, float top_p, float coin, uint32_t *n_cand);
 float *orc_state_ptr(OrcCtx *ctx, int32_t which);
 double orc_generate_ids(OrcCtx *ctx, uint32_t *ids, uint32_t n_prompt, uint32_t n_decode, float *logits_out);
 void orc_seq2seq_ids(OrcCtx *ctx, const uint32_t *in_ids, uint32_t *out_ids, uint32_t max_seq_len);

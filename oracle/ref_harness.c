@@ -18,6 +18,7 @@
 #include "infer.h"
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -32,6 +33,8 @@ float *llm_forward(Nano_Context *ctx, uint32_t token, uint32_t pos, uint32_t max
                    uint32_t is_causal, LLM *llm, LoRA *lora);
 uint32_t random_u32(uint64_t *state);
 float random_f32(uint64_t *state);
+int sample_argmax(Nano_Context *ctx, float *probabilities, int n);
+int sample_top_p(Nano_Context *ctx, float *probabilities, int n, float top_p, ProbIndex *probindex, float coin);
 
 /* ---------------------------------------------------------------------------------------------
  * observation hooks
@@ -255,6 +258,29 @@ void ref_op_dequantize_q4k(uint8_t *T, float *out) {
     dequantize_tensor_q4k(T, out, &ndim, shape);
 }
 void ref_op_matmul_q4k(float *out, uint8_t *x, uint8_t *w, uint32_t layer) { matmul_q4k(out, x, w, layer); }
+
+/* The reference's sampler on caller-provided logits: the penalty / temperature loops of generate_next_token
+ * (infer/infer.c:1158-1178) spelled out here because they are inline there; softmax, sample_argmax and sample_top_p are
+ * the reference's own functions.  `vctx` only supplies the (no-op) observation hook.  Logits are overwritten. */
+uint32_t ref_sample_logits(void *vctx, float *logits, int32_t V, const uint32_t *history, uint32_t n_history, float rep_pen,
+                           float temperature, float top_p, float coin, uint32_t *n_cand) {
+    Nano_Context *ctx = (Nano_Context *)vctx;
+    uint32_t *tokenset = (uint32_t *)calloc((size_t)V, sizeof(uint32_t));
+    if (tokenset) {
+        for (uint32_t i = 0; i < n_history; i++) tokenset[history[i]] = 1;
+        for (int32_t id = 0; id < V; id++) if (tokenset[id] == 1) logits[id] /= rep_pen;
+        free(tokenset);
+    }
+    if (n_cand) *n_cand = 0;
+    if (temperature == 0.0f) return (uint32_t)sample_argmax(ctx, logits, V);
+    for (int32_t q = 0; q < V; q++) logits[q] /= temperature;
+    softmax(logits, V);
+    if (n_cand) { const float cutoff = (1.0f - top_p) / (V - 1); uint32_t n0 = 0; for (int32_t i = 0; i < V; i++) n0 += logits[i] >= cutoff; *n_cand = n0; }
+    ProbIndex *pi = (ProbIndex *)calloc((size_t)V, sizeof(ProbIndex));
+    const uint32_t tok = (uint32_t)sample_top_p(ctx, logits, V, top_p, pi, coin);
+    free(pi);
+    return tok;
+}
 
 uint32_t ref_random_u32(uint64_t *state) { return random_u32(state); }
 float ref_random_f32(uint64_t *state) { return random_f32(state); }

@@ -109,6 +109,41 @@ def make_e2e(tmpdir):
         print("sample", name, quant, tag, "ids", ids[n_prompt:].tolist())
 
 
+def make_sampler_logits(tmpdir):
+    """The reference's sampler (softmax / sample_top_p / sample_argmax of the compiled reference) on seeded logits of
+    Qwen3's vocabulary size: tokens for several coins, candidate counts, softmax denominators."""
+    from nano_amd import sampler_cases as sc
+    ref, orc = ob.load_ref(), ob.load_oracle()
+    spec = mf.preset("tiny-nano", "f32")
+    path = os.path.join(tmpdir, "tiny-nano-f32.bin")
+    mf.write_model(path, spec, seed=39)
+    ctx = ob.OracleCtx(ref, path, max_seq_len=8)            # only supplies the observation hook
+    toks = np.zeros((len(sc.CASES), len(sc.COINS)), np.uint32)
+    ncand = np.zeros(len(sc.CASES), np.uint32)
+    denom = np.zeros(len(sc.CASES), np.uint32)
+    for ci, (seed, sigma, mode, rp, temp, top_p, nh) in enumerate(sc.CASES):
+        l = sc.logits_of(seed, sigma, mode)
+        h = sc.history_of(seed, nh)
+        for ki, coin in enumerate(sc.COINS):
+            t, n = ref.sample_logits(l, h, rp, temp, top_p, coin, ctx=ctx.h)
+            t2, n2 = orc.sample_logits(l, h, rp, temp, top_p, coin)
+            assert (t, n) == (t2, n2), "restatement disagrees with the compiled reference"
+            toks[ci, ki], ncand[ci] = t, n
+        if temp != 0.0:
+            y = l.copy()
+            seen = np.zeros(l.size, bool); seen[h] = True
+            y[seen] = y[seen] / np.float32(rp)
+            y = (y / np.float32(temp)).astype(np.float32)
+            p_ref = y.copy(); ref.op_softmax(p_ref, p_ref.size)
+            p_orc = y.copy(); orc.op_softmax(p_orc, p_orc.size)
+            assert np.array_equal(p_ref.view(np.uint32), p_orc.view(np.uint32))
+            denom[ci] = np.float32(orc.softmax_denominator(y, y.size)).view(np.uint32)
+        print("sampler_logits", ci, mode, "tokens", toks[ci].tolist(), "candidates", int(ncand[ci]), "denominator", float(denom[ci:ci + 1].view(np.float32)[0]))
+    ctx.close()
+    np.savez_compressed(os.path.join(GOLD, "sampler_logits.npz"), cases=np.array([repr(c) for c in sc.CASES]), coins=np.array(sc.COINS, np.float32),
+                        tokens=toks, n_candidates=ncand, denominator_bits=denom, V=sc.V_QWEN3)
+
+
 LORA_CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano-odd", "f32", 0)]
 
 
@@ -212,4 +247,5 @@ if __name__ == "__main__":
     extract_sort_model()
     make_e2e(tmp)
     make_lora(tmp)
+    make_sampler_logits(tmp)
     make_ops()
