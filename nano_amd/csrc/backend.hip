@@ -597,7 +597,7 @@ static int sampler_init(NanoHipModel *m) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_y = take(npad * 4), o_e = take(npad * 4), o_seen = take(npad), o_approx = take(nch * 4), o_spec = take(nch * 4),
-                 o_fn = take(nch * 8), o_cells = take(256), o_bins = take(SAMPLE_BINS * 12), o_cand = take((size_t)SAMPLE_MAX_CANDIDATES * 8), o_res = take(sizeof(NanoHipSample)),
+                 o_fn = take(nch * 8), o_cells = take(256), o_pmax = take(nch), o_bins = take(SAMPLE_BINS * 12), o_cand = take((size_t)SAMPLE_MAX_CANDIDATES * 8), o_res = take(sizeof(NanoHipSample)),
                  o_hist = take((size_t)sp->hist_cap * 4);
     if (hipMalloc(&sp->block, off) != hipSuccess || hipMemset(sp->block, 0, off) != hipSuccess ||
         hipHostMalloc(&sp->h_hist, (size_t)sp->hist_cap * 4) != hipSuccess || hipHostMalloc(&sp->h_res, sizeof(NanoHipSample)) != hipSuccess) {
@@ -611,8 +611,9 @@ static int sampler_init(NanoHipModel *m) {
     a.V = V; a.nch = nch;
     a.y = (float *)(b + o_y); a.e = (float *)(b + o_e); sp->seen = b + o_seen;
     a.approx = (float *)(b + o_approx); a.spec = (uint32_t *)(b + o_spec); a.fn = (uint2 *)(b + o_fn);
-    a.maxcell = (uint32_t *)(b + o_cells); a.ncand = a.maxcell + 1; a.sum = (float *)(a.maxcell + 2);
-    a.ndrop = a.maxcell + 3; a.dropmax = a.maxcell + 4; a.bstar = a.maxcell + 5;
+    uint32_t *cells = (uint32_t *)(b + o_cells);
+    a.ncand = cells + 1; a.sum = (float *)(cells + 2); a.ndrop = cells + 3; a.dropmax = cells + 4; a.bstar = cells + 5;
+    a.pmax = (float *)(b + o_pmax);
     a.bin_mass = (unsigned long long *)(b + o_bins); a.bin_cnt = (uint32_t *)(b + o_bins + SAMPLE_BINS * 8);
     a.cand = (unsigned long long *)(b + o_cand); a.cap = SAMPLE_MAX_CANDIDATES; a.res = (NanoHipSample *)(b + o_res);
     sp->hist = (uint32_t *)(b + o_hist);

@@ -144,7 +144,8 @@ struct SampleArgs {
     float *y, *e;                                 // penalised+tempered logits, softmax numerators
     const uint8_t *seen;                          // null when the penalty is 1
     float penalty, temperature, top_p, cutoff, coin;
-    uint32_t *maxcell, *ncand, *ndrop, *dropmax, *bstar;  // accumulators, left at 0 by the last kernel (bstar: set by propagate)
+    float *pmax;                                  // [nch/4] workgroup maxima of the prep kernel
+    uint32_t *ncand, *ndrop, *dropmax, *bstar;    // accumulators, left at 0 by the last kernel (bstar: set by propagate)
     uint32_t *bin_cnt; unsigned long long *bin_mass;      // [SAMPLE_BINS], likewise
     float *approx; uint32_t *spec; uint2 *fn;     // per chunk: approximate sum, guessed exponent field, chunk function
     float *sum;

@@ -27,7 +27,6 @@ using namespace nano_exact;
 static constexpr int CH = SAMPLE_CHUNK;           // elements per chunk = one wave x float4
 static_assert(SAMPLE_BINS == 256, "the histogram is zeroed / flushed by 256-thread workgroups and scanned 4 bins per lane");
 
-__device__ __forceinline__ uint32_t ord_of(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 // histogram bin of a softmax numerator e in [0, 1]: 8 bins per binade, bin 7 = {1.0}, larger e -> smaller bin,
 // everything below 2^-31 (and 0) in the last bin
 __device__ __forceinline__ uint32_t exp_bin(float e) {
@@ -35,14 +34,13 @@ __device__ __forceinline__ uint32_t exp_bin(float e) {
     const uint32_t b = (127u - f) * 8u + (7u - ((u >> 20) & 7u));
     return f > 127u ? 0u : (b > SAMPLE_BINS - 1 ? SAMPLE_BINS - 1 : b);
 }
-__device__ __forceinline__ float ord_to(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
 
 __global__ __launch_bounds__(256) void seen_set_kernel(const uint32_t *ids, uint32_t n, uint8_t *seen) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) seen[ids[i]] = 1;
 }
 
-// K1: y = (seen ? l / penalty : l) / temperature over the padded range (padding = -inf -> numerator 0), running max
+// K1: y = (seen ? l / penalty : l) / temperature over the padded range (padding = -inf -> numerator 0), one max per workgroup
 __global__ __launch_bounds__(256) void samp_prep_kernel(const SampleArgs a) {
     const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     float v[4];
@@ -60,16 +58,22 @@ __global__ __launch_bounds__(256) void samp_prep_kernel(const SampleArgs a) {
     }
     *reinterpret_cast<float4 *>(a.y + i0) = make_float4(v[0], v[1], v[2], v[3]);
     if (a.temperature == 0.0f) return;            // penalised arg-max only: no softmax
+    __shared__ float wmax[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(a.maxcell, ord_of(mx));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) a.pmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
 // K2: numerators e = expf(y - max) and one approximate float sum per chunk (used only to guess each chunk's binade)
 __global__ __launch_bounds__(256) void samp_exp_kernel(const SampleArgs a) {
     const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= a.nch) return;
-    const float m = ord_to(*a.maxcell);
+    float m = -INFINITY;                                           // max over the nch/4 workgroup maxima of K1 (<= 256)
+    for (uint32_t j = lane; j < a.nch / 4; j += 64) m = fmaxf(m, a.pmax[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     const float4 y = reinterpret_cast<const float4 *>(a.y)[c * 64 + lane];
     float4 e;
     e.x = exact_expf_nonpos(y.x - m, kExp2Tab); e.y = exact_expf_nonpos(y.y - m, kExp2Tab);
@@ -121,25 +125,49 @@ __global__ __launch_bounds__(256) void samp_chunkfn_kernel(const SampleArgs a) {
 
 // K4: one wave carries the exact running sum through the chunk functions; where one does not apply (the sum is in
 // another binade than guessed, or leaves it inside the chunk) the chunk's 256 numerators are added one by one.
+__device__ __attribute__((noinline)) uint32_t samp_walk_chunk(const float *e, uint32_t c, uint32_t lane, uint32_t sb) {
+    const float4 v = reinterpret_cast<const float4 *>(e)[c * 64 + lane];
+    float s = __uint_as_float(sb);
+#pragma unroll
+    for (int k = 0; k < 64; k++) {                                  // elements 4k..4k+3 of the chunk live in lane k
+        s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), k));
+        s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), k));
+        s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), k));
+        s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.w), k));
+    }
+    return __builtin_amdgcn_readfirstlane(__float_as_uint(s));
+}
+
 __global__ __launch_bounds__(64) void samp_propagate_kernel(const SampleArgs a) {
-    __shared__ uint32_t s_dE[SAMPLE_MAX_CHUNKS], s_dO[SAMPLE_MAX_CHUNKS], s_spec[SAMPLE_MAX_CHUNKS];
-    __shared__ float4 s_buf[64];
+    __shared__ uint32_t s_dE[SAMPLE_MAX_CHUNKS + 64], s_dO[SAMPLE_MAX_CHUNKS + 64], s_spec[SAMPLE_MAX_CHUNKS + 64];
     const uint32_t lane = threadIdx.x;
-    for (uint32_t c = lane; c < a.nch; c += 64) { const uint2 f = a.fn[c]; s_dE[c] = f.x; s_dO[c] = f.y; s_spec[c] = a.spec[c]; }
+    for (uint32_t c = lane; c < a.nch + 64; c += 64) {
+        const bool in = c < a.nch;
+        const uint2 f = in ? a.fn[c] : make_uint2(0u, 0u);
+        s_dE[c] = f.x; s_dO[c] = f.y; s_spec[c] = in ? a.spec[c] : 0xffffffffu;      // past the end: applies to no sum
+    }
     __syncthreads();
-    uint32_t sb = 0, walks = 0;
-    for (uint32_t c = 0; c < a.nch; c++) {
-        const ChunkFn f{s_dE[c], s_dO[c]};
-        if (!chunk_apply(sb, f, s_spec[c])) {                       // wave-uniform
-            s_buf[lane] = reinterpret_cast<const float4 *>(a.e)[c * 64 + lane];
-            __syncthreads();
-            float s = __uint_as_float(sb);
-#pragma unroll 8
-            for (int k = 0; k < 64; k++) { const float4 w = s_buf[k]; s += w.x; s += w.y; s += w.z; s += w.w; }
-            sb = __float_as_uint(s);
-            walks++;
-            __syncthreads();
+    // Each step the 64 lanes look at the next 64 chunk functions: an inclusive scan composes them, the running sum jumps
+    // over the longest prefix that applies (same binade as guessed, mantissa stays below 2^24), and the first chunk
+    // that does not apply is added element by element.  ~15 steps for Qwen3's 594 chunks.
+    uint32_t sb = 0, walks = 0, cur = 0;
+    while (cur < a.nch) {
+        const uint32_t E = sum_exp(sb), M = sum_man(sb);
+        ChunkFn f{s_dE[cur + lane], s_dO[cur + lane]};
+        bool valid = s_spec[cur + lane] == E;
+#pragma unroll
+        for (int st = 1; st < 64; st <<= 1) {
+            ChunkFn g;
+            g.dE = __shfl_up(f.dE, st, 64); g.dO = __shfl_up(f.dO, st, 64);
+            const int gv = __shfl_up((int)valid, st, 64);
+            if (lane >= (uint32_t)st) { f = chunk_then(g, f); valid = valid && gv; }
         }
+        const uint32_t tot = M + ((M & 1u) ? f.dO : f.dE);
+        const unsigned long long ok = __ballot(valid && tot < (1u << 24));
+        const uint32_t n = ok == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ok);         // ok is a prefix of the lanes
+        if (n) { sb = ((E - 1u) << 23) + (uint32_t)__builtin_amdgcn_readlane((int)tot, (int)n - 1); cur += n; }
+        if (n < 64 && cur < a.nch) { sb = samp_walk_chunk(a.e, cur, lane, sb); walks++; cur++; }
+        sb = __builtin_amdgcn_readfirstlane(sb); cur = __builtin_amdgcn_readfirstlane(cur);
     }
     const float sum = __uint_as_float(sb);
     // Which tokens have to be sorted?  All candidates if they fit; otherwise the bins down to the first one at which
@@ -215,7 +243,7 @@ __global__ __launch_bounds__(1024) void samp_pick_kernel(const SampleArgs a) {
     const uint32_t n0 = *a.ncand, ndrop = *a.ndrop;
     const float dropmax = __uint_as_float(*a.dropmax);
     __syncthreads();
-    if (tid == 0) { *a.ncand = 0; *a.maxcell = 0; *a.ndrop = 0; *a.dropmax = 0; a.res->n_candidates = n0 + ndrop; a.res->n_sorted = n0; }
+    if (tid == 0) { *a.ncand = 0; *a.ndrop = 0; *a.dropmax = 0; a.res->n_candidates = n0 + ndrop; a.res->n_sorted = n0; }
     if (tid < SAMPLE_BINS) { a.bin_cnt[tid] = 0; a.bin_mass[tid] = 0; }
     if (n0 == 0 || n0 > a.cap || (ndrop && n0 < 6)) { if (tid == 0) { a.res->status = NANO_SAMPLE_FALLBACK; a.res->token = 0; } return; }
     uint32_t n = 2;

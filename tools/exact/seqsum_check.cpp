@@ -9,7 +9,7 @@
 #include <random>
 using namespace nano_exact;
 static const int CH = 256;
-static long g_walks = 0, g_chunks = 0;
+static long g_walks = 0, g_chunks = 0, g_steps = 0;
 
 static float seq_sum(const std::vector<float> &e) { float s = 0.0f; for (float v : e) s += v; return s; }
 
@@ -34,15 +34,33 @@ static float par_sum(const std::vector<float> &e) {
         for (int st = 1; st < 64; st <<= 1) for (int l = 0; l + st < 64; l += 2 * st) lane[l] = chunk_then(lane[l], lane[l + st]);
         fn[c] = lane[0];
     }
+    // propagation as the device does it: 64 lanes look at the next 64 chunk functions, an inclusive scan composes them,
+    // the running sum jumps over the longest applicable prefix, the first chunk that does not apply is added one by one
     uint32_t sb = 0;
-    for (int c = 0; c < nch; c++) {
-        g_chunks++;
-        if (!chunk_apply(sb, fn[c], spec[c])) {
-            g_walks++;
-            float s = bits_f32(sb);
-            for (int i = c * CH; i < (c + 1) * CH && i < V; i++) s += e[i];
-            sb = f32_bits(s);
+    int c = 0;
+    while (c < nch) {
+        const uint32_t E = sum_exp(sb), M = sum_man(sb);
+        ChunkFn f[64]; bool valid[64];
+        for (int l = 0; l < 64; l++) { const int cc = c + l; valid[l] = cc < nch && spec[cc] == E; f[l] = cc < nch ? fn[cc] : ChunkFn{0, 0}; }
+        for (int st = 1; st < 64; st <<= 1) {
+            ChunkFn g[64]; bool gv[64];
+            for (int l = 0; l < 64; l++) { g[l] = l >= st ? f[l - st] : ChunkFn{0, 0}; gv[l] = l >= st ? valid[l - st] : true; }
+            for (int l = st; l < 64; l++) { f[l] = chunk_then(g[l], f[l]); valid[l] = valid[l] && gv[l]; }
         }
+        int n = 0; uint32_t tot_n = 0;
+        for (int l = 0; l < 64; l++) {
+            const uint32_t tot = M + ((M & 1u) ? f[l].dO : f[l].dE);
+            if (valid[l] && tot < (1u << 24)) { n = l + 1; tot_n = tot; } else break;
+        }
+        if (n) { sb = ((E - 1u) << 23) + tot_n; c += n; g_chunks += n; }
+        if (n < 64 && c < nch) {
+            g_walks++; g_chunks++;
+            float sf = bits_f32(sb);
+            for (int i = c * CH; i < (c + 1) * CH && i < V; i++) sf += e[i];
+            sb = f32_bits(sf);
+            c++;
+        }
+        g_steps++;
     }
     return bits_f32(sb);
 }
@@ -80,6 +98,6 @@ int main() {
         cases++;
         if (f32_bits(a) != f32_bits(b)) { bad++; if (bad < 10) fprintf(stderr, "adv V=%d: seq=%a par=%a\n", V, a, b); }
     }
-    printf("%ld cases, %ld mismatches; %ld chunks, %ld walked element by element (%.2f%%)\n", cases, bad, g_chunks, g_walks, 100.0 * g_walks / g_chunks);
+    printf("%ld cases, %ld mismatches; %ld chunks, %ld walked element by element (%.2f%%), %ld propagation steps\n", cases, bad, g_chunks, g_walks, 100.0 * g_walks / g_chunks, g_steps);
     return bad ? 1 : 0;
 }
