@@ -473,4 +473,36 @@ hipError_t launch_attn_combine(const float *part, const float *ml, float *out, u
     return hipGetLastError();
 }
 
+// The combine of the Wo GEMV's prologue (gemv_common.h combine_weights / combine4) as a kernel of its own, for steps
+// whose Wo cannot fold it in (batched prefill through the MFMA GEMM): same weights (8 slots, pairwise-tree sum of
+// l_s * exp(m_s - M), e / L), same ascending accumulation — the bits of x are those of the decode path.
+__global__ __launch_bounds__(128) void attn_combine_tokens_kernel(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit) {
+    const uint32_t h = blockIdx.x, b = blockIdx.y, q_dim = n_head * hd;
+    const float *mlh = ml + (((size_t)b * n_head + h) * nsplit) * 2;
+    float mm[8], e[8], v[8], w[8];
+    float M = -INFINITY;
+#pragma unroll
+    for (uint32_t s = 0; s < 8; s++) {
+        const bool in = s < nsplit;
+        mm[s] = in ? mlh[2 * s] : -INFINITY; v[s] = in ? mlh[2 * s + 1] : 0.0f;
+        if (v[s] > 0.0f) M = fmaxf(M, mm[s]);
+    }
+#pragma unroll
+    for (uint32_t s = 0; s < 8; s++) { e[s] = v[s] > 0.0f ? expf(mm[s] - M) : 0.0f; v[s] = v[s] * e[s]; }
+    const float L = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+    for (uint32_t s = 0; s < 8; s++) w[s] = e[s] / L;
+    const float *pb = part + (size_t)b * nsplit * q_dim + (size_t)h * hd;
+    for (uint32_t i = threadIdx.x; i < hd; i += blockDim.x) {
+        float acc = 0.0f;
+#pragma unroll
+        for (uint32_t s = 0; s < 8; s++) { const float o = s < nsplit ? pb[(size_t)s * q_dim + i] : 0.0f; acc += o * w[s]; }
+        out[(size_t)b * q_dim + (size_t)h * hd + i] = acc;
+    }
+}
+hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb, hipStream_t st) {
+    hipLaunchKernelGGL(attn_combine_tokens_kernel, dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit);
+    return hipGetLastError();
+}
+
 }  // namespace nano

@@ -413,7 +413,11 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     const NanoModelDesc &d = m->d;
     const uint32_t E = d.n_embd, H = d.n_hidden, QD = m->QD, KD = m->KD, L = d.n_layer, S = m->S;
     hipError_t e;
-    const uint32_t nsplit = step_nsplit(m, nb, range_hint);
+    // Batched prefill splits every token's attention exactly as that token's own decode step would (chunks start on
+    // multiples of the 64-position bucket, so one range_hint covers them) and combines with a kernel of its own: the KV
+    // rows and the following logits then carry the bits of token-by-token ingestion.
+    const uint32_t nsplit = m->pf ? step_nsplit(m, 1, range_hint) : step_nsplit(m, nb, range_hint);
+    const bool pf_combine = m->pf && nsplit > 1;
     m->nsplit = nsplit;
     EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
                   m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0 };
@@ -467,6 +471,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 a.prep_only = 0;
             }
             if (!(skip & 2) && (e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
+            if (pf_combine && (e = launch_attn_combine_tokens(m->attn_part, m->attn_ml, m->xba, d.n_head, m->hd, nsplit, nb, m->st)) != hipSuccess) return e;
         }
         {   // x += Wo . xba   reference infer.c:885-908
             GemvArgs a{};
@@ -479,7 +484,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 if ((e = launch_lora_o(la_, nb, m->st)) != hipSuccess) return e;
                 a.resid_add = m->lora_o1; a.resid_add_bstride = E;
             }
-            if (nsplit > 1) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
+            if (nsplit > 1 && !pf_combine) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
             if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
@@ -720,7 +725,7 @@ extern "C" int nano_hip_lora_enable(NanoHipModel *m, int on) {
 // Batched prefill: feeds `count` prompt tokens at positions pos0 .. pos0+count-1 of sequence `slot` in
 // passes of up to 64 (Q80, int8 MFMA GEMM) / 8 tokens per weight read instead of one decode step per token; no
 // logits (the reference computes and discards them for prompt positions, infer.c:1146-1149).  The KV rows and every
-// later logit are the ones token-by-token feeding produces (same kernels per token).
+// later logit are the ones token-by-token feeding produces, bit for bit (same kernels and the same attention split per token).
 extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *tokens, uint32_t pos0, uint32_t count) {
     if (!m || !tokens) FAIL(NANO_HIP_EINVAL, "null argument");
     if (slot >= m->maxB) FAIL(NANO_HIP_EINVAL, "slot %u out of range (max_batch %u)", slot, m->maxB);
@@ -729,7 +734,9 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
     HIP_TRY(hipSetDevice(m->device));
     const uint32_t chunk_max = m->d.quant_type == NANO_QUANT_Q80 ? 64u : 8u;
     for (uint32_t done = 0; done < count;) {
-        const uint32_t nb = (count - done < chunk_max) ? count - done : chunk_max;
+        uint32_t nb = (count - done < chunk_max) ? count - done : chunk_max;
+        const uint32_t to_bucket_end = 64u - (pos0 + done) % 64u;          // one attention range bucket per chunk (see enqueue_step)
+        if (nb > to_bucket_end) nb = to_bucket_end;
         for (uint32_t i = 0; i < nb; i++) { m->h_tokens[i] = tokens[done + i]; m->h_pos[i] = pos0 + done + i; }
         HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, nb * 4, hipMemcpyHostToDevice, m->st));
         HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, nb * 4, hipMemcpyHostToDevice, m->st));

@@ -90,6 +90,7 @@ struct AttnArgs {
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
+hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb, hipStream_t st);
 
 // ---- LoRA side branches (lora.hip) -------------------------------------------------------------------
 struct LoraArgs {

@@ -127,7 +127,7 @@ def test_large_batch_mfma_gemm_path(model_dir, B):
     assert worst < TOL["q80"]
 
 
-@pytest.mark.parametrize("preset,quant,gs,T", [("tiny-qwen3", "q80", 64, 5), ("tiny-qwen3", "q80", 64, 23), ("tiny-qwen3", "q80", 64, 70),
+@pytest.mark.parametrize("preset,quant,gs,T", [("tiny-qwen3", "q80", 64, 5), ("tiny-qwen3", "q80", 64, 23), ("tiny-qwen3", "q80", 64, 70), ("tiny-qwen3", "q80", 64, 93),
                                                ("tiny-nano", "f32", 0, 11), ("tiny-nano-odd", "q4k", 0, 13), ("tiny-qwen3", "f32", 0, 9)])
 def test_batched_prefill_equals_token_by_token(model_dir, preset, quant, gs, T):
     """nano_hip_prefill (<= 64 / 8 prompt tokens per weight read) leaves the KV cache and the next logits exactly as
@@ -154,7 +154,7 @@ def test_batched_prefill_equals_token_by_token(model_dir, preset, quant, gs, T):
     worst = max(rel_err(g, r) for g, r in zip(got, ref))
     exact = all(np.array_equal(g, r) for g, r in zip(got, ref)) and np.array_equal(got_k, ref_k) and np.array_equal(got_v, ref_v)
     print(f"prefill {preset}/{quant} T={T}: worst rel err of the next 3 logits {worst:.3e}, bit-identical (logits + KV rows): {exact}")
-    assert worst < TOL[quant] * 1e-2 and rel_err(got_k, ref_k) < 1e-6 and rel_err(got_v, ref_v) < 1e-6
+    assert exact, "batched prefill must reproduce token-by-token ingestion bit for bit"
 
 
 @pytest.mark.parametrize("preset,quant,gs", [("tiny-qwen3", "q80", 64), ("tiny-nano-odd", "f32", 0)])
