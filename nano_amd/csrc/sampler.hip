@@ -7,13 +7,14 @@
 //
 // Every step whose result depends on evaluation order is evaluated in the reference's order:
 //   * expf        exact_expf_nonpos (exact_math.h): the same double-precision operation sequence as the pinned libm;
-//   * the sum     chunk functions (exact_math.h): integer mantissa increments per 256-element chunk, folded as a tree,
-//                 then one wave walks the 594 chunk functions (Qwen3 vocabulary) and adds element by element only where
-//                 the running sum changes binade (about ten chunks);
-//   * the sort    a total order (probability desc, index asc) in LDS, so any network gives the stable result; only a
-//                 superset of the nucleus is sorted when the candidates are many: a 32-bin histogram of the numerators'
-//                 exponents gives a lower bound of the mass above each power of two, tokens below the first bound that
-//                 exceeds top_p are dropped, and the cut is accepted only if it fell strictly above every dropped token;
+//   * the sum     chunk functions (exact_math.h): integer mantissa increments per 256-element chunk, folded as a tree;
+//                 one wave then scans 64 chunk functions per step, jumps the running sum over the longest prefix that
+//                 applies and adds element by element only the chunk in which the sum changes binade (about ten of the
+//                 594 chunks of Qwen3's vocabulary);
+//   * the sort    a total order (probability desc, index asc) in LDS, so any network gives the stable result; when the
+//                 candidates are many only a superset of the nucleus is sorted: a 256-bin histogram of the numerators
+//                 (counts + fixed-point masses) tells at which bin the mass passes top_p, tokens in later bins are
+//                 dropped, and the cut is accepted only if it fell strictly above every dropped token;
 //   * the cut and the draw   one thread, sequential, over the sorted nucleus.
 // Six dependent kernels, ~V*4 B each way through L2; nothing but a 52-byte result crosses PCIe.
 #include "kernels.h"
