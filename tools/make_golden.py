@@ -144,6 +144,39 @@ def make_sampler_logits(tmpdir):
                         tokens=toks, n_candidates=ncand, denominator_bits=denom, V=sc.V_QWEN3)
 
 
+# BASELINE.json configs[1] and configs[2] at their real sizes: (preset, quant, gs, n_prompt, n_decode)
+FULLSIZE_CASES = [("nano-168m", "f32", 0, 12, 20), ("qwen3-0.6b", "q80", 64, 16, 16)]
+FULLSIZE_STRIDE = 61          # logits are stored every 61st vocabulary entry (plus arg-max, top-2 gap, max|logit|)
+
+
+def make_fullsize(tmpdir):
+    """Greedy decode of the compiled reference (strict build) on the full-size synthetic models; per decode step the
+    arg-max id, the gap to the runner-up, max|logit| and a strided sample of the logits."""
+    ref, orc = ob.load_ref(), ob.load_oracle()
+    for (name, quant, gs, n_prompt, n_decode) in FULLSIZE_CASES:
+        spec = mf.preset(name, quant, group_size=gs)
+        path = os.path.join(tmpdir, f"{name}-{quant}.bin")
+        if not os.path.exists(path):
+            mf.write_model(path, spec, seed=39)
+        prompt = mf.prompt_ids(39, n_prompt, spec.vocab_size)
+        ctx = ob.OracleCtx(ref, path, max_seq_len=64)
+        ids, logits, secs = ctx.generate(prompt, n_decode, want_logits=True)
+        ctx.close()
+        octx = ob.OracleCtx(orc, path, max_seq_len=64)          # the restatement at full size, first decode step
+        for pos in range(n_prompt - 1):
+            octx.forward(int(prompt[pos]), pos)
+        o0 = octx.forward(int(prompt[-1]), n_prompt - 1).copy()
+        octx.close()
+        assert np.array_equal(o0.view(np.uint32), logits[0].view(np.uint32)), "restatement != compiled reference at full size"
+        srt = np.sort(logits, axis=1)
+        np.savez_compressed(os.path.join(GOLD, f"fullsize_{name}_{quant}.npz"), preset=name, quant=quant, gs=spec.group_size, seed=39,
+                            max_seq_len=64, prompt=prompt, ids=ids, stride=FULLSIZE_STRIDE, logits_strided=logits[:, ::FULLSIZE_STRIDE].copy(),
+                            argmax=np.argmax(logits, axis=1).astype(np.uint32), top2_gap=(srt[:, -1] - srt[:, -2]).astype(np.float32),
+                            max_abs=np.abs(logits).max(axis=1).astype(np.float32), model_sha256=sha256(path))
+        print("fullsize", name, quant, f"{n_decode / secs:.1f} tok/s (strict reference build)", "ids", ids[n_prompt:].tolist(),
+              "min top-2 gap / max|logit|", float(((srt[:, -1] - srt[:, -2]) / np.abs(logits).max(axis=1)).min()))
+
+
 LORA_CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano-odd", "f32", 0)]
 
 
@@ -248,4 +281,5 @@ if __name__ == "__main__":
     make_e2e(tmp)
     make_lora(tmp)
     make_sampler_logits(tmp)
+    make_fullsize(tmp)
     make_ops()
