@@ -128,3 +128,19 @@ def test_oracle_vs_compiled_reference_traces(oracle, ref_strict, model_dir, pres
         for x, y in zip(ra, rb):
             assert x[:3] == y[:3] and np.array_equal(bits(x[3]), bits(y[3])), x[:3]
     a.close(); b.close()
+
+
+def test_oracle_fullsize_first_decode_step_matches_reference_golden(oracle, model_dir):
+    """BASELINE.json configs[1] (Nano-168M FP32, 673 MB synthetic file) at its real size: the restatement's logits of
+    the first decode step carry the compiled reference's bits (strided sample stored in the golden file)."""
+    g = np.load(os.path.join(GOLD, "fullsize_nano-168m_f32.npz"))
+    path, spec = synth_model(model_dir, "nano-168m", "f32", 0)
+    assert file_sha256(path) == str(g["model_sha256"])
+    ctx = ob.OracleCtx(oracle, path, max_seq_len=int(g["max_seq_len"]))
+    prompt = g["prompt"]
+    for pos in range(len(prompt) - 1):
+        ctx.forward(int(prompt[pos]), pos)
+    lg = ctx.forward(int(prompt[-1]), len(prompt) - 1).copy()
+    ctx.close()
+    assert np.array_equal(bits(lg[::int(g["stride"])]), bits(g["logits_strided"][0]))
+    assert int(np.argmax(lg)) == int(g["argmax"][0]) == int(g["ids"][len(prompt)])
