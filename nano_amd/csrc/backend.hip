@@ -95,6 +95,7 @@ struct NanoHipModel {
     std::map<uint64_t, hipGraphExec_t> graphs;
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
+    uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
 };
@@ -341,6 +342,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     if (hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
         hipEventCreate(&m->ev1) != hipSuccess || hipEventCreate(&m->ev2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "stream/event creation failed"); }
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
+    if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
@@ -359,28 +361,40 @@ static GemvSeg mkseg(const TensorRef &t, float *out, uint32_t rows, uint32_t bst
     return s;
 }
 
+// every workgroup of a multi-sequence GEMV launch re-quantizes the nb x n activations: ~ workgroups x elements of redundant work
+static bool gemv_is_heavy(const GemvArgs &a) {
+    uint32_t rows = 0;
+    if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
+    return (uint64_t)(rows / 16) * a.nb * a.n > (4u << 20);
+}
+// Q80 launches that go to the int8 MFMA GEMM (gemm_q80.hip): 9..64 sequences always; 8 sequences when the matrix is
+// large (measured on Qwen3-4B's matrices: 152 vs 183 us per layer; on Qwen3-0.6B's the GEMV kernels win up to 8)
+static bool takes_mfma(const NanoHipModel *m, const GemvArgs &a) {
+    if (m->d.quant_type != NANO_QUANT_Q80 || !m->gq || !m->gxs) return false;
+    if (a.nb >= m->mfma_min_nb) return true;
+    return a.nb == 8 && !a.attn_part && !a.resid_add && gemv_is_heavy(a);
+}
+
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     const uint32_t max_wg = (uint32_t)m->cus * 8;
     if (m->d.quant_type == NANO_QUANT_Q4K) return launch_gemv_q4k(a, max_wg, m->st);
-    if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 8) {
-        // 9..64 sequences: quantize every sequence's activation once, then the int8 MFMA GEMM (gemm_q80.hip)
-        if (a.attn_part || a.resid_add || !m->gq || !m->gxs) return hipErrorInvalidValue;
+    if (takes_mfma(m, a)) {
+        // quantize every sequence's activation once, then the int8 MFMA GEMM
+        if (a.attn_part || a.resid_add) return hipErrorInvalidValue;
         hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
         if (e != hipSuccess) return e;
         a.xq_in = m->gq; a.xs_in = m->gxs;
-        return launch_gemm_q80(a, m->st);
+        e = launch_gemm_q80(a, m->st);
+        if (e != hipErrorInvalidValue || a.nb >= m->mfma_min_nb) return e;
+        a.norm_w = nullptr;                                        // a shape the GEMM does not take (8 sequences: optional
+        return launch_gemv(m->d.quant_type, a, max_wg, m->st);     // routing): the GEMV reads the same quantized activations
     }
-    if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 1 && !a.attn_part && m->gq && m->gxs) {
-        // every workgroup of a GEMV launch re-quantizes the nb x n activations; when that redundant work outweighs a
-        // launch (~3 us) the activations are quantized once (quant_rows_kernel) and the GEMV reads them back
-        uint32_t rows = 0;
-        if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
-        const uint64_t redundant = (uint64_t)(rows / 16) * a.nb * a.n;          // ~ workgroups x elements
-        if (redundant > (4u << 20)) {
-            hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
-            if (e != hipSuccess) return e;
-            a.xq_in = m->gq; a.xs_in = m->gxs; a.norm_w = nullptr;
-        }
+    if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 1 && !a.attn_part && m->gq && m->gxs && gemv_is_heavy(a)) {
+        // when the redundant quantization outweighs a launch (~3 us) the activations are quantized once
+        // (quant_rows_kernel) and the GEMV reads them back
+        hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
+        if (e != hipSuccess) return e;
+        a.xq_in = m->gq; a.xs_in = m->gxs; a.norm_w = nullptr;
     }
     return launch_gemv(m->d.quant_type, a, max_wg, m->st);
 }
@@ -390,7 +404,7 @@ static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *nti
     a.nseg = 1; a.seg[0] = mkseg(m->cls, m->logits, m->d.vocab_size, m->d.vocab_size);
     a.n = m->d.n_embd; a.gs = m->d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = m->d.n_embd;
     a.epi = GEMV_EPI_STORE; a.norm_w = m->rms_final; a.pos = m->pos;
-    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K) {      // per-tile arg-max partials for the sampler
+    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && !takes_mfma(m, a)) {      // per-tile arg-max partials for the sampler
         a.tile_max = m->tile_max;
         *ntiles_out = gemv_tiles(m->d.quant_type, a);
     }
@@ -402,7 +416,7 @@ static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *nti
 static uint32_t step_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_hint) {
     uint32_t ns = attention_nsplit(range_hint, m->hd);
     if (nb >= 4) { const uint32_t div = nb / 2; ns = (ns + div - 1) / div; }
-    if (nb > 8) ns = 1;                 // the MFMA GEMM path takes plain activations only
+    if (nb >= m->mfma_min_nb) ns = 1;   // the MFMA GEMM path takes plain activations only
     if (m->lora_on) ns = 1;             // the LoRA o-branch reads the combined attention output
     if (nb > 1 && (uint64_t)(m->d.n_embd / 16) * nb * m->QD > (4u << 20)) ns = 1;   // ditto the quantize-once GEMV path (see gemv())
     return ns ? ns : 1;

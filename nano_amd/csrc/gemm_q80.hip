@@ -251,6 +251,170 @@ __global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
     }
 }
 
+// ---- up to 16 tokens per weight read: one token tile, the row length split over the four waves -----------------------
+// With a single token tile the kernel above keeps one wave busy and exposes a memory round trip per pass.  Here a
+// workgroup still owns a 16-row tile, but every pass (KC bytes of each row) is consumed by all four waves: wave w
+// forms the MFMA group sums of groups w, w+4, ... of the pass and writes the products ((float)ival * ws) * xs of its
+// groups to an LDS table; then thread (row, token) adds the pass's products to its accumulator in ascending group
+// order — the same float operations in the same order as the GEMV kernels, so the result is still bit-identical.
+// The activations of the 16 tokens are staged in LDS next to the weights (one coalesced read per pass), and the
+// loads of pass p+1 are in flight while pass p is multiplied and folded (the compute phase touches only LDS).
+template <int GS, bool SW, int KCK>
+__global__ __launch_bounds__(256) void gemm_q80_ksplit_kernel(const GemmDev a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int FR = GS >= 64 ? GS / 64 : 1;
+    constexpr uint32_t nmat = SW ? 2u : 1u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n = a.n, ng = a.ng, ngp = ng | 1u;
+    constexpr uint32_t KC = (uint32_t)KCK * 1024u, KP = KC + 16u, GPP = KC / (uint32_t)GS;      // compile-time: the group loops unroll
+    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
+    const uint32_t grow0 = blockIdx.x * 16u;
+    const int sel = SW ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
+    const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
+    const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
+    float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
+    const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
+    const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
+    const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
+    const uint32_t lrow0 = grow0 - (sel == 0 ? 0u : sel == 1 ? b0 : b1);
+
+    // LDS: wt[nmat][16][KP] int8 | xt[16][KP] int8 | wsl[nmat][16][ngp] | xsl[16][ngp] | prod[nmat][GPP][16][17]
+    int8_t *wt = reinterpret_cast<int8_t *>(smem);
+    int8_t *xt = wt + (size_t)nmat * 16u * KP;
+    float *wsl = reinterpret_cast<float *>(xt + (size_t)16u * KP);
+    float *xsl = wsl + (size_t)nmat * 16u * ngp;
+    float *prod = xsl + (size_t)16u * ngp;
+
+    const __amdgpu_buffer_rsrc_t rw0 = mkrsrc(w0, rows0 * n), rw1 = mkrsrc(SW ? a.w[1] : nullptr, SW ? rows0 * n : 0u);
+    const __amdgpu_buffer_rsrc_t rs0 = mkrsrc(ws0, rows0 * ng * 4u), rs1 = mkrsrc(SW ? a.ws[1] : nullptr, SW ? rows0 * ng * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xq, a.nb * a.n16), rxs = mkrsrc(a.xs, a.nb * ng * 4u);
+
+    // staging registers of one pass: this wave's 4 weight rows (per matrix) and 4 tokens, up to 2 x 1 KiB columns each
+    int4 sw[SW ? 2 : 1][4][2], sx[4][2];
+    auto issue = [&](uint32_t c0) {
+#pragma unroll
+        for (int jc = 0; jc < 2; jc++) {
+            if ((uint32_t)jc * 1024u < KC) {                       // uniform: an out-of-range load is not free
+                const uint32_t col = c0 + (uint32_t)jc * 1024u + (uint32_t)lane * 16u;
+#pragma unroll
+                for (int mt = 0; mt < (int)nmat; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t row = lrow0 + (uint32_t)wid * 4u + r;
+                        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mt ? rw1 : rw0, (int)(col < n ? row * n + col : OOB), 0, 2);
+                        sw[mt][r][jc] = make_int4(v.x, v.y, v.z, v.w);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t tok = (uint32_t)wid * 4u + r;
+                    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((col < n && tok < a.nb) ? tok * a.n16 + col : OOB), 0, 0);
+                    sx[r][jc] = make_int4(v.x, v.y, v.z, v.w);
+                }
+            }
+        }
+    };
+    issue(0);
+
+    // scales of the whole row length: ws tile(s) and the 16 tokens' xs -> LDS (up to 4 x 256 float4 items in flight)
+    const uint32_t nf4 = 4u * ng;                                  // float4 items per 16 x ng block (ng % 4 == 0)
+    for (uint32_t base = 0; base < nf4; base += 1024u) {
+        float4 tw[4], tw1[4], tx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i4 = base + (uint32_t)k * 256u + (uint32_t)tid;
+            const uint32_t off = i4 < nf4 ? i4 * 16u : OOB;
+            tw1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            tw[k] = bload_f4(rs0, off == OOB ? OOB : lrow0 * ng * 4u + off);
+            if (SW) tw1[k] = bload_f4(rs1, off == OOB ? OOB : lrow0 * ng * 4u + off);
+            tx[k] = bload_f4(rxs, off);                            // tokens >= nb lie past the buffer: 0
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i4 = base + (uint32_t)k * 256u + (uint32_t)tid;
+            if (i4 < nf4) {
+                const uint32_t e = i4 * 4u, r = (e * a.magic_ng) >> 20, g = e - r * ng;      // e / ng, e < 16 * ng
+                float *dw = wsl + r * ngp + g; dw[0] = tw[k].x; dw[1] = tw[k].y; dw[2] = tw[k].z; dw[3] = tw[k].w;
+                if (SW) { float *d1 = wsl + 16u * ngp + r * ngp + g; d1[0] = tw1[k].x; d1[1] = tw1[k].y; d1[2] = tw1[k].z; d1[3] = tw1[k].w; }
+                float *dx = xsl + r * ngp + g; dx[0] = tx[k].x; dx[1] = tx[k].y; dx[2] = tx[k].z; dx[3] = tx[k].w;
+            }
+        }
+    }
+
+    const uint32_t m = (uint32_t)lane & 15u, kq = (uint32_t)lane >> 4;    // MFMA lane coordinates
+    const uint32_t fr = (uint32_t)tid >> 4, ftok = (uint32_t)tid & 15u;   // the (row, token) this thread accumulates
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (uint32_t c0 = 0; c0 < n; c0 += KC) {
+        if (c0) __syncthreads();                                   // the previous pass is multiplied and folded
+#pragma unroll
+        for (int jc = 0; jc < 2; jc++) {
+            const uint32_t col = (uint32_t)jc * 1024u + (uint32_t)lane * 16u;
+            if (col < KC) {
+#pragma unroll
+                for (int mt = 0; mt < (int)nmat; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) *reinterpret_cast<int4 *>(wt + ((size_t)mt * 16u + (uint32_t)wid * 4u + r) * KP + col) = sw[mt][r][jc];
+#pragma unroll
+                for (int r = 0; r < 4; r++) *reinterpret_cast<int4 *>(xt + ((size_t)(uint32_t)wid * 4u + r) * KP + col) = sx[r][jc];
+            }
+        }
+        __syncthreads();
+        if (c0 + KC < n) issue(c0 + KC);                           // in flight while this pass is consumed from LDS
+        const uint32_t gbeg = c0 / (uint32_t)GS;
+        const uint32_t gcnt = ng - gbeg < GPP ? ng - gbeg : GPP;
+        // this wave's groups of the pass: independent chains (LDS fragments -> MFMA -> products), unrolled so that
+        // their latencies overlap
+        Frag<GS> fa[GPP / 4][FR], fb[GPP / 4][FR], fa1[SW ? GPP / 4 : 1][FR];
+#pragma unroll
+        for (uint32_t j = 0; j < GPP / 4; j++) {
+            const uint32_t koff = (j * 4u + (uint32_t)wid) * (uint32_t)GS;
+#pragma unroll
+            for (int ks = 0; ks < FR; ks++) {
+                fa[j][ks] = lds_frag<GS>(wt + (size_t)m * KP, koff, kq, ks);
+                fb[j][ks] = lds_frag<GS>(xt + (size_t)m * KP, koff, kq, ks);
+                if (SW) fa1[j][ks] = lds_frag<GS>(wt + ((size_t)16u + m) * KP, koff, kq, ks);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < GPP / 4; j++) {
+            const uint32_t gl = j * 4u + (uint32_t)wid, g = gbeg + gl;
+            if (gl < gcnt) {
+                const float xsc = xsl[m * ngp + g];
+                v4i c0v = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < FR; ks++) c0v = mma<GS>(fa[j][ks], fb[j][ks], c0v);
+#pragma unroll
+                for (int i = 0; i < 4; i++) prod[((size_t)gl * 16u + kq * 4u + i) * 17u + m] = ((float)c0v[i] * wsl[(kq * 4u + i) * ngp + g]) * xsc;      // infer.c:672
+                if (SW) {
+                    v4i c1v = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < FR; ks++) c1v = mma<GS>(fa1[j][ks], fb[j][ks], c1v);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) prod[((size_t)(GPP + gl) * 16u + kq * 4u + i) * 17u + m] = ((float)c1v[i] * wsl[16u * ngp + (kq * 4u + i) * ngp + g]) * xsc;
+                }
+            }
+        }
+        __syncthreads();
+        // ascending groups: the reference's order (infer.c:668-674); the LDS reads of a block of 8 go out together
+#pragma unroll
+        for (uint32_t g8 = 0; g8 < GPP; g8 += 8u) {
+            float p0[8], p1[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                p0[k] = prod[((size_t)(g8 + k) * 16u + fr) * 17u + ftok];
+                p1[k] = SW ? prod[((size_t)(GPP + g8 + k) * 16u + fr) * 17u + ftok] : 0.0f;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++)
+                if (g8 + k < gcnt) { acc0 += p0[k]; if (SW) acc1 += p1[k]; }
+        }
+    }
+    if (ftok < a.nb && lrow0 + fr < rows0) {
+        float *o = out0 + (size_t)ftok * obs + (ops ? (size_t)a.pos[ftok] * ops : 0) + lrow0 + fr;
+        *o = finish_epi(a.epi, acc0, acc1, a.epi == GEMV_EPI_RESID ? *o : 0.0f);
+    }
+}
+
 template <int GS>
 static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
     GemmDev d{};
@@ -273,6 +437,22 @@ static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
     if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
     if (d.ttiles > 4) return hipErrorInvalidValue;
     const uint32_t nmat = a.epi == GEMV_EPI_SWIGLU ? 2 : 1;
+    if (d.ttiles == 1 && !getenv("NANO_GEMM_NO_KSPLIT")) {        // <= 16 tokens: the row length is split over the waves
+        const uint32_t ngp1 = d.ng | 1u, n1k1 = (d.n + 1023) & ~1023u;
+        for (uint32_t kc = nmat == 2 ? 1024u : 2048u; kc >= 1024u; kc -= 1024u) {
+            if (kc > n1k1 && kc > 1024u) continue;                 // short rows: one 1 KiB pass
+            d.kc = kc;
+            const uint32_t gpp = kc / GS;
+            const size_t lds = (size_t)(nmat + 1) * 16 * (kc + 16) + ((size_t)(nmat + 1) * 16 * ngp1 + (size_t)nmat * gpp * 16 * 17) * sizeof(float);
+            if (gpp < 8 || lds > 160 * 1024) continue;
+#define KSPLIT_GO(SW_, KCK_) do { auto kern = &gemm_q80_ksplit_kernel<GS, SW_, KCK_>; \
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL(kern, dim3((rows + 15) / 16), dim3(256), lds, st, d); return hipGetLastError(); } while (0)
+            if constexpr (1024 / GS >= 8) { if (nmat == 2) KSPLIT_GO(true, 1); if (kc == 1024u) KSPLIT_GO(false, 1); }
+            if constexpr (2048 / GS >= 8) { if (nmat == 1 && kc == 2048u) KSPLIT_GO(false, 2); }
+#undef KSPLIT_GO
+        }
+    }
     d.kc = nmat == 2 ? 2048u : 4096u;                            // row bytes staged per pass (<= 66 KB of LDS for the weights)
     const uint32_t n1k = (d.n + 1023) & ~1023u;
     if (d.kc > n1k) d.kc = n1k;

@@ -33,6 +33,8 @@
 //          Measured 5.6-5.7 TB/s (cold), 95 % of what a plain read of the same bytes achieves.
 //
 // MFMA is not used: 2 flop/byte at batch <= 8, no tile forms.
+#include <string.h>
+#include <stdio.h>
 #include "gemv_common.h"
 #include "gemv_q80_host.h"
 
@@ -493,6 +495,16 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
         while (rw > 4 && (size_t)B * nmat * rw * pitch * 4 > 64 * 1024) rw /= 2;
         while (rw > 4 && (rw / 4) * nchunk * nmat > 64) rw /= 2;          // <= 16 waves x 4 units
     }
+    // measurement only: NANO_SLAB_PLAN="ROWSxN:rw:nw,..." pins the slab shape of the matrices with that many rows / columns
+    uint32_t force_nw = 0;
+    {
+        static const char *env = getenv("NANO_SLAB_PLAN");
+        for (const char *q = env; q && *q;) {
+            unsigned r_ = 0, n_ = 0, rw_ = 0, nw_ = 0;
+            if (sscanf(q, "%ux%u:%u:%u", &r_, &n_, &rw_, &nw_) == 4 && r_ == rows && n_ == a.n && rw_ >= 4) { rw = rw_; force_nw = nw_; }
+            q = strchr(q, ','); if (q) q++;
+        }
+    }
     const uint32_t units = (rw / 4) * nchunk * nmat;
     uint32_t nw = units < 4 ? units : 4;
     uint32_t want = (a.n * (uint32_t)(B > 2 ? B / 2 : 1) + 511) / 512;     // idle waves still help the activation prologue
@@ -502,6 +514,7 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     if (nw < 2) nw = 2;
     uint32_t upw = (units + nw - 1) / nw;
     while (upw > 4 && nw < 16) { nw++; upw = (units + nw - 1) / nw; }
+    if (force_nw) { nw = force_nw; upw = (units + nw - 1) / nw; }
     SlabPlan p{rw, nw, upw, (a.n + 256 * nw - 1) / (256 * nw)};
     return p;
 }
