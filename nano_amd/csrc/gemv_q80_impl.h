@@ -495,6 +495,25 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
         while (rw > 4 && (size_t)B * nmat * rw * pitch * 4 > 64 * 1024) rw /= 2;
         while (rw > 4 && (rw / 4) * nchunk * nmat > 64) rw /= 2;          // <= 16 waves x 4 units
     }
+    // Large matrices (Qwen3-4B's layers: 10-50 MB each) are bandwidth rather than latency bound; swept on a MI355X with
+    // tools/wide_sweep.sh: a slab of 64-160 KB of weights per workgroup, chosen to minimise (rounds of 256 workgroups) x
+    // (rows per workgroup), the larger slab on a tie, and 8-16 waves.  13.0 -> 10.6 us (W2), 16.3 -> 13.0 us (W1|W3).
+    uint32_t large_nw = 0;
+    if (B == 1 && (uint64_t)rows * a.n * nmat >= (8u << 20)) {
+        uint32_t best = 0, best_cost = ~0u;
+        for (uint32_t c = 4; c <= 64; c *= 2) {
+            const uint64_t bytes = (uint64_t)c * a.n * nmat;
+            if (nseg > 1 && (align % c) != 0) continue;
+            if (bytes < (64u << 10) || bytes > (160u << 10) || (c / 4) * nchunk * nmat > 64) continue;
+            const uint32_t wgs = (rows + c - 1) / c, cost = ((wgs + 255) / 256) * c;
+            if (cost <= best_cost) { best_cost = cost; best = c; }
+        }
+        if (best) {
+            rw = best;
+            const uint32_t u = (rw / 4) * nchunk * nmat;
+            large_nw = u / 2 < 8 ? 8 : (u / 2 > 16 ? 16 : u / 2);
+        }
+    }
     // measurement only: NANO_SLAB_PLAN="ROWSxN:rw:nw,..." pins the slab shape of the matrices with that many rows / columns
     uint32_t force_nw = 0;
     {
@@ -514,6 +533,7 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     if (nw < 2) nw = 2;
     uint32_t upw = (units + nw - 1) / nw;
     while (upw > 4 && nw < 16) { nw++; upw = (units + nw - 1) / nw; }
+    if (large_nw) { nw = large_nw; upw = (units + nw - 1) / nw; while (upw > 4 && nw < 16) { nw++; upw = (units + nw - 1) / nw; } }
     if (force_nw) { nw = force_nw; upw = (units + nw - 1) / nw; }
     SlabPlan p{rw, nw, upw, (a.n + 256 * nw - 1) / (256 * nw)};
     return p;
