@@ -37,7 +37,7 @@ PROMPT_LEN = 16
 SEQ_LEN = 512
 # HBM bytes per classifier launch from the rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE corrected as
 # MI355X_MICROARCH.md prescribes), keyed by (model, quant, group size); None = not collected
-TRAFFIC_BYTES = {("qwen3-0.6b", "q80", 64): 165500014}    # profiles/r01_pmc_fetch_size.txt: FETCH_SIZE 80810.55 KB x 1024 x 2
+TRAFFIC_BYTES = {("qwen3-0.6b", "q80", 64): 165490705}    # profiles/r01_pmc_fetch_size.txt: FETCH_SIZE 80806.01 KB x 1024 x 2
 
 
 def log(*a):
