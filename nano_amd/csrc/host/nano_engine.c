@@ -384,6 +384,7 @@ void free_sampler(Sampler *s) { if (s) { free(s->probindex); free(s); } }
 static int g_position_prefilled = 0;
 /* NANO_HOST_SAMPLER=1: copy the logits back and run the sampler loops on the host (A/B checks) */
 static int g_host_sampler = -1;
+static int g_fallback_streak = 0, g_host_turns = 0;
 
 /* reference infer/infer.c:1135-1193 */
 uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t pos, int is_prefilling) {
@@ -417,7 +418,8 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
     const float coin = sp->temperature != 0.0f ? xorshift_f32(&sp->rng_state) : 0.0f;
     const int V = sp->vocab_size;
     float *logits = NULL;
-    if (!g_host_sampler) {
+    if (!g_host_sampler && g_host_turns > 0) g_host_turns--;            /* a flat distribution was seen: stay on the host loops for a while */
+    else if (!g_host_sampler) {
         /* the sampler runs on the device behind the forward: one 52-byte result comes back */
         NanoHipSample r;
         observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
@@ -425,6 +427,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
             die_hip("generate_next_token");
         observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
         if (r.status == NANO_SAMPLE_OK) {
+            g_fallback_streak = 0;
             if (sp->temperature != 0.0f && ctx->observation) {
                 Nano_Observation o; memset(&o, 0, sizeof o);
                 o.layer = -1; o.phase = NANO_LLM_PHASE_SAMPLE;
@@ -433,10 +436,13 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
             }
             return r.token;
         }
-        /* more candidates than the device nucleus holds (near-uniform distribution): same logits, host loops */
+        /* more candidates than the device nucleus holds (near-uniform distribution): same logits, host loops; after two
+         * such tokens in a row the next 32 skip the device attempt (its ~0.1 ms would be wasted) */
+        if (++g_fallback_streak >= 2) g_host_turns = 32;
         logits = llm->state.logits;
         if (nano_hip_read_state(dev, 0, 4, 0, 0, logits, (size_t)V) != NANO_HIP_OK) die_hip("generate_next_token");
-    } else {
+    }
+    if (!logits) {
         logits = llm_forward(ctx, token, pos, ctx->max_seq_len, 1, llm, ctx->lora);
         observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
     }

@@ -92,3 +92,20 @@ def test_forward_sample_follows_history(oracle, model_dir):
             assert r.status == 0 and r.token == want, (start, p)
             ids.append(int(r.token))
     m.close()
+
+
+def test_engine_flat_distribution_falls_back_to_host_loops(oracle, model_dir):
+    """Random weights at temperature 1 under Qwen3's vocabulary: ~152 k candidates, the nucleus does not fit the device
+    sorter, so generate_next_token runs the host loops on the device's logits (and, after two such tokens, skips the
+    device attempt for a while).  The ids are the oracle engine's for the same seed."""
+    from oracle import binding as ob
+    path, spec = synth_model(model_dir, "bigvocab-qwen3", "f32", 0)
+    from nano_amd import modelfile as mf
+    prompt = mf.prompt_ids(21, 5, spec.vocab_size)
+    octx = ob.OracleCtx(oracle, path, max_seq_len=32, rep_pen=1.1, temperature=1.0, top_p=0.9, top_k=0, seed=77)
+    want, _, _ = octx.generate(prompt, 9)
+    octx.close()
+    e = nb.Engine(path, max_seq_len=32, rep_pen=1.1, temperature=1.0, top_p=0.9, top_k=0, seed=77)
+    got = e.generate(prompt, 9)
+    e.close()
+    assert np.array_equal(got, want)
