@@ -372,7 +372,7 @@ static bool gemv_is_heavy(const GemvArgs &a) {
 static bool takes_mfma(const NanoHipModel *m, const GemvArgs &a) {
     if (m->d.quant_type != NANO_QUANT_Q80 || !m->gq || !m->gxs) return false;
     if (a.nb >= m->mfma_min_nb) return true;
-    return a.nb == 8 && !a.attn_part && !a.resid_add && gemv_is_heavy(a);
+    return a.nb == 8 && m->mfma_min_nb == 9 && !a.attn_part && !a.resid_add && gemv_is_heavy(a);    // (NANO_MFMA_MIN_NB != 9 disables this rule: A/B runs)
 }
 
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
@@ -399,11 +399,16 @@ static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     return launch_gemv(m->d.quant_type, a, max_wg, m->st);
 }
 
-static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
+static GemvArgs classifier_args(const NanoHipModel *m, uint32_t nb) {
     GemvArgs a{};
     a.nseg = 1; a.seg[0] = mkseg(m->cls, m->logits, m->d.vocab_size, m->d.vocab_size);
     a.n = m->d.n_embd; a.gs = m->d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = m->d.n_embd;
     a.epi = GEMV_EPI_STORE; a.norm_w = m->rms_final; a.pos = m->pos;
+    return a;
+}
+
+static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
+    GemvArgs a = classifier_args(m, nb);
     if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && !takes_mfma(m, a)) {      // per-tile arg-max partials for the sampler
         a.tile_max = m->tile_max;
         *ntiles_out = gemv_tiles(m->d.quant_type, a);
@@ -520,7 +525,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     uint32_t ntiles = 0;
     // probe: Q80 STREAM classifier (batch <= 8) -> the kernel's own start / stop timestamps (hipExtLaunchKernelGGL);
     // other classifiers -> events recorded around the launch (ev1..ev2 = an empty pair, the event overhead)
-    const bool probe_ext = m->probe_cls && d.quant_type == NANO_QUANT_Q80 && nb <= 8 && d.vocab_size >= 16384;
+    const bool probe_ext = m->probe_cls && d.quant_type == NANO_QUANT_Q80 && nb <= 8 && d.vocab_size >= 16384 && !takes_mfma(m, classifier_args(m, nb));
     if (probe_ext) { g_q80_probe_start = m->ev0; g_q80_probe_stop = m->ev1; }
     else if (m->probe_cls && (e = hipEventRecord(m->ev0, m->st)) != hipSuccess) return e;
     if (!(skip & 32) && (e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;
