@@ -1,7 +1,7 @@
 // exact_math.h — bit-exact restatements of the host arithmetic the reference's sampler relies on, usable from device
 // code and (for the CPU checks in tests/) from plain C++.
 //
-// The reference's softmax (infer/infer.c:1026-1040, restated in oracle/) calls libm's expf() and sums the results in index
+// The reference's softmax (infer/infer.c:616-634, restated in oracle/) calls libm's expf() and sums the results in index
 // order; its sampled token therefore depends on the host libm.  The build this repo is pinned against is glibc 2.35 on
 // x86-64 with FMA (this image, and the GPU hosts): expf there is the table-driven double-precision algorithm published
 // as ARM optimized-routines `expf` (N = 32 table, cubic polynomial), compiled with fused multiply-adds.  exact_expf()
@@ -65,7 +65,7 @@ NANO_HD float exact_expf_nonpos(float x, const uint64_t *tab) {
 
 
 // ---- sequential float sums, evaluated in parallel ----------------------------------------------------------------
-// The reference adds the V softmax numerators into one float in index order (infer/infer.c:1033-1036).  That sum is
+// The reference adds the V softmax numerators into one float in index order (infer/infer.c:625-629).  That sum is
 // not associative, but while the running sum stays inside one binade it is integer arithmetic: with the sum written
 // as M * 2^(E-150) (M < 2^24 the mantissa with its hidden bit, E the exponent field, denormals folded into E = 1),
 // adding x >= 0 gives M + RN(x / 2^(E-150)), the rounding being to nearest with ties to the even *result*.  Only a tie

@@ -414,7 +414,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
     }
 
     /* Sampling with a penalty and/or a temperature.  The coin is drawn exactly when the reference draws it
-     * (only on the softmax branch, infer.c:1180); nothing else consumes the generator. */
+     * (only on the softmax branch, infer.c:1181); nothing else consumes the generator. */
     const float coin = sp->temperature != 0.0f ? xorshift_f32(&sp->rng_state) : 0.0f;
     const int V = sp->vocab_size;
     float *logits = NULL;

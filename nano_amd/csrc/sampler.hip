@@ -1,6 +1,6 @@
 // sampler.hip — the reference's sampler on the device, token-for-token identical to the host code.
 //
-// Reference: generate_next_token / softmax / sample_top_p (infer/infer.c:1026-1109, 1156-1189): repetition penalty
+// Reference: generate_next_token (infer/infer.c:1156-1189), softmax (:616-634), sample_top_p (:1062-1109): repetition penalty
 // (divide the logits of every token seen so far), divide by the temperature, softmax (first-max, libm expf, index-order
 // float sum, divide), keep p >= (1-top_p)/(V-1), qsort by probability (glibc's merge sort: stable, so equal
 // probabilities stay in index order), cut where the running sum passes top_p, draw with one xorshift64* coin.

@@ -821,7 +821,7 @@ static int pick_top_p(struct ProbIdx *pi, const float *p, int n, float top_p, fl
     return pi[last].index;
 }
 
-/* the denominator of the reference's softmax (infer/infer.c:1026-1040: first max, expf, float sum in index order) */
+/* the denominator of the reference's softmax (infer/infer.c:616-634: first max, expf, float sum in index order) */
 float orc_softmax_denominator(const float *x, int32_t n) {
     float m = x[0];
     for (int i = 1; i < n; i++) if (x[i] > m) m = x[i];
