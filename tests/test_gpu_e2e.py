@@ -273,9 +273,10 @@ def test_sort_model_known_answer_on_gpu():
 
 
 # ---- the host C engine (reference API surface) on the GPU ------------------------------------------------
-@pytest.mark.parametrize("name", ["sample_tiny-nano_f32_rp13", "sample_tiny-nano_f32_t08p09"])
+@pytest.mark.parametrize("name", ["sample_tiny-nano_f32_rp13", "sample_tiny-nano_f32_t08p09", "sample_tiny-qwen3_q80_rp13", "sample_tiny-qwen3_q4k_t10p05"])
 def test_engine_sampler_ids_vs_reference_golden(model_dir, name):
-    """generate_next_token through the C engine with the reference's sampler settings: FP32 ids identical."""
+    """generate_next_token through the C engine (device sampler) with the reference's sampler settings: ids identical to
+    the compiled reference's (FP32, and the two-layer Q80 / Q4K models whose logits agree to ~1e-7)."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     path, spec = synth_model(model_dir, str(g["preset"]), str(g["quant"]), int(g["gs"]))
     e = nb.Engine(path, max_seq_len=int(g["max_seq_len"]), rep_pen=float(g["rep_pen"]), temperature=float(g["temperature"]),
