@@ -214,6 +214,14 @@ int nano_forward_batch(Nano_Context *ctx, const uint32_t *tokens, const uint32_t
 Nano_Session *nano_session_init_ids(Nano_Context *ctx, const uint32_t *prompt_ids, uint32_t n_prompt, uint32_t max_seq_len);
 /* Like llm_session_step but never touches the tokenizer (output_text stays NULL). */
 int32_t nano_session_step_ids(Nano_Context *ctx, Nano_Session *session);
+/* Per-phase observation (debug aid).  The reference fires ctx->observation eight times per layer and three times per
+ * token from inside llm_forward (infer/infer.c:755-949, 985-1003; consumer infer/ui_llm.c:695-706).  The fused device
+ * forward has no host boundary between phases, so by default the hook fires at token granularity (EMBEDDING,
+ * FINAL_NORM, CLASSIFY, SAMPLE).  nano_set_phase_observation(1) (or NANO_OBSERVE_PHASES=1 in the environment) makes
+ * the forwards of contexts that have a hook installed run the backend's eager per-operator replay (strict mode of
+ * nano_mi355x.h): all twelve phases fire in the reference's order with that phase's tensors finished on the device,
+ * the sampler runs in host C on the returned logits.  Slow; never on a timed path. */
+void nano_set_phase_observation(int on);
 /* Opaque device model behind an LLM (NanoHipModel*, nano_mi355x.h) for measurement tools. */
 void *nano_device_model(const LLM *llm);
 

@@ -149,6 +149,21 @@ int nano_hip_forward_sample(NanoHipModel *m, uint32_t token, uint32_t pos, const
 int nano_hip_op_sample(NanoHipModel *m, const float *logits, const uint32_t *history, uint32_t n_history,
                        float repetition_penalty, float temperature, float top_p, float coin, NanoHipSample *out);
 
+/* ---- strict-parity / per-phase mode -------------------------------------------------------------------------
+ * nano_hip_set_strict(m, 1): every later forward / prefill runs eagerly, one kernel per reference operator, with
+ * every float reduction (rmsnorm, q.k, softmax sum, weighted V, FP32 matmul) in the reference's sequential order
+ * and the pinned libm's expf: the logits equal the reference CPU engine's BIT FOR BIT for F32, Q80 and Q4K models
+ * (tests/test_gpu_strict.py).  Slow (a thread walks each chain); it exists as the parity proof and as the
+ * un-fused replay behind the per-phase observation hook.  Also switched on by NANO_STRICT=1 in the environment
+ * at model creation.  LoRA side branches are not covered (the call fails with NANO_HIP_EINVAL).
+ * nano_hip_set_phase_hook: in strict mode fn(env, layer, phase) is called on the caller's thread at the twelve
+ * points the reference fires ctx->observation from inside its forward (reference infer/infer.c:755-949, 985-1003;
+ * phase = NANO_LLM_PHASE_* 1..11, layer = -1 / 0..L-1 / L), after all device work queued before that point has
+ * finished, so nano_hip_read_state() inside the hook sees the tensors of that phase.  fn = NULL removes it. */
+typedef void (*nano_hip_phase_fn)(void *env, int32_t layer, int32_t phase);
+int nano_hip_set_strict(NanoHipModel *m, int on);
+int nano_hip_set_phase_hook(NanoHipModel *m, nano_hip_phase_fn fn, void *env);
+
 /* Blocks until all work queued on the model's stream has finished. */
 int nano_hip_sync(NanoHipModel *m);
 

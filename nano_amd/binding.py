@@ -32,6 +32,9 @@ class NanoHipError(RuntimeError):
     pass
 
 
+PHASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32)        # nano_hip_phase_fn(env, layer, phase)
+
+
 _lib = None
 
 
@@ -66,6 +69,8 @@ def lib() -> C.CDLL:
     fn("nano_hip_forward_sample", C.c_int, [vp, C.c_uint32, C.c_uint32, u32p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NanoHipSample)])
     fn("nano_hip_op_sample", C.c_int, [vp, f32p, u32p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NanoHipSample)])
     fn("nano_hip_sync", C.c_int, [vp])
+    fn("nano_hip_set_strict", C.c_int, [vp, C.c_int])
+    fn("nano_hip_set_phase_hook", C.c_int, [vp, PHASE_FN, vp])
     fn("nano_hip_time_classifier", C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64)])
     fn("nano_hip_time_classifier_in_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_float)])
     fn("nano_hip_time_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)])
@@ -200,6 +205,15 @@ class DeviceModel:
 
     def sync(self):
         check(lib().nano_hip_sync(self.h))
+
+    def set_strict(self, on: bool = True):
+        """Strict-parity mode: eager, reference summation order, logits bit-identical to the reference CPU engine."""
+        check(lib().nano_hip_set_strict(self.h, 1 if on else 0))
+
+    def set_phase_hook(self, fn=None):
+        """fn(layer, phase) at the reference's twelve observation points of a strict-mode forward; None removes it."""
+        self._phase_cb = PHASE_FN(lambda env, layer, phase: fn(int(layer), int(phase))) if fn else C.cast(None, PHASE_FN)
+        check(lib().nano_hip_set_phase_hook(self.h, self._phase_cb, None))
 
     def time_classifier(self, batch: int = 1, iters: int = 20):
         ms, nbytes = C.c_float(0), C.c_uint64(0)

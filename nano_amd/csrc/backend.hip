@@ -98,6 +98,11 @@ struct NanoHipModel {
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
+    uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
+    // strict-parity / per-phase mode (strict.hip): eager, one kernel per reference operator, reference summation order
+    bool strict = false;
+    float *xn = nullptr, *hb2 = nullptr, *att = nullptr;   // normalised x [Bs][E], W3 output [Bs][H], attention scores [Bs][n_head][S]
+    nano_hip_phase_fn phase_fn = nullptr; void *phase_env = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -159,7 +164,8 @@ static void destroy(NanoHipModel *m) {
     if (m->st) (void)hipStreamSynchronize(m->st);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
-                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1 };
+                    m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
+                    m->xn, m->hb2, m->att };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -286,6 +292,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     auto F = [&](size_t o) { return reinterpret_cast<const float *>(m->arena + o); };
     m->rms_attn = F(o_rms_attn); m->rms_ffn = F(o_rms_ffn); m->rms_final = F(o_rms_final);
     m->rope_cos = F(o_cos); m->rope_sin = F(o_sin);
+    m->rope_rows = (d.arch == NANO_ARCH_QWEN3) ? (uint32_t)rope_rows : d.block_size;
     if (d.arch == NANO_ARCH_QWEN3) { m->q_norm = F(o_qn); m->k_norm = F(o_kn); }
     m->tok.w = m->arena + o_tok_w; m->tok.s = (d.quant_type == NANO_QUANT_Q80) ? F(o_tok_s) : nullptr;
     for (int k = 0; k < WCOUNT; k++) {
@@ -346,6 +353,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
+    if (const char *sm = getenv("NANO_STRICT")) if (*sm && *sm != '0') return nano_hip_set_strict(m, 1);
     return NANO_HIP_OK;
 }
 
@@ -372,24 +380,46 @@ static bool gemv_is_heavy(const GemvArgs &a) {
 static bool takes_mfma(const NanoHipModel *m, const GemvArgs &a) {
     if (m->d.quant_type != NANO_QUANT_Q80 || !m->gq || !m->gxs) return false;
     if (a.nb >= m->mfma_min_nb) return true;
-    return a.nb == 8 && m->mfma_min_nb == 9 && !a.attn_part && !a.resid_add && gemv_is_heavy(a);    // (NANO_MFMA_MIN_NB != 9 disables this rule: A/B runs)
+    return a.nb == 8 && m->mfma_min_nb == 9 && gemv_is_heavy(a);    // (NANO_MFMA_MIN_NB != 9 disables this rule: A/B runs)
+}
+
+// the sequences [b0, b0 + cnt) of a launch, as a launch of their own (every per-sequence pointer advanced)
+static GemvArgs gemv_slice(const GemvArgs &a, uint32_t b0, uint32_t cnt) {
+    GemvArgs s = a;
+    s.nb = cnt;
+    for (uint32_t i = 0; i < a.nseg; i++) if (s.seg[i].out) s.seg[i].out += (size_t)b0 * a.seg[i].out_bstride;
+    if (a.xin) s.xin += (size_t)b0 * a.xin_bstride;
+    if (a.pos) s.pos += b0;
+    if (a.xq_in) s.xq_in += (size_t)b0 * ((a.n + 15) & ~15u);
+    if (a.xs_in) s.xs_in += (size_t)b0 * (a.n / a.gs);
+    if (a.attn_part) { s.attn_part += (size_t)b0 * a.attn_nsplit * a.n; s.attn_ml += (size_t)b0 * a.attn_n_head * a.attn_nsplit * 2; }
+    if (a.resid_add) s.resid_add += (size_t)b0 * a.resid_add_bstride;
+    s.tile_max = nullptr;
+    return s;
 }
 
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     const uint32_t max_wg = (uint32_t)m->cus * 8;
     if (m->d.quant_type == NANO_QUANT_Q4K) return launch_gemv_q4k(a, max_wg, m->st);
-    if (takes_mfma(m, a)) {
+    if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && gemm_q80_supports(a)) {
         // quantize every sequence's activation once, then the int8 MFMA GEMM
-        if (a.attn_part || a.resid_add) return hipErrorInvalidValue;
         hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
         if (e != hipSuccess) return e;
         a.xq_in = m->gq; a.xs_in = m->gxs;
-        e = launch_gemm_q80(a, m->st);
-        if (e != hipErrorInvalidValue || a.nb >= m->mfma_min_nb) return e;
-        a.norm_w = nullptr;                                        // a shape the GEMM does not take (8 sequences: optional
-        return launch_gemv(m->d.quant_type, a, max_wg, m->st);     // routing): the GEMV reads the same quantized activations
+        return launch_gemm_q80(a, m->st);
     }
-    if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 1 && !a.attn_part && m->gq && m->gxs && gemv_is_heavy(a)) {
+    if (a.nb > 8) {
+        // More sequences than a GEMV launch takes and a launch the GEMM does not take (row length / group size not a
+        // multiple of 4 groups, segment rows not multiples of 16, the LoRA o-branch addend): groups of 8 through the
+        // GEMV kernels.  Same arithmetic per sequence, the weights are read once per group.
+        for (uint32_t b0 = 0; b0 < a.nb; b0 += 8) {
+            GemvArgs s = gemv_slice(a, b0, a.nb - b0 < 8 ? a.nb - b0 : 8u);
+            const hipError_t e = launch_gemv(m->d.quant_type, s, max_wg, m->st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 1 && !a.attn_part && !a.xq_in && m->gq && m->gxs && gemv_is_heavy(a)) {
         // when the redundant quantization outweighs a launch (~3 us) the activations are quantized once
         // (quant_rows_kernel) and the GEMV reads them back
         hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
@@ -409,7 +439,7 @@ static GemvArgs classifier_args(const NanoHipModel *m, uint32_t nb) {
 
 static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
     GemvArgs a = classifier_args(m, nb);
-    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && !takes_mfma(m, a)) {      // per-tile arg-max partials for the sampler
+    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && nb <= 8 && !(takes_mfma(m, a) && gemm_q80_supports(a))) {      // per-tile arg-max partials for the sampler
         a.tile_max = m->tile_max;
         *ntiles_out = gemv_tiles(m->d.quant_type, a);
     }
@@ -544,10 +574,143 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------------------
+// strict-parity step (strict.hip): eager, one kernel per reference operator, every float chain in the reference's order.
+// Quantizers, quantized GEMVs, embedding, RoPE, residual adds and arg-max are the fast path's own (bit-exact) kernels, fed
+// with un-normalised launches (norm_w = nullptr); rmsnorm / attention / SwiGLU / the FP32 matmul are strict.hip's.
+// Sequence b of the step lives in KV slot slot0 + b.  The optional phase hook fires where the reference fires its
+// observation callback (infer.c:755-949, 985-1003), after everything queued before it has finished.
+// ------------------------------------------------------------------------------------------------
+static hipError_t strict_phase(NanoHipModel *m, int32_t layer, int32_t phase) {
+    if (!m->phase_fn) return hipSuccess;
+    const hipError_t e = hipStreamSynchronize(m->st);
+    if (e != hipSuccess) return e;
+    m->phase_fn(m->phase_env, layer, phase);
+    return hipSuccess;
+}
+
+// out = W . act for one weight tensor / a run of them, strict flavour: FP32 -> sequential matmul per segment (residual
+// added in place), Q80 / Q4K -> the bit-exact GEMV kernels on the un-normalised input
+static hipError_t strict_project(NanoHipModel *m, GemvArgs &a) {
+    if (m->d.quant_type != NANO_QUANT_F32) return gemv(m, a);
+    for (uint32_t s = 0; s < a.nseg; s++) {
+        const GemvSeg &g = a.seg[s];
+        const hipError_t e = launch_strict_matmul_f32(g.out, a.xin, reinterpret_cast<const float *>(g.w), a.n, g.rows, a.nb, a.xin_bstride,
+                                                      g.out_bstride, g.out_pstride, a.pos, a.epi == GEMV_EPI_RESID, m->st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static hipError_t enqueue_step_strict(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t slot0) {
+    const NanoModelDesc &d = m->d;
+    const uint32_t E = d.n_embd, H = d.n_hidden, QD = m->QD, KD = m->KD, L = d.n_layer, S = m->S;
+    hipError_t e;
+#define ST(expr) do { if ((e = (expr)) != hipSuccess) return e; } while (0)
+    if (m->lora_on) return hipErrorNotSupported;
+    m->nsplit = 1;                                                      // xba holds final head outputs (nano_hip_read_state, also from inside the hook)
+    ST(strict_phase(m, -1, 1));                                         // NANO_LLM_PHASE_EMBEDDING
+    EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
+                  m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0 };
+    ST(launch_embed(ea, nb, m->st));
+    const size_t slot_off = (size_t)slot0 * L * S * KD;
+    for (uint32_t l = 0; l < L; l++) {
+        const size_t layer_rows = (size_t)l * S;
+        ST(strict_phase(m, (int32_t)l, 2));                             // ATTN_NORM   infer.c:755-758
+        ST(launch_strict_rmsnorm(m->xn, m->x, m->rms_attn + (size_t)l * E, E, nb, E, E, m->st));
+        ST(strict_phase(m, (int32_t)l, 3));                             // QKV         infer.c:768-786
+        {
+            GemvArgs a{};
+            a.nseg = 3;
+            a.seg[0] = mkseg(m->W[WQ][l], m->q, QD, QD);
+            a.seg[1] = mkseg(m->W[WK][l], m->kraw, KD, KD);
+            a.seg[2] = mkseg(m->W[WV][l], m->vcache + slot_off + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
+            a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->xn; a.xin_bstride = E; a.epi = GEMV_EPI_STORE; a.pos = m->pos;
+            ST(strict_project(m, a));
+        }
+        ST(strict_phase(m, (int32_t)l, 4));                             // QK_ROPE     infer.c:812-835
+        StrictAttnArgs sa{};
+        sa.q = m->q; sa.kraw = m->kraw; sa.kcache = m->kcache; sa.vcache = m->vcache; sa.pos = m->pos;
+        sa.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
+        sa.k_norm = m->k_norm ? m->k_norm + (size_t)l * m->hd : nullptr;
+        sa.rope_cos = m->rope_cos; sa.rope_sin = m->rope_sin; sa.att = m->att; sa.xba = m->xba;
+        sa.n_head = d.n_head; sa.n_kv_head = d.n_kv_head; sa.hd = m->hd; sa.q_dim = QD; sa.kv_dim = KD;
+        sa.layer = l; sa.n_layer = L; sa.S = S; sa.slot0 = slot0; sa.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); sa.is_causal = is_causal;
+        ST(launch_strict_qk(sa, nb, m->st));
+        ST(strict_phase(m, (int32_t)l, 5));                             // MHA         infer.c:839-879
+        ST(launch_strict_attention(sa, nb, m->st));
+        ST(strict_phase(m, (int32_t)l, 6));                             // O           infer.c:883-908
+        {
+            GemvArgs a{};
+            a.nseg = 1; a.seg[0] = mkseg(m->W[WO][l], m->x, E, E);
+            a.n = QD; a.gs = d.group_size; a.nb = nb; a.xin = m->xba; a.xin_bstride = QD; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
+            ST(strict_project(m, a));
+        }
+        ST(strict_phase(m, (int32_t)l, 7));                             // FFN_NORM    infer.c:912-914
+        ST(launch_strict_rmsnorm(m->xn, m->x, m->rms_ffn + (size_t)l * E, E, nb, E, E, m->st));
+        ST(strict_phase(m, (int32_t)l, 8));                             // W1W3        infer.c:919-944
+        {
+            GemvArgs a{};
+            a.nseg = 2; a.seg[0] = mkseg(m->W[W1][l], m->hb, H, H); a.seg[1] = mkseg(m->W[W3][l], m->hb2, H, H);
+            a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->xn; a.xin_bstride = E; a.epi = GEMV_EPI_STORE; a.pos = m->pos;
+            ST(strict_project(m, a));
+            ST(launch_strict_swiglu(m->hb, m->hb2, H, nb, H, m->st));
+        }
+        ST(strict_phase(m, (int32_t)l, 9));                             // W2          infer.c:948-965
+        {
+            GemvArgs a{};
+            a.nseg = 1; a.seg[0] = mkseg(m->W[W2][l], m->x, E, E);
+            a.n = H; a.gs = d.group_size; a.nb = nb; a.xin = m->hb; a.xin_bstride = H; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
+            ST(strict_project(m, a));
+        }
+    }
+    if (mode == MODE_NOCLS) return hipSuccess;
+    ST(strict_phase(m, (int32_t)L, 10));                                // FINAL_NORM  infer.c:997-999
+    ST(launch_strict_rmsnorm(m->xn, m->x, m->rms_final, E, nb, E, E, m->st));
+    ST(strict_phase(m, (int32_t)L, 11));                                // CLASSIFY    infer.c:1003-1015
+    {
+        GemvArgs a = classifier_args(m, nb);
+        a.xin = m->xn; a.norm_w = nullptr;
+        ST(strict_project(m, a));
+    }
+    if (mode == MODE_ARGMAX || mode == MODE_LOOP) {
+        ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, m->pos, nullptr, m->pos0, nb, nullptr, 0 };
+        if (mode == MODE_LOOP) { aa.tokens = m->tokens; aa.trace = m->trace; }
+        ST(launch_argmax(aa, nb, m->st));
+    }
+#undef ST
+    return hipSuccess;
+}
+
+extern "C" int nano_hip_set_strict(NanoHipModel *m, int on) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    if (on && !m->xn) {
+        const size_t Bs = m->Bs;
+        if (hipMalloc(&m->xn, Bs * m->d.n_embd * 4) != hipSuccess || hipMalloc(&m->hb2, Bs * m->d.n_hidden * 4) != hipSuccess ||
+            hipMalloc(&m->att, Bs * (size_t)m->d.n_head * m->S * 4) != hipSuccess)
+            FAIL(NANO_HIP_ENOMEM, "hipMalloc for the strict-mode scratch failed");
+    }
+    m->strict = on != 0;
+    return NANO_HIP_OK;
+}
+
+extern "C" int nano_hip_set_phase_hook(NanoHipModel *m, nano_hip_phase_fn fn, void *env) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    m->phase_fn = fn; m->phase_env = env;
+    return NANO_HIP_OK;
+}
+
 // max_pos: largest position among the sequences of this step (host knowledge; the device reads the exact pos[b])
 static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t max_pos) {
     uint32_t range_hint = is_causal ? ((max_pos + 1 + 63) / 64) * 64 : m->S;
     if (range_hint > m->S) range_hint = m->S;
+    if (m->strict) {
+        const hipError_t e = enqueue_step_strict(m, nb, is_causal, mode, 0);
+        if (e == hipErrorNotSupported) FAIL(NANO_HIP_EINVAL, "strict mode does not cover the LoRA side branches");
+        HIP_TRY(e);
+        return 0;
+    }
     if (!m->use_graph) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); return 0; }
     const uint64_t key = ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
@@ -584,6 +747,7 @@ static int check_batch(NanoHipModel *m, const uint32_t *tokens, const uint32_t *
     for (uint32_t i = 0; i < batch; i++) {
         if (tokens[i] >= m->d.vocab_size) FAIL(NANO_HIP_EINVAL, "token %u out of vocabulary", tokens[i]);
         if ((uint64_t)pos[i] + (extra_steps ? extra_steps - 1 : 0) >= (uint64_t)m->S) FAIL(NANO_HIP_EINVAL, "position %u (+%u steps) exceeds max_seq_len %u", pos[i], extra_steps, m->S);
+        if ((uint64_t)pos[i] + (extra_steps ? extra_steps - 1 : 0) >= (uint64_t)m->rope_rows) FAIL(NANO_HIP_EINVAL, "position %u (+%u steps) exceeds the model's RoPE table (%u rows = block_size)", pos[i], extra_steps, m->rope_rows);
     }
     return 0;
 }
@@ -725,6 +889,9 @@ extern "C" int nano_hip_lora_attach(NanoHipModel *m, uint32_t rank, uint32_t alp
     size_t total = 0; for (size_t v : len) total += v;
     if (n_floats < total) FAIL(NANO_HIP_EINVAL, "LoRA parameter block too small: %zu floats, need %zu", n_floats, total);
     HIP_TRY(hipStreamSynchronize(m->st));
+    // graphs captured with the previous module carry its device pointers and rank in their kernel arguments
+    for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    m->graphs.clear();
     if (m->lora_buf) { (void)hipFree(m->lora_buf); m->lora_buf = nullptr; }
     if (!m->lora_o1) HIP_TRY(hipMalloc(&m->lora_o1, (size_t)m->Bs * E * 4));
     HIP_TRY(hipMalloc(&m->lora_buf, total * 4));
@@ -749,8 +916,21 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
     if (!m || !tokens) FAIL(NANO_HIP_EINVAL, "null argument");
     if (slot >= m->maxB) FAIL(NANO_HIP_EINVAL, "slot %u out of range (max_batch %u)", slot, m->maxB);
     if ((uint64_t)pos0 + count > m->S) FAIL(NANO_HIP_EINVAL, "positions %u..%u exceed max_seq_len %u", pos0, pos0 + count, m->S);
+    if ((uint64_t)pos0 + count > m->rope_rows) FAIL(NANO_HIP_EINVAL, "positions %u..%u exceed the model's RoPE table (%u rows = block_size)", pos0, pos0 + count, m->rope_rows);
     for (uint32_t i = 0; i < count; i++) if (tokens[i] >= m->d.vocab_size) FAIL(NANO_HIP_EINVAL, "token %u out of vocabulary", tokens[i]);
     HIP_TRY(hipSetDevice(m->device));
+    if (m->strict) {                                                        // strict mode: one reference-order forward per prompt token
+        for (uint32_t i = 0; i < count; i++) {
+            m->h_tokens[0] = tokens[i]; m->h_pos[0] = pos0 + i;
+            HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, 4, hipMemcpyHostToDevice, m->st));
+            HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, 4, hipMemcpyHostToDevice, m->st));
+            const hipError_t e = enqueue_step_strict(m, 1, 1, MODE_NOCLS, slot);
+            if (e == hipErrorNotSupported) FAIL(NANO_HIP_EINVAL, "strict mode does not cover the LoRA side branches");
+            HIP_TRY(e);
+            HIP_TRY(hipStreamSynchronize(m->st));
+        }
+        return 0;
+    }
     const uint32_t chunk_max = m->d.quant_type == NANO_QUANT_Q80 ? 64u : 8u;
     for (uint32_t done = 0; done < count;) {
         uint32_t nb = (count - done < chunk_max) ? count - done : chunk_max;

@@ -37,13 +37,15 @@ NANO_HD uint64_t f64_bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 NANO_HD uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 NANO_HD float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-// expf for x <= 0 (the softmax argument x - max); x > 0 is outside the sampler's domain and not handled.
-NANO_HD float exact_expf_nonpos(float x, const uint64_t *tab) {
+// expf for any float: the whole published routine (x <= 0 is the softmax argument x - max; SwiGLU's expf(-h) takes
+// either sign and may overflow to +inf above log(2^128), reference infer/infer.c:941).
+NANO_HD float exact_expf(float x, const uint64_t *tab) {
     const uint32_t ix = f32_bits(x);
     const uint32_t abstop = (ix >> 20) & 0x7ff;
     if (abstop > 0x42a) {                                   // |x| >= 88: the slow cases of the published routine
         if (ix == 0xff800000u) return 0.0f;                 // -inf
-        if (abstop > 0x7f7) return x + x;                   // nan
+        if (abstop > 0x7f7) return x + x;                   // nan, +inf
+        if (x > 0x1.62e42ep6f) return bits_f32(0x7f800000u);// overflow: 2^97 * 2^97 rounds to +inf
         if (x < -0x1.9fe368p6f) return 0.0f;                // underflow: 2^-95 * 2^-95 rounds to +0
         if (x < -0x1.9d1d9ep6f) return bits_f32(1u);        // "may underflow": 0x1.4p-75^2 rounds to 2^-149
     }
@@ -62,6 +64,8 @@ NANO_HD float exact_expf_nonpos(float x, const uint64_t *tab) {
     y = y * s;
     return (float)y;
 }
+// the sampler's name for it (its arguments are never positive)
+NANO_HD float exact_expf_nonpos(float x, const uint64_t *tab) { return exact_expf(x, tab); }
 
 
 // ---- sequential float sums, evaluated in parallel ----------------------------------------------------------------

@@ -472,11 +472,25 @@ static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
 
 }  // namespace
 
+// Host-side predicate: does the GEMM take this launch?  (What it does not take goes through the GEMV kernels in groups
+// of 8 sequences, backend.hip gemv().)  Not taken: row lengths whose group count is not a multiple of 4 (the scale
+// staging reads float4s: e.g. n_embd 768 at group size 128), interior segments that are not multiples of the 16-row
+// tile, a split-attention input, the LoRA o-branch addend.
+bool gemm_q80_supports(const GemvArgs &a) {
+    if (a.nb == 0 || a.nb > 64 || a.gs == 0 || a.n % a.gs || a.n % 16 || a.nseg == 0 || a.nseg > 3 || a.attn_part || a.resid_add) return false;
+    if (!(a.gs == 32 || a.gs == 64 || a.gs == 128 || a.gs == 256)) return false;
+    if (a.epi != GEMV_EPI_SWIGLU && a.nseg > 1)
+        for (uint32_t s = 0; s + 1 < a.nseg; s++) if (a.seg[s].rows % 16) return false;     // a 16-row tile stays inside one segment
+    const uint32_t ng = a.n / a.gs;
+    if (ng % 4) return false;
+    const uint32_t magic = ((1u << 20) + ng - 1) / ng;         // the kernels' e / ng == (e * magic) >> 20
+    for (uint32_t e = 0; e < 16 * ng; e += 4) if (((e * magic) >> 20) != e / ng) return false;
+    return true;
+}
+
 // xq_in / xs_in of `a`: the quantized activations of all a.nb tokens, [nb][(n+15)&~15] int8 and [nb][n/gs] float
 hipError_t launch_gemm_q80(const GemvArgs &a, hipStream_t st) {
-    if (a.nb == 0 || a.nb > 64 || !a.xq_in || !a.xs_in || a.gs == 0 || a.n % a.gs || a.n % 16 || a.nseg == 0 || a.nseg > 3 || a.attn_part) return hipErrorInvalidValue;
-    if (a.epi != GEMV_EPI_SWIGLU && a.nseg > 1)
-        for (uint32_t s = 0; s + 1 < a.nseg; s++) if (a.seg[s].rows % 16) return hipErrorInvalidValue;     // a 16-row tile stays inside one segment
+    if (!a.xq_in || !a.xs_in || !gemm_q80_supports(a)) return hipErrorInvalidValue;
     switch (a.gs) {
     case 32: return launch_gs<32>(a, st);
     case 64: return launch_gs<64>(a, st);

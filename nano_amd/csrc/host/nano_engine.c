@@ -54,21 +54,31 @@ static int pick_device(void) {
     return e ? atoi(e) : 0;
 }
 
+/* One entry per loaded LLM: its device twin and the engine-side state that belongs to that model (two contexts may
+ * be stepped alternately by one caller thread; the reference keeps all of this inside LLM / Nano_Context, whose
+ * layouts are the ABI and cannot grow). */
 #define MAX_MODELS 64
-static struct { const LLM *llm; NanoHipModel *dev; uint32_t max_seq_len; } g_reg[MAX_MODELS];
+typedef struct ModelEntry {
+    const LLM *llm; NanoHipModel *dev; uint32_t max_seq_len;
+    int fallback_streak, host_turns;                 /* device sampler: consecutive fall-backs / host-loop turns left */
+    const Nano_Session *pf_session; uint32_t pf_upto; /* session whose prompt positions [0, pf_upto) one batched prefill fed */
+    int position_prefilled;                          /* set while step_core calls generate_next_token for such a position */
+} ModelEntry;
+static ModelEntry g_reg[MAX_MODELS];
 
 static void reg_put(const LLM *llm, NanoHipModel *dev, uint32_t max_seq_len) {
     for (int i = 0; i < MAX_MODELS; i++)
-        if (!g_reg[i].llm) { g_reg[i].llm = llm; g_reg[i].dev = dev; g_reg[i].max_seq_len = max_seq_len; return; }
+        if (!g_reg[i].llm) { memset(&g_reg[i], 0, sizeof g_reg[i]); g_reg[i].llm = llm; g_reg[i].dev = dev; g_reg[i].max_seq_len = max_seq_len; return; }
     fprintf(stderr, "too many models loaded\n");
     exit(EXIT_FAILURE);
 }
-static NanoHipModel *reg_get(const LLM *llm) {
-    for (int i = 0; i < MAX_MODELS; i++) if (g_reg[i].llm == llm) return g_reg[i].dev;
+static ModelEntry *reg_entry(const LLM *llm) {
+    for (int i = 0; i < MAX_MODELS; i++) if (g_reg[i].llm == llm) return &g_reg[i];
     return NULL;
 }
+static NanoHipModel *reg_get(const LLM *llm) { ModelEntry *e = reg_entry(llm); return e ? e->dev : NULL; }
 static void reg_del(const LLM *llm) {
-    for (int i = 0; i < MAX_MODELS; i++) if (g_reg[i].llm == llm) { g_reg[i].llm = NULL; g_reg[i].dev = NULL; }
+    for (int i = 0; i < MAX_MODELS; i++) if (g_reg[i].llm == llm) memset(&g_reg[i], 0, sizeof g_reg[i]);
 }
 void *nano_device_model(const LLM *llm) { return reg_get(llm); }
 
@@ -292,11 +302,34 @@ static inline void observe(Nano_Context *ctx, int32_t layer, int32_t phase) {
     }
 }
 
-/* the reference's use_lora = (lora != NULL) of each forward call (infer.c:721) */
+/* the reference's use_lora = (lora != NULL) of each forward call (infer.c:721): a flag store on the device model */
 static void lora_select(NanoHipModel *dev, const LoRA *lora) {
-    static const NanoHipModel *last_dev = NULL; static int last_on = -1;
     const int on = lora != NULL;
-    if (dev != last_dev || on != last_on) { if (nano_hip_lora_enable(dev, on) != NANO_HIP_OK && on) die_hip("lora"); last_dev = dev; last_on = on; }
+    if (nano_hip_lora_enable(dev, on) != NANO_HIP_OK && on) die_hip("lora");
+}
+
+/* Per-phase observation (reference infer.c:755-949, 985-1003: eight callbacks per layer plus three per token from
+ * INSIDE the forward).  The fused device forward has no host boundary between phases, so by default the hooks fire at
+ * token granularity.  nano_set_phase_observation(1) (or NANO_OBSERVE_PHASES=1) switches forwards of contexts that
+ * have a hook installed to the backend's eager per-operator replay (strict mode, include/nano_mi355x.h), which calls
+ * back at exactly the reference's points with the phase's tensors finished on the device.  Debug aid: never timed. */
+static int g_phase_observation = -1;
+void nano_set_phase_observation(int on) { g_phase_observation = on ? 1 : 0; }
+static int phase_mode(const Nano_Context *ctx) {
+    if (g_phase_observation < 0) { const char *e = getenv("NANO_OBSERVE_PHASES"); g_phase_observation = (e && *e && *e != '0') ? 1 : 0; }
+    return g_phase_observation && ctx && ctx->observation;
+}
+static void phase_bridge(void *env, int32_t layer, int32_t phase) { observe((Nano_Context *)env, layer, phase); }
+static int g_env_strict = -1;
+static int phase_begin(Nano_Context *ctx, NanoHipModel *dev) {
+    if (!phase_mode(ctx)) return 0;
+    if (nano_hip_set_strict(dev, 1) != NANO_HIP_OK || nano_hip_set_phase_hook(dev, phase_bridge, ctx) != NANO_HIP_OK) die_hip("per-phase observation");
+    return 1;
+}
+static void phase_end(NanoHipModel *dev) {
+    if (g_env_strict < 0) { const char *e = getenv("NANO_STRICT"); g_env_strict = (e && *e && *e != '0') ? 1 : 0; }
+    (void)nano_hip_set_phase_hook(dev, NULL, NULL);
+    if (!g_env_strict) (void)nano_hip_set_strict(dev, 0);
 }
 
 float *llm_forward(Nano_Context *ctx, uint32_t token, uint32_t pos, uint32_t max_seq_len, uint32_t is_causal, LLM *llm, LoRA *lora) {
@@ -304,6 +337,11 @@ float *llm_forward(Nano_Context *ctx, uint32_t token, uint32_t pos, uint32_t max
     NanoHipModel *dev = reg_get(llm);
     if (!dev) { fprintf(stderr, "llm_forward: model is not resident on a device\n"); exit(EXIT_FAILURE); }
     lora_select(dev, lora);
+    if (phase_begin(ctx, dev)) {                       /* eager per-operator replay: the backend fires all eleven phases */
+        if (nano_hip_forward(dev, &token, &pos, 1, is_causal, llm->state.logits, NULL) != NANO_HIP_OK) die_hip("llm_forward");
+        phase_end(dev);
+        return llm->state.logits;
+    }
     /* The fused device forward has no per-layer host boundary: phase hooks fire at token granularity. */
     observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
     if (nano_hip_forward(dev, &token, &pos, 1, is_causal, llm->state.logits, NULL) != NANO_HIP_OK) die_hip("llm_forward");
@@ -380,20 +418,42 @@ Sampler *build_sampler(int vocab_size, float repetition_penalty, float temperatu
 }
 void free_sampler(Sampler *s) { if (s) { free(s->probindex); free(s); } }
 
-/* set by step_core while it calls generate_next_token for a prompt position its batched prefill already covered */
-static int g_position_prefilled = 0;
 /* NANO_HOST_SAMPLER=1: copy the logits back and run the sampler loops on the host (A/B checks) */
 static int g_host_sampler = -1;
-static int g_fallback_streak = 0, g_host_turns = 0;
+
+/* the sampler loops of generate_next_token on a host copy of the logits (reference infer.c:1156-1189) */
+static uint32_t host_sample(Nano_Context *ctx, Sampler *sp, float *logits, const uint32_t *output_ids, uint32_t pos, float coin) {
+    const int V = sp->vocab_size;
+    uint32_t *seen = (uint32_t *)calloc((size_t)V, sizeof(uint32_t));
+    if (seen) {
+        for (uint32_t i = 0; i < pos; i++) seen[output_ids[i]] = 1;
+        for (int id = 0; id < V; id++) if (seen[id] == 1) logits[id] /= sp->repetition_penalty;
+        free(seen);
+    }
+    if (sp->temperature == 0.0f) return (uint32_t)argmax_first(logits, V);
+    for (int i = 0; i < V; i++) logits[i] /= sp->temperature;
+    softmax_inplace(logits, V);
+    return (uint32_t)nucleus(ctx, logits, V, sp->top_p, sp->probindex, coin);   /* top-p always (infer.c:1183) */
+}
 
 /* reference infer/infer.c:1135-1193 */
 uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t pos, int is_prefilling) {
     LLM *llm = ctx->llm;
     Sampler *sp = ctx->sampler;
-    NanoHipModel *dev = reg_get(llm);
+    ModelEntry *me = reg_entry(llm);
+    NanoHipModel *dev = me ? me->dev : NULL;
     if (!dev) { fprintf(stderr, "generate_next_token: model is not resident on a device\n"); exit(EXIT_FAILURE); }
     uint32_t token = output_ids[pos];
     lora_select(dev, ctx->lora);
+    if (phase_mode(ctx)) {
+        /* per-phase observation: the reference's own sequence -- forward (all phases from inside it), SAMPLE hook,
+         * host sampler loops (infer.c:1135-1193) */
+        float *lg = llm_forward(ctx, token, pos, ctx->max_seq_len, 1, llm, ctx->lora);
+        if (is_prefilling == 1) return output_ids[pos + 1];
+        observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
+        /* the coin is drawn exactly when the reference draws it: only on the softmax branch (infer.c:1181) */
+        return host_sample(ctx, sp, lg, output_ids, pos, sp->temperature != 0.0f ? xorshift_f32(&sp->rng_state) : 0.0f);
+    }
     if (g_host_sampler < 0) { const char *e = getenv("NANO_HOST_SAMPLER"); g_host_sampler = (e && *e && *e != '0') ? 1 : 0; }
 
     if (is_prefilling == 1) {
@@ -401,7 +461,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
          * skip the classifier, the KV rows written are the same.  Inside a session step the whole prompt may
          * already have been fed by one batched prefill (step_core): nothing left to do for this position. */
         observe(ctx, -1, NANO_LLM_PHASE_EMBEDDING);
-        if (!g_position_prefilled && nano_hip_forward(dev, &token, &pos, 1, 1, NULL, NULL) != NANO_HIP_OK) die_hip("generate_next_token");
+        if (!me->position_prefilled && nano_hip_forward(dev, &token, &pos, 1, 1, NULL, NULL) != NANO_HIP_OK) die_hip("generate_next_token");
         return output_ids[pos + 1];
     }
 
@@ -418,7 +478,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
     const float coin = sp->temperature != 0.0f ? xorshift_f32(&sp->rng_state) : 0.0f;
     const int V = sp->vocab_size;
     float *logits = NULL;
-    if (!g_host_sampler && g_host_turns > 0) g_host_turns--;            /* a flat distribution was seen: stay on the host loops for a while */
+    if (!g_host_sampler && me->host_turns > 0) me->host_turns--;        /* a flat distribution was seen: stay on the host loops for a while */
     else if (!g_host_sampler) {
         /* the sampler runs on the device behind the forward: one 52-byte result comes back */
         NanoHipSample r;
@@ -427,7 +487,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
             die_hip("generate_next_token");
         observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
         if (r.status == NANO_SAMPLE_OK) {
-            g_fallback_streak = 0;
+            me->fallback_streak = 0;
             if (sp->temperature != 0.0f && ctx->observation) {
                 Nano_Observation o; memset(&o, 0, sizeof o);
                 o.layer = -1; o.phase = NANO_LLM_PHASE_SAMPLE;
@@ -438,7 +498,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
         }
         /* more candidates than the device nucleus holds (near-uniform distribution): same logits, host loops; after two
          * such tokens in a row the next 32 skip the device attempt (its ~0.1 ms would be wasted) */
-        if (++g_fallback_streak >= 2) g_host_turns = 32;
+        if (++me->fallback_streak >= 2) me->host_turns = 32;
         logits = llm->state.logits;
         if (nano_hip_read_state(dev, 0, 4, 0, 0, logits, (size_t)V) != NANO_HIP_OK) die_hip("generate_next_token");
     }
@@ -446,16 +506,7 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
         logits = llm_forward(ctx, token, pos, ctx->max_seq_len, 1, llm, ctx->lora);
         observe(ctx, -1, NANO_LLM_PHASE_SAMPLE);
     }
-    uint32_t *seen = (uint32_t *)calloc((size_t)V, sizeof(uint32_t));
-    if (seen) {
-        for (uint32_t i = 0; i < pos; i++) seen[output_ids[i]] = 1;
-        for (int id = 0; id < V; id++) if (seen[id] == 1) logits[id] /= sp->repetition_penalty;
-        free(seen);
-    }
-    if (sp->temperature == 0.0f) return (uint32_t)argmax_first(logits, V);
-    for (int i = 0; i < V; i++) logits[i] /= sp->temperature;
-    softmax_inplace(logits, V);
-    return (uint32_t)nucleus(ctx, logits, V, sp->top_p, sp->probindex, coin);   /* top-p always (infer.c:1183) */
+    return host_sample(ctx, sp, logits, output_ids, pos, coin);
 }
 
 /* =====================================================================================================
@@ -508,21 +559,20 @@ static int32_t step_core(Nano_Context *ctx, Nano_Session *s, int with_text) {
     /* Batched prefill: at the first step of a session the prompt positions 0 .. n-2 are fed in one
      * call (<= 64 / 8 tokens per weight read) instead of one forward per step; the per-step protocol (status codes,
      * callbacks, output_text) is unchanged, the following prefilling steps just find their position done.
-     * NANO_NO_BATCHED_PREFILL=1 restores one forward per prompt token. */
-    static const Nano_Session *pf_session = NULL;
-    static uint32_t pf_upto = 0;
+     * NANO_NO_BATCHED_PREFILL=1 (and per-phase observation) restore one forward per prompt token. */
+    ModelEntry *me = reg_entry(ctx->llm);
+    if (!me) { fprintf(stderr, "llm_session_step: model is not resident on a device\n"); return LLM_STOPPED_WITH_ERROR; }
     if (s->pos == 0) {
-        pf_session = NULL;
-        NanoHipModel *dev = reg_get(ctx->llm);
-        if (dev && s->num_prompt_tokens > 2 && s->num_prompt_tokens - 1 <= s->max_seq_len && !getenv("NANO_NO_BATCHED_PREFILL")) {
-            lora_select(dev, ctx->lora);
-            if (nano_hip_prefill(dev, 0, s->output_ids, 0, s->num_prompt_tokens - 1) != NANO_HIP_OK) die_hip("llm_session_step (prefill)");
-            pf_session = s; pf_upto = s->num_prompt_tokens - 1;
+        me->pf_session = NULL;
+        if (s->num_prompt_tokens > 2 && s->num_prompt_tokens - 1 <= s->max_seq_len && !phase_mode(ctx) && !getenv("NANO_NO_BATCHED_PREFILL")) {
+            lora_select(me->dev, ctx->lora);
+            if (nano_hip_prefill(me->dev, 0, s->output_ids, 0, s->num_prompt_tokens - 1) != NANO_HIP_OK) die_hip("llm_session_step (prefill)");
+            me->pf_session = s; me->pf_upto = s->num_prompt_tokens - 1;
         }
     }
-    g_position_prefilled = (pf_session == s && s->is_prefilling == 1 && s->pos < pf_upto) ? 1 : 0;
+    me->position_prefilled = (me->pf_session == s && s->is_prefilling == 1 && s->pos < me->pf_upto) ? 1 : 0;
     s->next_token = generate_next_token(ctx, s->output_ids, s->pos, s->is_prefilling);
-    g_position_prefilled = 0;
+    me->position_prefilled = 0;
     const uint32_t arch = ctx->llm->arch;
     if (arch != LLM_ARCH_NANO && arch != LLM_ARCH_QWEN2 && arch != LLM_ARCH_QWEN3) { printf("Error: unknown LLM arch.\n"); return LLM_STOPPED_WITH_ERROR; }
     uint32_t *text_ids; uint32_t text_n;
@@ -582,6 +632,8 @@ void seq2seq(Nano_Context *ctx, wchar_t *input_list, wchar_t *output_list, uint3
     uint32_t *in = encode_nano(ctx->tokenizer, input_list, &n);
     uint32_t *out = (uint32_t *)calloc(max_seq_len, sizeof(uint32_t));
     NanoHipModel *dev = reg_get(ctx->llm);
+    if (!dev) { fprintf(stderr, "seq2seq: model is not resident on a device\n"); exit(EXIT_FAILURE); }
+    lora_select(dev, NULL);                                  /* the reference passes lora = NULL to every forward here (infer.c:1381,1388) */
     for (uint32_t l = 0; l < ctx->llm->config.n_layer; l++)
         for (uint32_t pos = 0; pos < max_seq_len; pos++)
             if (nano_hip_forward(dev, &in[pos], &pos, 1, 0, NULL, NULL) != NANO_HIP_OK) die_hip("seq2seq");

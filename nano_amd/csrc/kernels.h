@@ -57,6 +57,7 @@ hipError_t launch_gemv_q80(const GemvArgs &a, hipStream_t st);      // gemv_q80.
 hipError_t launch_gemv_f32(const GemvArgs &a, hipStream_t st);      // gemv_f32.hip
 // 9..64 tokens per weight read on the int8 matrix cores (gemm_q80.hip); a.xq_in / a.xs_in = quantized activations of all tokens
 hipError_t launch_gemm_q80(const GemvArgs &a, hipStream_t st);
+bool gemm_q80_supports(const GemvArgs &a);                          // host predicate: shapes / features the GEMM takes
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                              int8_t *xq, float *xs, hipStream_t st);
 uint32_t gemv_q80_partials(const GemvArgs &a);
@@ -91,6 +92,27 @@ hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
 hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb, hipStream_t st);
+
+// ---- strict-parity kernels (strict.hip): every float reduction in the reference's own order --------------
+struct StrictAttnArgs {
+    float *q;               // [nb][q_dim] raw q, finished (norm + RoPE) in place
+    const float *kraw;      // [nb][kv_dim] raw k of the current position
+    float *kcache, *vcache; // [slots][L][S][kv_dim]
+    const uint32_t *pos;    // [nb]
+    const float *q_norm, *k_norm;          // [hd] of this layer or nullptr
+    const float *rope_cos, *rope_sin;      // [rows][hd/2]
+    float *att;             // [nb][n_head][S] scores -> probabilities
+    float *xba;             // [nb][q_dim] head outputs
+    uint32_t n_head, n_kv_head, hd, q_dim, kv_dim, layer, n_layer, S;
+    uint32_t slot0;         // KV slot of sequence 0 of this step (sequence b lives in slot0 + b)
+    uint32_t rope_qwen3, is_causal, _pad;
+};
+hipError_t launch_strict_rmsnorm(float *o, const float *x, const float *w, uint32_t n, uint32_t nvec, uint32_t x_stride, uint32_t o_stride, hipStream_t st);
+hipError_t launch_strict_qk(const StrictAttnArgs &a, uint32_t nb, hipStream_t st);
+hipError_t launch_strict_attention(const StrictAttnArgs &a, uint32_t nb, hipStream_t st);
+hipError_t launch_strict_swiglu(float *hb, const float *hb2, uint32_t n, uint32_t nb, uint32_t bstride, hipStream_t st);
+hipError_t launch_strict_matmul_f32(float *out, const float *x, const float *w, uint32_t n, uint32_t d, uint32_t nb, uint32_t x_bstride,
+                                    uint32_t out_bstride, uint32_t out_pstride, const uint32_t *pos, int resid, hipStream_t st);
 
 // ---- LoRA side branches (lora.hip) -------------------------------------------------------------------
 struct LoraArgs {

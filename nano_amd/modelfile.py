@@ -353,21 +353,29 @@ def write_model(path: str, spec: ModelSpec, seed: int = 39, weight_std: float = 
                 shp = shape + [0] * (6 - len(shape))
                 f.write(struct.pack("<QII6II", total, QUANT_Q4K, len(shape), *shp, n_blocks))
                 for i in range(cnt):
-                    rows_per = max(1, (1 << 24) // n)
+                    rows_per = max(1, (1 << 20) // n)
                     for r0 in range(0, d, rows_per):
                         r1 = min(d, r0 + rows_per)
                         w = (std * rng.standard_normal((r1 - r0) * n, dtype=np.float32)).astype(np.float32)
                         framed = quantize_q4k_tensor(w, (r1 - r0, n))
                         f.write(framed[Q4K_FRAME_PREFIX:])
             else:
+                # Row chunks of <= 4 M weights: the generator's stream is consumed in the same order as one call per
+                # tensor (same bytes, checked against the golden files' sha256) without multi-GB temporaries.
+                rows_per = max(1, (1 << 22) // n)
                 for i in range(cnt):
-                    w = (std * rng.standard_normal(d * n, dtype=np.float32)).astype(np.float32)
-                    if spec.quant_type == QUANT_F32:
-                        f.write(w.tobytes())
-                    else:
-                        q, s = quantize_q80_weights(w, spec.group_size)
-                        f.write(q.tobytes())
-                        f.write(s.tobytes())
+                    scales = []
+                    for r0 in range(0, d, rows_per):
+                        r1 = min(d, r0 + rows_per)
+                        w = (std * rng.standard_normal((r1 - r0) * n, dtype=np.float32)).astype(np.float32)
+                        if spec.quant_type == QUANT_F32:
+                            f.write(w.tobytes())
+                        else:
+                            q, s = quantize_q80_weights(w, spec.group_size)
+                            f.write(q.tobytes())
+                            scales.append(s)
+                    if spec.quant_type == QUANT_Q80:
+                        f.write(np.concatenate(scales).tobytes())
         if spec.arch == ARCH_QWEN3:
             f.write(norm_w(L * spec.hd).tobytes())
             f.write(norm_w(L * spec.hd).tobytes())

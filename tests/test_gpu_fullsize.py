@@ -93,37 +93,71 @@ def test_c_abi_rejects_bad_arguments(q3):
     assert np.isfinite(lg).all()
 
 
-@pytest.mark.parametrize("name,quant,gs,tol", [("nano-168m", "f32", 0, 1e-4), ("qwen3-0.6b", "q80", 64, 2e-2)])
-def test_fullsize_logits_vs_reference_golden(model_dir, name, quant, gs, tol):
-    """BASELINE.json configs[1] / configs[2] against the compiled reference's own greedy run on the same synthetic file
-    (tests/golden/fullsize_*.npz, tools/make_golden.py): teacher-forced logits (every 61st entry is stored) within the
-    north-star tolerance at every decode step, arg-max ids bit-exact for FP32 (for Q80 wherever the reference's top-2 gap
-    exceeds the measured error), and the greedy loop on the device reproduces the reference's ids."""
+# BASELINE.json configs[1..4] at their own size.  tol = bar for the FAST path (FP32: the north-star's 1e-4; Q80 / Q4K: the
+# reference's own inter-build noise floor); the STRICT path is held to every bit of every logit.
+FULLSIZE = [("nano-168m", "f32", 0, 1e-4), ("qwen3-0.6b", "q80", 64, 2e-2), ("qwen3-0.6b", "q4k", 0, 1.5e-1), ("qwen3-4b", "q80", 64, 2e-2)]
+
+
+@pytest.mark.parametrize("name,quant,gs,tol", FULLSIZE)
+def test_fullsize_vs_reference_golden(model_dir, name, quant, gs, tol):
+    """The compiled reference's own greedy run on the same synthetic file, from the prompt to the LAST position of the
+    context (seq_len 512 for configs[1..3]; tests/golden/fullsize_*.npz, tools/make_golden.py), teacher-forced:
+      strict mode   every decode step's logits equal the reference's bit for bit (CRC-32 over all vocab floats) and
+                    the arg-max is the reference's greedy token -- positions up to 511 included;
+      fast path     strided logits within `tol` * max|logit| at the kept steps (first 16, around every 64-position
+                    bucket boundary where the attention split count changes, last 12), arg-max equal wherever the
+                    reference's top-2 gap exceeds 4x the measured error; FP32: the on-device greedy loop reproduces
+                    the reference's ids to the end of the context."""
     import os
+    import zlib
     from conftest import GOLD, file_sha256
+    if name == "qwen3-4b" and os.environ.get("NANO_SKIP_4B") == "1":
+        pytest.skip("NANO_SKIP_4B=1")
     g = np.load(os.path.join(GOLD, f"fullsize_{name}_{quant}.npz"))
     path, spec = synth_model(model_dir, name, quant, gs)
     assert file_sha256(path) == str(g["model_sha256"]), "the synthetic model writer does not reproduce the golden file"
-    m = nb.load_model_file(path, max_seq_len=int(g["max_seq_len"]), max_batch=1)
+    S = int(g["max_seq_len"])
+    m = nb.load_model_file(path, max_seq_len=S, max_batch=1)
     ids, n_prompt, stride = g["ids"], len(g["prompt"]), int(g["stride"])
-    for pos in range(n_prompt - 1):
-        m.forward([int(ids[pos])], [pos], want_logits=False)
-    worst, agree = 0.0, 0
     n_decode = len(ids) - n_prompt
+    assert n_prompt - 1 + n_decode == S                      # the run ends at position S - 1
+
+    # ---- strict mode: bit for bit, every step -----------------------------------------------------------------
+    m.set_strict(True)
+    m.prefill(ids[:n_prompt - 1], 0)
     for i in range(n_decode):
         pos = n_prompt - 1 + i
         logits, am = m.forward([int(ids[pos])], [pos], want_argmax=True)
-        err = float(np.abs(logits[0, ::stride].astype(np.float64) - g["logits_strided"][i]).max())
-        worst = max(worst, err / float(g["max_abs"][i]))
+        assert zlib.crc32(logits[0].tobytes()) == int(g["crc32"][i]), f"strict logits differ from the reference at position {pos}"
+        assert int(am[0]) == int(g["argmax"][i]) == int(ids[pos + 1])
+    m.set_strict(False)
+
+    # ---- fast path: tolerance at the kept steps -----------------------------------------------------------------
+    keep = {int(k): j for j, k in enumerate(g["keep"])}
+    for pos in range(n_prompt - 1):
+        m.forward([int(ids[pos])], [pos], want_logits=False)
+    worst, worst_pos, agree, checked = 0.0, -1, 0, 0
+    for i in range(n_decode):
+        pos = n_prompt - 1 + i
+        if i not in keep:
+            m.forward([int(ids[pos])], [pos], want_logits=False)
+            continue
+        logits, am = m.forward([int(ids[pos])], [pos], want_argmax=True)
+        err = float(np.abs(logits[0, ::stride].astype(np.float64) - g["logits_strided"][keep[i]]).max())
+        if err / float(g["max_abs"][i]) > worst:
+            worst, worst_pos = err / float(g["max_abs"][i]), pos
         same = int(am[0]) == int(g["argmax"][i])
-        agree += same
+        agree += same; checked += 1
         if quant == "f32" or float(g["top2_gap"][i]) > 4.0 * err:
             assert same, (i, int(am[0]), int(g["argmax"][i]))
     for pos in range(n_prompt - 1):
         m.forward([int(ids[pos])], [pos], want_logits=False)
     out = m.decode_greedy([int(ids[n_prompt - 1])], [n_prompt - 1], n_decode)[:, 0]
     m.close()
-    print(f"{name}/{quant}: worst max|dlogit|/max|logit| over {n_decode} steps = {worst:.3e}; arg-max agrees on {agree}/{n_decode}; greedy ids identical: {np.array_equal(out, ids[n_prompt:])}")
+    n_same = int(np.argmin(np.append(out == ids[n_prompt:], False)))
+    print(f"{name}/{quant}: strict == reference bit for bit at all {n_decode} steps (positions {n_prompt - 1}..{S - 1}); fast path: worst "
+          f"max|dlogit|/max|logit| over {checked} kept steps = {worst:.3e} (position {worst_pos}), arg-max agrees on {agree}/{checked}, "
+          f"free-running greedy ids identical for the first {n_same} of {n_decode} steps")
     assert worst < tol
     if quant == "f32":
         assert np.array_equal(out, ids[n_prompt:])

@@ -144,37 +144,58 @@ def make_sampler_logits(tmpdir):
                         tokens=toks, n_candidates=ncand, denominator_bits=denom, V=sc.V_QWEN3)
 
 
-# BASELINE.json configs[1] and configs[2] at their real sizes: (preset, quant, gs, n_prompt, n_decode)
-FULLSIZE_CASES = [("nano-168m", "f32", 0, 12, 20), ("qwen3-0.6b", "q80", 64, 16, 16)]
-FULLSIZE_STRIDE = 61          # logits are stored every 61st vocabulary entry (plus arg-max, top-2 gap, max|logit|)
+# BASELINE.json configs[1..4] at their real sizes: (preset, quant, gs, n_prompt, max_seq_len).  The reference decodes
+# greedily from the prompt up to the last position of the context (configs[1..3]: seq_len 512, so the 3..8-way split
+# attention of the long ranges is compared with the reference, not with itself); Qwen3-4B (configs[4], 4.3 GB, about a
+# second per forward on this box's CPU) runs a short context.
+FULLSIZE_CASES = [("nano-168m", "f32", 0, 12, 512), ("qwen3-0.6b", "q80", 64, 16, 512), ("qwen3-0.6b", "q4k", 0, 16, 512),
+                  ("qwen3-4b", "q80", 64, 16, 32)]
+FULLSIZE_STRIDE = 61          # logits are stored every 61st vocabulary entry (plus arg-max, top-2 gap, max|logit|, CRC-32 of all of them)
 
 
-def make_fullsize(tmpdir):
-    """Greedy decode of the compiled reference (strict build) on the full-size synthetic models; per decode step the
-    arg-max id, the gap to the runner-up, max|logit| and a strided sample of the logits."""
+def fullsize_keep(n_prompt, S):
+    """Decode steps whose strided logits are stored: the first 16, the steps around every 64-position bucket boundary
+    (where the attention split count of the fast path changes) and the last 12."""
+    first = n_prompt - 1
+    keep = [i for i in range(S - first) if i < 16 or (first + i) % 64 in (62, 63, 0, 1) or first + i >= S - 12]
+    return np.array(keep, np.uint32)
+
+
+def make_fullsize(tmpdir, only=None):
+    """Greedy decode of the compiled reference (strict build) on the full-size synthetic models; for EVERY decode step
+    the arg-max id, the gap to the runner-up, max|logit| and the CRC-32 of the logits' bytes (what the strict-parity
+    mode is held to, bit for bit); for the kept steps a strided sample of the logits (what the fast path is held to)."""
+    import zlib
     ref, orc = ob.load_ref(), ob.load_oracle()
-    for (name, quant, gs, n_prompt, n_decode) in FULLSIZE_CASES:
+    for (name, quant, gs, n_prompt, S) in FULLSIZE_CASES:
+        if only and f"{name}_{quant}" not in only:
+            continue
         spec = mf.preset(name, quant, group_size=gs)
         path = os.path.join(tmpdir, f"{name}-{quant}.bin")
         if not os.path.exists(path):
             mf.write_model(path, spec, seed=39)
         prompt = mf.prompt_ids(39, n_prompt, spec.vocab_size)
-        ctx = ob.OracleCtx(ref, path, max_seq_len=64)
+        n_decode = S - n_prompt + 1                              # last forward at position S - 1
+        ctx = ob.OracleCtx(ref, path, max_seq_len=S)
         ids, logits, secs = ctx.generate(prompt, n_decode, want_logits=True)
         ctx.close()
-        octx = ob.OracleCtx(orc, path, max_seq_len=64)          # the restatement at full size, first decode step
+        octx = ob.OracleCtx(orc, path, max_seq_len=S)            # the restatement at full size, first decode step
         for pos in range(n_prompt - 1):
             octx.forward(int(prompt[pos]), pos)
         o0 = octx.forward(int(prompt[-1]), n_prompt - 1).copy()
         octx.close()
         assert np.array_equal(o0.view(np.uint32), logits[0].view(np.uint32)), "restatement != compiled reference at full size"
-        srt = np.sort(logits, axis=1)
+        keep = fullsize_keep(n_prompt, S)
+        part = np.partition(logits, -2, axis=1)[:, -2:]
+        crc = np.array([zlib.crc32(np.ascontiguousarray(logits[i]).tobytes()) for i in range(n_decode)], np.uint32)
         np.savez_compressed(os.path.join(GOLD, f"fullsize_{name}_{quant}.npz"), preset=name, quant=quant, gs=spec.group_size, seed=39,
-                            max_seq_len=64, prompt=prompt, ids=ids, stride=FULLSIZE_STRIDE, logits_strided=logits[:, ::FULLSIZE_STRIDE].copy(),
-                            argmax=np.argmax(logits, axis=1).astype(np.uint32), top2_gap=(srt[:, -1] - srt[:, -2]).astype(np.float32),
+                            max_seq_len=S, prompt=prompt, ids=ids, stride=FULLSIZE_STRIDE, keep=keep,
+                            logits_strided=logits[keep][:, ::FULLSIZE_STRIDE].copy(), crc32=crc,
+                            argmax=np.argmax(logits, axis=1).astype(np.uint32), top2_gap=(part[:, 1] - part[:, 0]).astype(np.float32),
                             max_abs=np.abs(logits).max(axis=1).astype(np.float32), model_sha256=sha256(path))
-        print("fullsize", name, quant, f"{n_decode / secs:.1f} tok/s (strict reference build)", "ids", ids[n_prompt:].tolist(),
-              "min top-2 gap / max|logit|", float(((srt[:, -1] - srt[:, -2]) / np.abs(logits).max(axis=1)).min()))
+        print("fullsize", name, quant, f"{n_decode} steps to position {S - 1}, {n_decode / secs:.1f} tok/s (strict reference build)",
+              "first ids", ids[n_prompt:n_prompt + 8].tolist(), "min top-2 gap / max|logit|",
+              float(((part[:, 1] - part[:, 0]) / np.abs(logits).max(axis=1)).min()))
 
 
 LORA_CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano-odd", "f32", 0)]
@@ -277,6 +298,9 @@ if __name__ == "__main__":
     tmp = "/tmp/nano_golden"
     os.makedirs(tmp, exist_ok=True)
     assert ob.load_ref() is not None, "build oracle/_ref first: make -C oracle ref"
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":          # python tools/make_golden.py fullsize [name_quant ...]
+        make_fullsize(tmp, set(sys.argv[2:]))
+        sys.exit(0)
     extract_sort_model()
     make_e2e(tmp)
     make_lora(tmp)
