@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int q = 0; q < QV; q++) {
                 const uint32_t f = j + (uint32_t)LPR * q;                  // float4 index inside the head
-                const uint32_t off = (f * 4u < hd && t < range_hint && !(a.dbg & 1u)) ? t * a.kv_dim * 4u + f * 16u : OOB;
+                const uint32_t off = (f * 4u < hd && t < range_hint) ? t * a.kv_dim * 4u + f * 16u : OOB;
                 kreg[p][q] = bload_f4(rk, off);
                 vreg[p][q] = bload_f4(rv, off);
             }
@@ -190,9 +190,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     // ---- 2. position, RoPE row, norms ------------------------------------------------------------------------------
     const uint32_t pos = fixed_range ? (fixed_range - 1) : a.pos[b];
     const uint32_t range = fixed_range ? fixed_range : (causal ? (pos + 1) : a.S);
-    if (a.dbg & 8u) return;
     if constexpr (REGQK) {
-        if (MODE == 1 && !(a.dbg & 4u)) {                         // rmsnorm over the head (infer.c:601-614, 824-835), tree order
+        if (MODE == 1) {                         // rmsnorm over the head (infer.c:601-614, 824-835), tree order
             float sk = 0.0f, sq[KVM];
 #pragma unroll
             for (int m = 0; m < KVM; m++) sq[m] = 0.0f;
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
     const uint32_t per_round = NP * nsplit * R;
     const uint32_t limit = range < range_hint ? range : range_hint;
-    const uint32_t nround = (a.dbg & 2u) ? 0u : (limit + per_round - 1) / per_round;
+    const uint32_t nround = (limit + per_round - 1) / per_round;
     for (uint32_t round = 0; round < nround; round++) {
         if (round) issue_kv(round);
         float sc[KVM][NP];

@@ -269,7 +269,14 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     }
     if (!d.is_shared_classifier) {
         if (d.quant_type == NANO_QUANT_Q80) { o_cls_w = add(V * E); o_cls_s = add(4 * (V * E / d.group_size)); }
-        /* FP32 un-shared: the reference aliases the START of the blob (stale pointer, infer.c:215) */
+        else if (d.quant_type == NANO_QUANT_F32) {
+            // FP32 un-shared: the reference's classifier pointer is the stale START of the parameter blob (infer.c:215):
+            // it reads vocab x n_embd floats from there (norm weights, then the embedding table).  The tensors are re-based
+            // individually in the arena, so the aliased view gets a contiguous copy of its own.
+            doff = align_up(doff, 256);
+            pieces.push_back(Piece{ 0, 4 * V * E, doff });
+            o_cls_w = doff; doff += 4 * V * E;
+        }
     }
     if (so > params_bytes) { destroy(m); FAIL(NANO_HIP_EINVAL, "parameter blob too small: need %zu bytes, got %zu", so, params_bytes); }
 
@@ -305,7 +312,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     }
     if (d.is_shared_classifier) m->cls = m->tok;
     else if (d.quant_type == NANO_QUANT_Q80) { m->cls.w = m->arena + o_cls_w; m->cls.s = F(o_cls_s); }
-    else m->cls.w = m->arena + o_rms_attn;   /* sic (see above) */
+    else m->cls.w = m->arena + o_cls_w;      /* FP32: the copy of the blob's first vocab x n_embd floats (see above) */
 
     {   // algorithmic weight bytes per decode step
         const uint64_t P = (uint64_t)V * E + L * (2 * (uint64_t)QD * E + 2 * (uint64_t)KD * E + 3 * (uint64_t)H * E);
@@ -508,7 +515,6 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
-            { static const char *dbg = getenv("NANO_ATTN_DBG"); a.dbg = dbg ? (uint32_t)atoi(dbg) : 0u; }
             if (m->pf) {
                 // batched prefill: the nb tokens are consecutive positions of ONE sequence.  Pass 1 finishes every k row
                 // (norm + RoPE + cache write, nothing else) so that pass 2 finds the rows of the earlier tokens of the
@@ -712,7 +718,7 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
         return 0;
     }
     if (!m->use_graph) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); return 0; }
-    const uint64_t key = ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
+    const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         // first use: run eagerly once (sets kernel attributes, validates launches) then capture
@@ -1048,6 +1054,18 @@ extern "C" int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos,
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
     if (ms_per_step) *ms_per_step = ms / iters;
     return 0;
+}
+
+// Measurement: the step with some kernel kinds left out (mask bits: 1 QKV GEMV, 2 attention, 4 Wo GEMV, 8 W1|W3 GEMV,
+// 16 W2 GEMV, 32 classifier, 64 arg-max, 128 embedding).  step(0) - step(mask) = what those launches cost where they
+// run: inside the dependent chain of a graph replay.  The results of a masked step are meaningless.
+extern "C" int nano_hip_time_step_masked(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, uint32_t skip_mask, float *ms_per_step) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    const uint32_t keep = m->skip_mask;
+    m->skip_mask = skip_mask & 0xffu;
+    const int rc = nano_hip_time_step(m, batch, pos, iters, ms_per_step);
+    m->skip_mask = keep;
+    return rc;
 }
 
 extern "C" int nano_hip_membw(int device, size_t bytes, uint32_t iters, float *gbps) {

@@ -86,7 +86,7 @@ struct AttnArgs {
     uint32_t cache_bstride_rows;   // = L*S rows between slots (in units of kv_dim floats)
     uint32_t fixed_range;          // op-test mode: attend over rows [0, fixed_range) of an externally filled cache
     uint32_t prep_only;            // 1: finish and store the k row of pos[b] (norm + RoPE), then return (batched prefill, pass 1)
-    uint32_t dbg;                  // measurement only (NANO_ATTN_DBG): 1 no K/V loads, 2 no score/softmax rounds, 4 no norm/RoPE math, 8 return after the loads
+    uint32_t _pad;
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);

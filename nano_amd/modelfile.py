@@ -83,8 +83,11 @@ class ModelSpec:
 
 
 # named presets (shapes from SURVEY 8 header)
-def preset(name: str, quant: str = "f32", group_size: int = 0, block_size: Optional[int] = None) -> ModelSpec:
+def preset(name: str, quant: str = "f32", group_size: int = 0, block_size: Optional[int] = None,
+           shared_classifier: int = 1) -> ModelSpec:
     qt = {"f32": QUANT_F32, "q80": QUANT_Q80, "q4k": QUANT_Q4K}[quant]
+    if name.endswith("-ucls"):                  # "<preset>-ucls": the same shapes with an un-shared classifier (infer.c:206-216)
+        name, shared_classifier = name[:-5], 0
     table = {
         # arch, block, vocab, L, E, heads, kv, hidden, head_dim
         "nano-56m":   (ARCH_NANO, 512, 16384, 16, 512, 16, 8, 1408, 0),
@@ -95,6 +98,9 @@ def preset(name: str, quant: str = "f32", group_size: int = 0, block_size: Optio
         "tiny-nano":  (ARCH_NANO, 64, 512, 2, 128, 4, 2, 384, 0),
         "tiny-nano-odd": (ARCH_NANO, 64, 512, 2, 192, 4, 2, 352, 0),   # head_dim 48, hidden%256!=0
         "tiny-qwen3": (ARCH_QWEN3, 128, 1024, 2, 256, 4, 2, 768, 64),
+        # Qwen2 architecture: adjacent-pair RoPE with head_dim = n_embd / n_head, q/k/v bias block in the file that the
+        # forward never applies (reference infer/infer.c:788-790, 814-823), BPE tokenizer section
+        "tiny-qwen2": (ARCH_QWEN2, 64, 512, 2, 128, 4, 2, 384, 0),
         # one layer with Qwen3-4B's row lengths (2560 / 4096 / 9728: partial 1 KiB chunks, many chunks per row,
         # 4 q heads per KV head) and a vocabulary tall enough for the classifier's STREAM kernel
         "wide-qwen3": (ARCH_QWEN3, 128, 20000, 1, 2560, 32, 8, 9728, 128),
@@ -108,9 +114,9 @@ def preset(name: str, quant: str = "f32", group_size: int = 0, block_size: Optio
         group_size = 128 if a == ARCH_NANO else 64
         while E % group_size:
             group_size //= 2
-    if a == ARCH_NANO:
+    if a != ARCH_QWEN3:
         hd = E // nh
-    return ModelSpec(a, bs, V, L, E, nh, nkv, H, hd, 1, qt, group_size if qt == QUANT_Q80 else 0)
+    return ModelSpec(a, bs, V, L, E, nh, nkv, H, hd, 1 if shared_classifier else 0, qt, group_size if qt == QUANT_Q80 else 0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -136,6 +142,18 @@ def nano_tokenizer_section(vocab_size: int) -> bytes:
     body = rec.tobytes()
     total = 8 + len(body)
     return struct.pack("<II", total, vocab_size) + body
+
+
+def nano_tokenizer_section_from_tokens(tokens: List[str], special: Optional[set] = None) -> bytes:
+    """Nano tokenizer section with an explicit token string per id (multi-character tokens go through the front-end's
+    trie, single characters through its unicode map; format: reference export.py:72-113, parser infer/infer.c:263-311)."""
+    body = b""
+    for tid, tok in enumerate(tokens):
+        cps = [ord(c) for c in tok]
+        assert 1 <= len(cps) <= 255
+        body += struct.pack("<BBBBI", len(cps), 1 if (special and tid in special) else 0, 0xFF, 0xFF, tid)
+        body += struct.pack("<%dI" % len(cps), *cps)
+    return struct.pack("<II", 8 + len(body), len(tokens)) + body
 
 
 def qwen_tokenizer_section() -> bytes:
@@ -292,6 +310,10 @@ def param_layout(spec: ModelSpec, tokenizer_bytes: Optional[int] = None) -> Layo
         else:
             bpl = (n + 255) // 256
             put(name, Q4K_FRAME_PREFIX + cnt * d * bpl * Q4K_BLOCK_BYTES)
+    if spec.arch == ARCH_QWEN2:                 # bq, bk, bv: mapped by the loader, never applied (infer.c:174-178, 788-790)
+        put("bq", 4 * L * spec.q_dim)
+        put("bk", 4 * L * spec.kv_dim)
+        put("bv", 4 * L * spec.kv_dim)
     if spec.arch == ARCH_QWEN3:
         put("q_norm", 4 * L * spec.hd)
         put("k_norm", 4 * L * spec.hd)
@@ -322,11 +344,12 @@ def _rope_tables(spec: ModelSpec) -> Tuple[np.ndarray, np.ndarray]:
 
 
 def write_model(path: str, spec: ModelSpec, seed: int = 39, weight_std: float = 0.02,
-                norm_jitter: float = 0.1, rope_in_file: bool = True) -> Layout:
-    """Write a seeded synthetic model.  Weights are generated tensor-by-tensor (bounded memory)."""
+                norm_jitter: float = 0.1, rope_in_file: bool = True, tokenizer: Optional[bytes] = None) -> Layout:
+    """Write a seeded synthetic model.  Weights are generated tensor-by-tensor (bounded memory).
+    `tokenizer`: an explicit tokenizer section (default: one single-code-point token per id / the dummy BPE table)."""
     rng = np.random.default_rng(seed)
     L, E = spec.n_layer, spec.n_embd
-    tok = tokenizer_section(spec)
+    tok = tokenizer if tokenizer is not None else tokenizer_section(spec)
     lay = param_layout(spec, len(tok))
     resid_std = weight_std / math.sqrt(2 * spec.n_layer)
 
@@ -376,6 +399,9 @@ def write_model(path: str, spec: ModelSpec, seed: int = 39, weight_std: float = 
                             scales.append(s)
                     if spec.quant_type == QUANT_Q80:
                         f.write(np.concatenate(scales).tobytes())
+        if spec.arch == ARCH_QWEN2:             # biases as large as the activations: applying them would be seen at once
+            for n in (spec.q_dim, spec.kv_dim, spec.kv_dim):
+                f.write(rng.standard_normal(L * n, dtype=np.float32).tobytes())
         if spec.arch == ARCH_QWEN3:
             f.write(norm_w(L * spec.hd).tobytes())
             f.write(norm_w(L * spec.hd).tobytes())

@@ -70,6 +70,21 @@ def synth_model(model_dir, preset, quant, gs=0, seed=39):
     return _model_cache[key]
 
 
+# every end-to-end golden case (tools/make_golden.py E2E_CASES): (preset, quant, group size)
+E2E_CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano", "q4k", 0),
+             ("tiny-nano-odd", "f32", 0), ("tiny-nano-odd", "q80", 32), ("tiny-nano-odd", "q4k", 0),
+             ("tiny-qwen3", "f32", 0), ("tiny-qwen3", "q80", 64), ("tiny-qwen3", "q4k", 0),
+             # loader branches: Qwen2 architecture, un-shared classifier, the Nano exporter's default group size
+             ("tiny-qwen2", "f32", 0), ("tiny-qwen2", "q80", 32), ("tiny-qwen2", "q4k", 0),
+             ("tiny-nano-ucls", "q80", 32), ("tiny-nano-ucls", "f32", 0), ("tiny-nano", "q80", 128)]
+
+
+def e2e_golden(preset, quant, gs):
+    """Path of the golden file of an end-to-end case."""
+    tag = f"{preset}_{quant}" + (f"_gs{gs}" if quant == "q80" and gs == 128 and "nano" in preset else "")
+    return os.path.join(GOLD, f"e2e_{tag}.npz")
+
+
 def file_sha256(path):
     import hashlib
     h = hashlib.sha256()

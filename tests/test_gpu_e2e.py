@@ -12,21 +12,19 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, rel_err, synth_model
+from conftest import E2E_CASES, GOLD, e2e_golden, rel_err, synth_model
 from nano_amd import binding as nb
 from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
 
 TOL = {"f32": 1e-4, "q80": 2e-2, "q4k": 2e-1}
-CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano", "q4k", 0),
-         ("tiny-nano-odd", "f32", 0), ("tiny-nano-odd", "q80", 32), ("tiny-nano-odd", "q4k", 0),
-         ("tiny-qwen3", "f32", 0), ("tiny-qwen3", "q80", 64), ("tiny-qwen3", "q4k", 0)]
+CASES = E2E_CASES
 
 
 @pytest.mark.parametrize("preset,quant,gs", CASES)
 def test_teacher_forced_logits_vs_golden(model_dir, preset, quant, gs):
-    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{quant}.npz"))
+    g = np.load(e2e_golden(preset, quant, gs))
     path, spec = synth_model(model_dir, preset, quant, gs)
     m = nb.load_model_file(path, max_seq_len=int(g["max_seq_len"]), max_batch=1)
     ids, gl = g["ids"], g["logits"]
@@ -44,7 +42,7 @@ def test_teacher_forced_logits_vs_golden(model_dir, preset, quant, gs):
 
 @pytest.mark.parametrize("preset,quant,gs", [c for c in CASES if c[1] == "f32"])
 def test_greedy_ids_identical_fp32(model_dir, preset, quant, gs):
-    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{quant}.npz"))
+    g = np.load(e2e_golden(preset, quant, gs))
     path, spec = synth_model(model_dir, preset, quant, gs)
     m = nb.load_model_file(path, max_seq_len=int(g["max_seq_len"]), max_batch=1)
     prompt = g["prompt"]
@@ -161,8 +159,11 @@ def test_batched_prefill_equals_token_by_token(model_dir, preset, quant, gs, T):
 def test_position_buckets_and_odd_seq_len(oracle, model_dir, preset, quant, gs):
     """max_seq_len that is not a multiple of the 64-position attention bucket; a graph-replayed greedy decode that crosses
     a bucket boundary (new graph, more attention splits) equals step-by-step forwards, and the logits stay on the oracle."""
-    path, spec = synth_model(model_dir, preset, quant, gs)
+    from nano_amd import modelfile as mf
     S = 100
+    spec = mf.preset(preset, quant, group_size=gs, block_size=128)      # RoPE tables must cover the 100 positions
+    path = os.path.join(model_dir, f"{preset}-{quant}-bs128.bin")
+    mf.write_model(path, spec, seed=39)
     m = nb.load_model_file(path, max_seq_len=S, max_batch=1)
     o = ob.OracleCtx(oracle, path, max_seq_len=S)
     tok, ids_fwd, worst = 5, [], 0.0
@@ -298,3 +299,133 @@ def test_engine_session_api_greedy(model_dir):
     e.close()
     assert out == g["ids"][len(prompt):].tolist()
     assert status in (12, -10)
+
+
+# ---- round-2 regression tests ---------------------------------------------------------------------------
+def test_session_with_long_prompt_on_a_shape_the_gemm_refuses(model_dir):
+    """Nano exporter's default group size 128 on n_embd 128 / n_hidden 384 gives 1 / 3 quantization groups per row -- not
+    the multiple of 4 the int8 MFMA GEMM stages.  A 12-token prompt makes llm_session_step feed 11 positions with ONE
+    batched prefill (> 8 tokens): the launches the GEMM refuses go through the GEMV kernels in groups of 8, the ids are
+    the reference's."""
+    from conftest import e2e_golden
+    g = np.load(e2e_golden("tiny-nano", "q80", 128))
+    path, spec = synth_model(model_dir, "tiny-nano", "q80", 128)
+    prompt = g["prompt"]
+    assert len(prompt) >= 10 and spec.group_size == 128
+    n_decode = len(g["ids"]) - len(prompt)
+    e = nb.Engine(path, max_seq_len=int(g["max_seq_len"]))
+    out, status = e.run_session(prompt, len(prompt) - 1 + n_decode)
+    e.close()
+    assert out == g["ids"][len(prompt):].tolist() and status in (12, -10)
+    # and the batched prefill is the token-by-token ingestion, bit for bit
+    m = nb.load_model_file(path, max_seq_len=32, max_batch=1)
+    for p in range(len(prompt) - 1):
+        m.forward([int(prompt[p])], [p], want_logits=False)
+    want = m.forward([int(prompt[-1])], [len(prompt) - 1])[0][0].copy()
+    m.prefill(prompt[:-1], 0)
+    got = m.forward([int(prompt[-1])], [len(prompt) - 1])[0][0]
+    m.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_large_batch_on_a_shape_the_gemm_refuses(model_dir):
+    """More than 8 sequences per step on the same shape: GEMV kernels in groups of 8, same logits as one by one."""
+    from nano_amd import modelfile as mf
+    path, spec = synth_model(model_dir, "tiny-nano", "q80", 128)
+    B, T = 13, 6
+    seqs = [mf.prompt_ids(700 + b, T, spec.vocab_size) for b in range(B)]
+    mb = nb.load_model_file(path, max_seq_len=16, max_batch=B)
+    batched = [mb.forward([int(s[pos]) for s in seqs], [pos] * B)[0] for pos in range(T)]
+    mb.close()
+    m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    for b in range(B):
+        for pos in range(T):
+            lg, _ = m1.forward([int(seqs[b][pos])], [pos])
+            assert np.array_equal(lg[0].view(np.uint32), batched[pos][b].view(np.uint32)), (b, pos)
+    m1.close()
+
+
+def test_q80_lora_prefill_of_more_than_eight_tokens_and_reattach(model_dir):
+    """Q80 base + LoRA: a batched prefill of 11 tokens (the o-branch addend keeps Wo off the GEMM) equals token-by-token
+    feeding; attaching a second module (other rank) after graphs were captured with the first one takes effect."""
+    from nano_amd import modelfile as mf
+    path, spec = synth_model(model_dir, "tiny-nano", "q80", 32)
+    l1 = os.path.join(model_dir, "tiny-nano-lora-r8.bin"); l2 = os.path.join(model_dir, "tiny-nano-lora-r4.bin")
+    mf.write_lora(l1, spec, rank=8, alpha=16, seed=7)
+    mf.write_lora(l2, spec, rank=4, alpha=8, seed=11)
+    ids = mf.prompt_ids(77, 13, spec.vocab_size)
+
+    def run(lora_path, batched):
+        m = nb.load_model_file(path, max_seq_len=32, max_batch=1)
+        m.lora_attach_file(lora_path)
+        if batched:
+            m.prefill(ids[:11], 0)
+        else:
+            for p in range(11):
+                m.forward([int(ids[p])], [p], want_logits=False)
+        lg = m.forward([int(ids[11])], [11])[0][0].copy()
+        m.close()
+        return lg
+    a, b = run(l1, False), run(l1, True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # re-attach on a model whose decode graphs already exist
+    m = nb.load_model_file(path, max_seq_len=32, max_batch=1)
+    m.lora_attach_file(l1)
+    for p in range(11):
+        m.forward([int(ids[p])], [p], want_logits=False)
+    first = m.forward([int(ids[11])], [11])[0][0].copy()
+    m.lora_attach_file(l2)                                    # frees the first module's buffer, other rank
+    for p in range(11):
+        m.forward([int(ids[p])], [p], want_logits=False)
+    second = m.forward([int(ids[11])], [11])[0][0].copy()
+    m.close()
+    assert np.array_equal(first.view(np.uint32), a.view(np.uint32))
+    assert np.array_equal(second.view(np.uint32), run(l2, False).view(np.uint32))
+    assert rel_err(second, first) > 1e-3
+
+
+def test_positions_beyond_the_rope_table_are_rejected(model_dir):
+    """max_seq_len larger than the model's block_size: the RoPE tables end at block_size rows (the reference reads past
+    them); the device call refuses such positions instead."""
+    path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)          # block_size 64
+    m = nb.load_model_file(path, max_seq_len=128, max_batch=1)
+    m.forward([1], [63], want_logits=False)
+    with pytest.raises(nb.NanoHipError):
+        m.forward([1], [64], want_logits=False)
+    with pytest.raises(nb.NanoHipError):
+        m.prefill([1] * 70, 0)
+    m.close()
+
+
+def test_engine_per_phase_observation(model_dir):
+    """nano_set_phase_observation(1): a context with an observation hook gets the reference's callback sequence from
+    inside every forward (infer.c:755-949, 985-1003, 1153) -- and the greedy ids stay the reference's (strict replay)."""
+    import ctypes as C
+    g = np.load(os.path.join(GOLD, "e2e_tiny-qwen3_q80.npz"))
+    path, spec = synth_model(model_dir, "tiny-qwen3", "q80", 64)
+    e = nb.Engine(path, max_seq_len=int(g["max_seq_len"]))
+
+    class Obs(C.Structure):
+        _fields_ = [("layer", C.c_int32), ("phase", C.c_int32)] + [(f"token_{i}", C.c_uint32) for i in range(6)]
+    seen = []
+    CB = C.CFUNCTYPE(None, Obs, C.c_void_p)
+    cb = CB(lambda o, env: seen.append((o.layer, o.phase)))
+
+    class Ctx(C.Structure):                                   # Nano_Context (infer.h:225-235)
+        _fields_ = [("llm", C.c_void_p), ("lora", C.c_void_p), ("tokenizer", C.c_void_p), ("sampler", C.c_void_p),
+                    ("max_seq_len", C.c_uint32), ("random_seed", C.c_uint64), ("observation", CB), ("observation_env", C.c_void_p)]
+    ctx = C.cast(e.ctx, C.POINTER(Ctx)).contents
+    ctx.observation = cb
+    e.L.nano_set_phase_observation.argtypes = [C.c_int]
+    e.L.nano_set_phase_observation(1)
+    try:
+        prompt = g["prompt"]
+        ids = e.generate(prompt, 3)
+    finally:
+        e.L.nano_set_phase_observation(0)
+    e.close()
+    L = spec.n_layer
+    fwd = [(-1, 1)] + [(l, p) for l in range(L) for p in range(2, 10)] + [(L, 10), (L, 11)]
+    want = fwd * (len(prompt) - 1) + (fwd + [(-1, 12)]) * 3
+    assert seen == want
+    assert np.array_equal(ids, g["ids"][:len(prompt) + 3])

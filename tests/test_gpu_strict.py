@@ -9,15 +9,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, rel_err, synth_model
+from conftest import E2E_CASES, GOLD, e2e_golden, rel_err, synth_model
 from nano_amd import binding as nb
 from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano", "q4k", 0),
-         ("tiny-nano-odd", "f32", 0), ("tiny-nano-odd", "q80", 32), ("tiny-nano-odd", "q4k", 0),
-         ("tiny-qwen3", "f32", 0), ("tiny-qwen3", "q80", 64), ("tiny-qwen3", "q4k", 0)]
+CASES = E2E_CASES
 
 
 def bits(a):
@@ -26,7 +24,7 @@ def bits(a):
 
 @pytest.mark.parametrize("preset,quant,gs", CASES)
 def test_strict_logits_bit_identical_to_reference_golden(model_dir, preset, quant, gs):
-    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{quant}.npz"))
+    g = np.load(e2e_golden(preset, quant, gs))
     path, spec = synth_model(model_dir, preset, quant, gs)
     m = nb.load_model_file(path, max_seq_len=int(g["max_seq_len"]), max_batch=1)
     m.set_strict(True)
@@ -54,7 +52,7 @@ def test_strict_logits_bit_identical_to_reference_golden(model_dir, preset, quan
 @pytest.mark.parametrize("preset,quant,gs", [("tiny-qwen3", "q80", 64), ("tiny-nano-odd", "q4k", 0), ("tiny-nano", "f32", 0)])
 def test_strict_greedy_loop_and_prefill(model_dir, preset, quant, gs):
     """The on-device greedy loop and the prefill entry in strict mode reproduce the reference's ids."""
-    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{quant}.npz"))
+    g = np.load(e2e_golden(preset, quant, gs))
     path, spec = synth_model(model_dir, preset, quant, gs)
     m = nb.load_model_file(path, max_seq_len=int(g["max_seq_len"]), max_batch=1)
     m.set_strict(True)

@@ -7,13 +7,11 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, file_sha256, synth_model
+from conftest import E2E_CASES, GOLD, e2e_golden, file_sha256, synth_model
 from nano_amd import modelfile as mf
 from oracle import binding as ob
 
-E2E = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano", "q4k", 0),
-       ("tiny-nano-odd", "f32", 0), ("tiny-nano-odd", "q80", 32), ("tiny-nano-odd", "q4k", 0),
-       ("tiny-qwen3", "f32", 0), ("tiny-qwen3", "q80", 64), ("tiny-qwen3", "q4k", 0)]
+E2E = E2E_CASES
 
 
 def bits(a):
@@ -22,7 +20,7 @@ def bits(a):
 
 @pytest.mark.parametrize("preset,quant,gs", E2E)
 def test_e2e_matches_reference_golden(oracle, model_dir, preset, quant, gs):
-    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{quant}.npz"))
+    g = np.load(e2e_golden(preset, quant, gs))
     path, spec = synth_model(model_dir, preset, quant, gs)
     assert file_sha256(path) == str(g["model_sha256"]), "synthetic model writer is not reproducing the golden model bytes"
     ctx = ob.OracleCtx(oracle, path, max_seq_len=int(g["max_seq_len"]))

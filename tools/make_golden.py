@@ -42,6 +42,15 @@ E2E_CASES = [
     ("tiny-qwen3", "f32", 0, 32, 8, 12),
     ("tiny-qwen3", "q80", 64, 32, 8, 12),
     ("tiny-qwen3", "q4k", 0, 32, 8, 12),
+    # loader branches (round 2): Qwen2 architecture (adjacent-pair RoPE, bias block skipped: infer.c:788-790, 814-823),
+    # un-shared classifier (Q80: its own tensor after the RoPE tables; FP32: the reference's stale pointer aliases the
+    # start of the blob, infer.c:206-216), the Nano exporter's default group size 128 (export.py:538)
+    ("tiny-qwen2", "f32", 0, 32, 8, 12),
+    ("tiny-qwen2", "q80", 32, 32, 8, 12),
+    ("tiny-qwen2", "q4k", 0, 32, 8, 12),
+    ("tiny-nano-ucls", "q80", 32, 32, 8, 12),
+    ("tiny-nano-ucls", "f32", 0, 32, 8, 12),
+    ("tiny-nano", "q80", 128, 32, 12, 12),
 ]
 # sampler variants: (preset, quant, gs, S, n_prompt, n_decode, rep_pen, temperature, top_p, tag)
 SAMPLER_CASES = [
@@ -82,19 +91,28 @@ def extract_sort_model():
               open(os.path.join(GOLD, "sort6_expected.json"), "w"), indent=1)
 
 
-def make_e2e(tmpdir):
+def e2e_tag(name, quant, gs):
+    """File tag of an e2e case: the default group size of a preset keeps the old name."""
+    return f"{name}_{quant}" + (f"_gs{gs}" if quant == "q80" and gs == 128 and "nano" in name else "")
+
+
+def make_e2e(tmpdir, only=None):
     ref = ob.load_ref()
     for (name, quant, gs, S, n_prompt, n_decode) in E2E_CASES:
+        if only and e2e_tag(name, quant, gs) not in only:
+            continue
         spec = mf.preset(name, quant, group_size=gs)
-        path = os.path.join(tmpdir, f"{name}-{quant}.bin")
+        path = os.path.join(tmpdir, f"{name}-{quant}-{gs}.bin")
         mf.write_model(path, spec, seed=39)
         ctx = ob.OracleCtx(ref, path, max_seq_len=S)
         prompt = mf.prompt_ids(39, n_prompt, spec.vocab_size)
         ids, logits, _ = ctx.generate(prompt, n_decode, want_logits=True)
         ctx.close()
-        np.savez_compressed(os.path.join(GOLD, f"e2e_{name}_{quant}.npz"), preset=name, quant=quant, gs=spec.group_size,
+        np.savez_compressed(os.path.join(GOLD, f"e2e_{e2e_tag(name, quant, gs)}.npz"), preset=name, quant=quant, gs=spec.group_size,
                             seed=39, max_seq_len=S, prompt=prompt, ids=ids, logits=logits, model_sha256=sha256(path))
-        print("e2e", name, quant, "ids", ids[n_prompt:].tolist())
+        print("e2e", name, quant, gs, "ids", ids[n_prompt:].tolist())
+    if only:
+        return
     for (name, quant, gs, S, n_prompt, n_decode, rp, temp, top_p, tag) in SAMPLER_CASES:
         spec = mf.preset(name, quant, group_size=gs)
         path = os.path.join(tmpdir, f"{name}-{quant}.bin")
@@ -300,6 +318,9 @@ if __name__ == "__main__":
     assert ob.load_ref() is not None, "build oracle/_ref first: make -C oracle ref"
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":          # python tools/make_golden.py fullsize [name_quant ...]
         make_fullsize(tmp, set(sys.argv[2:]))
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "e2e":               # python tools/make_golden.py e2e name_quant[_gs128] ...
+        make_e2e(tmp, set(sys.argv[2:]))
         sys.exit(0)
     extract_sort_model()
     make_e2e(tmp)
