@@ -96,6 +96,7 @@ struct NanoHipModel {
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
+    bool use_g2 = true;                                   // batched launches take gemm_q80.hip's G2 kernel (NANO_GEMM_G2=0: the round-1 kernels)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
@@ -358,6 +359,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
+    if (const char *g2 = getenv("NANO_GEMM_G2")) m->use_g2 = *g2 && *g2 != '0';
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
     if (const char *sm = getenv("NANO_STRICT")) if (*sm && *sm != '0') return nano_hip_set_strict(m, 1);
@@ -408,8 +410,15 @@ static GemvArgs gemv_slice(const GemvArgs &a, uint32_t b0, uint32_t cnt) {
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     const uint32_t max_wg = (uint32_t)m->cus * 8;
     if (m->d.quant_type == NANO_QUANT_Q4K) return launch_gemv_q4k(a, max_wg, m->st);
+    if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && m->use_g2 && gemm_q80_g2_supports(a)) {
+        // quantize every sequence's activation once, straight into MFMA fragment order, then the G2 GEMM
+        hipError_t e = launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
+        if (e != hipSuccess) return e;
+        a.xq_in = m->gq; a.xs_in = m->gxs;
+        return launch_gemm_q80_g2(a, m->st);
+    }
     if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && gemm_q80_supports(a)) {
-        // quantize every sequence's activation once, then the int8 MFMA GEMM
+        // (NANO_GEMM_G2=0: the round-1 kernels, kept for A/B measurements)
         hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
         if (e != hipSuccess) return e;
         a.xq_in = m->gq; a.xs_in = m->gxs;
@@ -446,7 +455,7 @@ static GemvArgs classifier_args(const NanoHipModel *m, uint32_t nb) {
 
 static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
     GemvArgs a = classifier_args(m, nb);
-    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && nb <= 8 && !(takes_mfma(m, a) && gemm_q80_supports(a))) {      // per-tile arg-max partials for the sampler
+    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && nb <= 8 && !(takes_mfma(m, a) && ((m->use_g2 && gemm_q80_g2_supports(a)) || gemm_q80_supports(a)))) {      // per-tile arg-max partials for the sampler
         a.tile_max = m->tile_max;
         *ntiles_out = gemv_tiles(m->d.quant_type, a);
     }

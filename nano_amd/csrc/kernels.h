@@ -58,6 +58,11 @@ hipError_t launch_gemv_f32(const GemvArgs &a, hipStream_t st);      // gemv_f32.
 // 9..64 tokens per weight read on the int8 matrix cores (gemm_q80.hip); a.xq_in / a.xs_in = quantized activations of all tokens
 hipError_t launch_gemm_q80(const GemvArgs &a, hipStream_t st);
 bool gemm_q80_supports(const GemvArgs &a);                          // host predicate: shapes / features the GEMM takes
+// G2, the batched kernel of the bandwidth-bound regime (gemm_q80.hip): activations in MFMA B-fragment order
+bool gemm_q80_g2_supports(const GemvArgs &a);
+hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st);   // a.xq_in / a.xs_in = launch_quant_rows_frag's output
+hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
+                                  int8_t *xf, float *xsf, hipStream_t st);
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                              int8_t *xq, float *xs, hipStream_t st);
 uint32_t gemv_q80_partials(const GemvArgs &a);
