@@ -96,6 +96,8 @@ struct NanoHipModel {
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
+    bool use_g4 = true;                                   // ... gemm_q80_g4.hip's wave-independent kernel first (NANO_GEMM_G4=0: off)
+    bool use_g3 = true;                                   // ... and gemm_q80_g3.hip's persistent kernel where the matrix has many rows (NANO_GEMM_G3=0: G2 only)
     bool use_g2 = true;                                   // batched launches take gemm_q80.hip's G2 kernel (NANO_GEMM_G2=0: the round-1 kernels)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
@@ -360,6 +362,8 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
     if (const char *g2 = getenv("NANO_GEMM_G2")) m->use_g2 = *g2 && *g2 != '0';
+    if (const char *g3 = getenv("NANO_GEMM_G3")) m->use_g3 = *g3 && *g3 != '0';
+    if (const char *g4 = getenv("NANO_GEMM_G4")) m->use_g4 = *g4 && *g4 != '0';
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
     if (const char *sm = getenv("NANO_STRICT")) if (*sm && *sm != '0') return nano_hip_set_strict(m, 1);
@@ -415,6 +419,17 @@ static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
         hipError_t e = launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
         if (e != hipSuccess) return e;
         a.xq_in = m->gq; a.xs_in = m->gxs;
+        // Three kernels, one arithmetic; the choice is by shape (measured on Qwen3-4B / 0.6B matrices, tools/batch_probe.sh):
+        //   G2  few (row tile, token tile) pairs and long rows (Wo, W2 up to 32 tokens): the row length is split over the
+        //       eight waves of a workgroup, so 160 tiles still fill the chip;
+        //   G3  64 tokens on a very tall matrix (the classifier): activations staged once per 64 rows, persistent tiles;
+        //   G4  everything else: wave-independent tiles, no barriers.
+        uint32_t rows = 0;
+        if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
+        const uint32_t ntiles = (rows + 15) / 16, tt = (a.nb + 15) / 16;
+        const bool g4 = m->use_g4 && gemm_q80_g4_supports(a), g3 = m->use_g3 && gemm_q80_g3_supports(a);
+        if (g3 && tt > 2 && ntiles >= 2048) return launch_gemm_q80_g3(a, max_wg, m->st);
+        if (g4 && !(ntiles * tt < 512 && tt <= 2)) return launch_gemm_q80_g4(a, m->st);
         return launch_gemm_q80_g2(a, m->st);
     }
     if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && gemm_q80_supports(a)) {

@@ -61,6 +61,12 @@ bool gemm_q80_supports(const GemvArgs &a);                          // host pred
 // G2, the batched kernel of the bandwidth-bound regime (gemm_q80.hip): activations in MFMA B-fragment order
 bool gemm_q80_g2_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st);   // a.xq_in / a.xs_in = launch_quant_rows_frag's output
+// G3, persistent many-row variant (gemm_q80_g3.hip): same inputs as G2; max_wg = 8 x CUs
+bool gemm_q80_g3_supports(const GemvArgs &a);
+hipError_t launch_gemm_q80_g3(const GemvArgs &a, uint32_t max_wg, hipStream_t st);
+// G4, wave-independent variant (gemm_q80_g4.hip): same inputs as G2
+bool gemm_q80_g4_supports(const GemvArgs &a);
+hipError_t launch_gemm_q80_g4(const GemvArgs &a, hipStream_t st);
 hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                                   int8_t *xf, float *xsf, hipStream_t st);
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
