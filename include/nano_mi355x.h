@@ -78,6 +78,15 @@ int         nano_hip_device_info(int device, char *name, size_t cap, uint64_t *t
  * Replaces: memory_map_params + malloc_fwd_buffer (reference infer/infer.c:15-85,100-217). */
 int  nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *desc, const void *params, size_t params_bytes,
                            int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch);
+/* The same with option flags.  NANO_HIP_KV_F16 (opt-in because it changes results): the KV cache holds FP16
+ * rows instead of the reference's FP32 (infer/infer.c:46-51) -- half the cache memory and half the bytes attention reads
+ * per position; every row is rounded once (to nearest even) when it is written, the current token attends to its own
+ * rounded row, all arithmetic stays FP32.  Logits stay within the Q80 noise floor of the FP32-cache path (stated and
+ * tested in tests/test_gpu_kv16.py).  Not combinable with strict mode or LoRA.  nano_hip_model_create() applies it when
+ * NANO_KV_F16=1 is set in the environment. */
+#define NANO_HIP_KV_F16 1u
+int  nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc *desc, const void *params, size_t params_bytes,
+                              int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch, uint32_t flags);
 void nano_hip_model_destroy(NanoHipModel *m);
 /* number of parameter-blob bytes the backend expects for `desc` (0 if it cannot be derived
  * without reading the blob, i.e. Q4K whose tensor frames carry their own sizes) */

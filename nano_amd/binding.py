@@ -58,6 +58,7 @@ def lib() -> C.CDLL:
     fn("nano_hip_last_error", C.c_char_p, [])
     fn("nano_hip_device_info", C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)])
     fn("nano_hip_model_create", C.c_int, [C.POINTER(vp), C.POINTER(NanoModelDesc), vp, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_uint32])
+    fn("nano_hip_model_create_ex", C.c_int, [C.POINTER(vp), C.POINTER(NanoModelDesc), vp, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32])
     fn("nano_hip_model_destroy", None, [vp])
     fn("nano_hip_params_bytes", C.c_size_t, [C.POINTER(NanoModelDesc)])
     fn("nano_hip_weight_bytes_per_step", C.c_uint64, [vp])
@@ -128,12 +129,16 @@ class DeviceModel:
     """A model resident on one GPU: mirrors what the reference keeps in ``LLM`` (weights + FwdBuffer)."""
 
     def __init__(self, desc: NanoModelDesc, params, params_bytes: int, *, on_device: bool = False,
-                 device: int = 0, max_seq_len: int = 512, max_batch: int = 1):
+                 device: int = 0, max_seq_len: int = 512, max_batch: int = 1, kv_f16: Optional[bool] = None):
         self.desc = desc
         self.h = C.c_void_p(None)
         ptr = params if isinstance(params, int) else params.ctypes.data
-        check(lib().nano_hip_model_create(C.byref(self.h), C.byref(desc), C.c_void_p(ptr), params_bytes,
-                                          1 if on_device else 0, device, max_seq_len, max_batch))
+        if kv_f16 is None:           # environment default (NANO_KV_F16)
+            check(lib().nano_hip_model_create(C.byref(self.h), C.byref(desc), C.c_void_p(ptr), params_bytes,
+                                              1 if on_device else 0, device, max_seq_len, max_batch))
+        else:
+            check(lib().nano_hip_model_create_ex(C.byref(self.h), C.byref(desc), C.c_void_p(ptr), params_bytes,
+                                                 1 if on_device else 0, device, max_seq_len, max_batch, 1 if kv_f16 else 0))
         self.vocab = int(desc.vocab_size)
         self.max_seq_len, self.max_batch, self.device = max_seq_len, max_batch, device
 
@@ -252,7 +257,7 @@ def desc_from_spec(spec) -> NanoModelDesc:
                          spec.group_size)
 
 
-def load_model_file(path: str, *, device: int = 0, max_seq_len: int = 512, max_batch: int = 1) -> DeviceModel:
+def load_model_file(path: str, *, device: int = 0, max_seq_len: int = 512, max_batch: int = 1, kv_f16: Optional[bool] = None) -> DeviceModel:
     """Open a Nano ``.bin`` (header + tokenizer section + parameter blob) and upload it.
     The tokenizer section is skipped: this entry works on token ids."""
     from . import modelfile as mf
@@ -261,7 +266,7 @@ def load_model_file(path: str, *, device: int = 0, max_seq_len: int = 512, max_b
     tok_bytes = int(np.frombuffer(bytes(raw[256:260]), "<u4")[0])
     off = 256 + tok_bytes
     params = np.ascontiguousarray(raw[off:])         # private, aligned copy of the blob
-    m = DeviceModel(desc_from_spec(spec), params, params.size, device=device, max_seq_len=max_seq_len, max_batch=max_batch)
+    m = DeviceModel(desc_from_spec(spec), params, params.size, device=device, max_seq_len=max_seq_len, max_batch=max_batch, kv_f16=kv_f16)
     m.spec = spec
     return m
 

@@ -18,6 +18,7 @@
 //     o_s = sum_t exp(s_t - m_s) v_t with (m_s, l_s) which the Wo GEMV's prologue combines (gemv_q80.hip).
 // Softmax is algebraically the reference's (max-subtracted, infer.c:616-634); summation order differs and the
 // q.k / weighted-V accumulations use fused multiply-adds (tolerance 1e-5).
+#include <hip/hip_fp16.h>
 #include "device_common.h"
 #include "kernels.h"
 
@@ -58,6 +59,43 @@ __device__ __forceinline__ float bload_f(__amdgpu_buffer_rsrc_t r, uint32_t off)
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
 
+// ---- KV element format: FP32 rows (the reference's, infer/infer.c:46-51) or, opt-in, FP16 rows ------------
+// A lane's four consecutive elements of a row travel as one 16-byte (FP32) or 8-byte (FP16) load and stay in that raw
+// form until they are used, so that the loads remain in flight.
+template <bool KVH> struct KVRaw { float4 v; };
+template <> struct KVRaw<true> { uint2 v; };
+__device__ __forceinline__ float4 kv_cvt(const KVRaw<false> &r) { return r.v; }
+__device__ __forceinline__ float4 kv_cvt(const KVRaw<true> &r) {
+    const __half2 a = *reinterpret_cast<const __half2 *>(&r.v.x), b = *reinterpret_cast<const __half2 *>(&r.v.y);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    return make_float4(fa.x, fa.y, fb.x, fb.y);
+}
+__device__ __forceinline__ uint2 kv_pack_half(const float4 &v) {       // round to nearest even, like every later reader will see the row
+    const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+    uint2 r; r.x = *reinterpret_cast<const uint32_t *>(&a); r.y = *reinterpret_cast<const uint32_t *>(&b);
+    return r;
+}
+template <bool KVH> __device__ __forceinline__ float4 kv_round(const float4 &v) {      // what the cache will hold for v
+    if constexpr (!KVH) return v;
+    else { KVRaw<true> r; r.v = kv_pack_half(v); return kv_cvt(r); }
+}
+template <bool KVH> __device__ __forceinline__ float kv_round1(float v) {
+    if constexpr (!KVH) return v; else return __half2float(__float2half_rn(v));
+}
+template <bool KVH> __device__ __forceinline__ void kv_store4(float *row_base, uint32_t elem, const float4 &v) {   // row_base: start of the row (in the cache's own format)
+    if constexpr (!KVH) *reinterpret_cast<float4 *>(row_base + elem) = v;
+    else *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(row_base) + elem) = kv_pack_half(v);
+}
+template <bool KVH> __device__ __forceinline__ void kv_store1(float *row_base, uint32_t elem, float v) {
+    if constexpr (!KVH) row_base[elem] = v; else reinterpret_cast<__half *>(row_base)[elem] = __float2half_rn(v);
+}
+template <bool KVH> __device__ __forceinline__ KVRaw<KVH> kv_load4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    KVRaw<KVH> o;
+    if constexpr (!KVH) o.v = bload_f4(r, off);
+    else { typedef int i32x2 __attribute__((ext_vector_type(2))); const i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0); o.v = make_uint2((uint32_t)t.x, (uint32_t)t.y); }
+    return o;
+}
+
 constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight per round
 
 // A KV row (head_dim floats) is shared by LPR lanes, QV float4 each (lane j owns float4 j, j+LPR, ...: every load
@@ -66,7 +104,7 @@ constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight 
 // MODE resolves the feature flags at compile time for the decode launches (a taken branch costs ~40 cycles and every
 // instruction of the one wave per SIMD is on the critical path): 0 generic (run-time flags), 1 Qwen3 decode (q/k-norm,
 // half-split RoPE, staged RoPE row, fresh k, causal), 2 Nano/Qwen2 decode (adjacent-pair RoPE, staged row, fresh k, causal).
-template <int LPR, int QV, int KVM, int MODE>
+template <int LPR, int QV, int KVM, int MODE, bool KVH>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = 256 / LPR;                 // timesteps per block
@@ -97,12 +135,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     float *part = redl + KVM * R;
 
     // ---- 1. issue every load --------------------------------------------------------------------------------
+    constexpr uint32_t ESZ = KVH ? 2u : 4u;                    // bytes per cache element
     const size_t slot_rows = (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
-    const float *kc = a.kcache + slot_rows * a.kv_dim + (size_t)g * hd;
-    const float *vc = a.vcache + slot_rows * a.kv_dim + (size_t)g * hd;
-    const uint32_t cache_bytes = fixed_range ? fixed_range * a.kv_dim * 4u : a.S * a.kv_dim * 4u;   // rows >= S: out of range
-    const __amdgpu_buffer_rsrc_t rk = mkrsrc(kc, cache_bytes - g * hd * 4u);
-    const __amdgpu_buffer_rsrc_t rv = mkrsrc(vc, cache_bytes - g * hd * 4u);
+    // start of this KV head's rows, in the cache's own element size (typed float* for the FP32 path's arithmetic)
+    const float *kc = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.kcache) + (slot_rows * a.kv_dim + (size_t)g * hd) * ESZ);
+    const float *vc = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.vcache) + (slot_rows * a.kv_dim + (size_t)g * hd) * ESZ);
+    const uint32_t cache_bytes = (fixed_range ? fixed_range : a.S) * a.kv_dim * ESZ;   // rows >= S: out of range
+    const __amdgpu_buffer_rsrc_t rk = mkrsrc(kc, cache_bytes - g * hd * ESZ);
+    const __amdgpu_buffer_rsrc_t rv = mkrsrc(vc, cache_bytes - g * hd * ESZ);
     const uint32_t sub = (uint32_t)tid / LPR, j = (uint32_t)tid % LPR;
     const uint32_t range_hint = fixed_range ? fixed_range : a.range_hint;
 
@@ -111,10 +151,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     // RoPE partner of float4 f (f + head_dim/8 for the half-split style, the same float4 for adjacent pairs) lives in
     // the same lane, so rmsnorm + RoPE need one DPP reduction and no LDS / barrier; every sub-group does it redundantly.
     constexpr bool REGQK = MODE != 0;
-    float4 qv[KVM][QV], kfresh[QV];
+    float4 qv[KVM][QV], kfresh[QV], vfresh[QV];
     float4 qnw[QV], knw[QV], rcs[QV], rsn[QV];
     const __amdgpu_buffer_rsrc_t rq = mkrsrc(a.q + (size_t)b * a.q_dim, a.q_dim * 4u);
     const __amdgpu_buffer_rsrc_t rkr = mkrsrc(fresh_k ? a.kraw + (size_t)b * a.kv_dim : nullptr, fresh_k ? a.kv_dim * 4u : 0u);
+    // FP16 cache: the QKV GEMV leaves the fresh v row in scratch (FP32) and this kernel rounds and stores it next to k
+    const bool fresh_v = KVH && a.vraw != nullptr;
+    const __amdgpu_buffer_rsrc_t rvr = mkrsrc(fresh_v ? a.vraw + (size_t)b * a.kv_dim : nullptr, fresh_v ? a.kv_dim * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rqn = mkrsrc(a.q_norm, has_norm ? hd * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rkn = mkrsrc(a.k_norm, has_norm ? hd * 4u : 0u);
     float e0[VR][JJ], e1[VR][JJ], nw0[VR][JJ], nw1[VR][JJ];     // generic path: [vector round][jj]
@@ -129,6 +172,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int m = 0; m < KVM; m++) qv[m][q] = bload_f4(rq, fo == OOB ? OOB : (h0 + m) * hd * 4u + fo);
             kfresh[q] = bload_f4(rkr, fo == OOB ? OOB : g * hd * 4u + fo);
+            if (KVH) vfresh[q] = bload_f4(rvr, fo == OOB ? OOB : g * hd * 4u + fo);
             if (MODE == 1) {
                 qnw[q] = bload_f4(rqn, fo); knw[q] = bload_f4(rkn, fo);
                 const uint32_t fr = f % (half / 4u);                 // cos/sin of element i and i+half are those of pair i
@@ -171,7 +215,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
     }
     }
-    float4 kreg[NP][QV], vreg[NP][QV];
+    KVRaw<KVH> kreg[NP][QV], vreg[NP][QV];
     auto issue_kv = [&](uint32_t round) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
@@ -179,9 +223,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int q = 0; q < QV; q++) {
                 const uint32_t f = j + (uint32_t)LPR * q;                  // float4 index inside the head
-                const uint32_t off = (f * 4u < hd && t < range_hint) ? t * a.kv_dim * 4u + f * 16u : OOB;
-                kreg[p][q] = bload_f4(rk, off);
-                vreg[p][q] = bload_f4(rv, off);
+                const uint32_t off = (f * 4u < hd && t < range_hint) ? (t * a.kv_dim + f * 4u) * ESZ : OOB;
+                kreg[p][q] = kv_load4<KVH>(rk, off);
+                vreg[p][q] = kv_load4<KVH>(rv, off);
             }
         }
     };
@@ -241,10 +285,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                 for (int m = 0; m < KVM; m++) rot(qv[m][q], rcs[q], rsn[q]);
             }
         }
-        if (split == 0 && sub == 0 && (h0 % kv_mul) == 0) {      // the finished k row -> cache row pos
-            float *krow = const_cast<float *>(kc) + (size_t)pos * a.kv_dim;
 #pragma unroll
-            for (int q = 0; q < QV; q++) { const uint32_t f = j + (uint32_t)LPR * q; if (f * 4u < hd) *reinterpret_cast<float4 *>(krow + 4 * f) = kfresh[q]; }
+        for (int q = 0; q < QV; q++) { kfresh[q] = kv_round<KVH>(kfresh[q]); if (KVH) vfresh[q] = kv_round<KVH>(vfresh[q]); }   // what the cache holds
+        if (split == 0 && sub == 0 && (h0 % kv_mul) == 0) {      // the finished k row (FP16 cache: and the v row) -> cache row pos
+            float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)pos * a.kv_dim * ESZ);
+            float *vrow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)pos * a.kv_dim * ESZ);
+#pragma unroll
+            for (int q = 0; q < QV; q++) {
+                const uint32_t f = j + (uint32_t)LPR * q;
+                if (f * 4u < hd) { kv_store4<KVH>(krow, 4u * f, kfresh[q]); if (KVH && fresh_v) kv_store4<KVH>(vrow, 4u * f, vfresh[q]); }
+            }
         }
         if (a.prep_only) return;                                  // batched prefill, pass 1: the k row is all that was wanted
     } else {
@@ -286,11 +336,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                         if (rq3) { y0 = x0[jj] * c - x1[jj] * s; y1 = x1[jj] * c + x0[jj] * s; }     // infer.c:700-703
                         else { y0 = x0[jj] * c - x1[jj] * s; y1 = x0[jj] * s + x1[jj] * c; }                 // infer.c:686-687
                     }
+                    if (isk) { y0 = kv_round1<KVH>(y0); y1 = kv_round1<KVH>(y1); }
                     dst[i0] = y0; dst[i1] = y1;
-                    if (isk && split == 0 && (h0 % kv_mul) == 0) { float *krow = const_cast<float *>(kc) + (size_t)pos * a.kv_dim; krow[i0] = y0; krow[i1] = y1; }
+                    if (isk && split == 0 && (h0 % kv_mul) == 0) {
+                        float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)pos * a.kv_dim * ESZ);
+                        kv_store1<KVH>(krow, i0, y0); kv_store1<KVH>(krow, i1, y1);
+                    }
                     if (!isk && split == 0 && q_out) { float *qo = q_out + (size_t)b * a.q_dim + (size_t)(h0 + v) * hd; qo[i0] = y0; qo[i1] = y1; }
                 }
             }
+        }
+    }
+    if constexpr (KVH) {                                          // generic path: the fresh v row straight from scratch, rounded, stored by split 0
+#pragma unroll
+        for (int q = 0; q < QV; q++) {
+            const uint32_t f = j + (uint32_t)LPR * q;
+            const bool ok = f * 4u < hd;
+            vfresh[q] = kv_round<KVH>(bload_f4(rvr, ok ? g * hd * 4u + f * 16u : OOB));
+            if (fresh_v && ok && split == 0 && sub == 0 && (h0 % kv_mul) == 0)
+                kv_store4<KVH>(reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)pos * a.kv_dim * ESZ), 4u * f, vfresh[q]);
         }
     }
     __syncthreads();
@@ -330,7 +394,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                 float d = 0.0f;
 #pragma unroll
                 for (int q = 0; q < QV; q++) {
-                    const float4 kk = fresh ? kfresh[q] : kreg[p][q];
+                    const float4 kk = fresh ? kfresh[q] : kv_cvt(kreg[p][q]);
                     d = __builtin_fmaf(qv[m][q].x, kk.x, d); d = __builtin_fmaf(qv[m][q].y, kk.y, d); d = __builtin_fmaf(qv[m][q].z, kk.z, d); d = __builtin_fmaf(qv[m][q].w, kk.w, d);
                 }
                 d = group_sum_t<LPR>(d);
@@ -350,10 +414,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             for (int p = 0; p < NP; p++) {
                 const float e = (sc[m][p] == -INFINITY) ? 0.0f : expf(sc[m][p] - mx);
                 l += e;
+                const uint32_t tv = ((round * NP + p) * nsplit + split) * R + sub;
+                const bool vf = KVH && fresh_v && tv == pos;       // FP16 cache: the fresh v row is not in the cache yet
 #pragma unroll
                 for (int q = 0; q < QV; q++) {
-                    acc[m][q].x = __builtin_fmaf(e, vreg[p][q].x, acc[m][q].x); acc[m][q].y = __builtin_fmaf(e, vreg[p][q].y, acc[m][q].y);
-                    acc[m][q].z = __builtin_fmaf(e, vreg[p][q].z, acc[m][q].z); acc[m][q].w = __builtin_fmaf(e, vreg[p][q].w, acc[m][q].w);
+                    const float4 vv = vf ? vfresh[q] : kv_cvt(vreg[p][q]);
+                    acc[m][q].x = __builtin_fmaf(e, vv.x, acc[m][q].x); acc[m][q].y = __builtin_fmaf(e, vv.y, acc[m][q].y);
+                    acc[m][q].z = __builtin_fmaf(e, vv.z, acc[m][q].z); acc[m][q].w = __builtin_fmaf(e, vv.w, acc[m][q].w);
                 }
             }
             mrun[m] = mx; lrun[m] = l;
@@ -408,16 +475,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
 }
 
-template <int LPR, int QV, int MODE>
-static hipError_t launch_mode(const AttnArgs &a, uint32_t nb, hipStream_t st) {
+template <int LPR, int QV, int MODE, bool KVH>
+static hipError_t launch_mode_kv(const AttnArgs &a, uint32_t nb, hipStream_t st) {
     const uint32_t kv_mul = a.n_head / a.n_kv_head;
     const uint32_t hd4 = (a.hd + 3) & ~3u;
     constexpr uint32_t R = 256 / LPR;
     auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + kvm * R + (size_t)R * kvm * hd4) * sizeof(float); };
-    if (kv_mul == 2) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 2, MODE>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(2), st, a); }
-    else if (kv_mul == 4) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 4, MODE>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(4), st, a); }
-    else { hipLaunchKernelGGL((attention_kernel<LPR, QV, 1, MODE>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a); }
+    if (kv_mul == 2) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 2, MODE, KVH>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(2), st, a); }
+    else if (kv_mul == 4) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 4, MODE, KVH>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(4), st, a); }
+    else { hipLaunchKernelGGL((attention_kernel<LPR, QV, 1, MODE, KVH>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a); }
     return hipGetLastError();
+}
+template <int LPR, int QV, int MODE>
+static hipError_t launch_mode(const AttnArgs &a, uint32_t nb, hipStream_t st) {
+    return a.kv_half ? launch_mode_kv<LPR, QV, MODE, true>(a, nb, st) : launch_mode_kv<LPR, QV, MODE, false>(a, nb, st);
 }
 template <int LPR, int QV>
 static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {

@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_fp16.h>
 #include "../../include/nano_mi355x.h"
 #include "kernels.h"
 
@@ -102,6 +103,8 @@ struct NanoHipModel {
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
+    bool kv_half = false;         // opt-in FP16 KV cache: rows hold __half, v passes through vraw like k through kraw
+    float *vraw = nullptr;        // [Bs][KD] fresh v rows (FP16 cache only)
     // strict-parity / per-phase mode (strict.hip): eager, one kernel per reference operator, reference summation order
     bool strict = false;
     float *xn = nullptr, *hb2 = nullptr, *att = nullptr;   // normalised x [Bs][E], W3 output [Bs][H], attention scores [Bs][n_head][S]
@@ -168,7 +171,7 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att };
+                    m->xn, m->hb2, m->att, m->vraw };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -189,7 +192,15 @@ extern "C" void nano_hip_model_destroy(NanoHipModel *m) { destroy(m); }
 
 extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *desc, const void *params, size_t params_bytes,
                                      int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch) {
+    uint32_t flags = 0;
+    if (const char *kv = getenv("NANO_KV_F16")) if (*kv && *kv != '0') flags |= NANO_HIP_KV_F16;
+    return nano_hip_model_create_ex(out, desc, params, params_bytes, params_on_device, device, max_seq_len, max_batch, flags);
+}
+
+extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc *desc, const void *params, size_t params_bytes,
+                                        int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch, uint32_t flags) {
     if (!out || !desc || !params) FAIL(NANO_HIP_EINVAL, "null argument");
+    if (flags & ~NANO_HIP_KV_F16) FAIL(NANO_HIP_EINVAL, "unknown flags 0x%x", flags);
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(NANO_HIP_ENODEV, "no HIP device visible (this backend has no CPU fallback)");
@@ -218,6 +229,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     NanoHipModel *m = new NanoHipModel();
     m->d = d; m->device = device; m->cus = prop.multiProcessorCount;
     m->S = max_seq_len; m->maxB = max_batch; m->hd = hd; m->QD = QD; m->KD = KD;
+    m->kv_half = (flags & NANO_HIP_KV_F16) != 0;
     const uint8_t *src = reinterpret_cast<const uint8_t *>(params);
     const size_t L = d.n_layer, E = d.n_embd, H = d.n_hidden, V = d.vocab_size;
     const size_t each[WCOUNT] = { (size_t)QD * E, (size_t)KD * E, (size_t)KD * E, E * QD, H * E, E * H, H * E };
@@ -335,7 +347,8 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     bool ok = hipMalloc(&m->x, Bs * E * 4) == hipSuccess && hipMalloc(&m->q, Bs * QD * 4) == hipSuccess &&
               hipMalloc(&m->kraw, Bs * KD * 4) == hipSuccess && hipMalloc(&m->xba, Bs * QD * 4) == hipSuccess &&
               hipMalloc(&m->hb, Bs * H * 4) == hipSuccess && hipMalloc(&m->logits, B * V * 4) == hipSuccess &&
-              hipMalloc(&m->kcache, kvn * 4) == hipSuccess && hipMalloc(&m->vcache, kvn * 4) == hipSuccess &&
+              hipMalloc(&m->kcache, kvn * (m->kv_half ? 2 : 4)) == hipSuccess && hipMalloc(&m->vcache, kvn * (m->kv_half ? 2 : 4)) == hipSuccess &&
+              (!m->kv_half || hipMalloc(&m->vraw, Bs * KD * 4) == hipSuccess) &&
               hipMalloc(&m->tokens, Bs * 4) == hipSuccess && hipMalloc(&m->pos, Bs * 4) == hipSuccess &&
               hipMalloc(&m->amax, B * 4) == hipSuccess && hipMalloc(&m->trace, (size_t)m->trace_cap * 4) == hipSuccess &&
               hipMalloc(&m->pos0, B * 4) == hipSuccess &&
@@ -349,7 +362,7 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
     }
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
     // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
-    if (hipMemset(m->kcache, 0, kvn * 4) != hipSuccess || hipMemset(m->vcache, 0, kvn * 4) != hipSuccess ||
+    if (hipMemset(m->kcache, 0, kvn * (m->kv_half ? 2 : 4)) != hipSuccess || hipMemset(m->vcache, 0, kvn * (m->kv_half ? 2 : 4)) != hipSuccess ||
         hipMemset(m->x, 0, Bs * E * 4) != hipSuccess || hipMemset(m->logits, 0, B * V * 4) != hipSuccess ||
         hipMemset(m->tokens, 0, Bs * 4) != hipSuccess || hipMemset(m->pos, 0, Bs * 4) != hipSuccess ||
         hipMemset(m->pos0, 0, B * 4) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "hipMemset failed"); }
@@ -512,7 +525,8 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.seg[0] = mkseg(m->W[WQ][l], m->q, QD, QD);
             a.seg[1] = mkseg(m->W[WK][l], m->kraw, KD, KD);
             // v goes straight to its cache row; prefill: every token of the step is a position of KV slot pf_slot
-            a.seg[2] = m->pf ? mkseg(m->W[WV][l], m->vcache + ((size_t)m->pf_slot * L * S + layer_rows) * KD, KD, 0, KD)
+            a.seg[2] = m->kv_half ? mkseg(m->W[WV][l], m->vraw, KD, KD)          // FP16 cache: the attention kernel rounds and stores the row
+                     : m->pf ? mkseg(m->W[WV][l], m->vcache + ((size_t)m->pf_slot * L * S + layer_rows) * KD, KD, 0, KD)
                              : mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_STORE;
             a.norm_w = m->rms_attn + (size_t)l * E; a.pos = m->pos;
@@ -539,11 +553,14 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
+            a.kv_half = m->kv_half ? 1u : 0u; a.vraw = m->kv_half ? m->vraw : nullptr;
             if (m->pf) {
                 // batched prefill: the nb tokens are consecutive positions of ONE sequence.  Pass 1 finishes every k row
                 // (norm + RoPE + cache write, nothing else) so that pass 2 finds the rows of the earlier tokens of the
                 // chunk in the cache; pass 2 is the ordinary decode attention per token (it recomputes its own k row).
-                a.kcache = m->kcache + (size_t)m->pf_slot * L * S * KD; a.vcache = m->vcache + (size_t)m->pf_slot * L * S * KD;
+                const size_t slot_elems = (size_t)m->pf_slot * L * S * KD;            // (FP16 cache: float* arithmetic counts 4-byte units)
+                a.kcache = m->kv_half ? reinterpret_cast<float *>(reinterpret_cast<__half *>(m->kcache) + slot_elems) : m->kcache + slot_elems;
+                a.vcache = m->kv_half ? reinterpret_cast<float *>(reinterpret_cast<__half *>(m->vcache) + slot_elems) : m->vcache + slot_elems;
                 a.cache_bstride_rows = 0;
                 a.prep_only = 1;
                 if ((e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
@@ -637,7 +654,7 @@ static hipError_t enqueue_step_strict(NanoHipModel *m, uint32_t nb, uint32_t is_
     const uint32_t E = d.n_embd, H = d.n_hidden, QD = m->QD, KD = m->KD, L = d.n_layer, S = m->S;
     hipError_t e;
 #define ST(expr) do { if ((e = (expr)) != hipSuccess) return e; } while (0)
-    if (m->lora_on) return hipErrorNotSupported;
+    if (m->lora_on || m->kv_half) return hipErrorNotSupported;
     m->nsplit = 1;                                                      // xba holds final head outputs (nano_hip_read_state, also from inside the hook)
     ST(strict_phase(m, -1, 1));                                         // NANO_LLM_PHASE_EMBEDDING
     EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
@@ -737,10 +754,11 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
     if (range_hint > m->S) range_hint = m->S;
     if (m->strict) {
         const hipError_t e = enqueue_step_strict(m, nb, is_causal, mode, 0);
-        if (e == hipErrorNotSupported) FAIL(NANO_HIP_EINVAL, "strict mode does not cover the LoRA side branches");
+        if (e == hipErrorNotSupported) FAIL(NANO_HIP_EINVAL, "strict mode covers neither the LoRA side branches nor the FP16 KV cache");
         HIP_TRY(e);
         return 0;
     }
+    if (m->kv_half && m->lora_on) FAIL(NANO_HIP_EINVAL, "the LoRA side branches write FP32 v rows: not available with the FP16 KV cache");
     if (!m->use_graph) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); return 0; }
     const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
@@ -1132,6 +1150,13 @@ extern "C" int nano_hip_read_state(NanoHipModel *m, uint32_t slot, int which, ui
     default: FAIL(NANO_HIP_EINVAL, "unknown state id %d", which);
     }
     if (n > cap) FAIL(NANO_HIP_EINVAL, "n too large");
+    if (m->kv_half && (which == 5 || which == 6)) {              // FP16 cache rows come back widened
+        const __half *hsrc = reinterpret_cast<const __half *>(which == 5 ? m->kcache : m->vcache) + row;
+        std::vector<__half> tmp(n);
+        HIP_TRY(hipMemcpy(tmp.data(), hsrc, n * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) out[i] = __half2float(tmp[i]);
+        return 0;
+    }
     HIP_TRY(hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
     return 0;
 }

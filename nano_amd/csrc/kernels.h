@@ -97,7 +97,8 @@ struct AttnArgs {
     uint32_t cache_bstride_rows;   // = L*S rows between slots (in units of kv_dim floats)
     uint32_t fixed_range;          // op-test mode: attend over rows [0, fixed_range) of an externally filled cache
     uint32_t prep_only;            // 1: finish and store the k row of pos[b] (norm + RoPE), then return (batched prefill, pass 1)
-    uint32_t _pad;
+    uint32_t kv_half;              // 1: kcache / vcache hold FP16 elements (opt-in); the fresh v row comes from vraw
+    const float *vraw;             // FP16 cache: [nb][kv_dim] v of the current position from the QKV GEMV (FP32 scratch), else nullptr
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
