@@ -228,42 +228,52 @@ __device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, flo
 __device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *xn, XGroup *xg, float *tmp, uint32_t n4, int nbq) {
     const int n = (int)a.n, tid = threadIdx.x, nthr = blockDim.x;
     const int bpl = (n + 255) / 256, GT = bpl * 8;
-    for (int idx = tid; idx < nbq * bpl * 256; idx += nthr) {          // nthr % 64 == 0: a 32-element group = one half wave
-        const int t = idx & 255, j = (idx >> 8) % bpl, b = (idx >> 8) / bpl;
+    // phase 1: a thread owns FOUR consecutive elements (one 16-byte LDS read; the four divisions are independent), a
+    // 32-element group = 8 consecutive lanes (three DPP steps for min / max / nibble sum)
+    for (int idx = tid; idx < nbq * bpl * 64; idx += nthr) {
+        const int t4 = idx & 63, j = (idx >> 6) % bpl, b = (idx >> 6) / bpl;
         const int d = (n >= (j + 1) * 256) ? 256 : (n - j * 256);
-        const bool valid = t < d;
-        const float v = valid ? xn[(size_t)b * n4 + (size_t)j * d + t] : 0.0f;       // sic: j*d (reference tensor.c:307)
+        const int e0 = 4 * t4;                                            // first of this thread's elements inside the block (d % 4 == 0)
+        const bool valid = e0 < d;
+        const float4 v = valid ? *reinterpret_cast<const float4 *>(xn + (size_t)b * n4 + (size_t)j * d + e0) : make_float4(0.f, 0.f, 0.f, 0.f);   // sic: j*d (reference tensor.c:307)
         // reference: min starts at FLT_MAX, max at FLT_TRUE_MIN, strict comparisons (NaN ignored)
-        float lo = valid ? v : FLT_MAX, hi = valid ? v : FLT_TRUE_MIN;
-        lo = (lo < FLT_MAX) ? lo : FLT_MAX;
-        hi = (hi > FLT_TRUE_MIN) ? hi : FLT_TRUE_MIN;
-        // min / max over the 32 lanes of the group: DPP inside 16-lane rows, one cross-row exchange
+        float lo = FLT_MAX, hi = FLT_TRUE_MIN;
+        if (valid) {
+            lo = (v.x < lo) ? v.x : lo; lo = (v.y < lo) ? v.y : lo; lo = (v.z < lo) ? v.z : lo; lo = (v.w < lo) ? v.w : lo;
+            hi = (v.x > hi) ? v.x : hi; hi = (v.y > hi) ? v.y : hi; hi = (v.z > hi) ? v.z : hi; hi = (v.w > hi) ? v.w : hi;
+        }
         lo = fminf(lo, DPP_F(lo, 0xB1)); hi = fmaxf(hi, DPP_F(hi, 0xB1));
         lo = fminf(lo, DPP_F(lo, 0x4E)); hi = fmaxf(hi, DPP_F(hi, 0x4E));
         lo = fminf(lo, DPP_F(lo, 0x141)); hi = fmaxf(hi, DPP_F(hi, 0x141));
-        lo = fminf(lo, DPP_F(lo, 0x140)); hi = fmaxf(hi, DPP_F(hi, 0x140));
-        lo = fminf(lo, __shfl_xor(lo, 16, 64)); hi = fmaxf(hi, __shfl_xor(hi, 16, 64));
         const float gsc = (lo <= 0.0f) ? ((hi - lo) / 15.0f) : (hi / 15.0f);
         const float gbi = (lo <= 0.0f) ? (-lo) : 0.0f;
-        uint32_t nib = 0;
-        if (valid && gsc != 0.0f) nib = (uint32_t)(nearest_int_magic((v + gbi) / gsc) & 0x0f);
-        const int g = t >> 5, e = t & 31;
+        uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        if (valid && gsc != 0.0f) {
+            n0 = (uint32_t)(nearest_int_magic((v.x + gbi) / gsc) & 0x0f); n1 = (uint32_t)(nearest_int_magic((v.y + gbi) / gsc) & 0x0f);
+            n2 = (uint32_t)(nearest_int_magic((v.z + gbi) / gsc) & 0x0f); n3 = (uint32_t)(nearest_int_magic((v.w + gbi) / gsc) & 0x0f);
+        }
+        const int g = t4 >> 3, tg = t4 & 7;                               // group of the block, thread inside the group
         XGroup *o = xg + (size_t)b * GT + j * 8 + g;
-        reinterpret_cast<uint8_t *>(o)[((e & 1) ? 16 : 0) + (e >> 3) * 4 + ((e & 7) >> 1)] = (uint8_t)nib;   // split-nibble byte lane of element e
-        int sum = dpp_group_sum<16>((int)nib);
-        sum += __shfl_xor(sum, 16, 64);
-        if (e == 0) { o->sumq = sum; o->_pad = 0; float *tp = tmp + ((size_t)b * bpl + j) * 16; tp[g] = gsc; tp[8 + g] = gbi; }
+        // split-nibble byte lanes: elements 8m .. 8m+7 live in dword m; even elements -> lo[m], odd -> hi[m], byte (e & 7) >> 1
+        uint8_t *ob = reinterpret_cast<uint8_t *>(o) + (tg >> 1) * 4 + (tg & 1) * 2;
+        *reinterpret_cast<uint16_t *>(ob) = (uint16_t)(n0 | (n2 << 8));
+        *reinterpret_cast<uint16_t *>(ob + 16) = (uint16_t)(n1 | (n3 << 8));
+        const int sum = dpp_group_sum<8>((int)(n0 + n1 + n2 + n3));
+        if (tg == 0) { o->sumq = sum; o->_pad = 0; float *tp = tmp + ((size_t)b * bpl + j) * 16; tp[g] = gsc; tp[8 + g] = gbi; }
     }
     __syncthreads();
     for (int idx = tid; idx < nbq * GT; idx += nthr) {
         const int gg = idx % GT, b = idx / GT, j = gg >> 3, g = gg & 7;
         const float *tp = tmp + ((size_t)b * bpl + j) * 16;
-        float smax = FLT_TRUE_MIN, bmax = FLT_TRUE_MIN;
+        const float4 s0 = *reinterpret_cast<const float4 *>(tp), s1 = *reinterpret_cast<const float4 *>(tp + 4);      // the block's 8 group scales
+        const float4 c0 = *reinterpret_cast<const float4 *>(tp + 8), c1 = *reinterpret_cast<const float4 *>(tp + 12);  // ... and 8 group biases
+        const float sv[8] = { s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w }, bv[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+        float smax = FLT_TRUE_MIN, bmax = FLT_TRUE_MIN, sg = sv[0], bg = bv[0];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { if (tp[k] > smax) smax = tp[k]; if (tp[8 + k] > bmax) bmax = tp[8 + k]; }
+        for (int k = 0; k < 8; k++) { if (sv[k] > smax) smax = sv[k]; if (bv[k] > bmax) bmax = bv[k]; sg = (k == g) ? sv[k] : sg; bg = (k == g) ? bv[k] : bg; }
         const float s_scale = smax / 63.0f, s_bias = bmax / 63.0f;
-        const uint32_t s6 = (s_scale == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(tp[g] / s_scale) & 0x3f);
-        const uint32_t b6 = (s_bias == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(tp[8 + g] / s_bias) & 0x3f);
+        const uint32_t s6 = (s_scale == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(sg / s_scale) & 0x3f);
+        const uint32_t b6 = (s_bias == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(bg / s_bias) & 0x3f);
         XGroup *o = xg + (size_t)b * GT + gg;
         o->sq = (float)s6 * s_scale;       // what get_group_scale_and_bias() reads back (tensor.c:137-140)
         o->bq = (float)b6 * s_bias;
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t n = a.n, n4 = (n + 3) & ~3u;
-    const uint32_t bpl = (n + 255) / 256, GT = bpl * 8, GTP = GT + 1;
+    const uint32_t bpl = (n + 255) / 256, GT = bpl * 8, GTP = GT + 4;        // row pitch of the product table: 16-byte aligned rows
     const uint32_t RW = a.rw;
     const uint32_t epi = role_epi<ROLE>(a);
     const bool swiglu = epi == GEMV_EPI_SWIGLU;
@@ -405,13 +415,31 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     }
     __syncthreads();
 
-    // ordered fold (groups inside a block, then blocks along the row; reference tensor.c:359-434, 438-471)
+    // ordered fold (groups inside a block, then blocks along the row; reference tensor.c:359-434, 438-471).  The eight group
+    // values of a block are two 16-byte LDS reads; the reads of four blocks go out together and the block sums (independent
+    // chains) overlap -- only the sum over the blocks is serial.
     if (tid < (int)(RW * B)) {
         float res[2] = {0.0f, 0.0f};
+        const uint32_t nfull = n >> 8;                                   // whole 256-value blocks
         for (uint32_t mat = 0; mat < nmat; mat++) {
             const float *f = P + ((size_t)fb * nmat * RW + mat * RW + frl) * GTP;
             float line = 0.0f;
-            for (uint32_t blk = 0; blk < bpl; blk++) {
+            uint32_t blk = 0;
+            for (; blk + 4 <= nfull; blk += 4) {
+                float4 v[4][2];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { v[k][0] = *reinterpret_cast<const float4 *>(f + (blk + k) * 8); v[k][1] = *reinterpret_cast<const float4 *>(f + (blk + k) * 8 + 4); }
+                float ds[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float d = 0.0f;
+                    d += v[k][0].x; d += v[k][0].y; d += v[k][0].z; d += v[k][0].w;
+                    d += v[k][1].x; d += v[k][1].y; d += v[k][1].z; d += v[k][1].w;
+                    ds[k] = d;
+                }
+                line += ds[0]; line += ds[1]; line += ds[2]; line += ds[3];
+            }
+            for (; blk < bpl; blk++) {
                 const int d = ((int)n >= (int)(blk + 1) * 256) ? 256 : ((int)n - (int)blk * 256);
                 const int gv = (d + 31) >> 5;
                 float ds = 0.0f;
@@ -453,7 +481,7 @@ static hipError_t launch_q4k_t(const GemvDev &d, const Q4kPlan &p, uint32_t rows
     const uint32_t nmat = d.epi == GEMV_EPI_SWIGLU ? 2 : 1;
     const size_t n4 = (d.n + 3) & ~3u, bpl = (d.n + 255) / 256, GT = bpl * 8;
     const size_t lds = (size_t)B * GT * sizeof(XGroup) + (B * n4 + B * bpl * 16 + B * 16 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 8 : 0) +
-                                                           (size_t)B * nmat * p.rw * (GT + 1)) * 4;
+                                                           (size_t)B * nmat * p.rw * (GT + 4)) * 4 + 16;
     auto kern = &gemv_q4k_slab_kernel<ROLE, B, NV, IPT>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(p.nthr), lds, st, d);
