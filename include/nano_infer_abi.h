@@ -210,6 +210,11 @@ void nano_set_max_batch(uint32_t max_batch);
  * NANO_HIP_E* code (nano_mi355x.h). */
 int nano_forward_batch(Nano_Context *ctx, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
                        float *logits, uint32_t *argmax);
+/* Replicas of the context's model on the listed further GPUs of the node, in this process: nano_forward_batch then serves
+ * sequence i from replica i mod (1 + n_devices) (replica 0 = the context's own device) and the replicas decode their
+ * shares concurrently -- independent sequences shard trivially, no collective.  The one-process-per-GPU
+ * route with an RCCL broadcast of the weights is nano_amd/dist.py + bench.py.  Returns 0 or a NANO_HIP_E* code. */
+int nano_context_replicate(Nano_Context *ctx, const int *devices, int n_devices);
 /* Session over token ids (no tokenizer needed): like llm_session_init but the prompt is given as ids. */
 Nano_Session *nano_session_init_ids(Nano_Context *ctx, const uint32_t *prompt_ids, uint32_t n_prompt, uint32_t max_seq_len);
 /* Like llm_session_step but never touches the tokenizer (output_text stays NULL). */

@@ -108,6 +108,14 @@ uint64_t nano_hip_weight_bytes_per_step(const NanoHipModel *m);
 int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
                      uint32_t is_causal, float *logits_out, uint32_t *argmax_out);
 
+/* The same step in two halves: _begin queues it (and the copies back) on the model's stream and returns, _end waits and
+ * fills the caller's buffers (NULL = not wanted; what _begin was told to produce).  Between the two the caller may
+ * begin steps on OTHER models: replicas of one model on several GPUs of a node decode their shares of a prompt batch
+ * concurrently from one process (host/nano_engine.c nano_context_replicate; SURVEY 8e's "one process, 8 streams"). */
+int nano_hip_forward_begin(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
+                           uint32_t is_causal, int want_logits, int want_argmax);
+int nano_hip_forward_end(NanoHipModel *m, float *logits_out, uint32_t *argmax_out);
+
 /* Greedy on-device decode: starting from tokens[i] at pos[i], run `steps` steps feeding each
  * slot's arg-max back in, without host round trips (tokens/positions live on the device, each
  * step is one HIP-graph replay).  out_ids: host buffer [steps][batch].  Equivalent to calling

@@ -103,6 +103,7 @@ struct NanoHipModel {
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
+    uint32_t pending_batch = 0;   // sequences of the step queued by nano_hip_forward_begin
     bool kv_half = false;         // opt-in FP16 KV cache: rows hold __half, v passes through vraw like k through kraw
     float *vraw = nullptr;        // [Bs][KD] fresh v rows (FP16 cache only)
     // strict-parity / per-phase mode (strict.hip): eager, one kernel per reference operator, reference summation order
@@ -800,25 +801,44 @@ static int check_batch(NanoHipModel *m, const uint32_t *tokens, const uint32_t *
     return 0;
 }
 
-extern "C" int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
-                                uint32_t is_causal, float *logits_out, uint32_t *argmax_out) {
+// nano_hip_forward in two halves: _begin queues the step and the copies back on the model's stream and returns; _end waits
+// and hands the results over.  Several models (replicas on several GPUs, host/nano_engine.c nano_context_replicate) run
+// their steps concurrently between the two.
+extern "C" int nano_hip_forward_begin(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
+                                      uint32_t is_causal, int want_logits, int want_argmax) {
     int rc;
     if ((rc = check_batch(m, tokens, pos, batch, 0))) return rc;
     HIP_TRY(hipSetDevice(m->device));
     memcpy(m->h_tokens, tokens, batch * 4); memcpy(m->h_pos, pos, batch * 4);
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
-    const uint32_t mode = argmax_out ? MODE_ARGMAX : (logits_out ? MODE_LOGITS : MODE_NOCLS);
+    const uint32_t mode = want_argmax ? MODE_ARGMAX : (want_logits ? MODE_LOGITS : MODE_NOCLS);
     uint32_t max_pos = 0;
     for (uint32_t i = 0; i < batch; i++) if (pos[i] > max_pos) max_pos = pos[i];
     if ((rc = run_step(m, batch, is_causal ? 1u : 0u, mode, max_pos))) return rc;
     const size_t V = m->d.vocab_size;
-    if (logits_out) HIP_TRY(hipMemcpyAsync(m->h_logits, m->logits, batch * V * 4, hipMemcpyDeviceToHost, m->st));
-    if (argmax_out) HIP_TRY(hipMemcpyAsync(m->h_amax, m->amax, batch * 4, hipMemcpyDeviceToHost, m->st));
+    if (want_logits) HIP_TRY(hipMemcpyAsync(m->h_logits, m->logits, batch * V * 4, hipMemcpyDeviceToHost, m->st));
+    if (want_argmax) HIP_TRY(hipMemcpyAsync(m->h_amax, m->amax, batch * 4, hipMemcpyDeviceToHost, m->st));
+    m->pending_batch = batch;
+    return 0;
+}
+
+extern "C" int nano_hip_forward_end(NanoHipModel *m, float *logits_out, uint32_t *argmax_out) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->st));
+    const size_t V = m->d.vocab_size, batch = m->pending_batch;
     if (logits_out) memcpy(logits_out, m->h_logits, batch * V * 4);
     if (argmax_out) memcpy(argmax_out, m->h_amax, batch * 4);
+    m->pending_batch = 0;
     return 0;
+}
+
+extern "C" int nano_hip_forward(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
+                                uint32_t is_causal, float *logits_out, uint32_t *argmax_out) {
+    int rc;
+    if ((rc = nano_hip_forward_begin(m, tokens, pos, batch, is_causal, logits_out != nullptr, argmax_out != nullptr))) return rc;
+    return nano_hip_forward_end(m, logits_out, argmax_out);
 }
 
 // ---- device-side sampling (reference infer.c:1156-1189) ------------------------------------------------

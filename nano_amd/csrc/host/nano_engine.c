@@ -58,11 +58,15 @@ static int pick_device(void) {
  * be stepped alternately by one caller thread; the reference keeps all of this inside LLM / Nano_Context, whose
  * layouts are the ABI and cannot grow). */
 #define MAX_MODELS 64
+#define NANO_MAX_REPLICAS 8
 typedef struct ModelEntry {
     const LLM *llm; NanoHipModel *dev; uint32_t max_seq_len;
     int fallback_streak, host_turns;                 /* device sampler: consecutive fall-backs / host-loop turns left */
     const Nano_Session *pf_session; uint32_t pf_upto; /* session whose prompt positions [0, pf_upto) one batched prefill fed */
     int position_prefilled;                          /* set while step_core calls generate_next_token for such a position */
+    /* replicas on further GPUs (nano_context_replicate): what is needed to upload the model again, and the replicas */
+    NanoModelDesc desc; const uint8_t *params; size_t params_avail; uint32_t max_batch;
+    NanoHipModel *replica[NANO_MAX_REPLICAS]; int n_replica;       /* replica[0] == dev */
 } ModelEntry;
 static ModelEntry g_reg[MAX_MODELS];
 
@@ -163,6 +167,11 @@ void load_llm_from_buffer(LLM *llm, Tokenizer *tk, uint8_t *buffer, uint32_t max
     if (nano_hip_model_create(&dev, &d, params, avail, 0, pick_device(), max_seq_len, g_max_batch) != NANO_HIP_OK)
         die_hip("model upload failed");
     reg_put(llm, dev, max_seq_len);
+    {
+        ModelEntry *me = reg_entry(llm);
+        me->desc = d; me->params = params; me->params_avail = avail; me->max_batch = g_max_batch;
+        me->replica[0] = dev; me->n_replica = 1;
+    }
 
     llm->state.logits = (float *)calloc((size_t)c->vocab_size * g_max_batch, sizeof(float));
     if (!llm->state.logits) { fprintf(stderr, "mem alloc failed!\n"); exit(EXIT_FAILURE); }
@@ -183,7 +192,9 @@ void load_llm(LLM *llm, Tokenizer *tk, char *model_path, uint32_t max_seq_len) {
 }
 
 void free_llm(LLM *llm, Tokenizer *tk) {
-    NanoHipModel *dev = reg_get(llm);
+    ModelEntry *me = reg_entry(llm);
+    NanoHipModel *dev = me ? me->dev : NULL;
+    if (me) for (int r = 1; r < me->n_replica; r++) nano_hip_model_destroy(me->replica[r]);
     if (dev) nano_hip_model_destroy(dev);
     reg_del(llm);
     if (llm->buffer && llm->buffer != MAP_FAILED && llm->file_size) munmap(llm->buffer, llm->file_size);
@@ -350,11 +361,51 @@ float *llm_forward(Nano_Context *ctx, uint32_t token, uint32_t pos, uint32_t max
     return llm->state.logits;
 }
 
+/* Replicas of the context's model on further GPUs of the node, from ONE process (the alternative to one process per GPU,
+ * SURVEY 8e): devices[0..n) get a full copy of the weights and their own KV slots; nano_forward_batch then serves
+ * sequence i from replica i mod (1 + n) -- replica 0 is the context's own device -- and the replicas run their shares
+ * concurrently.  The parameter bytes must still be readable (load_llm keeps its mapping; a _from_buffer caller keeps
+ * its buffer).  Sequences keep their replica and slot for the life of the context. */
+int nano_context_replicate(Nano_Context *ctx, const int *devices, int n_devices) {
+    ModelEntry *me = ctx ? reg_entry(ctx->llm) : NULL;
+    if (!me || !devices || n_devices < 0 || me->n_replica + n_devices > NANO_MAX_REPLICAS) return NANO_HIP_EINVAL;
+    for (int i = 0; i < n_devices; i++) {
+        NanoHipModel *r = NULL;
+        const int rc = nano_hip_model_create(&r, &me->desc, me->params, me->params_avail, 0, devices[i], me->max_seq_len, me->max_batch);
+        if (rc != NANO_HIP_OK) return rc;
+        me->replica[me->n_replica++] = r;
+    }
+    return NANO_HIP_OK;
+}
+
 int nano_forward_batch(Nano_Context *ctx, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, float *logits, uint32_t *argmax) {
-    NanoHipModel *dev = reg_get(ctx->llm);
-    if (!dev) return NANO_HIP_EINVAL;
-    lora_select(dev, ctx->lora);
-    return nano_hip_forward(dev, tokens, pos, batch, 1, logits, argmax);
+    ModelEntry *me = reg_entry(ctx->llm);
+    if (!me || !me->dev) return NANO_HIP_EINVAL;
+    lora_select(me->dev, ctx->lora);
+    const uint32_t G = (uint32_t)me->n_replica;
+    if (G <= 1) return nano_hip_forward(me->dev, tokens, pos, batch, 1, logits, argmax);
+    /* sequence i -> replica i mod G, slot i / G: gather each replica's share, start all, then collect */
+    const size_t V = ctx->llm->config.vocab_size;
+    uint32_t tk[NANO_MAX_REPLICAS][NANO_MAX_BATCH], ps[NANO_MAX_REPLICAS][NANO_MAX_BATCH], cnt[NANO_MAX_REPLICAS] = {0};
+    if (batch > NANO_MAX_BATCH * G) return NANO_HIP_EINVAL;
+    for (uint32_t i = 0; i < batch; i++) { const uint32_t r = i % G; if (cnt[r] >= NANO_MAX_BATCH) return NANO_HIP_EINVAL; tk[r][cnt[r]] = tokens[i]; ps[r][cnt[r]] = pos[i]; cnt[r]++; }
+    int rc = NANO_HIP_OK;
+    for (uint32_t r = 0; r < G && rc == NANO_HIP_OK; r++)
+        if (cnt[r]) rc = nano_hip_forward_begin(me->replica[r], tk[r], ps[r], cnt[r], 1, logits != NULL, argmax != NULL);
+    float *lbuf = logits ? (float *)malloc((size_t)NANO_MAX_BATCH * V * sizeof(float)) : NULL;
+    uint32_t abuf[NANO_MAX_BATCH];
+    for (uint32_t r = 0; r < G; r++) {
+        if (!cnt[r]) continue;
+        const int e = nano_hip_forward_end(me->replica[r], lbuf, argmax ? abuf : NULL);
+        if (e != NANO_HIP_OK && rc == NANO_HIP_OK) rc = e;
+        for (uint32_t k = 0; k < cnt[r] && e == NANO_HIP_OK; k++) {
+            const uint32_t i = k * G + r;
+            if (logits) memcpy(logits + (size_t)i * V, lbuf + (size_t)k * V, V * sizeof(float));
+            if (argmax) argmax[i] = abuf[k];
+        }
+    }
+    free(lbuf);
+    return rc;
 }
 
 /* =====================================================================================================

@@ -429,3 +429,33 @@ def test_engine_per_phase_observation(model_dir):
     want = fwd * (len(prompt) - 1) + (fwd + [(-1, 12)]) * 3
     assert seen == want
     assert np.array_equal(ids, g["ids"][:len(prompt) + 3])
+
+
+def test_engine_replicas_serve_a_batch_concurrently(model_dir):
+    """nano_context_replicate: replicas of the model (here a second one on the same GPU -- a 1-GPU box) share a prompt
+    batch, sequence i on replica i mod G, steps begun on all replicas before any is waited for; every sequence's logits
+    and arg-max are those of decoding it alone."""
+    import ctypes as C
+    from nano_amd import modelfile as mf
+    path, spec = synth_model(model_dir, "tiny-qwen3", "q80", 64)
+    B, T = 5, 7
+    seqs = [mf.prompt_ids(40 + b, T, spec.vocab_size) for b in range(B)]
+    e = nb.Engine(path, max_seq_len=16, max_batch=3)
+    e.L.nano_context_replicate.restype = C.c_int
+    e.L.nano_context_replicate.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    devs = (C.c_int * 1)(0)
+    assert e.L.nano_context_replicate(e.ctx, devs, 1) == 0
+    got = []
+    for pos in range(T):
+        lg = np.empty((B, spec.vocab_size), np.float32); am = np.empty(B, np.uint32)
+        t = np.array([int(s[pos]) for s in seqs], np.uint32); p = np.full(B, pos, np.uint32)
+        assert e.L.nano_forward_batch(e.ctx, t, p, B, lg.ctypes.data, am.ctypes.data) == 0
+        assert np.array_equal(am, np.argmax(lg, axis=1))
+        got.append(lg)
+    e.close()
+    m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    for b in range(B):
+        for pos in range(T):
+            lg, _ = m1.forward([int(seqs[b][pos])], [pos])
+            assert np.array_equal(lg[0].view(np.uint32), got[pos][b].view(np.uint32)), (b, pos)
+    m1.close()
