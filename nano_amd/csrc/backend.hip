@@ -97,6 +97,7 @@ struct NanoHipModel {
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
+    bool use_g5 = true;                                   // gemm_q80_g5.hip's chained K-split kernel where it takes the launch (NANO_GEMM_G5=0: off)
     bool use_g4 = true;                                   // ... gemm_q80_g4.hip's wave-independent kernel first (NANO_GEMM_G4=0: off)
     bool use_g3 = true;                                   // ... and gemm_q80_g3.hip's persistent kernel where the matrix has many rows (NANO_GEMM_G3=0: G2 only)
     bool use_g2 = true;                                   // batched launches take gemm_q80.hip's G2 kernel (NANO_GEMM_G2=0: the round-1 kernels)
@@ -378,6 +379,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (const char *g2 = getenv("NANO_GEMM_G2")) m->use_g2 = *g2 && *g2 != '0';
     if (const char *g3 = getenv("NANO_GEMM_G3")) m->use_g3 = *g3 && *g3 != '0';
     if (const char *g4 = getenv("NANO_GEMM_G4")) m->use_g4 = *g4 && *g4 != '0';
+    if (const char *g5 = getenv("NANO_GEMM_G5")) m->use_g5 = *g5 && *g5 != '0';
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
     if (const char *sm = getenv("NANO_STRICT")) if (*sm && *sm != '0') return nano_hip_set_strict(m, 1);
@@ -441,6 +443,7 @@ static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
         uint32_t rows = 0;
         if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
         const uint32_t ntiles = (rows + 15) / 16, tt = (a.nb + 15) / 16;
+        if (m->use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, m->st);
         const bool g4 = m->use_g4 && gemm_q80_g4_supports(a), g3 = m->use_g3 && gemm_q80_g3_supports(a);
         if (g3 && tt > 2 && ntiles >= 2048) return launch_gemm_q80_g3(a, max_wg, m->st);
         if (g4 && !(ntiles * tt < 512 && tt <= 2)) return launch_gemm_q80_g4(a, m->st);

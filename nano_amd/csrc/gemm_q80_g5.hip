@@ -1,0 +1,256 @@
+// gemm_q80_g5.hip -- G5: batched Q80 (W8A8) GEMM, 2..64 tokens per weight read; the row length of a 16-row tile is
+// split over a TEAM of waves and the reference's ascending group order is kept by handing the running values from wave to
+// wave (a chain through LDS), so a matrix with few rows still has thousands of waves with all their loads in flight.
+//
+//   * unit of work: (16-row tile) x (half chunk = 8 quantization groups = 512 B of every row).  Wave kw of a team of nkw
+//     waves owns the half chunks kw, kw + nkw, kw + 2 nkw, ...; its first one's 16 x 512 B are issued at kernel entry
+//     (8 coalesced loads, two rows each), the next one is prefetched while the current one is consumed.
+//   * the pieces pass through a wave-private LDS buffer (row pitch 528 B) that turns them into MFMA A fragments
+//     (ds_read_b128); the activations arrive in B-fragment order (quant_rows_frag_kernel); one v_mfma_i32_16x16x64_i8 per
+//     (group, token tile) gives the exact int32 group sums; products ((float)ival * ws) * xs (infer/infer.c:672).
+//   * ALL token tiles (up to 4 x 16 tokens) are taken by the same wave, so a weight byte is read once from HBM and once
+//     from LDS per token tile, never again from L2.
+//   * the chain: per token tile a slot (256 running values) and a counter (half chunks folded so far) in LDS.  The owner
+//     of half chunk h forms its 8 x 4 products, waits until the counter says h, adds them to the slot's values in
+//     ascending group order (infer.c:668-674), stores the values back and sets the counter to h + 1: one short link per
+//     half chunk, the products of later half chunks and token tiles are formed while earlier links are still travelling.
+//     The owner of the last half chunk runs the epilogue.  SwiGLU: the W1 team and the W3 team of a row tile sit in the
+//     same workgroup; W3's last owner publishes, W1's last owner combines.
+// Bit-identical to the GEMV path and to the reference's matmul_quant (infer/infer.c:654-679).
+// Takes: group size 64, group count a multiple of 4, interior segments multiples of 16 rows.
+#include "gemv_common.h"
+
+namespace nano {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct G5Dev {
+    const int8_t *w[3]; const float *ws[3]; float *out[3];
+    uint32_t rows[3], out_bstride[3], out_pstride[3];
+    uint32_t n, ng, epi, nb, nhc, ntiles, tt, nkw, cpw, teams, nmat;
+    const int8_t *xf; const float *xsf; const uint32_t *pos;
+};
+
+constexpr uint32_t G5_PITCH = 528, G5_WBUF = 16 * G5_PITCH;           // transposition buffer of one wave: 16 rows x 512 B
+constexpr uint32_t G5_LDS_WAVE = G5_WBUF + 512 + 512;                 // + weight scales [8][16] + activation scales [8][16]
+constexpr uint32_t G5_MAX_WAVES = 12;
+
+__device__ __forceinline__ uint32_t lds_load_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store_rel(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <int TT>
+__global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const G5Dev a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nkw = a.nkw, nmat = a.nmat;
+    const uint32_t team = wid / nkw, kw = wid % nkw;
+    const uint32_t unit = blockIdx.x * a.teams + team;                  // (row tile, matrix)
+    const uint32_t tile = unit / nmat, mat = unit % nmat;
+    const uint32_t n = a.n, ng = a.ng, nhc = a.nhc, tt = a.tt;
+    const uint32_t m = lane & 15u, kq = lane >> 4;
+
+    const uint32_t nwaves = a.teams * nkw;
+    int8_t *wbuf = reinterpret_cast<int8_t *>(smem) + (size_t)wid * G5_LDS_WAVE;
+    float *wsl = reinterpret_cast<float *>(wbuf + G5_WBUF);            // [8 groups][16 rows]
+    float *xsl = wsl + 128;                                            // [8 groups][16 tokens]
+    float *slots = reinterpret_cast<float *>(smem + (size_t)nwaves * G5_LDS_WAVE);        // [team][TT][256]
+    uint32_t *flags = reinterpret_cast<uint32_t *>(slots + (size_t)a.teams * TT * 256u);  // [team][TT]
+    float *slot = slots + (size_t)team * TT * 256u;
+    uint32_t *flag = flags + team * TT;
+
+    // ---- which segment (q | k | v share a launch; SwiGLU: matrix 0 = W1, matrix 1 = W3 over the same rows) -----------------
+    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
+    const uint32_t grow0 = tile * 16u;
+    const int sel = nmat == 2 ? (int)mat : (int)(grow0 >= b0) + (int)(grow0 >= b1);
+    const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
+    const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
+    const int osel = nmat == 2 ? 0 : sel;
+    float *out0 = osel == 0 ? a.out[0] : osel == 1 ? a.out[1] : a.out[2];
+    const uint32_t rows0 = nmat == 2 ? a.rows[0] : sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
+    const uint32_t obs = osel == 0 ? a.out_bstride[0] : osel == 1 ? a.out_bstride[1] : a.out_bstride[2];
+    const uint32_t ops = osel == 0 ? a.out_pstride[0] : osel == 1 ? a.out_pstride[1] : a.out_pstride[2];
+    const uint32_t lrow0 = grow0 - (nmat == 2 ? 0u : sel == 0 ? 0u : sel == 1 ? b0 : b1);
+    const bool live = tile < a.ntiles;
+
+    const __amdgpu_buffer_rsrc_t rw = mkrsrc(w0, live ? rows0 * n : 0u);
+    const __amdgpu_buffer_rsrc_t rs = mkrsrc(ws0, live ? rows0 * ng * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rxf = mkrsrc(a.xf, tt * ng * 1024u);
+    const __amdgpu_buffer_rsrc_t rxs = mkrsrc(a.xsf, tt * ng * 64u);
+
+    const uint32_t hlast = nhc - 1u;                                   // its owner in the W1 / only team runs the epilogue
+
+    // ---- weight pieces of a half chunk: 16 rows x 512 B, two rows per load instruction (lane l: row 2r + l/32) -------------
+    int4 wA[8];
+    const uint32_t wrow = lane >> 5, wcol = (lane & 31u) * 16u;
+    auto issue_w = [&](uint32_t h) {
+        const uint32_t col = h * 512u + wcol;
+        const uint32_t base = (h < nhc && col < n) ? (lrow0 + wrow) * n + col : OOB;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            // rows beyond the segment: out of range -> 0 (the scalar offset takes part in the range check of a raw buffer only
+            // through the address, so the row step stays in the lane offset where the segment's last rows need the check)
+            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(base == OOB ? OOB : base + (uint32_t)(2 * r) * n), 0, 2);
+            wA[r] = make_int4(v.x, v.y, v.z, v.w);
+        }
+    };
+    issue_w(kw);
+    if (kw == 0u && lane < (uint32_t)TT) flag[lane] = 0u;
+    __syncthreads();                                                   // the only workgroup barrier: the counters are armed
+    if (!live) return;
+
+    auto load_fb = [&](i32x4 (&fb)[8], float4 &xsv, uint32_t g0, uint32_t t) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+            fb[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)((g0 + j < ng && t < tt) ? lane * 16u : OOB), (int)((t * ng + g0 + j) * 1024u), 0);   // uniform part in the scalar offset; the range check is on the lane part
+        const uint32_t xg = g0 + (lane >> 2);                           // lanes 0..31: group g0 + l/4, tokens 4 (l%4) .. +3
+        xsv = bload_f4(rxs, (lane < 32u && xg < ng && t < tt) ? ((t * ng + xg) * 16u + (lane & 3u) * 4u) * 4u : OOB);
+    };
+
+    for (uint32_t h = kw; h < nhc; h += nkw) {
+        const uint32_t g0 = h * 8u;
+        // 1. the half chunk's weight pieces: registers -> the transposition buffer
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<int4 *>(wbuf + (size_t)(2 * r + wrow) * G5_PITCH + wcol) = wA[r];
+        // 2. what this half chunk needs now: weight scales (lanes 0..31: row l/2, groups g0 + 4 (l%2) .. +3), first fragments
+        const uint32_t sg = g0 + (lane & 1u) * 4u;
+        const float4 wsv = bload_f4(rs, (lane < 32u && sg < ng) ? ((lrow0 + (lane >> 1)) * ng + sg) * 4u : OOB);
+        i32x4 fb[8]; float4 xsv;
+        load_fb(fb, xsv, g0, 0u);
+        issue_w(h + nkw);                                               // prefetch; behind the fragments in the load queue (loads return in issue order)
+        if (lane < 32u) {
+            const uint32_t r = lane >> 1, gq = (lane & 1u) * 4u;
+            wsl[(gq + 0u) * 16u + r] = wsv.x; wsl[(gq + 1u) * 16u + r] = wsv.y; wsl[(gq + 2u) * 16u + r] = wsv.z; wsl[(gq + 3u) * 16u + r] = wsv.w;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < (uint32_t)TT; t++) {
+            if (t < tt) {
+                if (lane < 32u) *reinterpret_cast<float4 *>(xsl + lane * 4u) = xsv;
+                // 3. 8 groups: A fragment from LDS, MFMA, products
+                float p[8][4];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) {
+                    const i32x4 fa = *reinterpret_cast<const i32x4 *>(wbuf + (size_t)m * G5_PITCH + j * 64u + kq * 16u);
+                    const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb[j], v4i{0, 0, 0, 0}, 0, 0, 0);
+                    const float4 wv = *reinterpret_cast<const float4 *>(wsl + j * 16u + kq * 4u);
+                    const float xsc = xsl[j * 16u + m];
+                    p[j][0] = ((float)cv[0] * wv.x) * xsc; p[j][1] = ((float)cv[1] * wv.y) * xsc;                 // infer.c:672
+                    p[j][2] = ((float)cv[2] * wv.z) * xsc; p[j][3] = ((float)cv[3] * wv.w) * xsc;
+                }
+                // 4. the next token tile's fragments, once this tile's are consumed (none left: out-of-range addresses)
+                if (t + 1u < (uint32_t)TT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_fb(fb, xsv, g0, t + 1u);
+                }
+                // 5. the chain link of (half chunk h, token tile t): the running values so far, this half chunk's groups in
+                //    ascending order, on to the owner of h + 1 -- or out through the epilogue
+                const uint32_t tok = t * 16u + m;
+                const bool fin = h == hlast && mat == 0u;
+                float *orow = out0 + (size_t)tok * obs + lrow0 + kq * 4u;
+                float oldv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (fin && a.epi == GEMV_EPI_RESID && tok < a.nb) {      // issued before the wait: the residual stream is never position indexed
+#pragma unroll
+                    for (int i = 0; i < 4; i++) if (lrow0 + kq * 4u + i < rows0) oldv[i] = orow[i];
+                }
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                if (h != 0u) {
+                    while (lds_load_acq(flag + t) != h) __builtin_amdgcn_s_sleep(1);
+                    const float4 in = *reinterpret_cast<const float4 *>(slot + t * 256 + lane * 4u);
+                    acc[0] = in.x; acc[1] = in.y; acc[2] = in.z; acc[3] = in.w;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) { acc[0] += p[j][0]; acc[1] += p[j][1]; acc[2] += p[j][2]; acc[3] += p[j][3]; }
+                if (!fin) {
+                    *reinterpret_cast<float4 *>(slot + t * 256 + lane * 4u) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    lds_store_rel(flag + t, h + 1u);
+                } else {
+                    // ---- epilogue: store | residual add | SwiGLU with the W3 team's values ------------------------------------
+                    float v1[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (nmat == 2u) {
+                        const uint32_t *f3 = flag + TT;                // the W3 team is the next team of the workgroup
+                        while (lds_load_acq(f3 + t) != nhc) __builtin_amdgcn_s_sleep(1);
+                        const float4 in = *reinterpret_cast<const float4 *>(slot + TT * 256 + t * 256 + lane * 4u);
+                        v1[0] = in.x; v1[1] = in.y; v1[2] = in.z; v1[3] = in.w;
+                    }
+                    if (tok < a.nb) {
+                        const uint32_t opos = ops ? a.pos[tok] : 0u;
+                        float *o = orow + (size_t)opos * ops;
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            if (lrow0 + kq * 4u + i < rows0) o[i] = finish_epi(a.epi, acc[i], v1[i], oldv[i]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+static uint32_t total_rows5(const GemvArgs &a) {
+    uint32_t rows = 0;
+    if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
+    return rows;
+}
+
+template <int TT>
+static void launch_tt(const G5Dev &d, uint32_t nwg, uint32_t waves, size_t lds, hipStream_t st) {
+    auto kern = &gemm_q80_g5_kernel<TT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(waves * 64), lds, st, d);
+}
+
+}  // namespace
+
+bool gemm_q80_g5_supports(const GemvArgs &a) {
+    if (!gemm_q80_g2_supports(a) || a.gs != 64) return false;
+    if ((a.n / a.gs) % 4 != 0) return false;                           // float4 runs of scales
+    if (a.nb > 64) return false;
+    for (uint32_t s = 0; s < a.nseg; s++) if ((uint64_t)a.seg[s].rows * a.n >= (1ull << 32) - (1u << 20)) return false;   // 32-bit buffer offsets per segment
+    return true;
+}
+
+// a.xq_in / a.xs_in: the activations in fragment order (launch_quant_rows_frag)
+hipError_t launch_gemm_q80_g5(const GemvArgs &a, hipStream_t st) {
+    if (!a.xq_in || !a.xs_in || !gemm_q80_g5_supports(a)) return hipErrorInvalidValue;
+    G5Dev d{};
+    for (int i = 0; i < 3; i++) {
+        const bool live = i < (int)a.nseg;
+        d.w[i] = live ? reinterpret_cast<const int8_t *>(a.seg[i].w) : nullptr;
+        d.ws[i] = live ? a.seg[i].ws : nullptr;
+        d.out[i] = live ? a.seg[i].out : nullptr;
+        d.rows[i] = live ? a.seg[i].rows : 0;
+        d.out_bstride[i] = live ? a.seg[i].out_bstride : 0;
+        d.out_pstride[i] = live ? a.seg[i].out_pstride : 0;
+    }
+    const bool sw = a.epi == GEMV_EPI_SWIGLU;
+    d.n = a.n; d.ng = a.n / a.gs; d.epi = a.epi; d.nb = a.nb; d.nhc = (d.ng + 7) / 8;
+    d.ntiles = (total_rows5(a) + 15) / 16;
+    d.tt = (a.nb + 15) / 16;
+    d.nmat = sw ? 2u : 1u;
+    d.xf = a.xq_in; d.xsf = a.xs_in; d.pos = a.pos;
+    // the split: enough waves to keep ~4 per SIMD busy, never more than the half chunks of a row or the waves of a workgroup
+    const uint32_t TTc = d.tt <= 1 ? 1u : d.tt == 2 ? 2u : 4u;
+    const uint32_t units = d.ntiles * d.nmat, maxkw = G5_MAX_WAVES / d.nmat;
+    uint32_t nkw = 4096u / (units ? units : 1u);
+    if (nkw < 1) nkw = 1;
+    if (nkw > maxkw) nkw = maxkw;
+    if (nkw > d.nhc) nkw = d.nhc;
+    d.cpw = (d.nhc + nkw - 1) / nkw;
+    d.nkw = (d.nhc + d.cpw - 1) / d.cpw;
+    // teams per workgroup: one unit (SwiGLU: one W1/W3 pair) while workgroups are scarce, 8 waves' worth when plentiful
+    uint32_t groups = 1;                                               // units (pairs) per workgroup
+    const uint32_t team_waves = d.nkw * d.nmat;
+    if (d.ntiles > 2048u) { groups = 4u / team_waves; if (groups < 1) groups = 1; }
+    d.teams = groups * d.nmat;
+    const uint32_t waves = d.teams * d.nkw;
+    const uint32_t tiles_per_wg = groups;
+    const uint32_t nwg = (d.ntiles + tiles_per_wg - 1) / tiles_per_wg;
+    const size_t lds = (size_t)waves * G5_LDS_WAVE + (size_t)d.teams * TTc * 1024u + (((size_t)d.teams * TTc * 4u + 15u) & ~(size_t)15u);
+    if (TTc == 1) launch_tt<1>(d, nwg, waves, lds, st);
+    else if (TTc == 2) launch_tt<2>(d, nwg, waves, lds, st);
+    else launch_tt<4>(d, nwg, waves, lds, st);
+    return hipGetLastError();
+}
+
+}  // namespace nano

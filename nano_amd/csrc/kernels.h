@@ -67,6 +67,9 @@ hipError_t launch_gemm_q80_g3(const GemvArgs &a, uint32_t max_wg, hipStream_t st
 // G4, wave-independent variant (gemm_q80_g4.hip): same inputs as G2
 bool gemm_q80_g4_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_g4(const GemvArgs &a, hipStream_t st);
+// G5, row length split over a chained team of waves, all token tiles per wave (gemm_q80_g5.hip): same inputs as G2
+bool gemm_q80_g5_supports(const GemvArgs &a);
+hipError_t launch_gemm_q80_g5(const GemvArgs &a, hipStream_t st);
 hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                                   int8_t *xf, float *xsf, hipStream_t st);
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
