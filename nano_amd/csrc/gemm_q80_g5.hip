@@ -229,23 +229,28 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, hipStream_t st) {
     d.tt = (a.nb + 15) / 16;
     d.nmat = sw ? 2u : 1u;
     d.xf = a.xq_in; d.xsf = a.xs_in; d.pos = a.pos;
-    // the split: enough waves to keep ~4 per SIMD busy, never more than the half chunks of a row or the waves of a workgroup
+    // The split.  A workgroup = one row tile (SwiGLU: the W1/W3 pair) x nkw waves; a CU holds 12 waves (3 per SIMD at
+    // <= 168 VGPRs).  Take the deepest split whose workgroups are ALL resident at once (no second round of workgroups, whose
+    // tail would run on a mostly idle chip); matrices too tall for that (the classifier) get one wave per tile, 4 per group.
     const uint32_t TTc = d.tt <= 1 ? 1u : d.tt == 2 ? 2u : 4u;
-    const uint32_t units = d.ntiles * d.nmat, maxkw = G5_MAX_WAVES / d.nmat;
-    uint32_t nkw = 4096u / (units ? units : 1u);
-    if (nkw < 1) nkw = 1;
-    if (nkw > maxkw) nkw = maxkw;
-    if (nkw > d.nhc) nkw = d.nhc;
-    d.cpw = (d.nhc + nkw - 1) / nkw;
-    d.nkw = (d.nhc + d.cpw - 1) / d.cpw;
-    // teams per workgroup: one unit (SwiGLU: one W1/W3 pair) while workgroups are scarce, 8 waves' worth when plentiful
-    uint32_t groups = 1;                                               // units (pairs) per workgroup
-    const uint32_t team_waves = d.nkw * d.nmat;
-    if (d.ntiles > 2048u) { groups = 4u / team_waves; if (groups < 1) groups = 1; }
+    static int cus = 0;
+    if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+    const uint32_t maxkw = G5_MAX_WAVES / d.nmat;
+    uint32_t nkw = 1, groups = 1;                                      // groups: row tiles (pairs) per workgroup
+    bool fits = false;
+    for (uint32_t k = maxkw < d.nhc ? maxkw : d.nhc; k >= 1; k--) {
+        const uint32_t cpw = (d.nhc + k - 1) / k, kk = (d.nhc + cpw - 1) / cpw;            // balanced: no wave owns more than cpw half chunks
+        const uint32_t wg_waves = kk * d.nmat;
+        const size_t wg_lds = (size_t)wg_waves * G5_LDS_WAVE + (size_t)d.nmat * TTc * 1040u;
+        uint32_t slots = G5_MAX_WAVES / wg_waves;
+        if ((size_t)slots * wg_lds > 160u * 1024u) slots = (uint32_t)(160u * 1024u / wg_lds);
+        if (slots && d.ntiles <= (uint32_t)cus * slots) { nkw = kk; fits = true; break; }
+    }
+    if (!fits) { nkw = 1; groups = 4u / d.nmat; }
+    d.nkw = nkw; d.cpw = (d.nhc + nkw - 1) / nkw;
     d.teams = groups * d.nmat;
     const uint32_t waves = d.teams * d.nkw;
-    const uint32_t tiles_per_wg = groups;
-    const uint32_t nwg = (d.ntiles + tiles_per_wg - 1) / tiles_per_wg;
+    const uint32_t nwg = (d.ntiles + groups - 1) / groups;
     const size_t lds = (size_t)waves * G5_LDS_WAVE + (size_t)d.teams * TTc * 1024u + (((size_t)d.teams * TTc * 4u + 15u) & ~(size_t)15u);
     if (TTc == 1) launch_tt<1>(d, nwg, waves, lds, st);
     else if (TTc == 2) launch_tt<2>(d, nwg, waves, lds, st);
