@@ -467,7 +467,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
         const uint32_t h = h0 + m;
         if (nsplit == 1) {
-            a.xba_out[(size_t)b * a.q_dim + (size_t)h * hd + i] = o / L;                              // softmax normalisation (infer.c:631-633)
+            const float val = o / L;                                                                  // softmax normalisation (infer.c:631-633)
+            a.xba_out[(size_t)b * a.q_dim + (size_t)h * hd + i] = val;
+            if (a.xf_out) {
+                // Q80 group of 64 = the 64 lanes of this wave (head_dim % 64 == 0): quantize (infer/tensor.c:21-46) and store in
+                // fragment order xf[token tile][group][kq * 16 + token % 16][16 bytes], byte j of a group at kq = j / 16
+                float mx = fabsf(val);
+#pragma unroll
+                for (int o2 = 1; o2 < 64; o2 <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+                const float scale = mx / 127.0f;
+                const uint32_t e = h * hd + i, g = e >> 6, jj = e & 63u, ng = a.q_dim >> 6;
+                const size_t gb = (size_t)(b >> 4) * ng + g;
+                a.xf_out[gb * 1024u + (size_t)((jj >> 4) * 16u + (b & 15u)) * 16u + (jj & 15u)] = (int8_t)q80_quant1(val, scale);
+                if (jj == 0) a.xsf_out[gb * 16u + (b & 15u)] = scale;
+            }
         } else {
             a.out[((size_t)b * nsplit + split) * a.q_dim + (size_t)h * hd + i] = o;
             if (i == 0) { float *ml = a.ml + (((size_t)b * a.n_head + h) * nsplit + split) * 2; ml[0] = M; ml[1] = L; }

@@ -97,10 +97,8 @@ struct NanoHipModel {
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
-    bool use_g5 = true;                                   // gemm_q80_g5.hip's chained K-split kernel where it takes the launch (NANO_GEMM_G5=0: off)
-    bool use_g4 = true;                                   // ... gemm_q80_g4.hip's wave-independent kernel first (NANO_GEMM_G4=0: off)
-    bool use_g3 = true;                                   // ... and gemm_q80_g3.hip's persistent kernel where the matrix has many rows (NANO_GEMM_G3=0: G2 only)
-    bool use_g2 = true;                                   // batched launches take gemm_q80.hip's G2 kernel (NANO_GEMM_G2=0: the round-1 kernels)
+    bool attn_quant = true;                               // batched steps: the attention kernel also writes the Wo GEMM's quantized input (NANO_ATTN_QUANT=0: quantizer launch)
+    bool use_g5 = true;                                   // batched Q80 launches of group size 64 take gemm_q80_g5.hip's chained K-split kernel (NANO_GEMM_G5=0: G2 everywhere)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
@@ -376,10 +374,8 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
-    if (const char *g2 = getenv("NANO_GEMM_G2")) m->use_g2 = *g2 && *g2 != '0';
-    if (const char *g3 = getenv("NANO_GEMM_G3")) m->use_g3 = *g3 && *g3 != '0';
-    if (const char *g4 = getenv("NANO_GEMM_G4")) m->use_g4 = *g4 && *g4 != '0';
     if (const char *g5 = getenv("NANO_GEMM_G5")) m->use_g5 = *g5 && *g5 != '0';
+    if (const char *aq = getenv("NANO_ATTN_QUANT")) m->attn_quant = *aq && *aq != '0';
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
     if (const char *sm = getenv("NANO_STRICT")) if (*sm && *sm != '0') return nano_hip_set_strict(m, 1);
@@ -430,31 +426,16 @@ static GemvArgs gemv_slice(const GemvArgs &a, uint32_t b0, uint32_t cnt) {
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     const uint32_t max_wg = (uint32_t)m->cus * 8;
     if (m->d.quant_type == NANO_QUANT_Q4K) return launch_gemv_q4k(a, max_wg, m->st);
-    if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && m->use_g2 && gemm_q80_g2_supports(a)) {
-        // quantize every sequence's activation once, straight into MFMA fragment order, then the G2 GEMM
-        hipError_t e = launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
-        if (e != hipSuccess) return e;
+    if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && gemm_q80_g2_supports(a)) {
+        // quantize every sequence's activation once, straight into MFMA fragment order, then the GEMM: G5 (group size 64: the
+        // row length split over a chained team of waves, gemm_q80_g5.hip) or the general G2 kernel.  One arithmetic, same bits.
+        if (!a.frag_ready) {
+            const hipError_t e = launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
+            if (e != hipSuccess) return e;
+        }
         a.xq_in = m->gq; a.xs_in = m->gxs;
-        // Three kernels, one arithmetic; the choice is by shape (measured on Qwen3-4B / 0.6B matrices, tools/batch_probe.sh):
-        //   G2  few (row tile, token tile) pairs and long rows (Wo, W2 up to 32 tokens): the row length is split over the
-        //       eight waves of a workgroup, so 160 tiles still fill the chip;
-        //   G3  64 tokens on a very tall matrix (the classifier): activations staged once per 64 rows, persistent tiles;
-        //   G4  everything else: wave-independent tiles, no barriers.
-        uint32_t rows = 0;
-        if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
-        const uint32_t ntiles = (rows + 15) / 16, tt = (a.nb + 15) / 16;
         if (m->use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, m->st);
-        const bool g4 = m->use_g4 && gemm_q80_g4_supports(a), g3 = m->use_g3 && gemm_q80_g3_supports(a);
-        if (g3 && tt > 2 && ntiles >= 2048) return launch_gemm_q80_g3(a, max_wg, m->st);
-        if (g4 && !(ntiles * tt < 512 && tt <= 2)) return launch_gemm_q80_g4(a, m->st);
         return launch_gemm_q80_g2(a, m->st);
-    }
-    if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && gemm_q80_supports(a)) {
-        // (NANO_GEMM_G2=0: the round-1 kernels, kept for A/B measurements)
-        hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
-        if (e != hipSuccess) return e;
-        a.xq_in = m->gq; a.xs_in = m->gxs;
-        return launch_gemm_q80(a, m->st);
     }
     if (a.nb > 8) {
         // More sequences than a GEMV launch takes and a launch the GEMM does not take (row length / group size not a
@@ -487,7 +468,7 @@ static GemvArgs classifier_args(const NanoHipModel *m, uint32_t nb) {
 
 static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
     GemvArgs a = classifier_args(m, nb);
-    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && nb <= 8 && !(takes_mfma(m, a) && ((m->use_g2 && gemm_q80_g2_supports(a)) || gemm_q80_supports(a)))) {      // per-tile arg-max partials for the sampler
+    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && nb <= 8 && !(takes_mfma(m, a) && gemm_q80_g2_supports(a))) {      // per-tile arg-max partials for the sampler
         a.tile_max = m->tile_max;
         *ntiles_out = gemv_tiles(m->d.quant_type, a);
     }
@@ -516,6 +497,14 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     const uint32_t nsplit = m->pf ? step_nsplit(m, 1, range_hint) : step_nsplit(m, nb, range_hint);
     const bool pf_combine = m->pf && nsplit > 1;
     m->nsplit = nsplit;
+    // Single-split attention of a step whose Wo launch goes to the batched GEMM: the attention kernel writes Wo's quantized
+    // input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
+    bool wo_frag = false;
+    if (m->attn_quant && nsplit == 1 && !m->lora_on && d.quant_type == NANO_QUANT_Q80 && d.group_size == 64 && m->hd % 64 == 0) {
+        GemvArgs wa{};
+        wa.nseg = 1; wa.seg[0] = mkseg(m->W[WO][0], m->x, E, E); wa.n = QD; wa.gs = 64; wa.nb = nb; wa.xin = m->xba; wa.xin_bstride = QD; wa.epi = GEMV_EPI_RESID;
+        wo_frag = takes_mfma(m, wa) && gemm_q80_g2_supports(wa);
+    }
     EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
                   m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0 };
     const uint32_t skip = m->skip_mask;
@@ -558,6 +547,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
             a.kv_half = m->kv_half ? 1u : 0u; a.vraw = m->kv_half ? m->vraw : nullptr;
+            if (wo_frag) { a.xf_out = m->gq; a.xsf_out = m->gxs; }
             if (m->pf) {
                 // batched prefill: the nb tokens are consecutive positions of ONE sequence.  Pass 1 finishes every k row
                 // (norm + RoPE + cache write, nothing else) so that pass 2 finds the rows of the earlier tokens of the
@@ -585,6 +575,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 a.resid_add = m->lora_o1; a.resid_add_bstride = E;
             }
             if (nsplit > 1 && !pf_combine) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
+            a.frag_ready = (wo_frag && !(skip & 2)) ? 1u : 0u;
             if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944

@@ -1,16 +1,12 @@
-// gemm_q80.hip -- Q80 (W8A8) skinny GEMM on the matrix cores for 9..64 tokens per weight read (large decode batches;
-// SURVEY 7 step 7 / 8f-1).  out[t][r] = matmul_quant(W[r,:], x_t) for every token t, BIT-IDENTICAL to the per-token
-// reference (infer/infer.c:654-679): one v_mfma_i32_16x16x64_i8 forms the exact int32 group sums of a 16-row x 16-token
-// tile for one 64-wide quantization group (K = group size -- this is where an int8 MFMA tile actually forms), the
-// group product ((float)ival * ws[r][g]) * xs[t][g] is applied on the VALU and accumulated per (row, token) in
-// ascending group order, exactly like the GEMV kernels.
-//
-// Mapping: a workgroup owns a 16-row tile and stages its weights in LDS with coalesced 1 KiB loads; wave w owns token
-// tile w and walks all groups of the row in order, so the weight bytes are read from HBM once for up to 64 tokens.
+// gemm_q80.hip -- Q80 (W8A8) skinny GEMM on the matrix cores for 9..64 tokens per weight read (large decode batches,
+// batched prefill): the general kernel (G2: any group size 32..256, any group count) and the
+// activation quantizers of the batched path.  gemm_q80_g5.hip holds the faster kernel for group size 64.
+// out[t][r] = matmul_quant(W[r,:], x_t) for every token t, BIT-IDENTICAL to the per-token reference
+// (infer/infer.c:654-679): one v_mfma_i32_16x16x64_i8 forms the exact int32 group sums of a 16-row x 16-token tile for one
+// 64-wide run of a quantization group, the group product ((float)ival * ws[r][g]) * xs[t][g] is applied on the VALU and
+// accumulated per (row, token) in ascending group order, exactly like the GEMV kernels.
 // MFMA operand layout (verified on gfx950, tools/kbench/mfma_probe.hip): lane l holds
 // A[m = l%16][k = 16*(l/16) .. +15], B[k = same][n = l%16]; result c[i] = C[m = 4*(l/16) + i][n = l%16].
-// The activations of all tokens are quantized once per GEMM by quant_rows_kernel (rmsnorm + quantize, reference
-// infer/tensor.c:21-46, infer.c:601-614) into a global scratch the GEMM reads through L2.
 #include <type_traits>
 #include "gemv_common.h"
 
@@ -57,31 +53,12 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const float *x, uint32_
     }
 }
 
-struct GemmDev {
-    const int8_t *w[3]; const float *ws[3]; float *out[3];
-    uint32_t rows[3], out_bstride[3], out_pstride[3];
-    uint32_t n, ng, epi, nb, ttiles, n16, magic_ng, kc;
-    const int8_t *xq; const float *xs; const uint32_t *pos;
-};
-
 // One quantization group of a 16x16 tile needs GS bytes of K per weight row and per token: FR = fragment registers
 // (one per MFMA) per group.  GS >= 64: FR = GS/64 MFMAs of K = 64, a lane holds 16 bytes per fragment; GS = 32: one
 // MFMA of K = 32, 8 bytes per lane.
 template <int GS> struct Frag { i32x4 v; };
 template <> struct Frag<32> { long v; };
 
-template <int GS>
-__device__ __forceinline__ Frag<GS> load_frag(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t kq, int ks) {
-    Frag<GS> f;
-    if constexpr (GS == 32) {
-        const uint32_t o = off == OOB ? OOB : off + kq * 8u;
-        const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(r, (int)o, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b32(r, (int)(o == OOB ? OOB : o + 4u), 0, 0);
-        f.v = (long)(((unsigned long)hi << 32) | lo);
-    } else {
-        f.v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off == OOB ? OOB : off + (uint32_t)ks * 64u + kq * 16u), 0, 0);
-    }
-    return f;
-}
 template <int GS>
 __device__ __forceinline__ v4i mma(const Frag<GS> &a, const Frag<GS> &b, v4i c) {
     if constexpr (GS == 32) return __builtin_amdgcn_mfma_i32_16x16x32_i8(a.v, b.v, c, 0, 0, 0);
@@ -97,332 +74,12 @@ __device__ __forceinline__ Frag<GS> lds_frag(const int8_t *row, uint32_t koff, u
     return f;
 }
 
-// One workgroup = one 16-row tile (both matrices for SwiGLU); wave w = token tile w.  The tile's weights are staged in
-// LDS with fully coalesced loads (each wave streams 4 rows, 1 KiB per load instruction), up to KC bytes of row length
-// per pass, all loads of a pass issued before the first LDS write; the MFMA A fragments are then ds_read_b128 at
-// row pitch KC+16 (conflict-free: consecutive rows are 4 banks apart).  B fragments (this wave's 16 tokens) come
-// straight from the quantized-activation scratch through L2, 16 in flight per batch.
-template <int GS, bool SW>
-__global__ __launch_bounds__(256) void gemm_q80_mfma_kernel(const GemmDev a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int FR = GS >= 64 ? GS / 64 : 1;                  // MFMA fragments per group
-    constexpr int GB = 16 / FR;                                 // groups per B-fragment batch
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t n = a.n, ng = a.ng, ngp = ng | 1u;            // odd LDS pitch for the scale tables
-    constexpr bool swiglu = SW;                                  // compile-time: no per-group branches
-    constexpr uint32_t nmat = SW ? 2u : 1u;
-    const uint32_t KC = a.kc, KP = KC + 16u;                     // row bytes staged per pass, LDS row pitch
-    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
-    const uint32_t grow0 = blockIdx.x * 16u;
-    const int sel = swiglu ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
-    const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
-    const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
-    float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
-    const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
-    const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
-    const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
-    const uint32_t lrow0 = grow0 - (sel == 0 ? 0u : sel == 1 ? b0 : b1);
-
-    // LDS: wt[nmat][16][KP] int8 | wsl[nmat][16][ngp] | xsl[4 waves][16][ngp]
-    int8_t *wt = reinterpret_cast<int8_t *>(smem);
-    float *wsl = reinterpret_cast<float *>(smem + (size_t)nmat * 16u * KP);
-    float *xsl = wsl + (size_t)nmat * 16u * ngp + (size_t)wid * 16u * ngp;
-
-    const uint32_t m = (uint32_t)lane & 15u, kq = (uint32_t)lane >> 4;
-    const __amdgpu_buffer_rsrc_t rw0 = mkrsrc(w0, rows0 * n), rw1 = mkrsrc(swiglu ? a.w[1] : nullptr, swiglu ? rows0 * n : 0u);
-    const __amdgpu_buffer_rsrc_t rs0 = mkrsrc(ws0, rows0 * ng * 4u), rs1 = mkrsrc(swiglu ? a.ws[1] : nullptr, swiglu ? rows0 * ng * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xq, a.nb * a.n16), rxs = mkrsrc(a.xs, a.nb * ng * 4u);
-    const bool has_tile = (uint32_t)wid < a.ttiles;               // waves beyond the token tiles only help staging
-    const uint32_t tok = (uint32_t)wid * 16u + m;
-    const uint32_t xrow = (has_tile && tok < a.nb) ? tok * a.n16 : OOB;
-
-    // ---- pass 0 loads first: this wave's 4 weight rows (per matrix), 4 x 1 KiB each, then the first B fragments ----
-    int4 stg[SW ? 2 : 1][4][4];                                   // [matrix][row of this wave][1 KiB column chunk]
-    auto issue_w = [&](uint32_t c0) {
-#pragma unroll
-        for (int mt = 0; mt < (int)nmat; mt++) {
-            {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t row = lrow0 + (uint32_t)wid * 4u + r;
-#pragma unroll
-                    for (int jc = 0; jc < 4; jc++) {
-                        const uint32_t col = (uint32_t)jc * 1024u + (uint32_t)lane * 16u;       // inside the pass
-                        if ((uint32_t)jc * 1024u < KC) {                                         // uniform: an out-of-range load is not free
-                            const uint32_t off = (c0 + col < n) ? row * n + c0 + col : OOB;
-                            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mt ? rw1 : rw0, (int)off, 0, 2);
-                            stg[mt][r][jc] = make_int4(v.x, v.y, v.z, v.w);
-                        }
-                    }
-                }
-            }
-        }
-    };
-    Frag<GS> fb[GB][FR];
-    auto issue_b = [&](uint32_t g0) {
-#pragma unroll
-        for (int gi = 0; gi < GB; gi++) {
-            const uint32_t g = g0 + gi;
-            const uint32_t xo = (g < ng && xrow != OOB) ? xrow + g * GS : OOB;
-#pragma unroll
-            for (int ks = 0; ks < FR; ks++) fb[gi][ks] = load_frag<GS>(rx, xo, kq, ks);
-        }
-    };
-    issue_w(0);
-    if (has_tile) issue_b(0);
-
-    // scales: ws tile (shared by the waves) and this wave's xs tile -> LDS, all loads of a pass before the first write
-    const uint32_t nf4 = 4u * ng;                                  // float4 items per 16 x ng block (ng % 4 == 0)
-    for (uint32_t base = 0; base < nf4; base += 256u) {           // 4 x 64 items per pass: one round trip for ng <= 64
-        float4 tw[4], tw1[4], tx[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i4 = base + (uint32_t)k * 64u + (uint32_t)lane;
-            const uint32_t off = i4 < nf4 ? i4 * 16u : OOB;
-            const bool mine = (uint32_t)k == (uint32_t)wid;       // the four waves split the weight-scale block
-            tw[k] = tw1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mine) { tw[k] = bload_f4(rs0, off == OOB ? OOB : lrow0 * ng * 4u + off); if (swiglu) tw1[k] = bload_f4(rs1, off == OOB ? OOB : lrow0 * ng * 4u + off); }
-            tx[k] = bload_f4(rxs, (off == OOB || !has_tile) ? OOB : (uint32_t)wid * 16u * ng * 4u + off);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i4 = base + (uint32_t)k * 64u + (uint32_t)lane;
-            if (i4 < nf4) {
-                const uint32_t e = i4 * 4u, r = (e * a.magic_ng) >> 20, g = e - r * ng;      // e / ng, e < 16 * ng
-                if ((uint32_t)k == (uint32_t)wid) {
-                    float *dw = wsl + r * ngp + g; dw[0] = tw[k].x; dw[1] = tw[k].y; dw[2] = tw[k].z; dw[3] = tw[k].w;
-                    if (swiglu) { float *d1 = wsl + 16u * ngp + r * ngp + g; d1[0] = tw1[k].x; d1[1] = tw1[k].y; d1[2] = tw1[k].z; d1[3] = tw1[k].w; }
-                }
-                float *dx = xsl + r * ngp + g; dx[0] = tx[k].x; dx[1] = tx[k].y; dx[2] = tx[k].z; dx[3] = tx[k].w;
-            }
-        }
-    }
-
-    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t c0 = 0; c0 < n; c0 += KC) {                     // passes over the row length (one for n <= KC)
-        if (c0) { __syncthreads(); issue_w(c0); }                  // everybody is done reading the previous pass
-#pragma unroll
-        for (int mt = 0; mt < (int)nmat; mt++) {
-            {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int jc = 0; jc < 4; jc++) {
-                        const uint32_t col = (uint32_t)jc * 1024u + (uint32_t)lane * 16u;
-                        if (col < KC) *reinterpret_cast<int4 *>(wt + ((size_t)mt * 16u + (uint32_t)wid * 4u + r) * KP + col) = stg[mt][r][jc];
-                    }
-            }
-        }
-        __syncthreads();
-        if (has_tile) {
-            const uint32_t gbeg = c0 / GS, gend = min(ng, (c0 + KC) / GS);
-            for (uint32_t g0 = gbeg; g0 < gend; g0 += GB) {       // ascending groups: the reference's order (infer.c:668-674)
-                if (g0) issue_b(g0);
-#pragma unroll
-                for (int gi = 0; gi < GB; gi++) {
-                    const uint32_t g = g0 + gi;
-                    if (g < gend) {
-                        const uint32_t koff = g * GS - c0;
-                        v4i c0v = {0, 0, 0, 0};
-#pragma unroll
-                        for (int ks = 0; ks < FR; ks++) c0v = mma<GS>(lds_frag<GS>(wt + (size_t)m * KP, koff, kq, ks), fb[gi][ks], c0v);
-                        const float xsc = xsl[m * ngp + g];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) acc0[i] += ((float)c0v[i] * wsl[(kq * 4u + i) * ngp + g]) * xsc;          // infer.c:672
-                        if (swiglu) {
-                            v4i c1v = {0, 0, 0, 0};
-#pragma unroll
-                            for (int ks = 0; ks < FR; ks++) c1v = mma<GS>(lds_frag<GS>(wt + ((size_t)16u + m) * KP, koff, kq, ks), fb[gi][ks], c1v);
-#pragma unroll
-                            for (int i = 0; i < 4; i++) acc1[i] += ((float)c1v[i] * wsl[16u * ngp + (kq * 4u + i) * ngp + g]) * xsc;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (has_tile && tok < a.nb) {
-        float *o = out0 + (size_t)tok * obs + (ops ? (size_t)a.pos[tok] * ops : 0);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t r = lrow0 + kq * 4u + (uint32_t)i;
-            if (r < rows0) o[r] = finish_epi(a.epi, acc0[i], acc1[i], a.epi == GEMV_EPI_RESID ? o[r] : 0.0f);
-        }
-    }
-}
-
-// ---- up to 16 tokens per weight read: one token tile, the row length split over the four waves -----------------------
-// With a single token tile the kernel above keeps one wave busy and exposes a memory round trip per pass.  Here a
-// workgroup still owns a 16-row tile, but every pass (KC bytes of each row) is consumed by all four waves: wave w
-// forms the MFMA group sums of groups w, w+4, ... of the pass and writes the products ((float)ival * ws) * xs of its
-// groups to an LDS table; then thread (row, token) adds the pass's products to its accumulator in ascending group
-// order — the same float operations in the same order as the GEMV kernels, so the result is still bit-identical.
-// The activations of the 16 tokens are staged in LDS next to the weights (one coalesced read per pass), and the
-// loads of pass p+1 are in flight while pass p is multiplied and folded (the compute phase touches only LDS).
-template <int GS, bool SW, int KCK>
-__global__ __launch_bounds__(256) void gemm_q80_ksplit_kernel(const GemmDev a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int FR = GS >= 64 ? GS / 64 : 1;
-    constexpr uint32_t nmat = SW ? 2u : 1u;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t n = a.n, ng = a.ng, ngp = ng | 1u;
-    constexpr uint32_t KC = (uint32_t)KCK * 1024u, KP = KC + 16u, GPP = KC / (uint32_t)GS;      // compile-time: the group loops unroll
-    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
-    const uint32_t grow0 = blockIdx.x * 16u;
-    const int sel = SW ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
-    const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
-    const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
-    float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
-    const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
-    const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
-    const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
-    const uint32_t lrow0 = grow0 - (sel == 0 ? 0u : sel == 1 ? b0 : b1);
-
-    // LDS: wt[nmat][16][KP] int8 | xt[16][KP] int8 | wsl[nmat][16][ngp] | xsl[16][ngp] | prod[nmat][GPP][16][17]
-    int8_t *wt = reinterpret_cast<int8_t *>(smem);
-    int8_t *xt = wt + (size_t)nmat * 16u * KP;
-    float *wsl = reinterpret_cast<float *>(xt + (size_t)16u * KP);
-    float *xsl = wsl + (size_t)nmat * 16u * ngp;
-    float *prod = xsl + (size_t)16u * ngp;
-
-    const __amdgpu_buffer_rsrc_t rw0 = mkrsrc(w0, rows0 * n), rw1 = mkrsrc(SW ? a.w[1] : nullptr, SW ? rows0 * n : 0u);
-    const __amdgpu_buffer_rsrc_t rs0 = mkrsrc(ws0, rows0 * ng * 4u), rs1 = mkrsrc(SW ? a.ws[1] : nullptr, SW ? rows0 * ng * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xq, a.nb * a.n16), rxs = mkrsrc(a.xs, a.nb * ng * 4u);
-
-    // staging registers of one pass: this wave's 4 weight rows (per matrix) and 4 tokens, up to 2 x 1 KiB columns each
-    int4 sw[SW ? 2 : 1][4][2], sx[4][2];
-    auto issue = [&](uint32_t c0) {
-#pragma unroll
-        for (int jc = 0; jc < 2; jc++) {
-            if ((uint32_t)jc * 1024u < KC) {                       // uniform: an out-of-range load is not free
-                const uint32_t col = c0 + (uint32_t)jc * 1024u + (uint32_t)lane * 16u;
-#pragma unroll
-                for (int mt = 0; mt < (int)nmat; mt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t row = lrow0 + (uint32_t)wid * 4u + r;
-                        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mt ? rw1 : rw0, (int)(col < n ? row * n + col : OOB), 0, 2);
-                        sw[mt][r][jc] = make_int4(v.x, v.y, v.z, v.w);
-                    }
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t tok = (uint32_t)wid * 4u + r;
-                    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((col < n && tok < a.nb) ? tok * a.n16 + col : OOB), 0, 0);
-                    sx[r][jc] = make_int4(v.x, v.y, v.z, v.w);
-                }
-            }
-        }
-    };
-    issue(0);
-
-    // scales of the whole row length: ws tile(s) and the 16 tokens' xs -> LDS (up to 4 x 256 float4 items in flight)
-    const uint32_t nf4 = 4u * ng;                                  // float4 items per 16 x ng block (ng % 4 == 0)
-    for (uint32_t base = 0; base < nf4; base += 1024u) {
-        float4 tw[4], tw1[4], tx[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i4 = base + (uint32_t)k * 256u + (uint32_t)tid;
-            const uint32_t off = i4 < nf4 ? i4 * 16u : OOB;
-            tw1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            tw[k] = bload_f4(rs0, off == OOB ? OOB : lrow0 * ng * 4u + off);
-            if (SW) tw1[k] = bload_f4(rs1, off == OOB ? OOB : lrow0 * ng * 4u + off);
-            tx[k] = bload_f4(rxs, off);                            // tokens >= nb lie past the buffer: 0
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i4 = base + (uint32_t)k * 256u + (uint32_t)tid;
-            if (i4 < nf4) {
-                const uint32_t e = i4 * 4u, r = (e * a.magic_ng) >> 20, g = e - r * ng;      // e / ng, e < 16 * ng
-                float *dw = wsl + r * ngp + g; dw[0] = tw[k].x; dw[1] = tw[k].y; dw[2] = tw[k].z; dw[3] = tw[k].w;
-                if (SW) { float *d1 = wsl + 16u * ngp + r * ngp + g; d1[0] = tw1[k].x; d1[1] = tw1[k].y; d1[2] = tw1[k].z; d1[3] = tw1[k].w; }
-                float *dx = xsl + r * ngp + g; dx[0] = tx[k].x; dx[1] = tx[k].y; dx[2] = tx[k].z; dx[3] = tx[k].w;
-            }
-        }
-    }
-
-    const uint32_t m = (uint32_t)lane & 15u, kq = (uint32_t)lane >> 4;    // MFMA lane coordinates
-    const uint32_t fr = (uint32_t)tid >> 4, ftok = (uint32_t)tid & 15u;   // the (row, token) this thread accumulates
-    float acc0 = 0.0f, acc1 = 0.0f;
-    for (uint32_t c0 = 0; c0 < n; c0 += KC) {
-        if (c0) __syncthreads();                                   // the previous pass is multiplied and folded
-#pragma unroll
-        for (int jc = 0; jc < 2; jc++) {
-            const uint32_t col = (uint32_t)jc * 1024u + (uint32_t)lane * 16u;
-            if (col < KC) {
-#pragma unroll
-                for (int mt = 0; mt < (int)nmat; mt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) *reinterpret_cast<int4 *>(wt + ((size_t)mt * 16u + (uint32_t)wid * 4u + r) * KP + col) = sw[mt][r][jc];
-#pragma unroll
-                for (int r = 0; r < 4; r++) *reinterpret_cast<int4 *>(xt + ((size_t)(uint32_t)wid * 4u + r) * KP + col) = sx[r][jc];
-            }
-        }
-        __syncthreads();
-        if (c0 + KC < n) issue(c0 + KC);                           // in flight while this pass is consumed from LDS
-        const uint32_t gbeg = c0 / (uint32_t)GS;
-        const uint32_t gcnt = ng - gbeg < GPP ? ng - gbeg : GPP;
-        // this wave's groups of the pass: independent chains (LDS fragments -> MFMA -> products), unrolled so that
-        // their latencies overlap
-        Frag<GS> fa[GPP / 4][FR], fb[GPP / 4][FR], fa1[SW ? GPP / 4 : 1][FR];
-#pragma unroll
-        for (uint32_t j = 0; j < GPP / 4; j++) {
-            const uint32_t koff = (j * 4u + (uint32_t)wid) * (uint32_t)GS;
-#pragma unroll
-            for (int ks = 0; ks < FR; ks++) {
-                fa[j][ks] = lds_frag<GS>(wt + (size_t)m * KP, koff, kq, ks);
-                fb[j][ks] = lds_frag<GS>(xt + (size_t)m * KP, koff, kq, ks);
-                if (SW) fa1[j][ks] = lds_frag<GS>(wt + ((size_t)16u + m) * KP, koff, kq, ks);
-            }
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < GPP / 4; j++) {
-            const uint32_t gl = j * 4u + (uint32_t)wid, g = gbeg + gl;
-            if (gl < gcnt) {
-                const float xsc = xsl[m * ngp + g];
-                v4i c0v = {0, 0, 0, 0};
-#pragma unroll
-                for (int ks = 0; ks < FR; ks++) c0v = mma<GS>(fa[j][ks], fb[j][ks], c0v);
-#pragma unroll
-                for (int i = 0; i < 4; i++) prod[((size_t)gl * 16u + kq * 4u + i) * 17u + m] = ((float)c0v[i] * wsl[(kq * 4u + i) * ngp + g]) * xsc;      // infer.c:672
-                if (SW) {
-                    v4i c1v = {0, 0, 0, 0};
-#pragma unroll
-                    for (int ks = 0; ks < FR; ks++) c1v = mma<GS>(fa1[j][ks], fb[j][ks], c1v);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) prod[((size_t)(GPP + gl) * 16u + kq * 4u + i) * 17u + m] = ((float)c1v[i] * wsl[16u * ngp + (kq * 4u + i) * ngp + g]) * xsc;
-                }
-            }
-        }
-        __syncthreads();
-        // ascending groups: the reference's order (infer.c:668-674); the LDS reads of a block of 8 go out together
-#pragma unroll
-        for (uint32_t g8 = 0; g8 < GPP; g8 += 8u) {
-            float p0[8], p1[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8u; k++) {
-                p0[k] = prod[((size_t)(g8 + k) * 16u + fr) * 17u + ftok];
-                p1[k] = SW ? prod[((size_t)(GPP + g8 + k) * 16u + fr) * 17u + ftok] : 0.0f;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 8u; k++)
-                if (g8 + k < gcnt) { acc0 += p0[k]; if (SW) acc1 += p1[k]; }
-        }
-    }
-    if (ftok < a.nb && lrow0 + fr < rows0) {
-        float *o = out0 + (size_t)ftok * obs + (ops ? (size_t)a.pos[ftok] * ops : 0) + lrow0 + fr;
-        *o = finish_epi(a.epi, acc0, acc1, a.epi == GEMV_EPI_RESID ? *o : 0.0f);
-    }
-}
-
-
 // =====================================================================================================================
 // G2: the batched kernel of the BANDWIDTH-BOUND regime (large matrices, 8..64 tokens per weight read).
 //
-// What bounded the two kernels above on Qwen3-4B-size matrices (round 1: 1.3-2.6 TB/s, profiles/r02_4b_*): one pass of
-// weights in flight per workgroup with the load latency exposed at every pass, one workgroup per CU, a single wave doing
-// all MFMA work of a token tile.  G2 keeps the arithmetic (exact int32 group sums on the matrix cores, products
+// (What bounded round 1's two kernels on Qwen3-4B-size matrices, 1.3-2.6 TB/s: one pass of weights in flight per
+// workgroup with the load latency exposed at every pass, one workgroup per CU, a single wave doing all MFMA work of a
+// token tile.)  G2 keeps the arithmetic (exact int32 group sums on the matrix cores, products
 // ((float)ival * ws) * xs, ascending-group fold: bit-identical to the GEMV path and the reference) and changes the data
 // flow:
 //   * a workgroup = 8 waves = one 16-row tile (W1 and W3 tiles of the same rows for SwiGLU) x ALL tokens (TT tiles of 16);
@@ -754,80 +411,11 @@ static hipError_t launch_g2(const GemvArgs &a, hipStream_t st) {
 #undef G2_GO
 }
 
-template <int GS>
-static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
-    GemmDev d{};
-    for (int i = 0; i < 3; i++) {
-        const bool live = i < (int)a.nseg;
-        d.w[i] = live ? reinterpret_cast<const int8_t *>(a.seg[i].w) : nullptr;
-        d.ws[i] = live ? a.seg[i].ws : nullptr;
-        d.out[i] = live ? a.seg[i].out : nullptr;
-        d.rows[i] = live ? a.seg[i].rows : 0;
-        d.out_bstride[i] = live ? a.seg[i].out_bstride : 0;
-        d.out_pstride[i] = live ? a.seg[i].out_pstride : 0;
-    }
-    if (a.epi == GEMV_EPI_SWIGLU) { d.rows[1] = 0; d.rows[2] = 0; }
-    d.n = a.n; d.ng = a.n / a.gs; d.epi = a.epi; d.nb = a.nb; d.ttiles = (a.nb + 15) / 16; d.n16 = (a.n + 15) & ~15u;
-    d.xq = a.xq_in; d.xs = a.xs_in; d.pos = a.pos;
-    d.magic_ng = ((1u << 20) + d.ng - 1) / d.ng;               // e / ng == (e * magic) >> 20 for e < 16 * ng (checked below)
-    for (uint32_t e = 0; e < 16 * d.ng; e += 4) if (((e * d.magic_ng) >> 20) != e / d.ng) return hipErrorInvalidValue;
-    if (d.ng % 4) return hipErrorInvalidValue;                 // TODO: scalar staging for ng % 4 != 0 (no BASELINE shape)
-    uint32_t rows = 0;
-    if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
-    if (d.ttiles > 4) return hipErrorInvalidValue;
-    const uint32_t nmat = a.epi == GEMV_EPI_SWIGLU ? 2 : 1;
-    if (d.ttiles == 1 && !getenv("NANO_GEMM_NO_KSPLIT")) {        // <= 16 tokens: the row length is split over the waves
-        const uint32_t ngp1 = d.ng | 1u, n1k1 = (d.n + 1023) & ~1023u;
-        for (uint32_t kc = nmat == 2 ? 1024u : 2048u; kc >= 1024u; kc -= 1024u) {
-            if (kc > n1k1 && kc > 1024u) continue;                 // short rows: one 1 KiB pass
-            d.kc = kc;
-            const uint32_t gpp = kc / GS;
-            const size_t lds = (size_t)(nmat + 1) * 16 * (kc + 16) + ((size_t)(nmat + 1) * 16 * ngp1 + (size_t)nmat * gpp * 16 * 17) * sizeof(float);
-            if (gpp < 8 || lds > 160 * 1024) continue;
-#define KSPLIT_GO(SW_, KCK_) do { auto kern = &gemm_q80_ksplit_kernel<GS, SW_, KCK_>; \
-                if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                hipLaunchKernelGGL(kern, dim3((rows + 15) / 16), dim3(256), lds, st, d); return hipGetLastError(); } while (0)
-            if constexpr (1024 / GS >= 8) { if (nmat == 2) KSPLIT_GO(true, 1); if (kc == 1024u) KSPLIT_GO(false, 1); }
-            if constexpr (2048 / GS >= 8) { if (nmat == 1 && kc == 2048u) KSPLIT_GO(false, 2); }
-#undef KSPLIT_GO
-        }
-    }
-    d.kc = nmat == 2 ? 2048u : 4096u;                            // row bytes staged per pass (<= 66 KB of LDS for the weights)
-    const uint32_t n1k = (d.n + 1023) & ~1023u;
-    if (d.kc > n1k) d.kc = n1k;
-    const uint32_t ngp = d.ng | 1u;
-    const size_t lds = (size_t)nmat * 16 * (d.kc + 16) + ((size_t)nmat * 16 * ngp + (size_t)4 * 16 * ngp) * sizeof(float);
-    if (nmat == 2) {
-        auto kern = &gemm_q80_mfma_kernel<GS, true>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((rows + 15) / 16), dim3(256), lds, st, d);
-    } else {
-        auto kern = &gemm_q80_mfma_kernel<GS, false>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((rows + 15) / 16), dim3(256), lds, st, d);
-    }
-    return hipGetLastError();
-}
-
 }  // namespace
 
 // Host-side predicate: does the GEMM take this launch?  (What it does not take goes through the GEMV kernels in groups
-// of 8 sequences, backend.hip gemv().)  Not taken: row lengths whose group count is not a multiple of 4 (the scale
-// staging reads float4s: e.g. n_embd 768 at group size 128), interior segments that are not multiples of the 16-row
-// tile, a split-attention input, the LoRA o-branch addend.
-bool gemm_q80_supports(const GemvArgs &a) {
-    if (a.nb == 0 || a.nb > 64 || a.gs == 0 || a.n % a.gs || a.n % 16 || a.nseg == 0 || a.nseg > 3 || a.attn_part || a.resid_add) return false;
-    if (!(a.gs == 32 || a.gs == 64 || a.gs == 128 || a.gs == 256)) return false;
-    if (a.epi != GEMV_EPI_SWIGLU && a.nseg > 1)
-        for (uint32_t s = 0; s + 1 < a.nseg; s++) if (a.seg[s].rows % 16) return false;     // a 16-row tile stays inside one segment
-    const uint32_t ng = a.n / a.gs;
-    if (ng % 4) return false;
-    const uint32_t magic = ((1u << 20) + ng - 1) / ng;         // the kernels' e / ng == (e * magic) >> 20
-    for (uint32_t e = 0; e < 16 * ng; e += 4) if (((e * magic) >> 20) != e / ng) return false;
-    return true;
-}
-
-// G2 (the bandwidth-regime kernel): what it takes
+// of 8 sequences, backend.hip gemv().)  Not taken: interior segments that are not multiples of the 16-row tile, a
+// split-attention input, the LoRA o-branch addend.
 bool gemm_q80_g2_supports(const GemvArgs &a) {
     if (a.nb == 0 || a.nb > 64 || a.gs == 0 || a.n % a.gs || a.n % 16 || a.nseg == 0 || a.nseg > 3 || a.attn_part || a.resid_add) return false;
     if (!(a.gs == 32 || a.gs == 64 || a.gs == 128 || a.gs == 256)) return false;
@@ -865,19 +453,7 @@ hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const floa
     return hipGetLastError();
 }
 
-// xq_in / xs_in of `a`: the quantized activations of all a.nb tokens, [nb][(n+15)&~15] int8 and [nb][n/gs] float
-hipError_t launch_gemm_q80(const GemvArgs &a, hipStream_t st) {
-    if (!a.xq_in || !a.xs_in || !gemm_q80_supports(a)) return hipErrorInvalidValue;
-    switch (a.gs) {
-    case 32: return launch_gs<32>(a, st);
-    case 64: return launch_gs<64>(a, st);
-    case 128: return launch_gs<128>(a, st);
-    case 256: return launch_gs<256>(a, st);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-// rmsnorm (optional) + Q80 quantization of nb activation rows into the GEMM's scratch
+// rmsnorm (optional) + Q80 quantization of nb activation rows, row-major (the quantize-once GEMV path of backend.hip)
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                              int8_t *xq, float *xs, hipStream_t st) {
     if (!nb || gs == 0 || n % gs || n % 4) return hipErrorInvalidValue;

@@ -33,9 +33,9 @@ struct GemvArgs {
     const float *norm_w;    // rmsnorm weight or nullptr
     const uint32_t *pos;    // device positions [nb] (for out_pstride)
     uint32_t tiles;         // filled by the launcher
-    uint32_t _pad;
+    uint32_t frag_ready;    // batched GEMM path: xq_in / xs_in already hold the fragment-order activations (the attention kernel wrote them)
     // operator-test inputs: an already quantized activation (skips the quantizing prologue)
-    const int8_t *xq_in;    // Q80 int8[n]
+    const int8_t *xq_in;    // Q80 int8[n] (batched GEMM path with frag_ready: all tokens, MFMA B-fragment order)
     const float *xs_in;     // Q80 float[n/gs]
     const uint8_t *x4_in;   // Q4K blocks[ceil(n/256)*160]
     // input = combination of split attention partials (attn.hip) instead of xin:
@@ -55,18 +55,10 @@ hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
 hipError_t launch_gemv_q80(const GemvArgs &a, hipStream_t st);      // gemv_q80.hip
 hipError_t launch_gemv_f32(const GemvArgs &a, hipStream_t st);      // gemv_f32.hip
-// 9..64 tokens per weight read on the int8 matrix cores (gemm_q80.hip); a.xq_in / a.xs_in = quantized activations of all tokens
-hipError_t launch_gemm_q80(const GemvArgs &a, hipStream_t st);
-bool gemm_q80_supports(const GemvArgs &a);                          // host predicate: shapes / features the GEMM takes
-// G2, the batched kernel of the bandwidth-bound regime (gemm_q80.hip): activations in MFMA B-fragment order
-bool gemm_q80_g2_supports(const GemvArgs &a);
-hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st);   // a.xq_in / a.xs_in = launch_quant_rows_frag's output
-// G3, persistent many-row variant (gemm_q80_g3.hip): same inputs as G2; max_wg = 8 x CUs
-bool gemm_q80_g3_supports(const GemvArgs &a);
-hipError_t launch_gemm_q80_g3(const GemvArgs &a, uint32_t max_wg, hipStream_t st);
-// G4, wave-independent variant (gemm_q80_g4.hip): same inputs as G2
-bool gemm_q80_g4_supports(const GemvArgs &a);
-hipError_t launch_gemm_q80_g4(const GemvArgs &a, hipStream_t st);
+// 9..64 tokens per weight read on the int8 matrix cores.  G2 (gemm_q80.hip): the general kernel, activations in MFMA
+// B-fragment order (a.xq_in / a.xs_in = launch_quant_rows_frag's output)
+bool gemm_q80_g2_supports(const GemvArgs &a);                       // host predicate: shapes / features the GEMM takes
+hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st);
 // G5, row length split over a chained team of waves, all token tiles per wave (gemm_q80_g5.hip): same inputs as G2
 bool gemm_q80_g5_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_g5(const GemvArgs &a, hipStream_t st);
@@ -102,6 +94,9 @@ struct AttnArgs {
     uint32_t prep_only;            // 1: finish and store the k row of pos[b] (norm + RoPE), then return (batched prefill, pass 1)
     uint32_t kv_half;              // 1: kcache / vcache hold FP16 elements (opt-in); the fresh v row comes from vraw
     const float *vraw;             // FP16 cache: [nb][kv_dim] v of the current position from the QKV GEMV (FP32 scratch), else nullptr
+    // single-split launches only, optional: the finished output also leaves as Q80 groups of 64 in MFMA B-fragment order (what
+    // quant_rows_frag_kernel would make of xba_out), so the batched Wo GEMM needs no quantizer launch.  head_dim % 64 == 0.
+    int8_t *xf_out; float *xsf_out;
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);

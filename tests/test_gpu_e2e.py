@@ -126,8 +126,8 @@ def test_large_batch_mfma_gemm_path(model_dir, B):
 
 
 @pytest.mark.parametrize("B", [9, 16, 33, 64])
-def test_chained_gemm_equals_the_other_gemm_kernels_on_wide_rows(model_dir, B):
-    """gemm_q80_g5.hip (row length split over a chained team of waves) against the G2/G3/G4 kernels (NANO_GEMM_G5=0) on
+def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
+    """gemm_q80_g5.hip (row length split over a chained team of waves) against the general G2 kernel (NANO_GEMM_G5=0) on
     Qwen3-4B's row lengths (2560 / 4096 / 9728: 5, 8 and 19 half chunks, several per wave) -- integer group sums and the
     ascending fp32 group order are the same arithmetic, so logits and KV rows must agree bit for bit; and against
     one-by-one decoding through the GEMV kernels."""
@@ -136,23 +136,25 @@ def test_chained_gemm_equals_the_other_gemm_kernels_on_wide_rows(model_dir, B):
     T = 3
     seqs = [mf.prompt_ids(900 + b, T, spec.vocab_size) for b in range(B)]
 
-    def run(g5):
-        old = os.environ.get("NANO_GEMM_G5")
-        os.environ["NANO_GEMM_G5"] = g5
+    def run(**env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
             m = nb.load_model_file(path, max_seq_len=16, max_batch=B)
         finally:
-            if old is None: os.environ.pop("NANO_GEMM_G5", None)
-            else: os.environ["NANO_GEMM_G5"] = old
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
         out = [m.forward([int(s[pos]) for s in seqs], [pos] * B)[0].copy() for pos in range(T)]
         kv = m.read_state("v", spec.kv_dim, slot=B - 1, layer=0, pos=T - 1).copy()
         m.close()
         return out, kv
-    a, akv = run("1")
-    b, bkv = run("0")
-    for pos in range(T):
-        assert np.array_equal(a[pos].view(np.uint32), b[pos].view(np.uint32)), pos
-    assert np.array_equal(akv.view(np.uint32), bkv.view(np.uint32))
+    a, akv = run()
+    # the general G2 kernel everywhere; Wo's input quantized by a launch of its own instead of by the attention kernel
+    for b, bkv in (run(NANO_GEMM_G5="0"), run(NANO_ATTN_QUANT="0")):
+        for pos in range(T):
+            assert np.array_equal(a[pos].view(np.uint32), b[pos].view(np.uint32)), pos
+        assert np.array_equal(akv.view(np.uint32), bkv.view(np.uint32))
     m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
     worst, exact = 0.0, True
     for bi in (0, B // 2, B - 1):
@@ -160,7 +162,7 @@ def test_chained_gemm_equals_the_other_gemm_kernels_on_wide_rows(model_dir, B):
             lg, _ = m1.forward([int(seqs[bi][pos])], [pos])
             worst = max(worst, rel_err(a[pos][bi], lg[0])); exact = exact and np.array_equal(lg[0], a[pos][bi])
     m1.close()
-    print(f"wide rows, batch {B}: G5 == G2/G4 bit for bit; vs one-by-one GEMV worst {worst:.3e}, bit-identical {exact}")
+    print(f"wide rows, batch {B}: G5 == G2 bit for bit; vs one-by-one GEMV worst {worst:.3e}, bit-identical {exact}")
     assert worst < TOL["q80"]
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Batched decode steps with the per-kernel table: usage tools/batch_probe.sh MODEL "B1 B2 ..." [tag]   (NANO_GEMM_G2=0 for the round-1 GEMM kernels)
+# Batched decode steps with the per-kernel table: usage tools/batch_probe.sh MODEL "B1 B2 ..." [tag]   (NANO_GEMM_G5=0: the general G2 kernel everywhere)
 MODEL=${1:-qwen3-4b}; BS=${2:-"64 32 16 8"}; TAG=${3:-g2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for b in $BS; do
