@@ -559,7 +559,8 @@ hipError_t launch_attn_combine(const float *part, const float *ml, float *out, u
 // The combine of the Wo GEMV's prologue (gemv_common.h combine_weights / combine4) as a kernel of its own, for steps
 // whose Wo cannot fold it in (batched prefill through the MFMA GEMM): same weights (8 slots, pairwise-tree sum of
 // l_s * exp(m_s - M), e / L), same ascending accumulation — the bits of x are those of the decode path.
-__global__ __launch_bounds__(128) void attn_combine_tokens_kernel(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit) {
+__global__ __launch_bounds__(128) void attn_combine_tokens_kernel(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit,
+                                                                  int8_t *xf_out, float *xsf_out) {
     const uint32_t h = blockIdx.x, b = blockIdx.y, q_dim = n_head * hd;
     const float *mlh = ml + (((size_t)b * n_head + h) * nsplit) * 2;
     float mm[8], e[8], v[8], w[8];
@@ -581,10 +582,22 @@ __global__ __launch_bounds__(128) void attn_combine_tokens_kernel(const float *p
 #pragma unroll
         for (uint32_t s = 0; s < 8; s++) { const float o = s < nsplit ? pb[(size_t)s * q_dim + i] : 0.0f; acc += o * w[s]; }
         out[(size_t)b * q_dim + (size_t)h * hd + i] = acc;
+        if (xf_out) {       // also as a Q80 group of 64 (= this wave's 64 lanes; head_dim % 64 == 0) in fragment order, see attention_kernel
+            float mx = fabsf(acc);
+#pragma unroll
+            for (int o2 = 1; o2 < 64; o2 <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+            const float scale = mx / 127.0f;
+            const uint32_t el = h * hd + i, g = el >> 6, jj = el & 63u, ng = q_dim >> 6;
+            const size_t gb = (size_t)(b >> 4) * ng + g;
+            xf_out[gb * 1024u + (size_t)((jj >> 4) * 16u + (b & 15u)) * 16u + (jj & 15u)] = (int8_t)q80_quant1(acc, scale);
+            if (jj == 0) xsf_out[gb * 16u + (b & 15u)] = scale;
+        }
     }
 }
-hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb, hipStream_t st) {
-    hipLaunchKernelGGL(attn_combine_tokens_kernel, dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit);
+hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb,
+                                      int8_t *xf_out, float *xsf_out, hipStream_t st) {
+    if (xf_out && (hd % 64u || !xsf_out)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_combine_tokens_kernel, dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit, xf_out, xsf_out);
     return hipGetLastError();
 }
 

@@ -497,10 +497,10 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     const uint32_t nsplit = m->pf ? step_nsplit(m, 1, range_hint) : step_nsplit(m, nb, range_hint);
     const bool pf_combine = m->pf && nsplit > 1;
     m->nsplit = nsplit;
-    // Single-split attention of a step whose Wo launch goes to the batched GEMM: the attention kernel writes Wo's quantized
-    // input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
+    // Single-split attention (or batched prefill's combine kernel) of a step whose Wo launch goes to the batched GEMM: that
+    // kernel writes Wo's quantized input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
     bool wo_frag = false;
-    if (m->attn_quant && nsplit == 1 && !m->lora_on && d.quant_type == NANO_QUANT_Q80 && d.group_size == 64 && m->hd % 64 == 0) {
+    if (m->attn_quant && (nsplit == 1 || pf_combine) && !m->lora_on && d.quant_type == NANO_QUANT_Q80 && d.group_size == 64 && m->hd % 64 == 0) {
         GemvArgs wa{};
         wa.nseg = 1; wa.seg[0] = mkseg(m->W[WO][0], m->x, E, E); wa.n = QD; wa.gs = 64; wa.nb = nb; wa.xin = m->xba; wa.xin_bstride = QD; wa.epi = GEMV_EPI_RESID;
         wo_frag = takes_mfma(m, wa) && gemm_q80_g2_supports(wa);
@@ -547,7 +547,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
             a.kv_half = m->kv_half ? 1u : 0u; a.vraw = m->kv_half ? m->vraw : nullptr;
-            if (wo_frag) { a.xf_out = m->gq; a.xsf_out = m->gxs; }
+            if (wo_frag && nsplit == 1) { a.xf_out = m->gq; a.xsf_out = m->gxs; }
             if (m->pf) {
                 // batched prefill: the nb tokens are consecutive positions of ONE sequence.  Pass 1 finishes every k row
                 // (norm + RoPE + cache write, nothing else) so that pass 2 finds the rows of the earlier tokens of the
@@ -561,7 +561,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 a.prep_only = 0;
             }
             if (!(skip & 2) && (e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
-            if (pf_combine && (e = launch_attn_combine_tokens(m->attn_part, m->attn_ml, m->xba, d.n_head, m->hd, nsplit, nb, m->st)) != hipSuccess) return e;
+            if (pf_combine && (e = launch_attn_combine_tokens(m->attn_part, m->attn_ml, m->xba, d.n_head, m->hd, nsplit, nb, wo_frag ? m->gq : nullptr, wo_frag ? m->gxs : nullptr, m->st)) != hipSuccess) return e;
         }
         {   // x += Wo . xba   reference infer.c:885-908
             GemvArgs a{};

@@ -101,7 +101,8 @@ struct AttnArgs {
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
-hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb, hipStream_t st);
+hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb,
+                                      int8_t *xf_out, float *xsf_out, hipStream_t st);   // xf_out: also Q80 fragments (AttnArgs::xf_out), or nullptr
 
 // ---- strict-parity kernels (strict.hip): every float reduction in the reference's own order --------------
 struct StrictAttnArgs {
