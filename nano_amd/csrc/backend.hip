@@ -425,7 +425,18 @@ static GemvArgs gemv_slice(const GemvArgs &a, uint32_t b0, uint32_t cnt) {
 
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     const uint32_t max_wg = (uint32_t)m->cus * 8;
-    if (m->d.quant_type == NANO_QUANT_Q4K) return launch_gemv_q4k(a, max_wg, m->st);
+    if (m->d.quant_type == NANO_QUANT_Q4K) {
+        // every workgroup stages the whole quantized activation of each sequence in LDS: long rows (Qwen3-4B's hidden size)
+        // take fewer sequences per launch
+        const uint32_t fit = a.nb > 1 ? gemv_q4k_fit_batch(a) : 1u;
+        if (a.nb <= fit) return launch_gemv_q4k(a, max_wg, m->st);
+        for (uint32_t b0 = 0; b0 < a.nb; b0 += fit) {
+            GemvArgs s = gemv_slice(a, b0, a.nb - b0 < fit ? a.nb - b0 : fit);
+            const hipError_t e = launch_gemv_q4k(s, max_wg, m->st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && gemm_q80_g2_supports(a)) {
         // quantize every sequence's activation once, straight into MFMA fragment order, then the GEMM: G5 (group size 64: the
         // row length split over a chained team of waves, gemm_q80_g5.hip) or the general G2 kernel.  One arithmetic, same bits.
@@ -1004,7 +1015,29 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
         uint32_t range_hint = ((pos0 + done + nb + 63) / 64) * 64;
         if (range_hint > m->S) range_hint = m->S;
         m->pf = true; m->pf_slot = slot;
-        hipError_t e = enqueue_step(m, nb, 1, MODE_NOCLS, range_hint);      // eager: one pass per chunk
+        hipError_t e = hipSuccess;
+        if (m->use_graph && nb == chunk_max && chunk_max == 64u && !m->skip_mask) {
+            // a full 64-token chunk recurs in every long prompt: one HIP graph per (KV slot, range bucket) -- positions and
+            // tokens are device data, the slot's cache addresses are baked into the nodes.  Other chunk lengths run eagerly
+            // (a capture costs more than the ~300 launches it would save once).
+            const uint64_t key = (1ull << 62) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)slot << 32) | ((uint64_t)range_hint << 8) | nb;
+            auto it = m->graphs.find(key);
+            if (it == m->graphs.end()) {
+                hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+                e = hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed);
+                if (e == hipSuccess) {
+                    e = enqueue_step(m, nb, 1, MODE_NOCLS, range_hint);
+                    const hipError_t e2 = hipStreamEndCapture(m->st, &g);
+                    if (e == hipSuccess) e = e2;
+                }
+                if (e == hipSuccess) e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                if (g) (void)hipGraphDestroy(g);
+                if (e == hipSuccess) it = m->graphs.emplace(key, ge).first;
+            }
+            if (e == hipSuccess) e = hipGraphLaunch(it->second, m->st);
+        } else {
+            e = enqueue_step(m, nb, 1, MODE_NOCLS, range_hint);            // eager: one pass per chunk
+        }
         m->pf = false;
         HIP_TRY(e);
         HIP_TRY(hipStreamSynchronize(m->st));                              // h_tokens / h_pos are reused by the next chunk

@@ -196,7 +196,12 @@ static uint32_t total_rows5(const GemvArgs &a) {
 template <int TT>
 static void launch_tt(const G5Dev &d, uint32_t nwg, uint32_t waves, size_t lds, hipStream_t st) {
     auto kern = &gemm_q80_g5_kernel<TT>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool armed[64] = {};                                        // once per instantiation and device: a host call per launch costs microseconds
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !armed[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (dev >= 0 && dev < 64) armed[dev] = true;
+    }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(waves * 64), lds, st, d);
 }
 

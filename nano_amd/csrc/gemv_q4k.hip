@@ -462,26 +462,39 @@ static Q4kPlan plan_q4k(const GemvArgs &a, int B) {
     if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
     // ~512 items (8 KB of nibbles) per workgroup, >= 128 workgroups; tall matrices: up to 2048 items
     uint32_t rw = 4;
-    const uint32_t cap = rows >= 16384 ? 2048u : 512u;
+    // Every workgroup quantizes the whole activation before its first product, so large matrices (Qwen3-4B's layers, >= 8 M
+    // weights) take up to 4096 items per workgroup: swept on the device with tools/q4k_wide.sh (QKV 17.0 -> 9.0 us, W1|W3
+    // 28.0 -> 19.9, Wo 10.4 -> 7.5); Qwen3-0.6B's are fastest at 512 (1024: -3 %).  NANO_Q4K_ITEMS overrides the former.
+    const bool large = (uint64_t)rows * a.n >= (8u << 20);
+    uint32_t cap = large ? 4096u : rows >= 16384 ? 2048u : 512u;
+    static const char *cap_env = getenv("NANO_Q4K_ITEMS");
+    if (cap_env && large) cap = (uint32_t)strtoul(cap_env, nullptr, 0);
     while (rw < 64 && (align % (rw * 2)) == 0 && (rw * 2) * GT * nmat <= cap && rows / (rw * 2) >= 128) rw *= 2;
-    const uint32_t items = rw * GT * nmat;
-    uint32_t nthr = ((items + 63) / 64) * 64;
-    if (nthr > 512) nthr = 512;
-    if (nthr < 256) nthr = 256;
-    uint32_t want = ((a.n / 4 + 63) / 64) * 64;            // the block quantizer is one thread per element: ~4 elements per thread
-    if (want > 1024) want = 1024;
-    if (nthr < want) nthr = want;
-    if (nthr < rw * (uint32_t)B) nthr = ((rw * (uint32_t)B + 63) / 64) * 64;
-    const uint32_t ipt = (items + nthr - 1) / nthr;
-    return Q4kPlan{rw, nthr, ipt, (a.n + 4 * nthr - 1) / (4 * nthr)};
+    for (;; rw /= 2) {
+        const uint32_t items = rw * GT * nmat;
+        uint32_t nthr = ((items + 63) / 64) * 64;
+        if (nthr > 512) nthr = 512;
+        if (nthr < 256) nthr = 256;
+        uint32_t want = ((a.n / 4 + 63) / 64) * 64;        // the block quantizer is one thread per element: ~4 elements per thread
+        if (want > 1024) want = 1024;
+        if (nthr < want) nthr = want;
+        if (nthr < rw * (uint32_t)B) nthr = ((rw * (uint32_t)B + 63) / 64) * 64;
+        const uint32_t ipt = (items + nthr - 1) / nthr;
+        if (ipt <= 4 || rw <= 4) return Q4kPlan{rw, nthr, ipt, (a.n + 4 * nthr - 1) / (4 * nthr)};   // the kernel is instantiated for <= 4 items per thread
+    }
+}
+
+// dynamic LDS of a launch with capacity B: quantized groups, the activations, block / sequence scratch, combine weights, products
+static size_t q4k_lds_bytes(uint32_t n, uint32_t epi, bool combine, uint32_t attn_n_head, uint32_t rw, uint32_t B) {
+    const uint32_t nmat = epi == GEMV_EPI_SWIGLU ? 2 : 1;
+    const size_t n4 = (n + 3) & ~3u, bpl = (n + 255) / 256, GT = bpl * 8;
+    return (size_t)B * GT * sizeof(XGroup) + (B * n4 + B * bpl * 16 + B * 16 + (combine ? (size_t)B * attn_n_head * 8 : 0) + (size_t)B * nmat * rw * (GT + 4)) * 4 + 16;
 }
 
 template <int ROLE, int B, int NV, int IPT>
 static hipError_t launch_q4k_t(const GemvDev &d, const Q4kPlan &p, uint32_t rows, hipStream_t st) {
-    const uint32_t nmat = d.epi == GEMV_EPI_SWIGLU ? 2 : 1;
-    const size_t n4 = (d.n + 3) & ~3u, bpl = (d.n + 255) / 256, GT = bpl * 8;
-    const size_t lds = (size_t)B * GT * sizeof(XGroup) + (B * n4 + B * bpl * 16 + B * 16 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 8 : 0) +
-                                                           (size_t)B * nmat * p.rw * (GT + 4)) * 4 + 16;
+    const size_t lds = q4k_lds_bytes(d.n, d.epi, (d.flags & F_COMBINE) != 0, d.attn_n_head, p.rw, B);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;                 // gemv_q4k_fit_batch() tells the caller how many sequences fit
     auto kern = &gemv_q4k_slab_kernel<ROLE, B, NV, IPT>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(p.nthr), lds, st, d);
@@ -523,6 +536,14 @@ static hipError_t launch_q4k_b(const GemvArgs &a, hipStream_t st) {
 }
 
 }  // namespace
+
+// Sequences per launch that fit the 160 KB of LDS (every workgroup holds the whole quantized activation of each sequence):
+// 8 for Qwen3-0.6B's row lengths, 2 for Qwen3-4B's hidden size 9728.  The caller slices larger steps (backend.hip gemv()).
+uint32_t gemv_q4k_fit_batch(const GemvArgs &a) {
+    for (uint32_t c = 8; c > 1; c >>= 1)
+        if (q4k_lds_bytes(a.n, a.epi, a.attn_part != nullptr, a.attn_n_head, plan_q4k(a, (int)c).rw, c) <= 160 * 1024) return c;
+    return 1;
+}
 
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
     (void)max_wg;

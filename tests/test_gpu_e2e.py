@@ -125,6 +125,25 @@ def test_large_batch_mfma_gemm_path(model_dir, B):
     assert worst < TOL["q80"]
 
 
+def test_q4k_batch_on_rows_too_long_for_one_launch(model_dir):
+    """Q4K, 8 sequences per step on Qwen3-4B's row lengths: a workgroup holds every sequence's quantized activation in LDS
+    and hidden size 9728 leaves room for two, so the step is sliced (gemv_q4k_fit_batch) -- same logits as one by one."""
+    path, spec = synth_model(model_dir, "wide-qwen3", "q4k", 0)
+    from nano_amd import modelfile as mf
+    B, T = 8, 2
+    seqs = [mf.prompt_ids(1300 + b, T, spec.vocab_size) for b in range(B)]
+    mb = nb.load_model_file(path, max_seq_len=16, max_batch=B)
+    batched = [mb.forward([int(s[pos]) for s in seqs], [pos] * B)[0].copy() for pos in range(T)]
+    mb.prefill(mf.prompt_ids(77, 7, spec.vocab_size), 0, slot=3)     # a 7-token prefill chunk takes the same sliced launches
+    mb.close()
+    m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    for b in (0, 3, 7):
+        for pos in range(T):
+            lg, _ = m1.forward([int(seqs[b][pos])], [pos])
+            assert np.array_equal(lg[0].view(np.uint32), batched[pos][b].view(np.uint32)), (b, pos)
+    m1.close()
+
+
 @pytest.mark.parametrize("B", [9, 16, 33, 64])
 def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
     """gemm_q80_g5.hip (row length split over a chained team of waves) against the general G2 kernel (NANO_GEMM_G5=0) on
