@@ -405,7 +405,14 @@ static bool gemv_is_heavy(const GemvArgs &a) {
 static bool takes_mfma(const NanoHipModel *m, const GemvArgs &a) {
     if (m->d.quant_type != NANO_QUANT_Q80 || !m->gq || !m->gxs) return false;
     if (a.nb >= m->mfma_min_nb) return true;
-    return a.nb == 8 && m->mfma_min_nb == 9 && gemv_is_heavy(a);    // (NANO_MFMA_MIN_NB != 9 disables this rule: A/B runs)
+    if (m->mfma_min_nb != 9) return false;                           // (NANO_MFMA_MIN_NB != 9 disables the rules below: A/B runs)
+    if (a.nb == 8 && gemv_is_heavy(a)) return true;
+    // per-layer matrices of >= 8 M weights (Qwen3-4B's): from 2 sequences on (measured on its row lengths, one layer +
+    // classifier per step, tools/wide_batch.sh: 2 sequences 88 vs 111 us, 4: 94 vs 134, 6: 91 vs 166); the classifier
+    // keeps its STREAM GEMV up to 7 sequences
+    uint32_t rows = 0;
+    if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
+    return a.nb >= 2 && rows < 65536u && (uint64_t)rows * a.n >= (8u << 20);
 }
 
 // the sequences [b0, b0 + cnt) of a launch, as a launch of their own (every per-sequence pointer advanced)
@@ -506,16 +513,19 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     // multiples of the 64-position bucket, so one range_hint covers them) and combines with a kernel of its own: the KV
     // rows and the following logits then carry the bits of token-by-token ingestion.
     const uint32_t nsplit = m->pf ? step_nsplit(m, 1, range_hint) : step_nsplit(m, nb, range_hint);
-    const bool pf_combine = m->pf && nsplit > 1;
-    m->nsplit = nsplit;
-    // Single-split attention (or batched prefill's combine kernel) of a step whose Wo launch goes to the batched GEMM: that
-    // kernel writes Wo's quantized input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
-    bool wo_frag = false;
-    if (m->attn_quant && (nsplit == 1 || pf_combine) && !m->lora_on && d.quant_type == NANO_QUANT_Q80 && d.group_size == 64 && m->hd % 64 == 0) {
+    // Does this step's Wo launch go to the batched GEMM (plain activations only)?  Then a split attention is combined by a
+    // kernel of its own (as in batched prefill) instead of in the Wo GEMV's prologue -- same arithmetic, same bits.
+    bool wo_gemm = false;
+    if (!m->lora_on && d.quant_type == NANO_QUANT_Q80) {
         GemvArgs wa{};
-        wa.nseg = 1; wa.seg[0] = mkseg(m->W[WO][0], m->x, E, E); wa.n = QD; wa.gs = 64; wa.nb = nb; wa.xin = m->xba; wa.xin_bstride = QD; wa.epi = GEMV_EPI_RESID;
-        wo_frag = takes_mfma(m, wa) && gemm_q80_g2_supports(wa);
+        wa.nseg = 1; wa.seg[0] = mkseg(m->W[WO][0], m->x, E, E); wa.n = QD; wa.gs = d.group_size; wa.nb = nb; wa.xin = m->xba; wa.xin_bstride = QD; wa.epi = GEMV_EPI_RESID;
+        wo_gemm = takes_mfma(m, wa) && gemm_q80_g2_supports(wa);
     }
+    const bool pf_combine = nsplit > 1 && (m->pf || wo_gemm);
+    m->nsplit = nsplit;
+    // Single-split attention (or the combine kernel) of a step whose Wo launch goes to the batched GEMM: that kernel writes
+    // Wo's quantized input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
+    const bool wo_frag = m->attn_quant && wo_gemm && d.group_size == 64 && m->hd % 64 == 0;
     EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
                   m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0 };
     const uint32_t skip = m->skip_mask;

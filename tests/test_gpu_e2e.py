@@ -125,6 +125,40 @@ def test_large_batch_mfma_gemm_path(model_dir, B):
     assert worst < TOL["q80"]
 
 
+def test_small_batch_on_large_layers_takes_the_gemm_with_a_split_attention(model_dir):
+    """Qwen3-4B's layer sizes, 3 sequences per step, positions past 64: the weight launches take the batched GEMM from 2
+    sequences on, the attention is split, so its partials are combined by the kernel that also writes Wo's Q80 fragments.
+    Same bits with the general GEMM kernel and with a quantizer launch of its own; one-by-one decoding within the Q80 bar."""
+    path, spec = synth_model(model_dir, "wide-qwen3", "q80", 64)
+    from nano_amd import modelfile as mf
+    B, T = 3, 70
+    seqs = [mf.prompt_ids(1500 + b, T, spec.vocab_size) for b in range(B)]
+
+    def run(**env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m = nb.load_model_file(path, max_seq_len=128, max_batch=B)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        out = []
+        for pos in range(T):
+            lg, _ = m.forward([int(s[pos]) for s in seqs], [pos] * B, want_logits=pos >= 62)
+            if pos >= 62: out.append(lg.copy())
+        m.close()
+        return out
+    a = run()
+    for other in (run(NANO_GEMM_G5="0"), run(NANO_ATTN_QUANT="0")):
+        for x, y in zip(a, other):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    gemv = run(NANO_MFMA_MIN_NB="65")                          # every launch through the GEMV kernels
+    worst = max(rel_err(x, y) for x, y in zip(a, gemv))
+    print(f"3 sequences on wide rows past position 64: GEMM path vs GEMV path worst {worst:.3e}")
+    assert worst < TOL["q80"]
+
+
 def test_q4k_batch_on_rows_too_long_for_one_launch(model_dir):
     """Q4K, 8 sequences per step on Qwen3-4B's row lengths: a workgroup holds every sequence's quantized activation in LDS
     and hidden size 9728 leaves room for two, so the step is sliced (gemv_q4k_fit_batch) -- same logits as one by one."""
@@ -144,7 +178,7 @@ def test_q4k_batch_on_rows_too_long_for_one_launch(model_dir):
     m1.close()
 
 
-@pytest.mark.parametrize("B", [9, 16, 33, 64])
+@pytest.mark.parametrize("B", [3, 9, 16, 33, 64])
 def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
     """gemm_q80_g5.hip (row length split over a chained team of waves) against the general G2 kernel (NANO_GEMM_G5=0) on
     Qwen3-4B's row lengths (2560 / 4096 / 9728: 5, 8 and 19 half chunks, several per wave) -- integer group sums and the
