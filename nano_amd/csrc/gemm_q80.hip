@@ -347,10 +347,19 @@ __global__ __launch_bounds__(256) void quant_rows_frag_kernel(const float *x, ui
     float4 w = (live && norm_w) ? *reinterpret_cast<const float4 *>(norm_w + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     float ss = 1.0f;
     if (norm_w) {                       // rmsnorm scale (infer.c:603-609), the GEMV prologue's tree order for 256 threads
+        // four row pieces per trip, all four loads in flight before the first is used (a load per trip would cost a memory
+        // round trip per 1024 elements); the additions keep their order: k ascending, x y z w
         float acc = 0.0f;
-        for (uint32_t k = tid * 4u; k < n; k += 1024u) {
-            const float4 u = *reinterpret_cast<const float4 *>(xr + k);
-            acc += u.x * u.x; acc += u.y * u.y; acc += u.z * u.z; acc += u.w * u.w;
+        for (uint32_t k0 = tid * 4u; k0 < n; k0 += 4096u) {
+            float4 u[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t k = k0 + 1024u * (uint32_t)q;
+                u[q] = k < n ? *reinterpret_cast<const float4 *>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (k0 + 1024u * (uint32_t)q < n) { acc += u[q].x * u[q].x; acc += u[q].y * u[q].y; acc += u[q].z * u[q].z; acc += u[q].w * u[q].w; }
         }
         acc = dpp_wave_sum(acc);
         if (lane == 0) red[wid] = acc;

@@ -116,8 +116,9 @@ hipError_t launch_quantize_q4k(const float *x, uint32_t n, uint8_t *blocks, hipS
 // and the per-group results land in an LDS table that one thread per (row, sequence) folds in the reference's order.
 namespace {
 
+// keep (NV > 0 only): the normalised values stay in r.x for quantize_q4k_regs() instead of going to xn
 template <int ROLE, int B, int NV>
-__device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, float *xn, float *red, uint32_t n4) {
+__device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, float *xn, float *red, uint32_t n4, bool keep) {
     // rmsnorm / split-attention combine of the activation into xn[B][n4] (same code path as the FP32 GEMV's staging)
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n;
     const uint32_t lane = tid & 63u, wid = tid >> 6, NW = nthr >> 6;
@@ -215,10 +216,68 @@ __device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, flo
                     v.x = r.nw[j].x * (ss[b] * v.x); v.y = r.nw[j].y * (ss[b] * v.y);
                     v.z = r.nw[j].z * (ss[b] * v.z); v.w = r.nw[j].w * (ss[b] * v.w);
                 }
-                if (i < n) *reinterpret_cast<float4 *>(xn + b * n4 + i) = v;
+                if (keep) r.x[b][j] = v;
+                else if (i < n) *reinterpret_cast<float4 *>(xn + b * n4 + i) = v;
             }
         }
-        __syncthreads();
+        if (!keep) __syncthreads();
+    }
+}
+
+// The block quantizer on values that are still in registers (whole blocks only: n % 256 == 0).  Thread t of a launch
+// holds elements 4 (t + j nthr) .. +3, so a 32-element group is 8 consecutive lanes and a 256-element block is exactly one
+// wave: group min / max / nibble sum by three DPP steps, the block's maximum scale and bias by three cross-lane steps more
+// -- no LDS round trip and no barrier between the phases (quantize_q4k_wg needs two).  Same values, same comparisons
+// (reference tensor.c:144-242).  Ends with a barrier: the staged groups are complete.
+template <int B, int NV>
+__device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged<B, NV> &r, XGroup *xg) {
+    if constexpr (NV == 0) { (void)a; (void)r; (void)xg; } else {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n, GT = (n >> 8) * 8u;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+        const bool valid = i < n;                                     // whole waves: n % 256 == 0
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (b < (int)a.nb) {
+                const float4 v = r.x[b][j];
+                float lo = FLT_MAX, hi = FLT_TRUE_MIN;                // reference: strict comparisons from these start values (NaN ignored)
+                lo = (v.x < lo) ? v.x : lo; lo = (v.y < lo) ? v.y : lo; lo = (v.z < lo) ? v.z : lo; lo = (v.w < lo) ? v.w : lo;
+                hi = (v.x > hi) ? v.x : hi; hi = (v.y > hi) ? v.y : hi; hi = (v.z > hi) ? v.z : hi; hi = (v.w > hi) ? v.w : hi;
+                lo = fminf(lo, DPP_F(lo, 0xB1)); hi = fmaxf(hi, DPP_F(hi, 0xB1));
+                lo = fminf(lo, DPP_F(lo, 0x4E)); hi = fmaxf(hi, DPP_F(hi, 0x4E));
+                lo = fminf(lo, DPP_F(lo, 0x141)); hi = fmaxf(hi, DPP_F(hi, 0x141));
+                const float gsc = (lo <= 0.0f) ? ((hi - lo) / 15.0f) : (hi / 15.0f);
+                const float gbi = (lo <= 0.0f) ? (-lo) : 0.0f;
+                uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+                if (gsc != 0.0f) {
+                    n0 = (uint32_t)(nearest_int_magic((v.x + gbi) / gsc) & 0x0f); n1 = (uint32_t)(nearest_int_magic((v.y + gbi) / gsc) & 0x0f);
+                    n2 = (uint32_t)(nearest_int_magic((v.z + gbi) / gsc) & 0x0f); n3 = (uint32_t)(nearest_int_magic((v.w + gbi) / gsc) & 0x0f);
+                }
+                const int sum = dpp_group_sum<8>((int)(n0 + n1 + n2 + n3));
+                // the block's 8 groups are the 8 lane-octets of this wave
+                float smax = (gsc > FLT_TRUE_MIN) ? gsc : FLT_TRUE_MIN, bmax = (gbi > FLT_TRUE_MIN) ? gbi : FLT_TRUE_MIN;   // the reference's strict comparisons
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    const float so = __shfl_xor(smax, o, 64), bo = __shfl_xor(bmax, o, 64);
+                    smax = (so > smax) ? so : smax; bmax = (bo > bmax) ? bo : bmax;
+                }
+                const float s_scale = smax / 63.0f, s_bias = bmax / 63.0f;
+                const uint32_t s6 = (s_scale == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(gsc / s_scale) & 0x3f);
+                const uint32_t b6 = (s_bias == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(gbi / s_bias) & 0x3f);
+                if (valid) {
+                    const uint32_t tg = tid & 7u;
+                    XGroup *o = xg + (size_t)b * GT + (i >> 5);
+                    // split-nibble byte lanes: elements 8m .. 8m+7 live in dword m; even elements -> lo[m], odd -> hi[m], byte (e & 7) >> 1
+                    uint8_t *ob = reinterpret_cast<uint8_t *>(o) + (tg >> 1) * 4 + (tg & 1) * 2;
+                    *reinterpret_cast<uint16_t *>(ob) = (uint16_t)(n0 | (n2 << 8));
+                    *reinterpret_cast<uint16_t *>(ob + 16) = (uint16_t)(n1 | (n3 << 8));
+                    if (tg == 0) { o->sq = (float)s6 * s_scale; o->bq = (float)b6 * s_bias; o->sumq = sum; o->_pad = 0; }   // sq / bq: what get_group_scale_and_bias() reads back (tensor.c:137-140)
+                }
+            }
+        }
+    }
+    __syncthreads();
     }
 }
 
@@ -371,8 +430,10 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
 
     if (has_flag<ROLE>(a, F_PRE)) unpack_q4k_wg(a, xg);
     else {
-        stage_xn<ROLE, B, NV>(a, sx, xn, red, n4);
-        quantize_q4k_wg(a, xn, xg, tmp, n4, (int)a.nb);
+        const bool regq = NV > 0 && (n & 255u) == 0u;                // whole blocks: quantize from registers, wave-local
+        stage_xn<ROLE, B, NV>(a, sx, xn, red, n4, regq);
+        if (regq) quantize_q4k_regs<B, NV>(a, sx, xg);
+        else quantize_q4k_wg(a, xn, xg, tmp, n4, (int)a.nb);
     }
 
 #pragma unroll
