@@ -52,8 +52,9 @@ elif [ "$1" = "b" ]; then
   for b in 16 64; do timeout 300 python bench.py --batch $b --steps 64 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_q06_b$b.json; python3 -c "import json;d=json.load(open('$O/${T}_bench_q06_b$b.json'));print('0.6B B=$b', d['value'], 'tok/s', d['ms_per_step'], 'ms', d['roofline']['frac'])"; done
 else
   rocprofv3 -L 2>/dev/null | grep -iE "mfma|SQ_BUSY_CY|VALU_BUSY|GRBM_GUI" | head -20 > $O/${T}_counters_available.txt; head -12 $O/${T}_counters_available.txt
-  for b in 1 8 16 64; do timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_b$b.json; python3 -c "import json;d=json.load(open('$O/${T}_bench_4b_b$b.json'));print('4B B=$b', d['value'], 'tok/s', d['ms_per_step'], 'ms', d['roofline']['frac'])"; done
-  timeout 500 python bench.py --model qwen3-4b --quant q4k --steps 64 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_q4k_b1.json; cut -c1-200 $O/${T}_bench_4b_q4k_b1.json; echo
+  for b in 1 2 4 8 16 64; do timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_b$b.json; python3 -c "import json;d=json.load(open('$O/${T}_bench_4b_b$b.json'));print('4B B=$b', d['value'], 'tok/s', d['ms_per_step'], 'ms', d['roofline']['frac'])"; done
+  NANO_KV_F16=1 timeout 400 python bench.py --model qwen3-4b --batch 64 --steps 32 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_b64_kv16.json; python3 -c "import json;d=json.load(open('$O/${T}_bench_4b_b64_kv16.json'));print('4B B=64 FP16 KV', d['value'], 'tok/s', d['ms_per_step'], 'ms')"
+  timeout 900 python bench.py --model qwen3-4b --quant q4k --steps 64 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_q4k_b1.json; cut -c1-200 $O/${T}_bench_4b_q4k_b1.json; echo
   timeout 400 python bench.py --model qwen3-4b --total-seqs 64 --steps 32 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_total64.json; cut -c1-250 $O/${T}_bench_4b_total64.json; echo
   prof 4b_b16 --model qwen3-4b --batch 16 --steps 8 --warmup 2
   prof 4b_b64 --model qwen3-4b --batch 64 --steps 8 --warmup 2
