@@ -159,6 +159,43 @@ def test_small_batch_on_large_layers_takes_the_gemm_with_a_split_attention(model
     assert worst < TOL["q80"]
 
 
+@pytest.mark.parametrize("quant,gs", [("q80", 64), ("f32", 0)])
+def test_long_context_vs_oracle(oracle, model_dir, quant, gs):
+    """max_seq_len 2048 (long context): every attention split runs several rounds, the range bucket moves through
+    32 HIP graphs, batched prefill combines 8 splits per token.  Strict mode stays bit-identical to the oracle at positions
+    past 1024; the fast path stays inside its bar; batched prefill leaves the same bits as token-by-token feeding."""
+    from nano_amd import modelfile as mf
+    S, T = 2048, 1800
+    spec = mf.preset("tiny-qwen3", quant, group_size=gs, block_size=S)      # the RoPE tables end at block_size rows
+    path = os.path.join(model_dir, f"tiny-qwen3-long-{quant}.bin")
+    mf.write_model(path, spec, seed=39)
+    ids = mf.prompt_ids(4242, T, spec.vocab_size)
+    o = ob.OracleCtx(oracle, path, max_seq_len=S)
+    probes = {1023, 1024, 1500, T - 1}
+    ref = {}
+    for pos in range(T):
+        lg = o.forward(int(ids[pos]), pos)
+        if pos in probes: ref[pos] = lg.copy()
+    o.close()
+    m = nb.load_model_file(path, max_seq_len=S, max_batch=1)
+    m.set_strict(True)
+    for pos in range(T):
+        lg, _ = m.forward([int(ids[pos])], [pos], want_logits=pos in probes)
+        if pos in probes:
+            assert np.array_equal(lg[0].view(np.uint32), ref[pos].view(np.uint32)), (quant, pos, rel_err(lg[0], ref[pos]))
+    m.set_strict(False)
+    worst, last = 0.0, None
+    for pos in range(T):
+        lg, _ = m.forward([int(ids[pos])], [pos], want_logits=pos in probes)
+        if pos in probes: worst = max(worst, rel_err(lg[0], ref[pos])); last = lg[0].copy()
+    m.prefill(ids[:T - 1], 0)
+    lg, _ = m.forward([int(ids[T - 1])], [T - 1])
+    m.close()
+    print(f"tiny-qwen3/{quant} at positions 1023..{T - 1}: strict == oracle bit for bit, fast path worst {worst:.3e}")
+    assert worst < TOL[quant]
+    assert np.array_equal(lg[0].view(np.uint32), last.view(np.uint32))           # prefill == token by token
+
+
 def test_q4k_batch_on_rows_too_long_for_one_launch(model_dir):
     """Q4K, 8 sequences per step on Qwen3-4B's row lengths: a workgroup holds every sequence's quantized activation in LDS
     and hidden size 9728 leaves room for two, so the step is sliced (gemv_q4k_fit_batch) -- same logits as one by one."""
