@@ -516,17 +516,20 @@ static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {
 // timesteps one workgroup covers per round for this head size
 static uint32_t steps_per_wg(uint32_t hd) { return NP * (256 / (hd > 128 ? 16 : 8)); }
 
-// number of splits for an upper bound `range_hint` of the attended range (<= 8; the partial buffers are sized for 8)
+// number of splits for an upper bound `range_hint` of the attended range: <= 8 up to ATTN_WIDE_FROM positions (what the Wo
+// GEMV's prologue combines); beyond, up to ATTN_MAX_NSPLIT so that a long range still spreads over the chip (8 KV groups
+// x 32 splits), combined by attn_combine_tokens_kernel -- a launch of its own, which pays from about four rounds per
+// workgroup on (Qwen3-0.6B, tools/long_ctx_probe.py: position 4095 1042 -> 958 us per step; 1023 would lose 90 us)
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd) {
-    const uint32_t per = steps_per_wg(hd);
+    const uint32_t per = steps_per_wg(hd), cap = range_hint > ATTN_WIDE_FROM ? ATTN_MAX_NSPLIT : 8u;
     uint32_t n = (range_hint + per - 1) / per;
     if (n < 1) n = 1;
-    if (n > 8) n = 8;
+    if (n > cap) n = cap;
     return n;
 }
 
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st) {
-    if (a.hd % 4 || a.hd > 256 || a.hd < 4 || a.nsplit == 0 || a.nsplit > 8) return hipErrorInvalidValue;
+    if (a.hd % 4 || a.hd > 256 || a.hd < 4 || a.nsplit == 0 || a.nsplit > ATTN_MAX_NSPLIT) return hipErrorInvalidValue;
     if (a.nsplit == 1 && !a.xba_out) return hipErrorInvalidValue;
     if (a.hd <= 32) return launch_lpr<8, 1>(a, nb, st);
     if (a.hd <= 64) return launch_lpr<8, 2>(a, nb, st);
@@ -559,28 +562,32 @@ hipError_t launch_attn_combine(const float *part, const float *ml, float *out, u
 // The combine of the Wo GEMV's prologue (gemv_common.h combine_weights / combine4) as a kernel of its own, for steps
 // whose Wo cannot fold it in (batched prefill through the MFMA GEMM): same weights (8 slots, pairwise-tree sum of
 // l_s * exp(m_s - M), e / L), same ascending accumulation — the bits of x are those of the decode path.
+// NS: slots (8: the Wo prologue's arithmetic exactly; 32: long ranges, the 8-slot tree per block of 8, blocks added in order)
+template <int NS>
 __global__ __launch_bounds__(128) void attn_combine_tokens_kernel(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit,
                                                                   int8_t *xf_out, float *xsf_out) {
     const uint32_t h = blockIdx.x, b = blockIdx.y, q_dim = n_head * hd;
     const float *mlh = ml + (((size_t)b * n_head + h) * nsplit) * 2;
-    float mm[8], e[8], v[8], w[8];
+    float mm[NS], e[NS], v[NS], w[NS];
     float M = -INFINITY;
 #pragma unroll
-    for (uint32_t s = 0; s < 8; s++) {
+    for (uint32_t s = 0; s < (uint32_t)NS; s++) {
         const bool in = s < nsplit;
         mm[s] = in ? mlh[2 * s] : -INFINITY; v[s] = in ? mlh[2 * s + 1] : 0.0f;
         if (v[s] > 0.0f) M = fmaxf(M, mm[s]);
     }
 #pragma unroll
-    for (uint32_t s = 0; s < 8; s++) { e[s] = v[s] > 0.0f ? expf(mm[s] - M) : 0.0f; v[s] = v[s] * e[s]; }
-    const float L = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (uint32_t s = 0; s < (uint32_t)NS; s++) { e[s] = v[s] > 0.0f ? expf(mm[s] - M) : 0.0f; v[s] = v[s] * e[s]; }
+    float L = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 #pragma unroll
-    for (uint32_t s = 0; s < 8; s++) w[s] = e[s] / L;
+    for (int k = 8; k < NS; k += 8) L += ((v[k] + v[k + 1]) + (v[k + 2] + v[k + 3])) + ((v[k + 4] + v[k + 5]) + (v[k + 6] + v[k + 7]));
+#pragma unroll
+    for (uint32_t s = 0; s < (uint32_t)NS; s++) w[s] = e[s] / L;
     const float *pb = part + (size_t)b * nsplit * q_dim + (size_t)h * hd;
     for (uint32_t i = threadIdx.x; i < hd; i += blockDim.x) {
         float acc = 0.0f;
 #pragma unroll
-        for (uint32_t s = 0; s < 8; s++) { const float o = s < nsplit ? pb[(size_t)s * q_dim + i] : 0.0f; acc += o * w[s]; }
+        for (uint32_t s = 0; s < (uint32_t)NS; s++) { const float o = s < nsplit ? pb[(size_t)s * q_dim + i] : 0.0f; acc += o * w[s]; }
         out[(size_t)b * q_dim + (size_t)h * hd + i] = acc;
         if (xf_out) {       // also as a Q80 group of 64 (= this wave's 64 lanes; head_dim % 64 == 0) in fragment order, see attention_kernel
             float mx = fabsf(acc);
@@ -597,7 +604,9 @@ __global__ __launch_bounds__(128) void attn_combine_tokens_kernel(const float *p
 hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb,
                                       int8_t *xf_out, float *xsf_out, hipStream_t st) {
     if (xf_out && (hd % 64u || !xsf_out)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_combine_tokens_kernel, dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit, xf_out, xsf_out);
+    if (nsplit == 0 || nsplit > ATTN_MAX_NSPLIT) return hipErrorInvalidValue;
+    if (nsplit <= 8) hipLaunchKernelGGL(attn_combine_tokens_kernel<8>, dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit, xf_out, xsf_out);
+    else hipLaunchKernelGGL((attn_combine_tokens_kernel<(int)ATTN_MAX_NSPLIT>), dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit, xf_out, xsf_out);
     return hipGetLastError();
 }
 

@@ -89,7 +89,8 @@ struct NanoHipModel {
     float *rope_cur = nullptr;                            // RoPE rows of the current positions [B][2][hd/2], staged by the embed kernel
     float *kcache = nullptr, *vcache = nullptr;
     uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
-    uint32_t trace_cap = 0, nsplit = 1;                  // nsplit: of the LAST enqueued step (<= 8, buffers sized for 8)
+    uint32_t trace_cap = 0, nsplit = 1;                  // nsplit: splits xba still has to be combined from after the LAST enqueued step (1: final)
+    uint32_t nsplit_cap = 8;                             // the partial buffers are sized for it (32 beyond 2048 positions)
     // pinned host staging
     uint32_t *h_tokens = nullptr, *h_pos = nullptr, *h_amax = nullptr;
     float *h_logits = nullptr;
@@ -343,7 +344,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     m->Bs = (uint32_t)Bs;
     const size_t kvn = B * L * max_seq_len * KD;
     m->trace_cap = max_seq_len * max_batch;
-    m->nsplit = 8;                                       // partial buffers are sized for the maximum
+    m->nsplit_cap = max_seq_len > ATTN_WIDE_FROM ? ATTN_MAX_NSPLIT : 8;     // partial buffers are sized for the maximum
     bool ok = hipMalloc(&m->x, Bs * E * 4) == hipSuccess && hipMalloc(&m->q, Bs * QD * 4) == hipSuccess &&
               hipMalloc(&m->kraw, Bs * KD * 4) == hipSuccess && hipMalloc(&m->xba, Bs * QD * 4) == hipSuccess &&
               hipMalloc(&m->hb, Bs * H * 4) == hipSuccess && hipMalloc(&m->logits, B * V * 4) == hipSuccess &&
@@ -352,8 +353,8 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
               hipMalloc(&m->tokens, Bs * 4) == hipSuccess && hipMalloc(&m->pos, Bs * 4) == hipSuccess &&
               hipMalloc(&m->amax, B * 4) == hipSuccess && hipMalloc(&m->trace, (size_t)m->trace_cap * 4) == hipSuccess &&
               hipMalloc(&m->pos0, B * 4) == hipSuccess &&
-              hipMalloc(&m->attn_part, Bs * m->nsplit * QD * 4) == hipSuccess &&
-              hipMalloc(&m->attn_ml, Bs * d.n_head * m->nsplit * 2 * 4) == hipSuccess &&
+              hipMalloc(&m->attn_part, Bs * m->nsplit_cap * QD * 4) == hipSuccess &&
+              hipMalloc(&m->attn_ml, Bs * d.n_head * m->nsplit_cap * 2 * 4) == hipSuccess &&
               hipMalloc(&m->tile_max, B * V * 2 * 4) == hipSuccess &&
               hipMalloc(&m->rope_cur, Bs * m->hd * 4 + 64) == hipSuccess;
     if (ok && Bs > 8 && d.quant_type == NANO_QUANT_Q80) {
@@ -504,6 +505,20 @@ static uint32_t step_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_h
     return ns ? ns : 1;
 }
 
+// the Wo launch of a step of nb sequences goes to the batched GEMM
+static bool wo_takes_gemm(const NanoHipModel *m, uint32_t nb) {
+    if (m->lora_on || m->d.quant_type != NANO_QUANT_Q80) return false;
+    GemvArgs wa{};
+    wa.nseg = 1; wa.seg[0] = mkseg(m->W[WO][0], m->x, m->d.n_embd, m->d.n_embd); wa.n = m->QD; wa.gs = m->d.group_size; wa.nb = nb;
+    wa.xin = m->xba; wa.xin_bstride = m->QD; wa.epi = GEMV_EPI_RESID;
+    return takes_mfma(m, wa) && gemm_q80_g2_supports(wa);
+}
+// splits nano_hip_read_state still has to combine xba from after a decode step (1: the step left it final)
+static uint32_t xba_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_hint) {
+    const uint32_t ns = step_nsplit(m, nb, range_hint);
+    return (ns > 1 && (wo_takes_gemm(m, nb) || ns > 8)) ? 1u : ns;
+}
+
 // range_hint: host-side upper bound of the attended range of every sequence (a multiple of 64, <= S)
 static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t range_hint) {
     const NanoModelDesc &d = m->d;
@@ -513,16 +528,12 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     // multiples of the 64-position bucket, so one range_hint covers them) and combines with a kernel of its own: the KV
     // rows and the following logits then carry the bits of token-by-token ingestion.
     const uint32_t nsplit = m->pf ? step_nsplit(m, 1, range_hint) : step_nsplit(m, nb, range_hint);
-    // Does this step's Wo launch go to the batched GEMM (plain activations only)?  Then a split attention is combined by a
-    // kernel of its own (as in batched prefill) instead of in the Wo GEMV's prologue -- same arithmetic, same bits.
-    bool wo_gemm = false;
-    if (!m->lora_on && d.quant_type == NANO_QUANT_Q80) {
-        GemvArgs wa{};
-        wa.nseg = 1; wa.seg[0] = mkseg(m->W[WO][0], m->x, E, E); wa.n = QD; wa.gs = d.group_size; wa.nb = nb; wa.xin = m->xba; wa.xin_bstride = QD; wa.epi = GEMV_EPI_RESID;
-        wo_gemm = takes_mfma(m, wa) && gemm_q80_g2_supports(wa);
-    }
-    const bool pf_combine = nsplit > 1 && (m->pf || wo_gemm);
-    m->nsplit = nsplit;
+    // Does this step's Wo launch go to the batched GEMM (plain activations only), or is the range split wider than the Wo
+    // GEMV's prologue combines?  Then a split attention is combined by a kernel of its own (as in batched prefill) -- for
+    // <= 8 splits the same arithmetic, same bits.
+    const bool wo_gemm = wo_takes_gemm(m, nb);
+    const bool pf_combine = nsplit > 1 && (m->pf || wo_gemm || nsplit > 8);
+    m->nsplit = pf_combine ? 1 : nsplit;
     // Single-split attention (or the combine kernel) of a step whose Wo launch goes to the batched GEMM: that kernel writes
     // Wo's quantized input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
     const bool wo_frag = m->attn_quant && wo_gemm && d.group_size == 64 && m->hd % 64 == 0;
@@ -792,7 +803,7 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
         (void)hipGraphDestroy(g);
         it = m->graphs.emplace(key, ge).first;
     }
-    m->nsplit = step_nsplit(m, nb, range_hint);
+    m->nsplit = xba_nsplit(m, nb, range_hint);
     HIP_TRY(hipGraphLaunch(it->second, m->st));
     return 0;
 }

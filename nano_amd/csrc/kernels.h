@@ -70,6 +70,7 @@ hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *no
 uint32_t gemv_q80_partials(const GemvArgs &a);
 
 // ---- attention ------------------------------------------------------------------------------------
+constexpr uint32_t ATTN_MAX_NSPLIT = 32, ATTN_WIDE_FROM = 2048;   // up to 32 splits of a range beyond 2048 positions (<= 8 below: attention_nsplit())
 struct AttnArgs {
     const float *q;         // [nb][q_dim] raw q from the QKV GEMV (normed + roped in LDS, head-local)
     float *q_out;           // optional [nb][q_dim]: finished q written back (debug / traces), or nullptr
