@@ -197,6 +197,34 @@ def test_long_context_vs_oracle(oracle, model_dir, quant, gs):
     assert np.array_equal(lg[0].view(np.uint32), last.view(np.uint32))           # prefill == token by token
 
 
+@pytest.mark.parametrize("preset,quant,gs,B", [("tiny-qwen3", "q80", 64, 1), ("tiny-qwen3", "q80", 64, 12), ("tiny-nano", "f32", 0, 3), ("tiny-nano-odd", "q4k", 0, 2)])
+def test_eager_launches_equal_graph_replays(model_dir, preset, quant, gs, B):
+    """NANO_HIP_NO_GRAPH=1 (the mode every rocprofv3 profile under profiles/ is taken in) enqueues the same kernels with the
+    same arguments as the captured graphs replay: logits and greedy ids bit for bit, over several range buckets."""
+    from nano_amd import modelfile as mf
+    path, spec = synth_model(model_dir, preset, quant, gs)
+    T = 70 if spec.block_size >= 128 else 40
+    seqs = [mf.prompt_ids(2100 + b, T, spec.vocab_size) for b in range(B)]
+
+    def run(eager):
+        old = os.environ.get("NANO_HIP_NO_GRAPH")
+        if eager: os.environ["NANO_HIP_NO_GRAPH"] = "1"
+        else: os.environ.pop("NANO_HIP_NO_GRAPH", None)
+        try:
+            m = nb.load_model_file(path, max_seq_len=min(128, spec.block_size), max_batch=B)
+        finally:
+            if old is None: os.environ.pop("NANO_HIP_NO_GRAPH", None)
+            else: os.environ["NANO_HIP_NO_GRAPH"] = old
+        out = [m.forward([int(s[pos]) for s in seqs], [pos] * B)[0].copy() for pos in range(T - 8)]
+        ids = m.decode_greedy([int(s[T - 8]) for s in seqs], [T - 8] * B, 8).copy()
+        m.close()
+        return out, ids
+    (a, ai), (b, bi) = run(False), run(True)
+    for pos, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), pos
+    assert np.array_equal(ai, bi)
+
+
 def test_q4k_batch_on_rows_too_long_for_one_launch(model_dir):
     """Q4K, 8 sequences per step on Qwen3-4B's row lengths: a workgroup holds every sequence's quantized activation in LDS
     and hidden size 9728 leaves room for two, so the step is sliced (gemv_q4k_fit_batch) -- same logits as one by one."""
