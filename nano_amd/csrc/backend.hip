@@ -817,7 +817,7 @@ extern "C" int nano_hip_sync(NanoHipModel *m) {
 
 static int check_batch(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, uint32_t extra_steps) {
     if (!m || !tokens || !pos) FAIL(NANO_HIP_EINVAL, "null argument");
-    const uint32_t cap = m->d.quant_type == NANO_QUANT_Q80 ? NANO_MAX_BATCH : 8u;      // > 8 sequences: Q80 MFMA GEMM path only
+    const uint32_t cap = NANO_MAX_BATCH;               // > 8 sequences: Q80 through the int8 MFMA GEMMs, FP32 / Q4K through their GEMV kernels in groups
     if (batch == 0 || batch > m->maxB || batch > cap) FAIL(NANO_HIP_EINVAL, "batch %u out of range (max %u, kernel capacity %u)", batch, m->maxB, cap);
     for (uint32_t i = 0; i < batch; i++) {
         if (tokens[i] >= m->d.vocab_size) FAIL(NANO_HIP_EINVAL, "token %u out of vocabulary", tokens[i]);
@@ -1096,7 +1096,7 @@ extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, c
 // measurement
 // ------------------------------------------------------------------------------------------------
 extern "C" int nano_hip_time_classifier(NanoHipModel *m, uint32_t batch, uint32_t iters, float *ms_per_launch, uint64_t *bytes_per_launch) {
-    if (!m || !iters || batch == 0 || batch > m->maxB || (batch > 8 && m->d.quant_type != NANO_QUANT_Q80)) FAIL(NANO_HIP_EINVAL, "bad argument");
+    if (!m || !iters || batch == 0 || batch > m->maxB || batch > NANO_MAX_BATCH) FAIL(NANO_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(enqueue_classifier(m, batch));                               // warm
     HIP_TRY(hipEventRecord(m->ev0, m->st));
@@ -1123,7 +1123,7 @@ static uint64_t classifier_bytes(const NanoHipModel *m) {
 // event span (end of the previous kernel -> end of the classifier); *ms_empty_pair the span of an empty event pair.
 extern "C" int nano_hip_time_classifier_in_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_launch,
                                                 uint64_t *bytes_per_launch, float *ms_empty_pair) {
-    if (!m || !iters || batch == 0 || batch > m->maxB || (batch > 8 && m->d.quant_type != NANO_QUANT_Q80) || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
+    if (!m || !iters || batch == 0 || batch > m->maxB || batch > NANO_MAX_BATCH || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     for (uint32_t i = 0; i < batch; i++) { m->h_tokens[i] = 1 % m->d.vocab_size; m->h_pos[i] = pos; }
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
@@ -1150,7 +1150,7 @@ extern "C" int nano_hip_time_classifier_in_step(NanoHipModel *m, uint32_t batch,
 }
 
 extern "C" int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_step) {
-    if (!m || !iters || batch == 0 || batch > m->maxB || (batch > 8 && m->d.quant_type != NANO_QUANT_Q80) || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
+    if (!m || !iters || batch == 0 || batch > m->maxB || batch > NANO_MAX_BATCH || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     for (uint32_t i = 0; i < batch; i++) { m->h_tokens[i] = 1 % m->d.vocab_size; m->h_pos[i] = pos; }
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));

@@ -488,14 +488,20 @@ def test_session_with_long_prompt_on_a_shape_the_gemm_refuses(model_dir):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def test_large_batch_on_a_shape_the_gemm_refuses(model_dir):
-    """More than 8 sequences per step on the same shape: GEMV kernels in groups of 8, same logits as one by one."""
+@pytest.mark.parametrize("preset,quant,gs,B", [("tiny-nano", "q80", 128, 13), ("tiny-nano", "f32", 0, 13), ("tiny-nano-odd", "q4k", 0, 11), ("tiny-qwen3", "q4k", 0, 64)])
+def test_large_batch_through_the_gemv_kernels(model_dir, preset, quant, gs, B):
+    """More than 8 sequences per step where no GEMM takes the launch (a Q80 shape it refuses, FP32, Q4K): GEMV kernels in
+    groups of 8 (Q4K: as many as fit its LDS), same logits as one by one."""
     from nano_amd import modelfile as mf
-    path, spec = synth_model(model_dir, "tiny-nano", "q80", 128)
-    B, T = 13, 6
+    path, spec = synth_model(model_dir, preset, quant, gs)
+    T = 6
     seqs = [mf.prompt_ids(700 + b, T, spec.vocab_size) for b in range(B)]
     mb = nb.load_model_file(path, max_seq_len=16, max_batch=B)
-    batched = [mb.forward([int(s[pos]) for s in seqs], [pos] * B)[0] for pos in range(T)]
+    batched = []
+    for pos in range(T):
+        lg, am = mb.forward([int(s[pos]) for s in seqs], [pos] * B, want_logits=True, want_argmax=True)
+        assert np.array_equal(am, np.argmax(lg, axis=1))
+        batched.append(lg)
     mb.close()
     m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
     for b in range(B):
