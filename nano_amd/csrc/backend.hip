@@ -86,6 +86,8 @@ struct NanoHipModel {
     const float *lora_t[8] = {nullptr};                   // qa qb ka kb va vb oa ob, each [L][...]
     uint32_t lora_rank = 0, lora_alpha = 0; bool lora_on = false;
     int8_t *gq = nullptr; float *gxs = nullptr;           // MFMA GEMM path (batch > 8, Q80): quantized activations of all sequences
+    int8_t *gq2 = nullptr; float *gxs2 = nullptr;         // ... second scratch: W2's input, written by the W1|W3 GEMM's epilogue
+    bool w2_quant = true;                                 // (NANO_W2_QUANT=0: a quantizer launch of its own)
     float *rope_cur = nullptr;                            // RoPE rows of the current positions [B][2][hd/2], staged by the embed kernel
     float *kcache = nullptr, *vcache = nullptr;
     uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
@@ -172,7 +174,7 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att, m->vraw };
+                    m->xn, m->hb2, m->att, m->vraw, m->gq2, m->gxs2 };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -359,7 +361,8 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
               hipMalloc(&m->rope_cur, Bs * m->hd * 4 + 64) == hipSuccess;
     if (ok && Bs > 8 && d.quant_type == NANO_QUANT_Q80) {
         size_t nmax = E > QD ? E : QD; if (H > nmax) nmax = H;
-        ok = hipMalloc(&m->gq, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, Bs * (nmax / d.group_size) * 4) == hipSuccess;
+        ok = hipMalloc(&m->gq, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, Bs * (nmax / d.group_size) * 4) == hipSuccess &&
+             hipMalloc(&m->gq2, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs2, Bs * (nmax / d.group_size) * 4) == hipSuccess;
     }
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
     // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
@@ -377,6 +380,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
     if (const char *g5 = getenv("NANO_GEMM_G5")) m->use_g5 = *g5 && *g5 != '0';
     if (const char *aq = getenv("NANO_ATTN_QUANT")) m->attn_quant = *aq && *aq != '0';
+    if (const char *wq = getenv("NANO_W2_QUANT")) m->w2_quant = *wq && *wq != '0';
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
     if (const char *sm = getenv("NANO_STRICT")) if (*sm && *sm != '0') return nano_hip_set_strict(m, 1);
@@ -452,8 +456,9 @@ static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
             const hipError_t e = launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
             if (e != hipSuccess) return e;
         }
-        a.xq_in = m->gq; a.xs_in = m->gxs;
-        if (m->use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, m->st);
+        a.xq_in = a.frag_ready == 2u ? m->gq2 : m->gq; a.xs_in = a.frag_ready == 2u ? m->gxs2 : m->gxs;
+        if (m->use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, a.frag_out, a.frag_scale_out, m->st);
+        if (a.frag_out) return hipErrorInvalidValue;               // the caller checked gemm_q80_g5_can_quantize_outputs()
         return launch_gemm_q80_g2(a, m->st);
     }
     if (a.nb > 8) {
@@ -610,17 +615,25 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.frag_ready = (wo_frag && !(skip & 2)) ? 1u : 0u;
             if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
         }
+        bool w2_frag = false;
         {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
             GemvArgs a{};
             a.nseg = 2; a.seg[0] = mkseg(m->W[W1][l], m->hb, H, H); a.seg[1] = mkseg(m->W[W3][l], m->hb, H, H);
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_SWIGLU;
             a.norm_w = m->rms_ffn + (size_t)l * E; a.pos = m->pos;
+            // both FFN launches on the batched GEMM path and this one on G5: its epilogue quantizes hb for W2 (64-row groups)
+            if (m->w2_quant && m->use_g5 && m->gq2 && !(skip & 8) && takes_mfma(m, a) && gemm_q80_g5_can_quantize_outputs(a)) {
+                GemvArgs w2{};
+                w2.nseg = 1; w2.seg[0] = mkseg(m->W[W2][l], m->x, E, E); w2.n = H; w2.gs = d.group_size; w2.nb = nb; w2.xin = m->hb; w2.xin_bstride = H; w2.epi = GEMV_EPI_RESID;
+                if (takes_mfma(m, w2) && gemm_q80_g2_supports(w2)) { w2_frag = true; a.frag_out = m->gq2; a.frag_scale_out = m->gxs2; }
+            }
             if (!(skip & 8) && (e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // x += W2 . hb   reference infer.c:950-965
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[W2][l], m->x, E, E);
             a.n = H; a.gs = d.group_size; a.nb = nb; a.xin = m->hb; a.xin_bstride = H; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
+            a.frag_ready = w2_frag ? 2u : 0u;
             if (!(skip & 16) && (e = gemv(m, a)) != hipSuccess) return e;
         }
     }

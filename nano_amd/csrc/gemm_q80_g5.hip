@@ -16,6 +16,9 @@
 //     half chunk, the products of later half chunks and token tiles are formed while earlier links are still travelling.
 //     The owner of the last half chunk runs the epilogue.  SwiGLU: the W1 team and the W3 team of a row tile sit in the
 //     same workgroup; W3's last owner publishes, W1's last owner combines.
+//   * SwiGLU launches can hand the W2 GEMM its quantized input: with four row-tile pairs per workgroup the four finishing
+//     waves hold one 64-row quantization group of hb for 16 tokens; they exchange their maxima through LDS and write the
+//     group in fragment order themselves (one activation-quantizer launch less per layer; same bits).
 // Bit-identical to the GEMV path and to the reference's matmul_quant (infer/infer.c:654-679).
 // Takes: group size 64, group count a multiple of 4, interior segments multiples of 16 rows.
 #include "gemv_common.h"
@@ -31,6 +34,9 @@ struct G5Dev {
     uint32_t rows[3], out_bstride[3], out_pstride[3];
     uint32_t n, ng, epi, nb, nhc, ntiles, tt, nkw, cpw, teams, nmat;
     const int8_t *xf; const float *xsf; const uint32_t *pos;
+    // SwiGLU launches, optional (4 row-tile pairs per workgroup): the outputs also leave as Q80 groups of 64 in fragment order,
+    // i.e. the next GEMM's activation operand (what quant_rows_frag_kernel would make of them); ng2 = rows / 64
+    int8_t *xf2; float *xsf2; uint32_t ng2;
 };
 
 constexpr uint32_t G5_PITCH = 528, G5_WBUF = 16 * G5_PITCH;           // transposition buffer of one wave: 16 rows x 512 B
@@ -60,6 +66,8 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
     uint32_t *flags = reinterpret_cast<uint32_t *>(slots + (size_t)a.teams * TT * 256u);  // [team][TT]
     float *slot = slots + (size_t)team * TT * 256u;
     uint32_t *flag = flags + team * TT;
+    float *gmax = reinterpret_cast<float *>(flags + ((a.teams * TT + 3u) & ~3u));          // [TT][4 row tiles][16 tokens] (fused group quantizer)
+    uint32_t *gcnt = reinterpret_cast<uint32_t *>(gmax + TT * 64);                         // [TT] finishers arrived
 
     // ---- which segment (q | k | v share a launch; SwiGLU: matrix 0 = W1, matrix 1 = W3 over the same rows) -----------------
     const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
@@ -98,6 +106,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
     };
     issue_w(kw);
     if (kw == 0u && lane < (uint32_t)TT) flag[lane] = 0u;
+    if (wid == 0u && lane < (uint32_t)TT) gcnt[lane] = 0u;
     __syncthreads();                                                   // the only workgroup barrier: the counters are armed
     if (!live) return;
 
@@ -174,12 +183,36 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                         const float4 in = *reinterpret_cast<const float4 *>(slot + TT * 256 + t * 256 + lane * 4u);
                         v1[0] = in.x; v1[1] = in.y; v1[2] = in.z; v1[3] = in.w;
                     }
+                    float val[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) val[i] = finish_epi(a.epi, acc[i], v1[i], oldv[i]);
                     if (tok < a.nb) {
                         const uint32_t opos = ops ? a.pos[tok] : 0u;
                         float *o = orow + (size_t)opos * ops;
 #pragma unroll
                         for (int i = 0; i < 4; i++)
-                            if (lrow0 + kq * 4u + i < rows0) o[i] = finish_epi(a.epi, acc[i], v1[i], oldv[i]);
+                            if (lrow0 + kq * 4u + i < rows0) o[i] = val[i];
+                    }
+                    if constexpr (TT == 1) if (a.xf2) {               // (one token tile only: measured slower with more, and its registers would cost the other instantiations)
+                        // ---- the 64-row Q80 group of these outputs (infer/tensor.c:21-46): this wave holds rows 16 rt .. +15 of
+                        //      it for 16 tokens, the three other finishing waves of the workgroup the rest; they exchange their
+                        //      maxima through LDS and each writes its quarter of the group in fragment order
+                        const uint32_t rt = (team >> 1) & 3u;
+                        float mx = fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3])));
+                        mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                        if (kq == 0u) gmax[(t * 4u + rt) * 16u + m] = mx;
+                        if (lane == 0u) __hip_atomic_fetch_add(gcnt + t, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        while (lds_load_acq(gcnt + t) != 4u) __builtin_amdgcn_s_sleep(1);
+                        const float g4 = fmaxf(fmaxf(gmax[(t * 4u + 0u) * 16u + m], gmax[(t * 4u + 1u) * 16u + m]),
+                                               fmaxf(gmax[(t * 4u + 2u) * 16u + m], gmax[(t * 4u + 3u) * 16u + m]));
+                        const float scale = g4 / 127.0f;
+                        const uint32_t packed = (uint32_t)(q80_quant1(val[0], scale) & 0xff) | ((uint32_t)(q80_quant1(val[1], scale) & 0xff) << 8) |
+                                                ((uint32_t)(q80_quant1(val[2], scale) & 0xff) << 16) | ((uint32_t)(q80_quant1(val[3], scale) & 0xff) << 24);
+                        if (tok < a.nb) {
+                            const size_t gb = (size_t)t * a.ng2 + (tile >> 2);
+                            *reinterpret_cast<uint32_t *>(a.xf2 + gb * 1024u + (size_t)(rt * 16u + m) * 16u + kq * 4u) = packed;
+                            if (rt == 0u && kq == 0u) a.xsf2[gb * 16u + m] = scale;
+                        }
                     }
                 }
             }
@@ -216,8 +249,15 @@ bool gemm_q80_g5_supports(const GemvArgs &a) {
 }
 
 // a.xq_in / a.xs_in: the activations in fragment order (launch_quant_rows_frag)
-hipError_t launch_gemm_q80_g5(const GemvArgs &a, hipStream_t st) {
+// xf2 / xsf2 (SwiGLU launches whose row count is a multiple of 64, or nullptr): the outputs also as the next GEMM's operand
+// Up to 16 tokens: with more the one-wave-per-row-tile split this needs is slower than the quantizer launch it saves
+// (Qwen3-4B W1|W3 at 64 tokens 31 -> 42 us; at 16 tokens the launch pair is 1.5 us per layer cheaper)
+bool gemm_q80_g5_can_quantize_outputs(const GemvArgs &a) {
+    return gemm_q80_g5_supports(a) && a.epi == GEMV_EPI_SWIGLU && a.seg[0].rows % 64u == 0 && a.nb <= 16;
+}
+hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipStream_t st) {
     if (!a.xq_in || !a.xs_in || !gemm_q80_g5_supports(a)) return hipErrorInvalidValue;
+    if (xf2 && (!xsf2 || !gemm_q80_g5_can_quantize_outputs(a))) return hipErrorInvalidValue;
     G5Dev d{};
     for (int i = 0; i < 3; i++) {
         const bool live = i < (int)a.nseg;
@@ -252,11 +292,12 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, hipStream_t st) {
         if (slots && d.ntiles <= (uint32_t)cus * slots) { nkw = kk; fits = true; break; }
     }
     if (!fits) { nkw = 1; groups = 4u / d.nmat; }
+    if (xf2) { nkw = 1; groups = 4; d.xf2 = xf2; d.xsf2 = xsf2; d.ng2 = a.seg[0].rows / 64u; }     // one 64-row group of outputs per workgroup
     d.nkw = nkw; d.cpw = (d.nhc + nkw - 1) / nkw;
     d.teams = groups * d.nmat;
     const uint32_t waves = d.teams * d.nkw;
     const uint32_t nwg = (d.ntiles + groups - 1) / groups;
-    const size_t lds = (size_t)waves * G5_LDS_WAVE + (size_t)d.teams * TTc * 1024u + (((size_t)d.teams * TTc * 4u + 15u) & ~(size_t)15u);
+    const size_t lds = (size_t)waves * G5_LDS_WAVE + (size_t)d.teams * TTc * 1024u + (((size_t)d.teams * TTc * 4u + 15u) & ~(size_t)15u) + (size_t)TTc * 256u + 16u;
     if (TTc == 1) launch_tt<1>(d, nwg, waves, lds, st);
     else if (TTc == 2) launch_tt<2>(d, nwg, waves, lds, st);
     else launch_tt<4>(d, nwg, waves, lds, st);

@@ -33,7 +33,9 @@ struct GemvArgs {
     const float *norm_w;    // rmsnorm weight or nullptr
     const uint32_t *pos;    // device positions [nb] (for out_pstride)
     uint32_t tiles;         // filled by the launcher
-    uint32_t frag_ready;    // batched GEMM path: xq_in / xs_in already hold the fragment-order activations (the attention kernel wrote them)
+    uint32_t frag_ready;    // batched GEMM path: the fragment-order activations already exist -- 1: in the step's first scratch (the attention
+                            // kernel wrote them), 2: in the second (the W1|W3 GEMM wrote them)
+    int8_t *frag_out; float *frag_scale_out;   // SwiGLU launch through G5: also write the outputs as the next GEMM's fragments, or nullptr
     // operator-test inputs: an already quantized activation (skips the quantizing prologue)
     const int8_t *xq_in;    // Q80 int8[n] (batched GEMM path with frag_ready: all tokens, MFMA B-fragment order)
     const float *xs_in;     // Q80 float[n/gs]
@@ -62,7 +64,8 @@ bool gemm_q80_g2_supports(const GemvArgs &a);                       // host pred
 hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st);
 // G5, row length split over a chained team of waves, all token tiles per wave (gemm_q80_g5.hip): same inputs as G2
 bool gemm_q80_g5_supports(const GemvArgs &a);
-hipError_t launch_gemm_q80_g5(const GemvArgs &a, hipStream_t st);
+bool gemm_q80_g5_can_quantize_outputs(const GemvArgs &a);           // SwiGLU launches: the outputs also as Q80 fragments (xf2 / xsf2)
+hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipStream_t st);
 hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                                   int8_t *xf, float *xsf, hipStream_t st);
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,

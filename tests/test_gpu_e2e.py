@@ -150,7 +150,7 @@ def test_small_batch_on_large_layers_takes_the_gemm_with_a_split_attention(model
         m.close()
         return out
     a = run()
-    for other in (run(NANO_GEMM_G5="0"), run(NANO_ATTN_QUANT="0")):
+    for other in (run(NANO_GEMM_G5="0"), run(NANO_ATTN_QUANT="0"), run(NANO_W2_QUANT="0")):
         for x, y in zip(a, other):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     gemv = run(NANO_MFMA_MIN_NB="65")                          # every launch through the GEMV kernels
@@ -269,8 +269,9 @@ def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
         m.close()
         return out, kv
     a, akv = run()
-    # the general G2 kernel everywhere; Wo's input quantized by a launch of its own instead of by the attention kernel
-    for b, bkv in (run(NANO_GEMM_G5="0"), run(NANO_ATTN_QUANT="0")):
+    # the general G2 kernel everywhere; Wo's / W2's input quantized by a launch of its own instead of by the attention kernel /
+    # the W1|W3 GEMM's epilogue
+    for b, bkv in (run(NANO_GEMM_G5="0"), run(NANO_ATTN_QUANT="0"), run(NANO_W2_QUANT="0")):
         for pos in range(T):
             assert np.array_equal(a[pos].view(np.uint32), b[pos].view(np.uint32)), pos
         assert np.array_equal(akv.view(np.uint32), bkv.view(np.uint32))
