@@ -494,9 +494,17 @@ static hipError_t launch_mode_kv(const AttnArgs &a, uint32_t nb, hipStream_t st)
     const uint32_t hd4 = (a.hd + 3) & ~3u;
     constexpr uint32_t R = 256 / LPR;
     auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + kvm * R + (size_t)R * kvm * hd4) * sizeof(float); };
-    if (kv_mul == 2) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 2, MODE, KVH>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(2), st, a); }
-    else if (kv_mul == 4) { hipLaunchKernelGGL((attention_kernel<LPR, QV, 4, MODE, KVH>), dim3(a.n_kv_head, nb, a.nsplit), dim3(256), lds_for(4), st, a); }
-    else { hipLaunchKernelGGL((attention_kernel<LPR, QV, 1, MODE, KVH>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a); }
+    // q heads per workgroup (KVM; h0 = KVM grp, KV head h0 / kv_mul): fewer heads = more workgroups with less dependent work each,
+    // the K/V rows' repeated reads come from L2 (and the KV head's fresh k row is written by each of its workgroups: same
+    // bits).  Same per-head arithmetic whatever the choice.  One head per workgroup while that leaves at most one workgroup
+    // per CU, else two (measured: Qwen3-0.6B batch 1 6.15 -> 5.35 us per launch = +3.7 % tokens/s; Qwen3-4B's kv_mul 4:
+    // 8.65 -> 6.03 us at batch 1, 10.05 -> 7.22 with two heads at 16 sequences, where one head per workgroup costs 10.3).
+    static const uint32_t forced = getenv("NANO_ATTN_KVM") ? (uint32_t)atoi(getenv("NANO_ATTN_KVM")) : 0u;   // measurement knob
+    uint32_t kvm = ((uint64_t)a.n_head * nb * a.nsplit <= 256u || kv_mul % 2 != 0) ? 1u : 2u;
+    if (forced == 1u || (forced == 2u && kv_mul % 2 == 0) || (forced == 4u && kv_mul % 4 == 0)) kvm = forced;
+    if (kvm == 4) hipLaunchKernelGGL((attention_kernel<LPR, QV, 4, MODE, KVH>), dim3(a.n_head / 4, nb, a.nsplit), dim3(256), lds_for(4), st, a);
+    else if (kvm == 2) hipLaunchKernelGGL((attention_kernel<LPR, QV, 2, MODE, KVH>), dim3(a.n_head / 2, nb, a.nsplit), dim3(256), lds_for(2), st, a);
+    else hipLaunchKernelGGL((attention_kernel<LPR, QV, 1, MODE, KVH>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a);
     return hipGetLastError();
 }
 template <int LPR, int QV, int MODE>
