@@ -497,10 +497,12 @@ static hipError_t launch_mode_kv(const AttnArgs &a, uint32_t nb, hipStream_t st)
     // q heads per workgroup (KVM; h0 = KVM grp, KV head h0 / kv_mul): fewer heads = more workgroups with less dependent work each,
     // the K/V rows' repeated reads come from L2 (and the KV head's fresh k row is written by each of its workgroups: same
     // bits).  Same per-head arithmetic whatever the choice.  One head per workgroup while that leaves at most one workgroup
-    // per CU, else two (measured: Qwen3-0.6B batch 1 6.15 -> 5.35 us per launch = +3.7 % tokens/s; Qwen3-4B's kv_mul 4:
-    // 8.65 -> 6.03 us at batch 1, 10.05 -> 7.22 with two heads at 16 sequences, where one head per workgroup costs 10.3).
+    // per CU, two while at most two, else the whole KV group (measured: Qwen3-0.6B batch 1 6.15 -> 5.35 us per launch = +3.7 %
+    // tokens/s; Qwen3-4B's kv_mul 4: 8.65 -> 6.03 us at batch 1, 10.05 -> 7.22 with two heads at 16 sequences, where one head
+    // per workgroup costs 10.3; at 64 sequences the KV rows' bandwidth rules and four heads share them: 13.7 vs 16.4).
     static const uint32_t forced = getenv("NANO_ATTN_KVM") ? (uint32_t)atoi(getenv("NANO_ATTN_KVM")) : 0u;   // measurement knob
-    uint32_t kvm = ((uint64_t)a.n_head * nb * a.nsplit <= 256u || kv_mul % 2 != 0) ? 1u : 2u;
+    const uint64_t head_wgs = (uint64_t)a.n_head * nb * a.nsplit;
+    uint32_t kvm = (head_wgs <= 256u || kv_mul % 2 != 0) ? 1u : (head_wgs <= 1024u || kv_mul % 4 != 0) ? 2u : 4u;
     if (forced == 1u || (forced == 2u && kv_mul % 2 == 0) || (forced == 4u && kv_mul % 4 == 0)) kvm = forced;
     if (kvm == 4) hipLaunchKernelGGL((attention_kernel<LPR, QV, 4, MODE, KVH>), dim3(a.n_head / 4, nb, a.nsplit), dim3(256), lds_for(4), st, a);
     else if (kvm == 2) hipLaunchKernelGGL((attention_kernel<LPR, QV, 2, MODE, KVH>), dim3(a.n_head / 2, nb, a.nsplit), dim3(256), lds_for(2), st, a);
