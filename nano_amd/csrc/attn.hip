@@ -114,8 +114,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const uint32_t nsplit = a.nsplit;
     const uint32_t hd = a.hd, half = hd >> 1, hd4 = (hd + 3) & ~3u;
     const uint32_t kv_mul = a.n_head / a.n_kv_head;
-    const uint32_t h0 = (KVM == 1) ? grp : grp * KVM;          // first q head of this workgroup
-    const uint32_t g = h0 / kv_mul;                            // its KV head
+    // first q head of this workgroup and its KV head.  XCD-aware order (kv_log2 valid): x = sub * n_kv_head + KV head, so the
+    // kv_mul / KVM workgroups that read the same K/V rows have equal x mod 8 = the same XCD = one L2 fetch of every row
+    const bool xcd = a.kv_log2 != 0xffffffffu;
+    const uint32_t g = xcd ? (grp & ((1u << a.kv_log2) - 1u)) : (grp * KVM) / kv_mul;
+    const uint32_t h0 = xcd ? g * kv_mul + (grp >> a.kv_log2) * KVM : grp * KVM;
     constexpr bool G = MODE == 0;
     constexpr int VR = (KVM + 1 + 3) / 4;                      // rounds of vectors per wave (q heads + the k row over 4 waves)
     constexpr int JJ = (LPR == 16) ? 2 : 1;                    // RoPE pairs per lane (head_dim > 128 needs two)
@@ -489,9 +492,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 }
 
 template <int LPR, int QV, int MODE, bool KVH>
-static hipError_t launch_mode_kv(const AttnArgs &a, uint32_t nb, hipStream_t st) {
-    const uint32_t kv_mul = a.n_head / a.n_kv_head;
-    const uint32_t hd4 = (a.hd + 3) & ~3u;
+static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t st) {
+    const uint32_t kv_mul = a_in.n_head / a_in.n_kv_head;
+    const uint32_t hd4 = (a_in.hd + 3) & ~3u;
     constexpr uint32_t R = 256 / LPR;
     auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + kvm * R + (size_t)R * kvm * hd4) * sizeof(float); };
     // q heads per workgroup (KVM; h0 = KVM grp, KV head h0 / kv_mul): fewer heads = more workgroups with less dependent work each,
@@ -501,6 +504,10 @@ static hipError_t launch_mode_kv(const AttnArgs &a, uint32_t nb, hipStream_t st)
     // tokens/s; Qwen3-4B's kv_mul 4: 8.65 -> 6.03 us at batch 1, 10.05 -> 7.22 with two heads at 16 sequences, where one head
     // per workgroup costs 10.3; at 64 sequences the KV rows' bandwidth rules and four heads share them: 13.7 vs 16.4).
     static const uint32_t forced = getenv("NANO_ATTN_KVM") ? (uint32_t)atoi(getenv("NANO_ATTN_KVM")) : 0u;   // measurement knob
+    static const bool xcd_order = !(getenv("NANO_ATTN_XCD") && *getenv("NANO_ATTN_XCD") == '0');             // measurement knob
+    AttnArgs a = a_in;
+    a.kv_log2 = 0xffffffffu;
+    if (xcd_order && a.n_kv_head >= 8 && (a.n_kv_head & (a.n_kv_head - 1)) == 0) { uint32_t l2 = 0; while ((1u << l2) < a.n_kv_head) l2++; a.kv_log2 = l2; }
     const uint64_t head_wgs = (uint64_t)a.n_head * nb * a.nsplit;
     uint32_t kvm = (head_wgs <= 256u || kv_mul % 2 != 0) ? 1u : (head_wgs <= 1024u || kv_mul % 4 != 0) ? 2u : 4u;
     if (forced == 1u || (forced == 2u && kv_mul % 2 == 0) || (forced == 4u && kv_mul % 4 == 0)) kvm = forced;

@@ -49,6 +49,7 @@ extern "C" void nano_hip_set_error_(const char *msg) { g_err = msg ? msg : ""; }
     } while (0)
 
 enum { WQ = 0, WK, WV, WO, W1, W2, W3, WCOUNT };
+constexpr size_t PF_GRAPH_CAP = 64;                    // prefill-chunk graphs kept per model (keyed by KV slot x range bucket)
 
 struct TensorRef { const void *w = nullptr; const float *s = nullptr; };
 
@@ -97,6 +98,7 @@ struct NanoHipModel {
     uint32_t *h_tokens = nullptr, *h_pos = nullptr, *h_amax = nullptr;
     float *h_logits = nullptr;
     std::map<uint64_t, hipGraphExec_t> graphs;
+    std::vector<uint64_t> pf_graph_keys;                  // prefill-chunk graphs in creation order (bounded: PF_GRAPH_CAP)
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
@@ -437,6 +439,7 @@ static GemvArgs gemv_slice(const GemvArgs &a, uint32_t b0, uint32_t cnt) {
 
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     const uint32_t max_wg = (uint32_t)m->cus * 8;
+    a.cus = (uint32_t)m->cus;
     if (m->d.quant_type == NANO_QUANT_Q4K) {
         // every workgroup stages the whole quantized activation of each sequence in LDS: long rows (Qwen3-4B's hidden size)
         // take fewer sequences per launch
@@ -803,7 +806,9 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
     const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
-        // first use: run eagerly once (sets kernel attributes, validates launches) then capture
+        // first use: THIS step runs eagerly (the launchers set their kernel attributes and validate their arguments outside
+        // any capture), then the same enqueue is captured for the replays to come
+        HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint));
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
         hipError_t e = enqueue_step(m, nb, is_causal, mode, range_hint);
@@ -814,7 +819,9 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
         }
         HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
-        it = m->graphs.emplace(key, ge).first;
+        m->graphs.emplace(key, ge);
+        m->nsplit = xba_nsplit(m, nb, range_hint);
+        return 0;
     }
     m->nsplit = xba_nsplit(m, nb, range_hint);
     HIP_TRY(hipGraphLaunch(it->second, m->st));
@@ -998,7 +1005,7 @@ extern "C" int nano_hip_lora_attach(NanoHipModel *m, uint32_t rank, uint32_t alp
     HIP_TRY(hipStreamSynchronize(m->st));
     // graphs captured with the previous module carry its device pointers and rank in their kernel arguments
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
-    m->graphs.clear();
+    m->graphs.clear(); m->pf_graph_keys.clear();
     if (m->lora_buf) { (void)hipFree(m->lora_buf); m->lora_buf = nullptr; }
     if (!m->lora_o1) HIP_TRY(hipMalloc(&m->lora_o1, (size_t)m->Bs * E * 4));
     HIP_TRY(hipMalloc(&m->lora_buf, total * 4));
@@ -1057,22 +1064,35 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
             const uint64_t key = (1ull << 62) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)slot << 32) | ((uint64_t)range_hint << 8) | nb;
             auto it = m->graphs.find(key);
             if (it == m->graphs.end()) {
+                // first use: the chunk itself runs eagerly (kernel attributes are set outside the capture), then it is captured
+                // for the next prompt that reaches this (slot, bucket).  The cache of chunk graphs is bounded (oldest out).
+                e = enqueue_step(m, nb, 1, MODE_NOCLS, range_hint);
                 hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-                e = hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed);
-                if (e == hipSuccess) {
-                    e = enqueue_step(m, nb, 1, MODE_NOCLS, range_hint);
+                hipError_t ec = e == hipSuccess ? hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed) : e;
+                if (ec == hipSuccess) {
+                    ec = enqueue_step(m, nb, 1, MODE_NOCLS, range_hint);
                     const hipError_t e2 = hipStreamEndCapture(m->st, &g);
-                    if (e == hipSuccess) e = e2;
+                    if (ec == hipSuccess) ec = e2;
                 }
-                if (e == hipSuccess) e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                if (ec == hipSuccess) ec = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
                 if (g) (void)hipGraphDestroy(g);
-                if (e == hipSuccess) it = m->graphs.emplace(key, ge).first;
+                if (ec == hipSuccess) {
+                    if (m->pf_graph_keys.size() >= PF_GRAPH_CAP) {
+                        auto old = m->graphs.find(m->pf_graph_keys.front());
+                        if (old != m->graphs.end()) { (void)hipGraphExecDestroy(old->second); m->graphs.erase(old); }
+                        m->pf_graph_keys.erase(m->pf_graph_keys.begin());
+                    }
+                    m->graphs.emplace(key, ge);
+                    m->pf_graph_keys.push_back(key);
+                }                                                              // (a failed capture only costs the replays)
+            } else {
+                e = hipGraphLaunch(it->second, m->st);
             }
-            if (e == hipSuccess) e = hipGraphLaunch(it->second, m->st);
         } else {
             e = enqueue_step(m, nb, 1, MODE_NOCLS, range_hint);            // eager: one pass per chunk
         }
         m->pf = false;
+        m->nsplit = 1;                                                     // a prefill chunk leaves xba final (single split or the combine kernel), replayed or not
         HIP_TRY(e);
         HIP_TRY(hipStreamSynchronize(m->st));                              // h_tokens / h_pos are reused by the next chunk
         done += nb;

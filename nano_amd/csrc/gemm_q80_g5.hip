@@ -21,6 +21,9 @@
 //     group in fragment order themselves (one activation-quantizer launch less per layer; same bits).
 // Bit-identical to the GEMV path and to the reference's matmul_quant (infer/infer.c:654-679).
 // Takes: group size 64, group count a multiple of 4, interior segments multiples of 16 rows.
+// Round 3: BALANCED tiles -- a tile is trw <= 16 rows fitted to the CU count (launch_gemm_q80_g5), the matrix-core tile
+// stays 16 x 16 with its unused rows zero.
+#include <atomic>
 #include "gemv_common.h"
 
 namespace nano {
@@ -33,6 +36,7 @@ struct G5Dev {
     const int8_t *w[3]; const float *ws[3]; float *out[3];
     uint32_t rows[3], out_bstride[3], out_pstride[3];
     uint32_t n, ng, epi, nb, nhc, ntiles, tt, nkw, cpw, teams, nmat;
+    uint32_t trw, tc0, tc1, _padt;      // rows per tile (even, <= 16: balanced tiles), tiles up to the end of segment 0 / 1
     const int8_t *xf; const float *xsf; const uint32_t *pos;
     // SwiGLU launches, optional (4 row-tile pairs per workgroup): the outputs also leave as Q80 groups of 64 in fragment order,
     // i.e. the next GEMM's activation operand (what quant_rows_frag_kernel would make of them); ng2 = rows / 64
@@ -70,9 +74,10 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
     uint32_t *gcnt = reinterpret_cast<uint32_t *>(gmax + TT * 64);                         // [TT] finishers arrived
 
     // ---- which segment (q | k | v share a launch; SwiGLU: matrix 0 = W1, matrix 1 = W3 over the same rows) -----------------
-    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
-    const uint32_t grow0 = tile * 16u;
-    const int sel = nmat == 2 ? (int)mat : (int)(grow0 >= b0) + (int)(grow0 >= b1);
+    // A tile is trw <= 16 rows of ONE segment (balanced tiles: trw is fitted so that the tiles spread evenly over the CUs; the
+    // matrix-core tile stays 16 x 16, rows trw..15 of it are zero and never stored)
+    const uint32_t trw = a.trw;
+    const int sel = nmat == 2 ? (int)mat : (int)(tile >= a.tc0) + (int)(tile >= a.tc1);
     const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
     const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
     const int osel = nmat == 2 ? 0 : sel;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
     const uint32_t rows0 = nmat == 2 ? a.rows[0] : sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
     const uint32_t obs = osel == 0 ? a.out_bstride[0] : osel == 1 ? a.out_bstride[1] : a.out_bstride[2];
     const uint32_t ops = osel == 0 ? a.out_pstride[0] : osel == 1 ? a.out_pstride[1] : a.out_pstride[2];
-    const uint32_t lrow0 = grow0 - (nmat == 2 ? 0u : sel == 0 ? 0u : sel == 1 ? b0 : b1);
+    const uint32_t lrow0 = (tile - (nmat == 2 ? 0u : sel == 0 ? 0u : sel == 1 ? a.tc0 : a.tc1)) * trw;
     const bool live = tile < a.ntiles;
 
     const __amdgpu_buffer_rsrc_t rw = mkrsrc(w0, live ? rows0 * n : 0u);
@@ -100,7 +105,8 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
         for (int r = 0; r < 8; r++) {
             // rows beyond the segment: out of range -> 0 (the scalar offset takes part in the range check of a raw buffer only
             // through the address, so the row step stays in the lane offset where the segment's last rows need the check)
-            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(base == OOB ? OOB : base + (uint32_t)(2 * r) * n), 0, 2);
+            // (trw is even: rows 2r, 2r + 1 of the tile are live or dead together -- a wave-uniform select)
+            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)((base == OOB || (uint32_t)(2 * r) >= trw) ? OOB : base + (uint32_t)(2 * r) * n), 0, 2);
             wA[r] = make_int4(v.x, v.y, v.z, v.w);
         }
     };
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
         for (int r = 0; r < 8; r++) *reinterpret_cast<int4 *>(wbuf + (size_t)(2 * r + wrow) * G5_PITCH + wcol) = wA[r];
         // 2. what this half chunk needs now: weight scales (lanes 0..31: row l/2, groups g0 + 4 (l%2) .. +3), first fragments
         const uint32_t sg = g0 + (lane & 1u) * 4u;
-        const float4 wsv = bload_f4(rs, (lane < 32u && sg < ng) ? ((lrow0 + (lane >> 1)) * ng + sg) * 4u : OOB);
+        const float4 wsv = bload_f4(rs, (lane < 32u && (lane >> 1) < trw && sg < ng) ? ((lrow0 + (lane >> 1)) * ng + sg) * 4u : OOB);
         i32x4 fb[8]; float4 xsv;
         load_fb(fb, xsv, g0, 0u);
         issue_w(h + nkw);                                               // prefetch; behind the fragments in the load queue (loads return in issue order)
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                 float oldv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (fin && a.epi == GEMV_EPI_RESID && tok < a.nb) {      // issued before the wait: the residual stream is never position indexed
 #pragma unroll
-                    for (int i = 0; i < 4; i++) if (lrow0 + kq * 4u + i < rows0) oldv[i] = orow[i];
+                    for (int i = 0; i < 4; i++) if (kq * 4u + i < trw && lrow0 + kq * 4u + i < rows0) oldv[i] = orow[i];
                 }
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
                 if (h != 0u) {
@@ -169,6 +175,9 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                     const float4 in = *reinterpret_cast<const float4 *>(slot + t * 256 + lane * 4u);
                     acc[0] = in.x; acc[1] = in.y; acc[2] = in.z; acc[3] = in.w;
                 }
+                // groups beyond ng (the last half chunk when ng % 8 == 4) contribute products +0.0f: exact, because a running
+                // value that started at +0.0f (here as in the reference, infer.c:668) is never -0.0f -- x + (-0.0f) and
+                // x + (+0.0f) only differ for x == -0.0f
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) { acc[0] += p[j][0]; acc[1] += p[j][1]; acc[2] += p[j][2]; acc[3] += p[j][3]; }
                 if (!fin) {
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                         float *o = orow + (size_t)opos * ops;
 #pragma unroll
                         for (int i = 0; i < 4; i++)
-                            if (lrow0 + kq * 4u + i < rows0) o[i] = val[i];
+                            if (kq * 4u + i < trw && lrow0 + kq * 4u + i < rows0) o[i] = val[i];
                     }
                     if constexpr (TT == 1) if (a.xf2) {               // (one token tile only: measured slower with more, and its registers would cost the other instantiations)
                         // ---- the 64-row Q80 group of these outputs (infer/tensor.c:21-46): this wave holds rows 16 rt .. +15 of
@@ -229,11 +238,11 @@ static uint32_t total_rows5(const GemvArgs &a) {
 template <int TT>
 static void launch_tt(const G5Dev &d, uint32_t nwg, uint32_t waves, size_t lds, hipStream_t st) {
     auto kern = &gemm_q80_g5_kernel<TT>;
-    static bool armed[64] = {};                                        // once per instantiation and device: a host call per launch costs microseconds
-    int dev = 0; (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !armed[dev]) {
+    static std::atomic<bool> armed[64];                                // once per instantiation and device: a host call per launch costs microseconds
+    int dev = 0; (void)hipGetDevice(&dev);                             // (two threads arming the same device twice is harmless)
+    if (dev < 0 || dev >= 64 || !armed[dev].load(std::memory_order_acquire)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (dev >= 0 && dev < 64) armed[dev] = true;
+        if (dev >= 0 && dev < 64) armed[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(waves * 64), lds, st, d);
 }
@@ -270,7 +279,6 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
     }
     const bool sw = a.epi == GEMV_EPI_SWIGLU;
     d.n = a.n; d.ng = a.n / a.gs; d.epi = a.epi; d.nb = a.nb; d.nhc = (d.ng + 7) / 8;
-    d.ntiles = (total_rows5(a) + 15) / 16;
     d.tt = (a.nb + 15) / 16;
     d.nmat = sw ? 2u : 1u;
     d.xf = a.xq_in; d.xsf = a.xs_in; d.pos = a.pos;
@@ -278,8 +286,33 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
     // <= 168 VGPRs).  Take the deepest split whose workgroups are ALL resident at once (no second round of workgroups, whose
     // tail would run on a mostly idle chip); matrices too tall for that (the classifier) get one wave per tile, 4 per group.
     const uint32_t TTc = d.tt <= 1 ? 1u : d.tt == 2 ? 2u : 4u;
-    static int cus = 0;
-    if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+    const int cus = a.cus ? (int)a.cus : 256;                          // compute units of the model's device (backend.hip fills it in)
+    // BALANCED tiles (round 3).  A CU streams ~25 GB/s whatever it runs, so a launch lasts as long as the CU with the most
+    // rows: a tile is trw <= 16 rows (even), fitted to minimise (tiles per CU, rounded up) x trw -- 2560 rows: 160 tiles of 16
+    // keep 160 of 256 CUs busy, 256 tiles of 10 all of them.  Ties go to the taller tile (fewer waves re-reading the
+    // activation fragments).  The output quantizer of SwiGLU launches (xf2) works on 64-row groups of four full tiles.
+    static const bool balanced = [] { const char *e = getenv("NANO_G5_BALANCED"); return !(e && *e == '0'); }();
+    const uint32_t nseg5 = sw ? 1u : a.nseg;
+    auto tiles_for = [&](uint32_t trw, uint32_t *tc) {
+        uint32_t t = 0;
+        for (uint32_t s2 = 0; s2 < nseg5; s2++) { t += (a.seg[s2].rows + trw - 1) / trw; if (tc && s2 < 2) tc[s2] = t; }
+        return t;
+    };
+    uint32_t trw = 16;
+    if (balanced && !xf2) {
+        uint32_t best_cost = ~0u;
+        for (uint32_t c = 4; c <= 16; c += 2) {
+            const uint32_t t = tiles_for(c, nullptr), cost = ((t + (uint32_t)cus - 1) / (uint32_t)cus) * c;
+            if (cost <= best_cost) { best_cost = cost; trw = c; }
+        }
+    }
+    {
+        uint32_t tc[2] = {0xffffffffu, 0xffffffffu};
+        d.ntiles = tiles_for(trw, tc);
+        d.trw = trw;
+        d.tc0 = nseg5 > 1 ? tc[0] : 0xffffffffu;
+        d.tc1 = nseg5 > 2 ? tc[1] : 0xffffffffu;
+    }
     const uint32_t maxkw = G5_MAX_WAVES / d.nmat;
     uint32_t nkw = 1, groups = 1;                                      // groups: row tiles (pairs) per workgroup
     bool fits = false;

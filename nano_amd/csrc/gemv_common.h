@@ -70,6 +70,10 @@ struct GemvDev {
     const int8_t *w[3]; const float *ws[3]; float *out[3];
     uint32_t rows[3], out_bstride[3], out_pstride[3];
     uint32_t n, ng, rw, log2_tiles, nchunk, magic_nchunk, units, epi, flags, nb;
+    // Q80 slab launches: rw is ANY row count (balanced slabs: workgroups x rows fitted to the chip, not a power of two);
+    // tpw = ceil(rw / 4) four-row tiles per workgroup, magic_rw = 65536 / rw + 1 (thread -> (sequence, row) by multiply-shift),
+    // wg_c0 / wg_c1 = workgroups up to the end of segment 0 / 1 (a workgroup's rows lie inside one segment)
+    uint32_t tpw, magic_rw, wg_c0, wg_c1;
     const float *xin; const float *norm_w; const uint32_t *pos;
     uint32_t xin_bstride, _pad0;
     const int8_t *xq_in; const float *xs_in;

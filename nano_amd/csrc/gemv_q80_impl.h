@@ -189,31 +189,29 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     const uint32_t n = a.n, ng = a.ng;
     const uint32_t n16 = (n + 15) & ~15u, ng4 = (ng + 3) & ~3u;
     const uint32_t PITCH = (GC == 16) ? (((ng + 47) / 64) * 64 + 16) : (ng4 + 4);
-    const uint32_t RW = a.rw;
+    const uint32_t RW = a.rw, TPW = a.tpw, RWP = TPW * TR;         // rows of this workgroup, its four-row tiles, rows of the product table
     const uint32_t epi = role_epi<ROLE>(a);
     const bool swiglu = epi == GEMV_EPI_SWIGLU;
     const uint32_t nmat = swiglu ? 2 : 1;
     int8_t *xq = reinterpret_cast<int8_t *>(smem);                 // [B][n16]
     float *xs = reinterpret_cast<float *>(smem + B * n16);         // [B][ng4]
     float *red = xs + B * ng4;                                     // [B][16] (+ combine weights [B][n_head][8])
-    float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);   // [B][nmat][RW][PITCH]
+    float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);   // [B][nmat][RWP][PITCH]
 
     // ---- 1. activation loads (critical path) ------------------------------------------------------------
     Staged<B, NV> sx;
     stage_issue<ROLE, B, NV>(a, sx);
 
     // ---- 2. all weight / scale loads of this wave; the workgroup's rows lie inside ONE segment ------------
-    const uint32_t grow0 = blockIdx.x * RW;
-    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
-    const int sel = swiglu ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
+    const uint32_t bid = blockIdx.x;
+    const int sel = swiglu ? 0 : (int)(bid >= a.wg_c0) + (int)(bid >= a.wg_c1);
     const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
     const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
     float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
     const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
     const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
     const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
-    const uint32_t lrow0 = grow0 - (sel == 0 ? 0u : sel == 1 ? b0 : b1);
-    const uint32_t tmask = (1u << a.log2_tiles) - 1u;
+    const uint32_t lrow0 = (bid - (sel == 0 ? 0u : sel == 1 ? a.wg_c0 : a.wg_c1)) * RW;
 
     int4 wv[UPW][TR];
     float sv[UPW][NS];
@@ -222,25 +220,26 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         const uint32_t u = (uint32_t)wid + (uint32_t)k * NW;
         const uint32_t t = (u * a.magic_nchunk) >> 16;                 // u / nchunk
         const uint32_t c = u - t * a.nchunk;
-        const uint32_t tl = t & tmask, mat = t >> a.log2_tiles;
+        const uint32_t mat = t >= TPW ? 1u : 0u, tl = t - mat * TPW;
         const bool live = u < a.units;
         const __amdgpu_buffer_rsrc_t rw_ = mkrsrc(mat ? a.w[1] : w0, live ? rows0 * n : 0u);
         const __amdgpu_buffer_rsrc_t rs_ = mkrsrc(mat ? a.ws[1] : ws0, live ? rows0 * ng * 4u : 0u);
         const uint32_t lrow = lrow0 + tl * TR;
         const uint32_t col = (c << 10) + (uint32_t)lane * 16u;
         const uint32_t base = (col < n) ? lrow * n + col : OOB;
+        // rows of the tile beyond the workgroup's RW belong to the next workgroup (RW % 4 != 0): a wave-uniform select
 #pragma unroll
-        for (int r = 0; r < TR; r++) wv[k][r] = bload_w(rw_, base + (uint32_t)r * n);
+        for (int r = 0; r < TR; r++) wv[k][r] = bload_w(rw_, base + ((tl * TR + (uint32_t)r < RW) ? (uint32_t)r * n : OOB));
         const uint32_t g = c * GC + (uint32_t)lane / LPG;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const uint32_t r = ((uint32_t)lane % LPG) + s * LPG;
-            sv[k][s] = bload_f(rs_, (r < TR && g < ng) ? ((lrow + r) * ng + g) * 4u : OOB);
+            sv[k][s] = bload_f(rs_, (r < TR && tl * TR + r < RW && g < ng) ? ((lrow + r) * ng + g) * 4u : OOB);
         }
     }
     // ---- 3. the fold thread's output slot (residual: old value) -----------------------------------------------
-    const int lrw = (int)a.log2_tiles + 2;                              // log2(rows per workgroup)
-    const int fb = tid >> lrw, frl = tid & ((int)RW - 1);               // fold thread -> (sequence, local row)
+    const int fb = (int)(((uint32_t)tid * a.magic_rw) >> 16);          // tid / RW: fold thread -> (sequence, local row)
+    const int frl = tid - fb * (int)RW;
     const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
     // the position of a pos-indexed output (v-cache row) is fetched now and used only by the final store: no wait
     // here (a wait on it would also wait for every weight load issued above -- vmcnt counts in order)
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         if (u < a.units) {
             const uint32_t t = (u * a.magic_nchunk) >> 16;
             const uint32_t c = u - t * a.nchunk;
-            const uint32_t tl = t & tmask, mat = t >> a.log2_tiles;
+            const uint32_t mat = t >= TPW ? 1u : 0u, tl = t - mat * TPW;
             const uint32_t col = (c << 10) + (uint32_t)lane * 16u;
             const uint32_t g = c * GC + (uint32_t)lane / LPG;
 #pragma unroll
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
 #pragma unroll
                         for (int q = 1; q < TR; q++) v = (q == (int)r) ? iv[q] : v;
                         if (r < TR && g < ng)                                                   // infer.c:672
-                            P[(((size_t)b * nmat + mat) * RW + tl * TR + r) * PITCH + g] = ((float)v * sv[k][s]) * xsc;
+                            P[(((size_t)b * nmat + mat) * RWP + tl * TR + r) * PITCH + g] = ((float)v * sv[k][s]) * xsc;
                     }
                 }
             }
@@ -299,8 +298,8 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         // all LDS reads of a 16-group batch are issued before the dependent add chain; groups beyond ng add
         // +0.0f (exact: the running value is never -0.0f)
         float v0 = 0.0f, v1 = 0.0f;
-        const float *p0 = P + (((size_t)fb * nmat) * RW + frl) * PITCH;
-        const float *p1 = p0 + (size_t)RW * PITCH;
+        const float *p0 = P + (((size_t)fb * nmat) * RWP + frl) * PITCH;
+        const float *p1 = p0 + (size_t)RWP * PITCH;
         if ((ng & 15u) == 0) {              // whole 16-group batches (every BASELINE shape): no per-element selects
             for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
                 float4 t[4], u[4];
@@ -495,22 +494,39 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
         while (rw > 4 && (size_t)B * nmat * rw * pitch * 4 > 64 * 1024) rw /= 2;
         while (rw > 4 && (rw / 4) * nchunk * nmat > 64) rw /= 2;          // <= 16 waves x 4 units
     }
-    // Large matrices (Qwen3-4B's layers: 10-50 MB each) are bandwidth rather than latency bound; swept on a MI355X with
-    // tools/wide_sweep.sh: a slab of 64-160 KB of weights per workgroup, chosen to minimise (rounds of 256 workgroups) x
-    // (rows per workgroup), the larger slab on a tie, and 8-16 waves.  13.0 -> 10.6 us (W2), 16.3 -> 13.0 us (W1|W3).
+    // Large matrices (Qwen3-4B's layers: 10-50 MB each) are bandwidth rather than latency bound, and a CU pulls ~25 GB/s whatever
+    // it runs: the launch ends when the CU with the most rows ends.  BALANCED slabs (round 3): rw = ANY row count, chosen to
+    // minimise (rounds of `cus` workgroups) x rw = the rows the busiest CU streams; a power-of-two slab left 160 of 256 CUs
+    // busy on a 2560-row matrix (rw 16) where rw = 10 gives every CU one workgroup.  On a tie the larger slab (fewer
+    // workgroups re-staging the activation).  Round 2's rule (powers of two, 64-160 KB) is kept as NANO_SLAB_BALANCED=0.
     uint32_t large_nw = 0;
     if (B == 1 && (uint64_t)rows * a.n * nmat >= (8u << 20)) {
+        static const bool balanced = [] { const char *e = getenv("NANO_SLAB_BALANCED"); return !(e && *e == '0'); }();
+        const uint32_t cus = a.cus ? a.cus : 256u;
         uint32_t best = 0, best_cost = ~0u;
-        for (uint32_t c = 4; c <= 64; c *= 2) {
-            const uint64_t bytes = (uint64_t)c * a.n * nmat;
-            if (nseg > 1 && (align % c) != 0) continue;
-            if (bytes < (64u << 10) || bytes > (160u << 10) || (c / 4) * nchunk * nmat > 64) continue;
-            const uint32_t wgs = (rows + c - 1) / c, cost = ((wgs + 255) / 256) * c;
-            if (cost <= best_cost) { best_cost = cost; best = c; }
+        if (balanced) {
+            const uint32_t ng = a.n / a.gs, pitch = (1024 / a.gs == 16) ? (((ng + 47) / 64) * 64 + 16) : (((ng + 3) & ~3u) + 4);
+            for (uint32_t c = 4; c <= 64; c++) {
+                const uint32_t tpw = (c + 3) / 4;
+                if (tpw * nchunk * nmat > 64) break;                           // <= 16 waves x 4 units
+                if ((size_t)nmat * tpw * 4 * pitch * 4 > 96 * 1024) break;     // product table
+                uint32_t wgs = 0;
+                if (nseg > 1) for (uint32_t s2 = 0; s2 < nseg; s2++) wgs += (a.seg[s2].rows + c - 1) / c; else wgs = (rows + c - 1) / c;
+                const uint32_t cost = ((wgs + cus - 1) / cus) * c;
+                if (cost <= best_cost) { best_cost = cost; best = c; }
+            }
+        } else {
+            for (uint32_t c = 4; c <= 64; c *= 2) {
+                const uint64_t bytes = (uint64_t)c * a.n * nmat;
+                if (nseg > 1 && (align % c) != 0) continue;
+                if (bytes < (64u << 10) || bytes > (160u << 10) || (c / 4) * nchunk * nmat > 64) continue;
+                const uint32_t wgs = (rows + c - 1) / c, cost = ((wgs + 255) / 256) * c;
+                if (cost <= best_cost) { best_cost = cost; best = c; }
+            }
         }
         if (best) {
             rw = best;
-            const uint32_t u = (rw / 4) * nchunk * nmat;
+            const uint32_t u = ((rw + 3) / 4) * nchunk * nmat;
             large_nw = u / 2 < 8 ? 8 : (u / 2 > 16 ? 16 : u / 2);
         }
     }
@@ -524,7 +540,7 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
             q = strchr(q, ','); if (q) q++;
         }
     }
-    const uint32_t units = (rw / 4) * nchunk * nmat;
+    const uint32_t units = ((rw + 3) / 4) * nchunk * nmat;
     uint32_t nw = units < 4 ? units : 4;
     uint32_t want = (a.n * (uint32_t)(B > 2 ? B / 2 : 1) + 511) / 512;     // idle waves still help the activation prologue
     if (want > 16) want = 16;
@@ -540,14 +556,14 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
 }
 
 template <int ROLE, int GS, int B, int NV, int UPW>
-static hipError_t launch_slab_t(const GemvDev &d, const SlabPlan &p, uint32_t rows, hipStream_t st) {
+static hipError_t launch_slab_t(const GemvDev &d, const SlabPlan &p, uint32_t nwg, hipStream_t st) {
     const uint32_t nmat = d.epi == GEMV_EPI_SWIGLU ? 2 : 1;
     const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u;
     const size_t pitch = (1024 / GS == 16) ? (((d.ng + 47) / 64) * 64 + 16) : (ng4 + 4);
-    const size_t lds = B * n16 + B * ng4 * 4 + B * 64 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 32 : 0) + (size_t)B * nmat * p.rw * pitch * 4;
+    const size_t lds = B * n16 + B * ng4 * 4 + B * 64 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 32 : 0) + (size_t)B * nmat * (d.tpw * 4) * pitch * 4;
     auto kern = &gemv_q80_slab_kernel<ROLE, GS, B, NV, UPW>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(64 * p.nw), lds, st, d);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * p.nw), lds, st, d);
     return hipGetLastError();
 }
 template <int ROLE, int GS, int B>
@@ -570,10 +586,18 @@ template <int GS, int B>
 static hipError_t launch_slab_b(GemvDev &d, const GemvArgs &a, hipStream_t st) {
     const SlabPlan p = plan_slab(a, B);
     d.rw = p.rw;
-    uint32_t l2 = 0; while ((1u << l2) < p.rw / 4) l2++;
-    d.log2_tiles = l2;
-    d.units = (p.rw / 4) * d.nchunk * (d.epi == GEMV_EPI_SWIGLU ? 2 : 1);
-    const uint32_t rows = total_rows(a);
+    d.tpw = (p.rw + 3) / 4;
+    d.magic_rw = 65536u / p.rw + 1u;                                   // (tid * magic_rw) >> 16 == tid / rw for tid < 1024 <= 65536 / rw
+    d.log2_tiles = 0;
+    const bool sw = d.epi == GEMV_EPI_SWIGLU;
+    d.units = d.tpw * d.nchunk * (sw ? 2 : 1);
+    // workgroups per segment (a workgroup's rows lie inside one segment; the last one of a segment may be ragged)
+    uint32_t wg[3] = {0, 0, 0};
+    const uint32_t nseg = sw ? 1u : a.nseg;
+    for (uint32_t s2 = 0; s2 < nseg; s2++) wg[s2] = (a.seg[s2].rows + p.rw - 1) / p.rw;
+    d.wg_c0 = nseg > 1 ? wg[0] : 0xffffffffu;
+    d.wg_c1 = nseg > 2 ? wg[0] + wg[1] : 0xffffffffu;
+    const uint32_t rows = wg[0] + wg[1] + wg[2];                       // the grid
     if constexpr (B == 1) {         // the per-layer launches of a batch-1 step: flags resolved at compile time
         const uint32_t f = d.flags;
         if (f == F_NORM && d.epi == GEMV_EPI_STORE) return launch_slab_r<R_NORM_STORE, GS, B>(d, p, rows, st);

@@ -67,6 +67,8 @@ typedef struct ModelEntry {
     /* replicas on further GPUs (nano_context_replicate): what is needed to upload the model again, and the replicas */
     NanoModelDesc desc; const uint8_t *params; size_t params_avail; uint32_t max_batch;
     NanoHipModel *replica[NANO_MAX_REPLICAS]; int n_replica;       /* replica[0] == dev */
+    /* the LoRA module attached to the model (load_lora*): later replicas get it too */
+    const float *lora_params; size_t lora_floats; uint32_t lora_rank, lora_alpha;
 } ModelEntry;
 static ModelEntry g_reg[MAX_MODELS];
 
@@ -239,7 +241,14 @@ static LoRA *lora_from_buffer(LLM *llm, uint8_t *buffer, int owns) {
     p->params.wv_lora_a = f; f += L * r * E;  p->params.wv_lora_b = f; f += L * KD * r;
     p->params.wo_lora_a = f; f += L * r * E;  p->params.wo_lora_b = f; f += L * E * r;
     const size_t n_floats = (size_t)(f - (float *)(buffer + 256));
-    if (nano_hip_lora_attach(dev, c->lora_rank, c->lora_alpha, (const float *)(buffer + 256), n_floats) != NANO_HIP_OK) die_hip("load_lora");
+    /* every replica of the model applies the module (reference: one LLM, every forward of the context uses ctx->lora) */
+    ModelEntry *me = reg_entry(llm);
+    const int nrep = (me && me->n_replica > 0) ? me->n_replica : 1;
+    for (int r = 0; r < nrep; r++) {
+        NanoHipModel *d = (me && me->n_replica > 0) ? me->replica[r] : dev;
+        if (nano_hip_lora_attach(d, c->lora_rank, c->lora_alpha, (const float *)(buffer + 256), n_floats) != NANO_HIP_OK) die_hip("load_lora");
+    }
+    if (me) { me->lora_params = (const float *)(buffer + 256); me->lora_floats = n_floats; me->lora_rank = c->lora_rank; me->lora_alpha = c->lora_alpha; }
     return p;
 }
 LoRA *load_lora_from_buffer(LLM *llm, uint8_t *buffer) { return lora_from_buffer(llm, buffer, 0); }
@@ -257,8 +266,12 @@ LoRA *load_lora(LLM *llm, char *lora_path) {
 }
 void free_lora(LLM *llm, LoRA *lora) {
     if (!lora) return;
-    NanoHipModel *dev = llm ? reg_get(llm) : NULL;
-    if (dev) (void)nano_hip_lora_enable(dev, 0);
+    ModelEntry *me = llm ? reg_entry(llm) : NULL;
+    if (me) {
+        for (int r = 0; r < me->n_replica; r++) (void)nano_hip_lora_enable(me->replica[r], 0);
+        if (me->n_replica == 0 && me->dev) (void)nano_hip_lora_enable(me->dev, 0);
+        me->lora_params = NULL; me->lora_floats = 0;                /* the buffer below may be the module's storage */
+    }
     free(lora->data);                                        /* the loader's buffer (NULL for _from_buffer) */
     free(lora);
 }
@@ -371,8 +384,12 @@ int nano_context_replicate(Nano_Context *ctx, const int *devices, int n_devices)
     if (!me || !devices || n_devices < 0 || me->n_replica + n_devices > NANO_MAX_REPLICAS) return NANO_HIP_EINVAL;
     for (int i = 0; i < n_devices; i++) {
         NanoHipModel *r = NULL;
-        const int rc = nano_hip_model_create(&r, &me->desc, me->params, me->params_avail, 0, devices[i], me->max_seq_len, me->max_batch);
+        int rc = nano_hip_model_create(&r, &me->desc, me->params, me->params_avail, 0, devices[i], me->max_seq_len, me->max_batch);
         if (rc != NANO_HIP_OK) return rc;
+        if (me->lora_params) {                                      /* a module loaded before the replicas were made */
+            rc = nano_hip_lora_attach(r, me->lora_rank, me->lora_alpha, me->lora_params, me->lora_floats);
+            if (rc != NANO_HIP_OK) { nano_hip_model_destroy(r); return rc; }
+        }
         me->replica[me->n_replica++] = r;
     }
     return NANO_HIP_OK;
@@ -381,24 +398,34 @@ int nano_context_replicate(Nano_Context *ctx, const int *devices, int n_devices)
 int nano_forward_batch(Nano_Context *ctx, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, float *logits, uint32_t *argmax) {
     ModelEntry *me = reg_entry(ctx->llm);
     if (!me || !me->dev) return NANO_HIP_EINVAL;
-    lora_select(me->dev, ctx->lora);
     const uint32_t G = (uint32_t)me->n_replica;
-    if (G <= 1) return nano_hip_forward(me->dev, tokens, pos, batch, 1, logits, argmax);
+    if (G <= 1) { lora_select(me->dev, ctx->lora); return nano_hip_forward(me->dev, tokens, pos, batch, 1, logits, argmax); }
+    for (uint32_t r = 0; r < G; r++) lora_select(me->replica[r], ctx->lora);      /* use_lora of this forward, on every replica */
     /* sequence i -> replica i mod G, slot i / G: gather each replica's share, start all, then collect */
     const size_t V = ctx->llm->config.vocab_size;
     uint32_t tk[NANO_MAX_REPLICAS][NANO_MAX_BATCH], ps[NANO_MAX_REPLICAS][NANO_MAX_BATCH], cnt[NANO_MAX_REPLICAS] = {0};
+    int begun[NANO_MAX_REPLICAS] = {0};
     if (batch > NANO_MAX_BATCH * G) return NANO_HIP_EINVAL;
     for (uint32_t i = 0; i < batch; i++) { const uint32_t r = i % G; if (cnt[r] >= NANO_MAX_BATCH) return NANO_HIP_EINVAL; tk[r][cnt[r]] = tokens[i]; ps[r][cnt[r]] = pos[i]; cnt[r]++; }
+    float *lbuf = NULL;
+    if (logits) {
+        lbuf = (float *)malloc((size_t)NANO_MAX_BATCH * V * sizeof(float));
+        if (!lbuf) return NANO_HIP_ENOMEM;
+    }
     int rc = NANO_HIP_OK;
-    for (uint32_t r = 0; r < G && rc == NANO_HIP_OK; r++)
-        if (cnt[r]) rc = nano_hip_forward_begin(me->replica[r], tk[r], ps[r], cnt[r], 1, logits != NULL, argmax != NULL);
-    float *lbuf = logits ? (float *)malloc((size_t)NANO_MAX_BATCH * V * sizeof(float)) : NULL;
+    for (uint32_t r = 0; r < G && rc == NANO_HIP_OK; r++) {
+        if (!cnt[r]) continue;
+        rc = nano_hip_forward_begin(me->replica[r], tk[r], ps[r], cnt[r], 1, logits != NULL, argmax != NULL);
+        begun[r] = rc == NANO_HIP_OK;
+    }
+    /* every replica that was started is drained, also after an error; only complete, successful shares are handed over */
     uint32_t abuf[NANO_MAX_BATCH];
     for (uint32_t r = 0; r < G; r++) {
-        if (!cnt[r]) continue;
+        if (!begun[r]) continue;
         const int e = nano_hip_forward_end(me->replica[r], lbuf, argmax ? abuf : NULL);
-        if (e != NANO_HIP_OK && rc == NANO_HIP_OK) rc = e;
-        for (uint32_t k = 0; k < cnt[r] && e == NANO_HIP_OK; k++) {
+        if (e != NANO_HIP_OK) { if (rc == NANO_HIP_OK) rc = e; continue; }
+        if (rc != NANO_HIP_OK) continue;
+        for (uint32_t k = 0; k < cnt[r]; k++) {
             const uint32_t i = k * G + r;
             if (logits) memcpy(logits + (size_t)i * V, lbuf + (size_t)k * V, V * sizeof(float));
             if (argmax) argmax[i] = abuf[k];

@@ -50,6 +50,7 @@ struct GemvArgs {
     const float *resid_add; uint32_t resid_add_bstride, _pad3;
     // optional per-tile arg-max partials of a STORE launch: tile_max[b][tile] = (max value, row index bits)
     float *tile_max;
+    uint32_t cus, _pad4;    // compute units of the device the launch goes to (0: assume 256); sizes the work split
 };
 
 uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // tiles launch_gemv() will use (sizes tile_max)
@@ -102,6 +103,10 @@ struct AttnArgs {
     // single-split launches only, optional: the finished output also leaves as Q80 groups of 64 in MFMA B-fragment order (what
     // quant_rows_frag_kernel would make of xba_out), so the batched Wo GEMM needs no quantizer launch.  head_dim % 64 == 0.
     int8_t *xf_out; float *xsf_out;
+    // filled by launch_attention(): workgroup x -> q heads so that the workgroups sharing a KV head run on ONE XCD (workgroup
+    // index mod 8 = XCD, each XCD has its own L2): x = sub * n_kv_head + kv head, when n_kv_head is a power of two >= 8;
+    // kv_log2 = log2(n_kv_head), else 0xffffffff = plain order (x = first head / heads per workgroup)
+    uint32_t kv_log2, _pad5;
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
