@@ -231,6 +231,37 @@ int nano_hip_op_attention(int device, float *out, const float *q, const float *k
 int nano_hip_op_swiglu(int device, float *hb, const float *hb2, uint32_t n);
 int nano_hip_op_argmax(int device, const float *x, uint32_t n, uint32_t *idx);
 
+/* One FUSED decode GEMV launch exactly as a decode step issues it (the role-specialised kernels: rmsnorm + activation
+ * quantization prologue, optional split-attention combine, store / residual / SwiGLU epilogue), for operator tests of those
+ * kernels on caller-chosen inputs.  What it replaces in the reference: rmsnorm + quantize + matmul(_quant | _q4k) (+ the
+ * residual add / SwiGLU) of one projection, infer/infer.c:758-786 (kind 0), 885-908 and 950-965 (kind 1), 914-944 (kind 2).
+ * All pointers are host pointers. */
+typedef struct NanoFusedGemvDesc {
+    uint32_t quant;             /* NANO_QUANT_F32 / _Q80 / _Q4K */
+    uint32_t gs;                /* Q80 group size */
+    uint32_t kind;              /* 0: out = W act (up to 3 weight tensors, e.g. q | k | v); 1: out += W act; 2: out = silu(W0 act) * (W1 act) */
+    uint32_t n, nb, nseg;       /* row length, sequences (1..64), weight tensors (kind 2: 2) */
+    uint32_t rows[3];
+    const void *w[3];           /* F32: float[rows][n]; Q80: int8[rows][n]; Q4K: 160-byte blocks, no frame prefix */
+    const float *ws[3];         /* Q80: float[rows][n/gs] */
+    const float *x;             /* [nb][n] fp32 activation (NULL when attn_part is given) */
+    const float *norm_w;        /* rmsnorm weight [n], or NULL: no norm */
+    const float *attn_part;     /* optional, kind 1: [nb][nsplit][n] unnormalised attention partials, combined in the prologue */
+    const float *attn_ml;       /* [nb][n_head][nsplit][2] (max, exp-sum) per split */
+    uint32_t attn_nsplit, attn_n_head, attn_hd;
+    uint32_t use_gemm;          /* 1 (Q80): the batched route of a step -- activation quantizer launch + int8 MFMA GEMM */
+    float *out;                 /* [nb][sum of rows] (kind 2: [nb][rows[0]]); kind 1: holds the residual stream on entry */
+} NanoFusedGemvDesc;
+int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *d);
+
+/* Phase stamps -- measurement only.  The library built with `make -C nano_amd/csrc stamps` (libnano_mi355x_stamps.so) has its
+ * GEMV and attention kernels write shader-clock stamps per workgroup: [launch][2048 workgroups][8 stamps], stamp 0 = kernel
+ * entry ... (tools/stamp_probe.py names them).  _begin arms the buffer; the steps that follow run eagerly and number their
+ * launches; _read returns them with the launch kinds (1 QKV, 2 attention, 3 Wo, 4 W1|W3, 5 W2).  In the product library the
+ * kernels ignore the buffer and every stamp reads 0. */
+int nano_hip_stamps_begin(NanoHipModel *m);
+int nano_hip_stamps_read(NanoHipModel *m, unsigned long long *out, uint32_t *kinds, uint32_t cap_launches, uint32_t *n_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libnano_mi355x.so")
+LIB_PATH = os.environ.get("NANO_LIB") or os.path.join(HERE, "lib", "libnano_mi355x.so")     # NANO_LIB: a measurement build (libnano_mi355x_stamps.so)
 
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
@@ -26,6 +26,14 @@ class NanoModelDesc(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "arch", "block_size", "vocab_size", "n_layer", "n_embd", "n_head", "n_kv_head", "n_hidden",
         "is_shared_classifier", "head_dim", "quant_type", "group_size")]
+
+
+class NanoFusedGemvDesc(C.Structure):
+    """include/nano_mi355x.h NanoFusedGemvDesc: one fused decode GEMV launch as a step issues it."""
+    _fields_ = [("quant", C.c_uint32), ("gs", C.c_uint32), ("kind", C.c_uint32), ("n", C.c_uint32), ("nb", C.c_uint32), ("nseg", C.c_uint32),
+                ("rows", C.c_uint32 * 3), ("w", C.c_void_p * 3), ("ws", C.c_void_p * 3), ("x", C.c_void_p), ("norm_w", C.c_void_p),
+                ("attn_part", C.c_void_p), ("attn_ml", C.c_void_p), ("attn_nsplit", C.c_uint32), ("attn_n_head", C.c_uint32),
+                ("attn_hd", C.c_uint32), ("use_gemm", C.c_uint32), ("out", C.c_void_p)]
 
 
 class NanoHipError(RuntimeError):
@@ -88,6 +96,9 @@ def lib() -> C.CDLL:
     fn("nano_hip_op_attention", C.c_int, [C.c_int, f32p, f32p, f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32])
     fn("nano_hip_op_swiglu", C.c_int, [C.c_int, f32p, f32p, C.c_uint32])
     fn("nano_hip_op_argmax", C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)])
+    fn("nano_hip_op_fused_gemv", C.c_int, [C.c_int, C.POINTER(NanoFusedGemvDesc)])
+    fn("nano_hip_stamps_begin", C.c_int, [vp])
+    fn("nano_hip_stamps_read", C.c_int, [vp, vp, u32p, C.c_uint32, C.POINTER(C.c_uint32)])
     _lib = L
     return L
 
@@ -95,6 +106,10 @@ def lib() -> C.CDLL:
 def check(rc: int):
     if rc != 0:
         raise NanoHipError(f"nano_hip error {rc}: {lib().nano_hip_last_error().decode(errors='replace')}")
+
+
+def last_error() -> str:
+    return lib().nano_hip_last_error().decode(errors="replace")
 
 
 def device_count() -> int:
@@ -244,6 +259,15 @@ class DeviceModel:
         check(lib().nano_hip_time_step_masked(self.h, batch, pos, iters, skip_mask, C.byref(ms)))
         return float(ms.value)
 
+    def stamps_begin(self):
+        check(lib().nano_hip_stamps_begin(self.h))
+
+    def stamps_read(self, cap: int = 512):
+        """(stamps[n_launch, 2048, 8] uint64, kinds[n_launch]) of the steps run since stamps_begin()"""
+        out = np.zeros((cap, 2048, 8), np.uint64); kinds = np.zeros(cap, np.uint32); n = C.c_uint32(0)
+        check(lib().nano_hip_stamps_read(self.h, out.ctypes.data, kinds, cap, C.byref(n)))
+        return out[:n.value], kinds[:n.value]
+
     def read_state(self, name: str, n: int, slot: int = 0, layer: int = 0, pos: int = 0) -> np.ndarray:
         out = np.empty(n, np.float32)
         check(lib().nano_hip_read_state(self.h, slot, STATE_IDS[name], layer, pos, out, n))
@@ -303,6 +327,37 @@ def op_quantize_q4k(x, device=0):
 def op_matmul_q4k(x_blocks, w_blocks, n, d, device=0):
     out = np.empty(d, np.float32)
     check(lib().nano_hip_op_matmul_q4k(device, out, np.ascontiguousarray(x_blocks), np.ascontiguousarray(w_blocks), n, d)); return out
+
+
+def op_fused_gemv(quant, kind, n, weights, x=None, norm_w=None, *, gs=0, nb=1, resid=None, attn=None, use_gemm=False, device=0):
+    """One fused decode GEMV launch exactly as a decode step issues it (nano_hip_op_fused_gemv).
+    quant: 0x00 F32 / 0x80 Q80 / 0x42 Q4K; kind: 0 store, 1 residual add, 2 SwiGLU.
+    weights: list of (w, ws_or_None, rows) -- F32 float[rows, n]; Q80 int8[rows*n] + float scales; Q4K uint8 blocks (no frame).
+    x: [nb, n] fp32; resid: [nb, rows] old residual values (kind 1); attn = (part[nb, nsplit, n], ml[nb, n_head, nsplit, 2], n_head, hd).
+    Returns out[nb, rows_total]."""
+    d = NanoFusedGemvDesc()
+    d.quant, d.gs, d.kind, d.n, d.nb, d.nseg = quant, gs, kind, n, nb, len(weights)
+    keep = []
+    for i, (w, ws, rows) in enumerate(weights):
+        w = np.ascontiguousarray(w); keep.append(w)
+        d.rows[i] = rows; d.w[i] = w.ctypes.data
+        if ws is not None:
+            ws = np.ascontiguousarray(ws, np.float32); keep.append(ws); d.ws[i] = ws.ctypes.data
+    rows_total = weights[0][2] if kind == 2 else sum(r for _, _, r in weights)
+    if x is not None:
+        x = np.ascontiguousarray(x, np.float32); keep.append(x); d.x = x.ctypes.data
+    if norm_w is not None:
+        norm_w = np.ascontiguousarray(norm_w, np.float32); keep.append(norm_w); d.norm_w = norm_w.ctypes.data
+    if attn is not None:
+        part, ml, n_head, hd = attn
+        part = np.ascontiguousarray(part, np.float32); ml = np.ascontiguousarray(ml, np.float32); keep += [part, ml]
+        d.attn_part, d.attn_ml = part.ctypes.data, ml.ctypes.data
+        d.attn_nsplit, d.attn_n_head, d.attn_hd = part.shape[-2], n_head, hd
+    out = np.zeros((nb, rows_total), np.float32) if resid is None else np.array(resid, np.float32, copy=True).reshape(nb, rows_total)
+    d.use_gemm = 1 if use_gemm else 0
+    d.out = out.ctypes.data
+    check(lib().nano_hip_op_fused_gemv(device, C.byref(d)))
+    return out
 
 
 def op_rope(head, fcr, fci, qwen3, device=0):

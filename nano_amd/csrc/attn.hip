@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     float *redl = redm + KVM * 4;
     float *part = redl + KVM * R;
 
+    NANO_STAMP(a.stamps, 0, tid);
     // ---- 1. issue every load --------------------------------------------------------------------------------
     constexpr uint32_t ESZ = KVH ? 2u : 4u;                    // bytes per cache element
     const size_t slot_rows = (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
     };
     issue_kv(0);
+    NANO_STAMP(a.stamps, 1, tid);                              // every load issued
 
     // ---- 2. position, RoPE row, norms ------------------------------------------------------------------------------
     const uint32_t pos = fixed_range ? (fixed_range - 1) : a.pos[b];
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         kfresh[q] = (ok && fresh_k) ? *reinterpret_cast<const float4 *>(kh + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     }
+    NANO_STAMP(a.stamps, 2, qv[0][0].x);                       // q / k arrived, normalised and rotated
     const float sq_hd = sqrtf((float)hd);
     float mrun[KVM], lrun[KVM];
     float4 acc[KVM][QV];
@@ -430,6 +433,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
     }
 
+    NANO_STAMP(a.stamps, 3, acc[0][0].x);                      // K / V rows arrived, scores + running softmax done
     // ---- 4. combine the R sub-groups of the workgroup ----------------------------------------------------------------
     // maximum: across the sub-groups of a wave by cross-lane exchange, across waves through LDS
     constexpr int SPW = 64 / LPR;                     // sub-groups per wave
@@ -457,6 +461,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
     (void)SPW;
     __syncthreads();
+    NANO_STAMP(a.stamps, 4, redl[0]);                          // sub-group partials in LDS
     for (uint32_t idx = tid; idx < (uint32_t)KVM * hd; idx += 256) {
         const uint32_t m = idx / hd, i = idx - m * hd;
         float M = Mwg[0];
@@ -489,6 +494,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             if (i == 0) { float *ml = a.ml + (((size_t)b * a.n_head + h) * nsplit + split) * 2; ml[0] = M; ml[1] = L; }
         }
     }
+    NANO_STAMP(a.stamps, 5, Mwg[0]);                           // combined and stored
 }
 
 template <int LPR, int QV, int MODE, bool KVH>

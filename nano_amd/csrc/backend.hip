@@ -114,7 +114,17 @@ struct NanoHipModel {
     bool strict = false;
     float *xn = nullptr, *hb2 = nullptr, *att = nullptr;   // normalised x [Bs][E], W3 output [Bs][H], attention scores [Bs][n_head][S]
     nano_hip_phase_fn phase_fn = nullptr; void *phase_env = nullptr;
+    // measurement (stamps build, tools/stamp_probe.py): per-launch, per-workgroup phase stamps of the steps run after nano_hip_stamps_begin
+    unsigned long long *stamps = nullptr; uint32_t stamp_launches = 0; bool stamps_on = false;
+    std::vector<uint32_t> stamp_kinds;
 };
+constexpr uint32_t STAMP_MAX_LAUNCHES = 512, STAMP_WGS = 2048;
+// the stamp slab of the next launch of kind k (1 QKV, 2 attention, 3 Wo, 4 W1|W3, 5 W2, 6 classifier), or nullptr
+static unsigned long long *next_stamps(NanoHipModel *m, uint32_t kind) {
+    if (!m->stamps_on || m->stamp_launches >= STAMP_MAX_LAUNCHES) return nullptr;
+    m->stamp_kinds.push_back(kind);
+    return m->stamps + (size_t)(m->stamp_launches++) * STAMP_WGS * 8;
+}
 
 // ------------------------------------------------------------------------------------------------
 // device info
@@ -176,7 +186,7 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att, m->vraw, m->gq2, m->gxs2 };
+                    m->xn, m->hb2, m->att, m->vraw, m->gq2, m->gxs2, m->stamps };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -563,6 +573,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                              : mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_STORE;
             a.norm_w = m->rms_attn + (size_t)l * E; a.pos = m->pos;
+            a.stamps = next_stamps(m, 1);
             if (!(skip & 1) && (e = gemv(m, a)) != hipSuccess) return e;
             if (m->lora_on) {       // q / k / v += (alpha/rank) B (A xb)   reference infer.c:792-808
                 const size_t la = (size_t)l * m->lora_rank * E, lbq = (size_t)l * E * m->lora_rank, lbk = (size_t)l * KD * m->lora_rank;
@@ -600,6 +611,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 if ((e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
                 a.prep_only = 0;
             }
+            a.stamps = next_stamps(m, 2);
             if (!(skip & 2) && (e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
             if (pf_combine && (e = launch_attn_combine_tokens(m->attn_part, m->attn_ml, m->xba, d.n_head, m->hd, nsplit, nb, wo_frag ? m->gq : nullptr, wo_frag ? m->gxs : nullptr, m->st)) != hipSuccess) return e;
         }
@@ -616,6 +628,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             }
             if (nsplit > 1 && !pf_combine) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
             a.frag_ready = (wo_frag && !(skip & 2)) ? 1u : 0u;
+            a.stamps = next_stamps(m, 3);
             if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
         }
         bool w2_frag = false;
@@ -630,6 +643,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 w2.nseg = 1; w2.seg[0] = mkseg(m->W[W2][l], m->x, E, E); w2.n = H; w2.gs = d.group_size; w2.nb = nb; w2.xin = m->hb; w2.xin_bstride = H; w2.epi = GEMV_EPI_RESID;
                 if (takes_mfma(m, w2) && gemm_q80_g2_supports(w2)) { w2_frag = true; a.frag_out = m->gq2; a.frag_scale_out = m->gxs2; }
             }
+            a.stamps = next_stamps(m, 4);
             if (!(skip & 8) && (e = gemv(m, a)) != hipSuccess) return e;
         }
         {   // x += W2 . hb   reference infer.c:950-965
@@ -637,6 +651,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.nseg = 1; a.seg[0] = mkseg(m->W[W2][l], m->x, E, E);
             a.n = H; a.gs = d.group_size; a.nb = nb; a.xin = m->hb; a.xin_bstride = H; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
             a.frag_ready = w2_frag ? 2u : 0u;
+            a.stamps = next_stamps(m, 5);
             if (!(skip & 16) && (e = gemv(m, a)) != hipSuccess) return e;
         }
     }
@@ -802,7 +817,7 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
         return 0;
     }
     if (m->kv_half && m->lora_on) FAIL(NANO_HIP_EINVAL, "the LoRA side branches write FP32 v rows: not available with the FP16 KV cache");
-    if (!m->use_graph) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); return 0; }
+    if (!m->use_graph || m->stamps_on) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); m->nsplit = xba_nsplit(m, nb, range_hint); return 0; }
     const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
@@ -1259,5 +1274,29 @@ extern "C" int nano_hip_read_state(NanoHipModel *m, uint32_t slot, int which, ui
         return 0;
     }
     HIP_TRY(hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+
+// ---- phase stamps (measurement builds: make -C nano_amd/csrc stamps; in the product build the kernels ignore the buffer) ----
+extern "C" int nano_hip_stamps_begin(NanoHipModel *m) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t bytes = (size_t)STAMP_MAX_LAUNCHES * STAMP_WGS * 8 * sizeof(unsigned long long);
+    if (!m->stamps) HIP_TRY(hipMalloc(&m->stamps, bytes));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    HIP_TRY(hipMemset(m->stamps, 0, bytes));
+    m->stamp_launches = 0; m->stamp_kinds.clear(); m->stamps_on = true;
+    return 0;
+}
+extern "C" int nano_hip_stamps_read(NanoHipModel *m, unsigned long long *out, uint32_t *kinds, uint32_t cap_launches, uint32_t *n_launches) {
+    if (!m || !out || !kinds || !n_launches) FAIL(NANO_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    m->stamps_on = false;
+    const uint32_t n = m->stamp_launches < cap_launches ? m->stamp_launches : cap_launches;
+    if (n) HIP_TRY(hipMemcpy(out, m->stamps, (size_t)n * STAMP_WGS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) kinds[i] = m->stamp_kinds[i];
+    *n_launches = n;
     return 0;
 }

@@ -13,6 +13,20 @@
 
 #define NANO_WAVE 64
 
+// Phase stamps (measurement builds only: make stamps -> libnano_mi355x_stamps.so, tools/stamp_probe.py).  In the product build
+// NANO_STAMPS is 0 and every stamp site compiles to nothing.  A stamp is the shader clock (s_memtime) read by the first wave
+// of a workgroup; `dep` ties the read behind the value it is meant to follow (the compiler cannot hoist it above the wait).
+#ifndef NANO_STAMPS
+#define NANO_STAMPS 0
+#endif
+#if NANO_STAMPS
+#define NANO_STAMP(buf, k, dep) do { if ((buf) && threadIdx.x < 64) { unsigned long long t_; \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); \
+        if (threadIdx.x == 0) (buf)[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (k)] = t_; } } while (0)
+#else
+#define NANO_STAMP(buf, k, dep) do { } while (0)
+#endif
+
 namespace nano {
 
 // ---- cross-lane --------------------------------------------------------------------------------

@@ -291,7 +291,11 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
     // rows: a tile is trw <= 16 rows (even), fitted to minimise (tiles per CU, rounded up) x trw -- 2560 rows: 160 tiles of 16
     // keep 160 of 256 CUs busy, 256 tiles of 10 all of them.  Ties go to the taller tile (fewer waves re-reading the
     // activation fragments).  The output quantizer of SwiGLU launches (xf2) works on 64-row groups of four full tiles.
-    static const bool balanced = [] { const char *e = getenv("NANO_G5_BALANCED"); return !(e && *e == '0'); }();
+    // MEASURED (round 3, Qwen3-4B, whole steps on one box): 8 sequences 2.220 ms balanced vs 2.181 ms with 16-row tiles, 64
+    // sequences 4.51 vs 4.06 ms -- the shorter tiles multiply the waves that each re-read the activation fragments and the
+    // kernels are not CU-bandwidth bound at these sizes.  Default therefore OFF (NANO_G5_BALANCED=1 switches it on for A/B runs);
+    // the balanced slabs of the batch-1 GEMV (gemv_q80_impl.h plan_slab) did pay: 1.588 -> 1.526 ms.
+    static const bool balanced = [] { const char *e = getenv("NANO_G5_BALANCED"); return e && *e && *e != '0'; }();
     const uint32_t nseg5 = sw ? 1u : a.nseg;
     auto tiles_for = [&](uint32_t trw, uint32_t *tc) {
         uint32_t t = 0;

@@ -81,6 +81,7 @@ struct GemvDev {
     uint32_t attn_nsplit, attn_n_head, attn_hd, ntiles;
     float *tile_max;
     const float *resid_add; uint32_t resid_add_bstride, _pad1;
+    unsigned long long *stamps;     // measurement builds only (-DNANO_STAMPS=1, tools/stamp_probe.py): [workgroup][8] shader-clock stamps, or nullptr
 };
 
 template <int ROLE> __device__ __forceinline__ bool has_flag(const GemvDev &a, uint32_t f) {
@@ -220,6 +221,7 @@ static GemvDev to_dev(const GemvArgs &a) {
     d.attn_part = a.attn_part; d.attn_ml = a.attn_ml; d.attn_nsplit = a.attn_nsplit; d.attn_n_head = a.attn_n_head; d.attn_hd = a.attn_hd;
     d.tile_max = a.tile_max;
     d.resid_add = a.resid_add; d.resid_add_bstride = a.resid_add_bstride;
+    d.stamps = a.stamps;
     return d;
 }
 

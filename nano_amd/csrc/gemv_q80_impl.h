@@ -150,6 +150,7 @@ __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r,
                 ss[b] = 1.0f / sqrtf(t);
             }
         }
+        NANO_STAMP(a.stamps, 2, ss[0] + r.x[0][0].x);                // the activation arrived (and its norm scale is known)
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     float *red = xs + B * ng4;                                     // [B][16] (+ combine weights [B][n_head][8])
     float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);   // [B][nmat][RWP][PITCH]
 
+    NANO_STAMP(a.stamps, 0, tid);
     // ---- 1. activation loads (critical path) ------------------------------------------------------------
     Staged<B, NV> sx;
     stage_issue<ROLE, B, NV>(a, sx);
@@ -251,8 +253,10 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     const bool has_add = epi == GEMV_EPI_RESID && a.resid_add != nullptr;
     if (has_add && fold_live) addv = a.resid_add[(size_t)fb * a.resid_add_bstride + lrow0 + frl];
 
+    NANO_STAMP(a.stamps, 1, oldv);                                  // every load issued
     // ---- 4. rmsnorm + quantization from registers (weights in flight) ----------------------------------------
     stage_finish<ROLE, GS, B, NV>(a, sx, xq, xs, red, n16, ng4);
+    NANO_STAMP(a.stamps, 3, xs[0]);                                 // activation normalised + quantized in LDS (stamp 2: inside, the activation arrived)
 
     // ---- 5. integer dots, group products into the LDS table ----------------------------------------------------
 #pragma unroll
@@ -291,7 +295,9 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
             }
         }
     }
+    NANO_STAMP(a.stamps, 4, wv[UPW - 1][TR - 1].w);                 // this wave's weights arrived, its products are in the table
     __syncthreads();
+    NANO_STAMP(a.stamps, 5, P[0]);                                  // every wave's products are in the table
 
     // ---- 6. ordered fold (infer.c:668-674) + epilogue -------------------------------------------------------------
     if (tid < (int)(RW * B)) {
@@ -335,6 +341,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
             }
         }
         if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
+        NANO_STAMP(a.stamps, 6, v0);                                // folded and stored
     }
 }
 

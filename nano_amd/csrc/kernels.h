@@ -51,6 +51,7 @@ struct GemvArgs {
     // optional per-tile arg-max partials of a STORE launch: tile_max[b][tile] = (max value, row index bits)
     float *tile_max;
     uint32_t cus, _pad4;    // compute units of the device the launch goes to (0: assume 256); sizes the work split
+    unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
 
 uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // tiles launch_gemv() will use (sizes tile_max)
@@ -107,6 +108,7 @@ struct AttnArgs {
     // index mod 8 = XCD, each XCD has its own L2): x = sub * n_kv_head + kv head, when n_kv_head is a power of two >= 8;
     // kv_log2 = log2(n_kv_head), else 0xffffffff = plain order (x = first head / heads per workgroup)
     uint32_t kv_log2, _pad5;
+    unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);

@@ -171,3 +171,73 @@ extern "C" int nano_hip_op_argmax(int device, const float *x, uint32_t n, uint32
     OP_HIP(hipMemcpy(idx, di, 4, hipMemcpyDeviceToHost));
     return 0;
 }
+
+// One fused GEMV launch as enqueue_step() issues it (backend.hip): the role-specialised kernels on caller-chosen inputs.
+extern "C" int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *dp) {
+    int rc; if ((rc = begin(device))) return rc;
+    if (!dp) { nano_hip_set_error_("null descriptor"); return NANO_HIP_EINVAL; }
+    const NanoFusedGemvDesc &d = *dp;
+    if (d.kind > 2 || d.nseg == 0 || d.nseg > 3 || (d.kind == 2 && d.nseg != 2) || d.nb == 0 || d.nb > NANO_MAX_BATCH || !d.out || d.n % 4) {
+        nano_hip_set_error_("bad fused-gemv descriptor"); return NANO_HIP_EINVAL;
+    }
+    if (!d.x && !d.attn_part) { nano_hip_set_error_("no activation"); return NANO_HIP_EINVAL; }
+    if (d.quant == NANO_QUANT_Q80 && (!(d.gs == 32 || d.gs == 64 || d.gs == 128 || d.gs == 256) || d.n % d.gs || d.n % 16)) { nano_hip_set_error_("bad n / group size"); return NANO_HIP_EINVAL; }
+    DevBufs B;
+    GemvArgs a{};
+    const size_t bpl = (d.n + 255) / 256;
+    uint32_t rows_total = 0;
+    for (uint32_t s = 0; s < d.nseg; s++) {
+        const size_t rows = d.rows[s];
+        if (!d.w[s] || !rows) { nano_hip_set_error_("missing weight tensor"); return NANO_HIP_EINVAL; }
+        if (d.quant == NANO_QUANT_Q80) {
+            a.seg[s].w = B.upload(reinterpret_cast<const int8_t *>(d.w[s]), rows * d.n);
+            a.seg[s].ws = B.upload(d.ws[s], rows * d.n / d.gs);
+            OP_CHECK(a.seg[s].ws, "device alloc failed");
+        } else if (d.quant == NANO_QUANT_Q4K) a.seg[s].w = B.upload(reinterpret_cast<const uint8_t *>(d.w[s]), rows * bpl * 160);
+        else a.seg[s].w = B.upload(reinterpret_cast<const float *>(d.w[s]), rows * d.n);
+        OP_CHECK(a.seg[s].w, "device alloc failed");
+        a.seg[s].rows = d.rows[s];
+        if (d.kind != 2 || s == 0) rows_total += d.rows[s];
+    }
+    if (d.kind == 2 && d.rows[0] != d.rows[1]) { nano_hip_set_error_("W1 / W3 row counts differ"); return NANO_HIP_EINVAL; }
+    float *dout = B.upload(d.out, (size_t)d.nb * rows_total);       // (kind 1: the residual stream; otherwise overwritten)
+    OP_CHECK(dout, "device alloc failed");
+    uint32_t off = 0;
+    for (uint32_t s = 0; s < d.nseg; s++) {
+        a.seg[s].out = d.kind == 2 ? dout : dout + off;
+        a.seg[s].out_bstride = rows_total;
+        if (d.kind != 2) off += d.rows[s];
+    }
+    a.nseg = d.nseg; a.n = d.n; a.gs = d.gs; a.nb = d.nb;
+    a.epi = d.kind == 0 ? GEMV_EPI_STORE : d.kind == 1 ? GEMV_EPI_RESID : GEMV_EPI_SWIGLU;
+    if (d.x) { a.xin = B.upload(d.x, (size_t)d.nb * d.n); OP_CHECK(a.xin, "device alloc failed"); a.xin_bstride = d.n; }
+    if (d.norm_w) { a.norm_w = B.upload(d.norm_w, d.n); OP_CHECK(a.norm_w, "device alloc failed"); }
+    if (d.attn_part) {
+        if (!d.attn_ml || !d.attn_nsplit || d.attn_nsplit > 8 || !d.attn_n_head || d.attn_n_head * d.attn_hd != d.n || d.kind != 1 || d.nb > 8) { nano_hip_set_error_("bad attention partials"); return NANO_HIP_EINVAL; }
+        a.attn_part = B.upload(d.attn_part, (size_t)d.nb * d.attn_nsplit * d.n);
+        a.attn_ml = B.upload(d.attn_ml, (size_t)d.nb * d.attn_n_head * d.attn_nsplit * 2);
+        OP_CHECK(a.attn_part && a.attn_ml, "device alloc failed");
+        a.attn_nsplit = d.attn_nsplit; a.attn_n_head = d.attn_n_head; a.attn_hd = d.attn_hd;
+        if (!a.xin) { a.xin = a.attn_part; a.xin_bstride = d.n; }     // never read: the prologue combines the partials
+    }
+    hipDeviceProp_t prop; OP_HIP(hipGetDeviceProperties(&prop, device));
+    a.cus = (uint32_t)prop.multiProcessorCount;
+    hipError_t e;
+    if (d.use_gemm) {
+        if (d.quant != NANO_QUANT_Q80 || a.attn_part || !gemm_q80_g2_supports(a)) { nano_hip_set_error_("the batched GEMM route does not take this launch"); return NANO_HIP_EINVAL; }
+        const size_t n16 = (d.n + 15) & ~(size_t)15, tt = (d.nb + 15) / 16;
+        int8_t *xf = B.alloc<int8_t>(tt * 16 * n16); float *xsf = B.alloc<float>(tt * 16 * (d.n / d.gs));
+        OP_CHECK(xf && xsf, "device alloc failed");
+        OP_HIP(launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, xf, xsf, 0));
+        a.xq_in = xf; a.xs_in = xsf;
+        e = gemm_q80_g5_supports(a) ? launch_gemm_q80_g5(a, nullptr, nullptr, 0) : launch_gemm_q80_g2(a, 0);
+    } else if (d.nb > 8) {
+        nano_hip_set_error_("more than 8 sequences need use_gemm"); return NANO_HIP_EINVAL;
+    } else {
+        e = (d.quant == NANO_QUANT_Q4K) ? launch_gemv_q4k(a, 2048, 0) : launch_gemv(d.quant, a, 2048, 0);
+    }
+    OP_HIP(e);
+    OP_HIP(hipDeviceSynchronize());
+    OP_HIP(hipMemcpy(d.out, dout, (size_t)d.nb * rows_total * 4, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -626,3 +626,22 @@ def test_engine_replicas_serve_a_batch_concurrently(model_dir):
             lg, _ = m1.forward([int(seqs[b][pos])], [pos])
             assert np.array_equal(lg[0].view(np.uint32), got[pos][b].view(np.uint32)), (b, pos)
     m1.close()
+
+
+def test_bench_replicas_mode_runs_without_torch(tmp_path):
+    """bench.py --replicas 2: two weight replicas in ONE process (both on the one GPU of this box), driven only through the
+    C engine (nano_context_replicate + nano_forward_batch); the process never imports torch.  Same tokens as one replica."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    import os
+    outs = []
+    for n in (1, 2):
+        code = ("import sys, runpy; sys.argv = ['bench.py', '--replicas', '%d', '--total-seqs', '4', '--model', 'tiny-qwen3', '--steps', '12', '--warmup', '2'];\n"
+                "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    assert not e.code, e.code\n"
+                "assert 'torch' not in sys.modules, 'the replicas mode must not need torch'\n" % (n, os.path.join(ROOT, "bench.py")))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, NANO_BENCH_MODEL_DIR=str(tmp_path)))
+        assert r.returncode == 0, r.stderr[-800:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["config"]["replicas"] == n and d["config"]["sequences"] == 4 and d["value"] > 0 and d["steps"] == 12
+        outs.append(d)
+    assert outs[0]["scaling"] == outs[1]["scaling"] == "strong"

@@ -1,0 +1,238 @@
+"""GPU parity tests of the FUSED decode launches exactly as a step issues them (nano_hip_op_fused_gemv): the role-specialised
+kernels K1 (rmsnorm + quantize + q|k|v GEMV), K3 / K5 (quantize [+ split-attention combine] + GEMV + residual add) and K4
+(rmsnorm + quantize + W1|W3 GEMV + SwiGLU), plus their batched forms (GEMV kernels for 2..8 sequences, the int8 MFMA GEMM
+route for up to 64) -- at Qwen3-0.6B shapes, and at Qwen3-4B shapes where the round-3 balanced slabs (rows per workgroup
+that are not powers of two) apply.
+
+What makes these tests TIGHT: the device reduces sum(x^2) as a tree, the reference sequentially (infer/infer.c:601-614), and
+a last-ulp difference of the norm flips round(x / scale) decisions -- so on arbitrary inputs a fused launch can only be held
+to a loose tolerance.  Here the activations are ORDER-FREE: multiples of 2^-4 in [-2, 2], so every partial sum of squares
+is exactly representable and the tree and the sequential sum are the same number.  Then everything downstream (norm scale,
+normalised values, quantized activations, integer group sums, the ordered fp32 fold, the residual add) must equal the
+oracle's restatement of the reference BIT FOR BIT; only SwiGLU's expf (device vs libm, <= 2 ulp) keeps a tolerance.
+Reference lines: rmsnorm infer.c:601-614, quantize tensor.c:21-46 / 144-242, matmul_quant infer.c:654-679, matmul_q4k
+tensor.c:438-471, residual adds infer.c:906-908 / 963-965, SwiGLU infer.c:937-944."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from nano_amd import binding as nb
+
+pytestmark = pytest.mark.gpu
+
+Q80, Q4K = 0x80, 0x42
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def order_free(rng, shape):
+    """multiples of 2^-4 in [-2, 2]: sums of squares of up to 2^14 of them are exact in fp32 in any order"""
+    return (rng.integers(-32, 33, size=shape).astype(np.float32) / np.float32(16.0)).astype(np.float32)
+
+
+def q80_weights(rng, rows, n, gs):
+    wq = rng.integers(-127, 128, size=rows * n, dtype=np.int8)
+    ws = rng.uniform(1e-4, 2e-3, size=rows * n // gs).astype(np.float32)
+    return wq, ws
+
+
+def ref_q80(oracle, act, segs, n, gs):
+    xq, xs = oracle.quantize_q80(act, gs)
+    return np.concatenate([oracle.matmul_q80(xq, xs, wq, ws, n, rows, gs) for wq, ws, rows in segs])
+
+
+def silu_mul(a, b):
+    a = a.astype(np.float32)
+    return (a * (np.float32(1) / (np.float32(1) + np.exp(-a.astype(np.float64)).astype(np.float32))) * b).astype(np.float32)
+
+
+# (name, n, rows of the weight tensors): Qwen3-0.6B and Qwen3-4B per-layer shapes
+K1_SHAPES = [("q06", 1024, (2048, 1024, 1024)), ("4b", 2560, (4096, 1024, 1024))]
+K3_SHAPES = [("q06", 2048, 1024), ("4b", 4096, 2560)]
+K4_SHAPES = [("q06", 1024, 3072), ("4b", 2560, 9728)]
+K5_SHAPES = [("q06", 3072, 1024), ("4b", 9728, 2560)]
+
+
+@pytest.mark.parametrize("name,n,rows", K1_SHAPES)
+def test_k1_norm_qkv_q80_bit_exact(oracle, name, n, rows):
+    rng = np.random.default_rng(n + 1)
+    x = order_free(rng, n)
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    segs = [(*q80_weights(rng, r, n, 64), r) for r in rows]
+    ref = ref_q80(oracle, oracle.rmsnorm(x, nw), segs, n, 64)
+    out = nb.op_fused_gemv(Q80, 0, n, segs, x[None], nw, gs=64)[0]
+    assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
+
+
+@pytest.mark.parametrize("name,n,rows", K3_SHAPES + K5_SHAPES)
+def test_k3_k5_residual_q80_bit_exact(oracle, name, n, rows):
+    rng = np.random.default_rng(n + rows)
+    x = order_free(rng, n) * np.float32(3)                 # no norm in front of these launches: any values would do
+    old = rng.standard_normal(rows).astype(np.float32)
+    seg = (*q80_weights(rng, rows, n, 64), rows)
+    ref = (old + ref_q80(oracle, x, [seg], n, 64)).astype(np.float32)       # x[i] += xb[i]
+    out = nb.op_fused_gemv(Q80, 1, n, [seg], x[None], None, gs=64, resid=old[None])[0]
+    assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
+
+
+@pytest.mark.parametrize("nsplit,ls", [(2, (3, 5)), (4, (1, 3, 2, 2)), (8, (1, 1, 2, 4, 2, 2, 1, 3))])
+def test_k3_split_attention_combine_q80_bit_exact(oracle, nsplit, ls):
+    """Wo launch whose prologue combines split-attention partials (gemv_common.h combine_weights): equal split maxima make
+    every exp() an exact 1, the split sums add up to a power of two, the partials are order-free -> the combined activation
+    is exact on both sides and the launch must be bit-exact."""
+    n_head, hd, n, rows = 16, 128, 2048, 1024
+    rng = np.random.default_rng(nsplit)
+    part = order_free(rng, (1, nsplit, n))
+    ml = np.zeros((1, n_head, nsplit, 2), np.float32)
+    ml[..., 0] = 0.25
+    ml[..., 1] = np.asarray(ls, np.float32)
+    w = np.float32(1.0) / np.float32(sum(ls))
+    assert float(w) * sum(ls) == 1.0 and (sum(ls) & (sum(ls) - 1)) == 0
+    x = np.zeros(n, np.float32)
+    for s in range(nsplit):
+        x = (x + part[0, s] * w).astype(np.float32)
+    old = rng.standard_normal(rows).astype(np.float32)
+    seg = (*q80_weights(rng, rows, n, 64), rows)
+    ref = (old + ref_q80(oracle, x, [seg], n, 64)).astype(np.float32)
+    out = nb.op_fused_gemv(Q80, 1, n, [seg], None, None, gs=64, resid=old[None], attn=(part, ml, n_head, hd))[0]
+    assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
+
+
+@pytest.mark.parametrize("name,n,rows", K4_SHAPES)
+def test_k4_norm_swiglu_q80(oracle, name, n, rows):
+    rng = np.random.default_rng(n + 4)
+    x = order_free(rng, n)
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    w1 = (*q80_weights(rng, rows, n, 64), rows)
+    w3 = (*q80_weights(rng, rows, n, 64), rows)
+    xn = oracle.rmsnorm(x, nw)
+    h1, h3 = ref_q80(oracle, xn, [w1], n, 64), ref_q80(oracle, xn, [w3], n, 64)
+    out = nb.op_fused_gemv(Q80, 2, n, [w1, w3], x[None], nw, gs=64)[0]
+    # the two GEMV results inside are bit-exact (same kernels as K1's); the epilogue's expf is the device's (<= 2 ulp of libm)
+    assert np.allclose(out, silu_mul(h1, h3), rtol=3e-6, atol=1e-9), float(np.abs(out - silu_mul(h1, h3)).max())
+    # ... and the store form of the same pair of matrices pins the integer / fold part of this shape bit for bit
+    both = nb.op_fused_gemv(Q80, 0, n, [w1, w3], x[None], nw, gs=64)[0]
+    assert np.array_equal(bits(both), bits(np.concatenate([h1, h3])))
+
+
+@pytest.mark.parametrize("nb_", [2, 4, 8])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_batched_gemv_roles_q80_bit_exact(oracle, nb_, kind):
+    """2..8 sequences share each weight byte in the GEMV kernels (capacity templates 2 / 4 / 8): every sequence bit-exact"""
+    n, rows = (1024, (2048, 1024, 1024)) if kind == 0 else (3072, (1024,))
+    rng = np.random.default_rng(nb_ * 10 + kind)
+    x = order_free(rng, (nb_, n))
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32) if kind == 0 else None
+    segs = [(*q80_weights(rng, r, n, 64), r) for r in rows]
+    old = rng.standard_normal((nb_, sum(rows))).astype(np.float32)
+    out = nb.op_fused_gemv(Q80, kind, n, segs, x, nw, gs=64, nb=nb_, resid=old if kind == 1 else None)
+    for b in range(nb_):
+        act = oracle.rmsnorm(x[b], nw) if kind == 0 else x[b]
+        ref = ref_q80(oracle, act, segs, n, 64)
+        if kind == 1:
+            ref = (old[b] + ref).astype(np.float32)
+        assert np.array_equal(bits(out[b]), bits(ref)), (b, float(np.abs(out[b] - ref).max()))
+
+
+GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (9, 1, 3072, (1024,)), (40, 1, 2048, (1024,)), (64, 0, 1024, (2048, 1024, 1024)),
+              (8, 1, 9728, (2560,)), (16, 0, 2560, (4096, 1024, 1024)), (33, 1, 4096, (2560,))]
+
+
+def gemm_route_case(oracle, nb_, kind, n, rows):
+    rng = np.random.default_rng(nb_ + n)
+    x = order_free(rng, (nb_, n))
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32) if kind == 0 else None
+    segs = [(*q80_weights(rng, r, n, 64), r) for r in rows]
+    old = rng.standard_normal((nb_, sum(rows))).astype(np.float32)
+    out = nb.op_fused_gemv(Q80, kind, n, segs, x, nw, gs=64, nb=nb_, resid=old if kind == 1 else None, use_gemm=True)
+    for b in range(nb_):
+        act = oracle.rmsnorm(x[b], nw) if kind == 0 else x[b]
+        ref = ref_q80(oracle, act, segs, n, 64)
+        if kind == 1:
+            ref = (old[b] + ref).astype(np.float32)
+        assert np.array_equal(bits(out[b]), bits(ref)), (b, float(np.abs(out[b] - ref).max()))
+
+
+@pytest.mark.parametrize("nb_,kind,n,rows", GEMM_CASES)
+def test_mfma_gemm_route_q80_bit_exact(oracle, nb_, kind, n, rows):
+    """the batched route of a step: quant_rows_frag_kernel (fragment-order activations) + the int8 MFMA GEMM (G5)"""
+    gemm_route_case(oracle, nb_, kind, n, rows)
+
+
+def test_mfma_gemm_route_balanced_tiles_bit_exact():
+    """NANO_G5_BALANCED=1 (tiles of fewer than 16 rows fitted to the CU count; the knob is read once per process)"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);\n"
+            "import test_gpu_fused_roles as t; from oracle import binding as ob; o = ob.load_oracle()\n"
+            "for c in t.GEMM_CASES: t.gemm_route_case(o, *c)\nprint('balanced ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NANO_G5_BALANCED="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "balanced ok" in r.stdout, r.stderr[-800:]
+
+
+# ---- Q4K: the whole-workgroup block quantizer inside the fused launches ---------------------------------------------------
+def q4k_weights(oracle, rng, rows, n):
+    w = (0.02 * rng.standard_normal(rows * n)).astype(np.float32)
+    return oracle.quantize_q4k(w, [rows, n])                # framed tensor (44-byte prefix)
+
+
+def ref_q4k(oracle, act, WTs, n):
+    XT = oracle.quantize_q4k(np.ascontiguousarray(act, np.float32), [n])
+    return np.concatenate([oracle.matmul_q4k(XT, WT, 0, rows) for WT, rows in WTs])
+
+
+@pytest.mark.parametrize("n,rows", [(1024, (2048, 1024, 1024)), (2560, (1024, 256, 256))])
+def test_k1_norm_qkv_q4k_bit_exact(oracle, n, rows):
+    rng = np.random.default_rng(n + 7)
+    x = order_free(rng, n)
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    WTs = [(q4k_weights(oracle, rng, r, n), r) for r in rows]
+    ref = ref_q4k(oracle, oracle.rmsnorm(x, nw), WTs, n)
+    out = nb.op_fused_gemv(Q4K, 0, n, [(WT[44:], None, r) for WT, r in WTs], x[None], nw)[0]
+    assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
+
+
+@pytest.mark.parametrize("n,rows", [(2048, 1024), (3072, 1024)])
+def test_k3_k5_residual_q4k_bit_exact(oracle, n, rows):
+    rng = np.random.default_rng(n + 9)
+    x = (rng.standard_normal(n) * 2).astype(np.float32)
+    old = rng.standard_normal(rows).astype(np.float32)
+    WT = q4k_weights(oracle, rng, rows, n)
+    ref = (old + ref_q4k(oracle, x, [(WT, rows)], n)).astype(np.float32)
+    out = nb.op_fused_gemv(Q4K, 1, n, [(WT[44:], None, rows)], x[None], None, resid=old[None])[0]
+    assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
+
+
+def test_k4_norm_swiglu_q4k(oracle):
+    n, rows = 1024, 3072
+    rng = np.random.default_rng(11)
+    x = order_free(rng, n)
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    W1, W3 = q4k_weights(oracle, rng, rows, n), q4k_weights(oracle, rng, rows, n)
+    xn = oracle.rmsnorm(x, nw)
+    h1, h3 = ref_q4k(oracle, xn, [(W1, rows)], n), ref_q4k(oracle, xn, [(W3, rows)], n)
+    out = nb.op_fused_gemv(Q4K, 2, n, [(W1[44:], None, rows), (W3[44:], None, rows)], x[None], nw)[0]
+    assert np.allclose(out, silu_mul(h1, h3), rtol=3e-6, atol=1e-9)
+    both = nb.op_fused_gemv(Q4K, 0, n, [(W1[44:], None, rows), (W3[44:], None, rows)], x[None], nw)[0]
+    assert np.array_equal(bits(both), bits(np.concatenate([h1, h3])))
+
+
+def test_split_attention_combine_q4k_bit_exact(oracle):
+    n_head, hd, n, rows, nsplit, ls = 16, 128, 2048, 1024, 4, (1, 3, 2, 2)
+    rng = np.random.default_rng(13)
+    part = order_free(rng, (1, nsplit, n))
+    ml = np.zeros((1, n_head, nsplit, 2), np.float32)
+    ml[..., 0] = -1.5
+    ml[..., 1] = np.asarray(ls, np.float32)
+    x = np.zeros(n, np.float32)
+    for s in range(nsplit):
+        x = (x + part[0, s] * np.float32(0.125)).astype(np.float32)
+    old = rng.standard_normal(rows).astype(np.float32)
+    WT = q4k_weights(oracle, rng, rows, n)
+    ref = (old + ref_q4k(oracle, x, [(WT, rows)], n)).astype(np.float32)
+    out = nb.op_fused_gemv(Q4K, 1, n, [(WT[44:], None, rows)], None, None, resid=old[None], attn=(part, ml, n_head, hd))[0]
+    assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
