@@ -96,6 +96,24 @@ template <bool KVH> __device__ __forceinline__ KVRaw<KVH> kv_load4(__amdgpu_buff
     return o;
 }
 
+// ---- reductions over the sub-groups of a wave (the lanes of equal l % LPR), result in every lane; VALU only ---------------
+// lane ^ 8: DPP row rotate by 8 (inside a 16-lane row); lane ^ 16 / lane ^ 32: v_permlane16_swap / v_permlane32_swap (gfx950):
+// with both operands = v the pair of results is { v of the even half, v of the odd half } in every lane of the pair of halves.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float xlane8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true)); }
+template <int LPR> __device__ __forceinline__ float xsub_sum(float v) {
+    if (LPR <= 8) v += xlane8(v);
+    { const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    { const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    return v;
+}
+template <int LPR> __device__ __forceinline__ float xsub_max(float v) {
+    if (LPR <= 8) v = fmaxf(v, xlane8(v));
+    { const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    { const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    return v;
+}
+
 constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight per round
 
 // A KV row (head_dim floats) is shared by LPR lanes, QV float4 each (lane j owns float4 j, j+LPR, ...: every load
@@ -112,13 +130,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t grp = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
     const uint32_t nsplit = a.nsplit;
-    const uint32_t hd = a.hd, half = hd >> 1, hd4 = (hd + 3) & ~3u;
-    const uint32_t kv_mul = a.n_head / a.n_kv_head;
+    const uint32_t hd = (MODE == 1) ? (uint32_t)(QV * LPR * 4) : a.hd, half = hd >> 1, hd4 = (hd + 3) & ~3u;    // Qwen3 decode mode: the head fills the sub-group exactly (launch_lpr)
     // first q head of this workgroup and its KV head.  XCD-aware order (kv_log2 valid): x = sub * n_kv_head + KV head, so the
-    // kv_mul / KVM workgroups that read the same K/V rows have equal x mod 8 = the same XCD = one L2 fetch of every row
-    const bool xcd = a.kv_log2 != 0xffffffffu;
-    const uint32_t g = xcd ? (grp & ((1u << a.kv_log2) - 1u)) : (grp * KVM) / kv_mul;
-    const uint32_t h0 = xcd ? g * kv_mul + (grp >> a.kv_log2) * KVM : grp * KVM;
+    // kv_mul / KVM workgroups that read the same K/V rows have equal x mod 8 = the same XCD = one L2 fetch of every row.
+    // The decode modes (MODE 1 / 2) always run in that order with power-of-two head counts (launch_lpr() checks): shifts and
+    // masks only -- the three integer divisions this used to take cost ~60 instructions before the first load was issued.
+    uint32_t kv_mul, g, h0;
+    bool first_of_group;                                       // this workgroup writes the KV head's fresh k (v) row
+    if constexpr (MODE != 0) {
+        kv_mul = 1u << a.kvmul_log2;
+        g = grp & ((1u << a.kv_log2) - 1u);
+        const uint32_t sub_wg = grp >> a.kv_log2;
+        h0 = (g << a.kvmul_log2) + sub_wg * KVM;
+        first_of_group = sub_wg == 0;
+    } else {
+        kv_mul = a.n_head / a.n_kv_head;
+        const bool xcd = a.kv_log2 != 0xffffffffu;
+        g = xcd ? (grp & ((1u << a.kv_log2) - 1u)) : (grp * KVM) / kv_mul;
+        h0 = xcd ? g * kv_mul + (grp >> a.kv_log2) * KVM : grp * KVM;
+        first_of_group = (h0 % kv_mul) == 0;
+    }
     constexpr bool G = MODE == 0;
     constexpr int VR = (KVM + 1 + 3) / 4;                      // rounds of vectors per wave (q heads + the k row over 4 waves)
     constexpr int JJ = (LPR == 16) ? 2 : 1;                    // RoPE pairs per lane (head_dim > 128 needs two)
@@ -130,14 +161,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const bool causal = G ? a.is_causal != 0 : true;
     float *const q_out = G ? a.q_out : nullptr;
 
-    // LDS: qh[KVM][hd4] kh[hd4] redm[KVM][4] redl[KVM][R] part[R][KVM][hd4]
+    // LDS: qh[KVM][hd4] kh[hd4] redm[KVM][4] redl[KVM][4] part[4 waves][KVM][hd4]
     float *qh = reinterpret_cast<float *>(smem);
     float *kh = qh + KVM * hd4;
     float *redm = kh + hd4;
     float *redl = redm + KVM * 4;
-    float *part = redl + KVM * R;
+    float *part = redl + KVM * 4;
 
     NANO_STAMP(a.stamps, 0, tid);
+    // Every kernel argument the prologue needs, fetched in ONE scalar round trip: left alone the compiler fetches the block in
+    // two or three dependent batches (each a ~0.2 us scalar-cache miss on the fresh kernarg segment) between the first loads.
+    if constexpr (MODE != 0)
+        asm volatile("" :: "s"(a.q), "s"(a.kraw), "s"(a.kcache), "s"(a.vcache), "s"(a.pos), "s"(a.q_norm), "s"(a.k_norm), "s"(a.rope_cur),
+                     "s"(a.out), "s"(a.ml), "s"(a.xba_out), "s"(a.nsplit), "s"(a.range_hint), "s"(a.layer), "s"(a.S), "s"(a.q_dim), "s"(a.kv_dim),
+                     "s"(a.cache_bstride_rows), "s"(a.kv_log2), "s"(a.kvmul_log2), "s"(a.vraw), "s"(a.xf_out));
+    // the position first: it is waited for before everything else, and vector loads return in issue order
+    const uint32_t pos_ld = (MODE == 0 && a.fixed_range) ? 0u : a.pos[blockIdx.y];
     // ---- 1. issue every load --------------------------------------------------------------------------------
     constexpr uint32_t ESZ = KVH ? 2u : 4u;                    // bytes per cache element
     const size_t slot_rows = (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
@@ -179,7 +218,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             if (KVH) vfresh[q] = bload_f4(rvr, fo == OOB ? OOB : g * hd * 4u + fo);
             if (MODE == 1) {
                 qnw[q] = bload_f4(rqn, fo); knw[q] = bload_f4(rkn, fo);
-                const uint32_t fr = f % (half / 4u);                 // cos/sin of element i and i+half are those of pair i
+                const uint32_t fr = f & (uint32_t)(QV * LPR / 2 - 1);    // = f % (half / 4): cos/sin of element i and i+half are those of pair i
                 rcs[q] = bload_f4(rr, fo == OOB ? OOB : fr * 16u);
                 rsn[q] = bload_f4(rr, fo == OOB ? OOB : (half + fr * 4u) * 4u);
             } else {                                                  // adjacent pairs (2p, 2p+1), p = 2f, 2f+1: .xy = cos, .zw = sin
@@ -234,10 +273,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
     };
     issue_kv(0);
+    __builtin_amdgcn_sched_barrier(0);                         // the K / V loads go out BEFORE anything waits for q (the scheduler otherwise sinks them below the q wait)
     NANO_STAMP(a.stamps, 1, tid);                              // every load issued
 
     // ---- 2. position, RoPE row, norms ------------------------------------------------------------------------------
-    const uint32_t pos = fixed_range ? (fixed_range - 1) : a.pos[b];
+    const uint32_t pos = fixed_range ? (fixed_range - 1) : pos_ld;
     const uint32_t range = fixed_range ? fixed_range : (causal ? (pos + 1) : a.S);
     if constexpr (REGQK) {
         if (MODE == 1) {                         // rmsnorm over the head (infer.c:601-614, 824-835), tree order
@@ -292,7 +332,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < QV; q++) { kfresh[q] = kv_round<KVH>(kfresh[q]); if (KVH) vfresh[q] = kv_round<KVH>(vfresh[q]); }   // what the cache holds
-        if (split == 0 && sub == 0 && (h0 % kv_mul) == 0) {      // the finished k row (FP16 cache: and the v row) -> cache row pos
+        if (split == 0 && sub == 0 && first_of_group) {          // the finished k row (FP16 cache: and the v row) -> cache row pos
             float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)pos * a.kv_dim * ESZ);
             float *vrow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)pos * a.kv_dim * ESZ);
 #pragma unroll
@@ -343,7 +383,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                     }
                     if (isk) { y0 = kv_round1<KVH>(y0); y1 = kv_round1<KVH>(y1); }
                     dst[i0] = y0; dst[i1] = y1;
-                    if (isk && split == 0 && (h0 % kv_mul) == 0) {
+                    if (isk && split == 0 && first_of_group) {
                         float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)pos * a.kv_dim * ESZ);
                         kv_store1<KVH>(krow, i0, y0); kv_store1<KVH>(krow, i1, y1);
                     }
@@ -358,7 +398,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             const uint32_t f = j + (uint32_t)LPR * q;
             const bool ok = f * 4u < hd;
             vfresh[q] = kv_round<KVH>(bload_f4(rvr, ok ? g * hd * 4u + f * 16u : OOB));
-            if (fresh_v && ok && split == 0 && sub == 0 && (h0 % kv_mul) == 0)
+            if (fresh_v && ok && split == 0 && sub == 0 && first_of_group)
                 kv_store4<KVH>(reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)pos * a.kv_dim * ESZ), 4u * f, vfresh[q]);
         }
     }
@@ -435,44 +475,36 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 
     NANO_STAMP(a.stamps, 3, acc[0][0].x);                      // K / V rows arrived, scores + running softmax done
     // ---- 4. combine the R sub-groups of the workgroup ----------------------------------------------------------------
-    // maximum: across the sub-groups of a wave by cross-lane exchange, across waves through LDS
-    constexpr int SPW = 64 / LPR;                     // sub-groups per wave
-    float Mwg[KVM];
+    // (a) inside each wave, in registers: the sub-groups of a wave hold the same head-dim slices in the lanes of equal
+    //     l % LPR, so the wave's maximum, its exp-sum and its weighted-V slices are three cross-lane steps each (VALU only);
+    // (b) across the four waves through LDS: 4 partial rows per head instead of one per sub-group.
+    // (round 3: the former layout -- every sub-group's row through LDS, 32-term sums -- cost 1.7 of the kernel's 4.8 us)
 #pragma unroll
     for (int m = 0; m < KVM; m++) {
-        float mx = mrun[m];
-#pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (lane == 0) redm[m * 4 + wid] = mx;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < KVM; m++) {
-        const float M = fmaxf(fmaxf(redm[m * 4], redm[m * 4 + 1]), fmaxf(redm[m * 4 + 2], redm[m * 4 + 3]));
-        Mwg[m] = M;
-        const float w = (mrun[m] == -INFINITY) ? 0.0f : expf(mrun[m] - M);
+        const float Mw = xsub_max<LPR>(mrun[m]);
+        const float w = (mrun[m] == -INFINITY) ? 0.0f : expf(mrun[m] - Mw);
+        const float lw = xsub_sum<LPR>(lrun[m] * w);
 #pragma unroll
         for (int q = 0; q < QV; q++) {
+            const float4 t = make_float4(xsub_sum<LPR>(acc[m][q].x * w), xsub_sum<LPR>(acc[m][q].y * w), xsub_sum<LPR>(acc[m][q].z * w), xsub_sum<LPR>(acc[m][q].w * w));
             const uint32_t f = j + (uint32_t)LPR * q;
-            if (f * 4u < hd)
-                *reinterpret_cast<float4 *>(part + ((size_t)sub * KVM + m) * hd4 + 4 * f) = make_float4(acc[m][q].x * w, acc[m][q].y * w, acc[m][q].z * w, acc[m][q].w * w);
+            if (lane < LPR && f * 4u < hd) *reinterpret_cast<float4 *>(part + ((size_t)wid * KVM + m) * hd4 + 4 * f) = t;
         }
-        if (j == 0) redl[m * R + sub] = lrun[m] * w;
+        if (lane == 0) { redm[m * 4 + wid] = Mw; redl[m * 4 + wid] = lw; }
     }
-    (void)SPW;
     __syncthreads();
-    NANO_STAMP(a.stamps, 4, redl[0]);                          // sub-group partials in LDS
+    NANO_STAMP(a.stamps, 4, redl[0]);                          // the four waves' partials are in LDS
     for (uint32_t idx = tid; idx < (uint32_t)KVM * hd; idx += 256) {
-        const uint32_t m = idx / hd, i = idx - m * hd;
-        float M = Mwg[0];
-#pragma unroll
-        for (int q = 1; q < KVM; q++) M = (q == (int)m) ? Mwg[q] : M;
-        float L = 0.0f, o = 0.0f;
-#pragma unroll 8
-        for (int s = 0; s < R; s++) {
-            L += redl[m * R + s];
-            o += part[((size_t)s * KVM + m) * hd4 + i];
-        }
+        uint32_t m = 0, i = idx;
+        if (KVM > 1) { m = idx / hd; i = idx - m * hd; }
+        const float4 mw = *reinterpret_cast<const float4 *>(redm + m * 4), lw4 = *reinterpret_cast<const float4 *>(redl + m * 4);
+        const float M = fmaxf(fmaxf(mw.x, mw.y), fmaxf(mw.z, mw.w));
+        const float e0 = (mw.x == -INFINITY) ? 0.0f : expf(mw.x - M), e1 = (mw.y == -INFINITY) ? 0.0f : expf(mw.y - M);
+        const float e2 = (mw.z == -INFINITY) ? 0.0f : expf(mw.z - M), e3 = (mw.w == -INFINITY) ? 0.0f : expf(mw.w - M);
+        const float *pp = part + (size_t)m * hd4 + i;
+        const size_t ws_ = (size_t)KVM * hd4;
+        float L = lw4.x * e0; L += lw4.y * e1; L += lw4.z * e2; L += lw4.w * e3;
+        float o = pp[0] * e0; o += pp[ws_] * e1; o += pp[2 * ws_] * e2; o += pp[3 * ws_] * e3;
         const uint32_t h = h0 + m;
         if (nsplit == 1) {
             const float val = o / L;                                                                  // softmax normalisation (infer.c:631-633)
@@ -494,7 +526,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             if (i == 0) { float *ml = a.ml + (((size_t)b * a.n_head + h) * nsplit + split) * 2; ml[0] = M; ml[1] = L; }
         }
     }
-    NANO_STAMP(a.stamps, 5, Mwg[0]);                           // combined and stored
+    NANO_STAMP(a.stamps, 5, mrun[0]);                          // combined and stored
 }
 
 template <int LPR, int QV, int MODE, bool KVH>
@@ -502,7 +534,8 @@ static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t 
     const uint32_t kv_mul = a_in.n_head / a_in.n_kv_head;
     const uint32_t hd4 = (a_in.hd + 3) & ~3u;
     constexpr uint32_t R = 256 / LPR;
-    auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + kvm * R + (size_t)R * kvm * hd4) * sizeof(float); };
+    auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + 4 * kvm + (size_t)4 * kvm * hd4) * sizeof(float); };
+    (void)R;
     // q heads per workgroup (KVM; h0 = KVM grp, KV head h0 / kv_mul): fewer heads = more workgroups with less dependent work each,
     // the K/V rows' repeated reads come from L2 (and the KV head's fresh k row is written by each of its workgroups: same
     // bits).  Same per-head arithmetic whatever the choice.  One head per workgroup while that leaves at most one workgroup
@@ -512,8 +545,11 @@ static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t 
     static const uint32_t forced = getenv("NANO_ATTN_KVM") ? (uint32_t)atoi(getenv("NANO_ATTN_KVM")) : 0u;   // measurement knob
     static const bool xcd_order = !(getenv("NANO_ATTN_XCD") && *getenv("NANO_ATTN_XCD") == '0');             // measurement knob
     AttnArgs a = a_in;
-    a.kv_log2 = 0xffffffffu;
-    if (xcd_order && a.n_kv_head >= 8 && (a.n_kv_head & (a.n_kv_head - 1)) == 0) { uint32_t l2 = 0; while ((1u << l2) < a.n_kv_head) l2++; a.kv_log2 = l2; }
+    a.kv_log2 = 0xffffffffu; a.kvmul_log2 = 0;
+    const bool kv_pow2 = (a.n_kv_head & (a.n_kv_head - 1)) == 0, mul_pow2 = (kv_mul & (kv_mul - 1)) == 0;
+    if (kv_pow2 && (MODE != 0 || (xcd_order && a.n_kv_head >= 8))) { uint32_t l2 = 0; while ((1u << l2) < a.n_kv_head) l2++; a.kv_log2 = l2; }
+    if (mul_pow2) { uint32_t l2 = 0; while ((1u << l2) < kv_mul) l2++; a.kvmul_log2 = l2; }
+    if (MODE != 0 && !(kv_pow2 && mul_pow2)) return hipErrorInvalidValue;       // launch_lpr() sends such shapes to the generic mode
     const uint64_t head_wgs = (uint64_t)a.n_head * nb * a.nsplit;
     uint32_t kvm = (head_wgs <= 256u || kv_mul % 2 != 0) ? 1u : (head_wgs <= 1024u || kv_mul % 4 != 0) ? 2u : 4u;
     if (forced == 1u || (forced == 2u && kv_mul % 2 == 0) || (forced == 4u && kv_mul % 4 == 0)) kvm = forced;
@@ -528,8 +564,11 @@ static hipError_t launch_mode(const AttnArgs &a, uint32_t nb, hipStream_t st) {
 }
 template <int LPR, int QV>
 static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {
-    const bool decode = a.kraw && a.rope_cos && a.rope_cur && !a.fixed_range && a.is_causal && !a.q_out;
-    if (decode && a.q_norm && a.rope_qwen3 && a.hd % 64 == 0) return launch_mode<LPR, QV, 1>(a, nb, st);
+    // the decode modes index with shifts and masks: power-of-two head counts (every BASELINE shape: 16 / 8 and 32 / 8 heads)
+    const uint32_t kv_mul = a.n_kv_head ? a.n_head / a.n_kv_head : 0;
+    const bool pow2 = a.n_kv_head && (a.n_kv_head & (a.n_kv_head - 1)) == 0 && kv_mul && (kv_mul & (kv_mul - 1)) == 0;
+    const bool decode = pow2 && a.kraw && a.rope_cos && a.rope_cur && !a.fixed_range && a.is_causal && !a.q_out;
+    if (decode && a.q_norm && a.rope_qwen3 && a.hd % 64 == 0 && a.hd == (uint32_t)(QV * LPR * 4)) return launch_mode<LPR, QV, 1>(a, nb, st);
     if (decode && !a.q_norm && !a.rope_qwen3) return launch_mode<LPR, QV, 2>(a, nb, st);
     return launch_mode<LPR, QV, 0>(a, nb, st);
 }

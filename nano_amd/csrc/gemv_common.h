@@ -2,6 +2,7 @@
 // gemv_q4k.hip): DPP reductions, buffer-descriptor loads, the device-side argument block, kernel roles, and the
 // workgroup-cooperative activation loads (plain vector or split-attention combine).
 #pragma once
+#include <stdlib.h>
 #include "device_common.h"
 #include "kernels.h"
 
@@ -82,6 +83,7 @@ struct GemvDev {
     float *tile_max;
     const float *resid_add; uint32_t resid_add_bstride, _pad1;
     unsigned long long *stamps;     // measurement builds only (-DNANO_STAMPS=1, tools/stamp_probe.py): [workgroup][8] shader-clock stamps, or nullptr
+    uint32_t dbg, _pad2;            // measurement builds only: experiment bits (NANO_DBG): 1 = no norm-weight load, 2 = weights issued before the activation
 };
 
 template <int ROLE> __device__ __forceinline__ bool has_flag(const GemvDev &a, uint32_t f) {
@@ -130,7 +132,7 @@ __device__ __forceinline__ void stage_issue(const GemvDev &a, Staged<B, NV> &r) 
 #pragma unroll
             for (int b = 0; b < B; b++) r.x[b][j] = bload_f4(rx, (b < (int)a.nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
         }
-        if (has_flag<ROLE>(a, F_NORM)) r.nw[j] = bload_f4(rn, off);
+        if (has_flag<ROLE>(a, F_NORM)) r.nw[j] = (NANO_STAMPS && (a.dbg & 1u)) ? make_float4(1.f, 1.f, 1.f, 1.f) : bload_f4(rn, off);
     }
     if constexpr (B == 1) {
       if (has_flag<ROLE>(a, F_COMBINE)) {     // uniform branch: an out-of-range load is not free, do not issue 8*NV of them
@@ -222,6 +224,7 @@ static GemvDev to_dev(const GemvArgs &a) {
     d.tile_max = a.tile_max;
     d.resid_add = a.resid_add; d.resid_add_bstride = a.resid_add_bstride;
     d.stamps = a.stamps;
+    { static const uint32_t dbg = getenv("NANO_DBG") ? (uint32_t)strtoul(getenv("NANO_DBG"), nullptr, 0) : 0u; d.dbg = dbg; }
     return d;
 }
 

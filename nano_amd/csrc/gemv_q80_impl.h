@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     NANO_STAMP(a.stamps, 0, tid);
     // ---- 1. activation loads (critical path) ------------------------------------------------------------
     Staged<B, NV> sx;
-    stage_issue<ROLE, B, NV>(a, sx);
+    if (!(NANO_STAMPS && (a.dbg & 2u))) stage_issue<ROLE, B, NV>(a, sx);
 
     // ---- 2. all weight / scale loads of this wave; the workgroup's rows lie inside ONE segment ------------
     const uint32_t bid = blockIdx.x;
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
             sv[k][s] = bload_f(rs_, (r < TR && tl * TR + r < RW && g < ng) ? ((lrow + r) * ng + g) * 4u : OOB);
         }
     }
+    if (NANO_STAMPS && (a.dbg & 2u)) stage_issue<ROLE, B, NV>(a, sx);          // (experiment: the activation behind the weights)
     // ---- 3. the fold thread's output slot (residual: old value) -----------------------------------------------
     const int fb = (int)(((uint32_t)tid * a.magic_rw) >> 16);          // tid / RW: fold thread -> (sequence, local row)
     const int frl = tid - fb * (int)RW;
@@ -519,7 +520,10 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
                 if ((size_t)nmat * tpw * 4 * pitch * 4 > 96 * 1024) break;     // product table
                 uint32_t wgs = 0;
                 if (nseg > 1) for (uint32_t s2 = 0; s2 < nseg; s2++) wgs += (a.seg[s2].rows + c - 1) / c; else wgs = (rows + c - 1) / c;
-                const uint32_t cost = ((wgs + cus - 1) / cus) * c;
+                // rows of the busiest CU; more than one workgroup per CU pays its prologue several times over on shared issue
+                // slots (measured: QKV of Qwen3-4B, 768 workgroups of 8 rows 7.4 us vs 192 of 32 rows 6.9), so x 1.15 then
+                uint32_t cost = ((wgs + cus - 1) / cus) * c * 100u;
+                if (wgs > cus) cost += cost * 15u / 100u;
                 if (cost <= best_cost) { best_cost = cost; best = c; }
             }
         } else {
@@ -549,7 +553,8 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     }
     const uint32_t units = ((rw + 3) / 4) * nchunk * nmat;
     uint32_t nw = units < 4 ? units : 4;
-    uint32_t want = (a.n * (uint32_t)(B > 2 ? B / 2 : 1) + 511) / 512;     // idle waves still help the activation prologue
+    static const uint32_t want_div = [] { const char *e = getenv("NANO_SLAB_WANT"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v >= 64 ? v : 512u; }();   // measurement knob
+    uint32_t want = (a.n * (uint32_t)(B > 2 ? B / 2 : 1) + want_div - 1) / want_div;     // idle waves still help the activation prologue
     if (want > 16) want = 16;
     if (nw < want) nw = want;
     if (nw * 64 < rw * (uint32_t)B) nw = (rw * (uint32_t)B + 63) / 64;      // one fold thread per (row, sequence)

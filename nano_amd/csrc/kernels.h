@@ -107,7 +107,7 @@ struct AttnArgs {
     // filled by launch_attention(): workgroup x -> q heads so that the workgroups sharing a KV head run on ONE XCD (workgroup
     // index mod 8 = XCD, each XCD has its own L2): x = sub * n_kv_head + kv head, when n_kv_head is a power of two >= 8;
     // kv_log2 = log2(n_kv_head), else 0xffffffff = plain order (x = first head / heads per workgroup)
-    uint32_t kv_log2, _pad5;
+    uint32_t kv_log2, kvmul_log2;   // kvmul_log2 = log2(n_head / n_kv_head) (decode modes: both head counts are powers of two)
     unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);

@@ -5,9 +5,9 @@ launch of ONE eager decode step, from the measurement build of the library:
     make -C nano_amd/csrc stamps
     NANO_LIB=nano_amd/lib/libnano_mi355x_stamps.so python tools/stamp_probe.py [model] [quant] [batch] [pos]
 
-Prints, per launch kind (averaged over the layers): workgroups, start skew (last workgroup's entry - first one's), and the
-mean / max over workgroups of each phase in microseconds at an assumed 2.1 GHz shader clock, plus the kernel span (first
-entry -> last end) and the gap to the next launch's first entry (eager launches: host-bound, not the graph's gap)."""
+Prints, per launch kind (averaged over the layers): workgroups and the mean / max over workgroups of each phase of a
+workgroup's first wave, in microseconds at an assumed 2.1 GHz shader clock (NANO_STAMP_GHZ).  The clock is per XCD, so only
+differences inside one workgroup are meaningful."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -46,22 +46,15 @@ for rep in range(3):
         nph = 6 if k != 2 else 5
         ends = s[:, nph]
         ok = ends > 0                                       # (fold threads exist in every workgroup)
-        t0 = s[:, 0].min()
+        # (the shader clock is per XCD: only differences INSIDE a workgroup mean anything)
         d = np.diff(s[:, :nph + 1], axis=1)[ok] / (GHZ * 1e3)
-        span = (ends[ok].max() - t0) / (GHZ * 1e3)
-        skew = (s[:, 0].max() - t0) / (GHZ * 1e3)
-        nxt = None
-        if i + 1 < len(kinds):
-            s2 = st[i + 1].astype(np.int64); l2 = s2[:, 0] > 0
-            if l2.any():
-                nxt = (s2[l2][:, 0].min() - ends[ok].max()) / (GHZ * 1e3)
-        agg.setdefault(k, []).append((live.sum(), skew, d.mean(axis=0), d.max(axis=0), span, nxt))
+        tot = (ends[ok] - s[ok, 0]) / (GHZ * 1e3)
+        agg.setdefault(k, []).append((live.sum(), d.mean(axis=0), d.max(axis=0), tot.mean(), tot.max()))
 print(f"{model} {quant} batch {B} position {pos}: phase stamps, microseconds at {GHZ} GHz (mean over workgroups / max), averaged over layers and 2 steps")
 for k in sorted(agg):
     rows = agg[k]
-    wg = np.mean([r[0] for r in rows]); skew = np.mean([r[1] for r in rows]); span = np.mean([r[4] for r in rows])
-    mean = np.mean([r[2] for r in rows], axis=0); mx = np.mean([r[3] for r in rows], axis=0)
-    gaps = [r[5] for r in rows if r[5] is not None]
-    print(f"{names.get(k, k):10s} wgs {wg:6.0f}  start skew {skew:5.2f}  span {span:5.2f}  gap-to-next(eager) {np.mean(gaps) if gaps else float('nan'):5.2f}")
+    wg = np.mean([r[0] for r in rows])
+    mean = np.mean([r[1] for r in rows], axis=0); mx = np.mean([r[2] for r in rows], axis=0)
+    print(f"{names.get(k, k):10s} wgs {wg:6.0f}  entry -> end of a workgroup's first wave: mean {np.mean([r[3] for r in rows]):5.2f}  max {np.mean([r[4] for r in rows]):5.2f}")
     print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(phases[1 if k != 2 else 2], mean, mx)))
 m.close()
