@@ -85,9 +85,22 @@ int  nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *desc, const 
  * tested in tests/test_gpu_kv16.py).  Not combinable with strict mode or LoRA.  nano_hip_model_create() applies it when
  * NANO_KV_F16=1 is set in the environment. */
 #define NANO_HIP_KV_F16 1u
+/* NANO_HIP_KV_PAGED (opt-in; results are BIT-IDENTICAL to the contiguous cache): the KV cache is a pool of pages
+ * of 64 positions ([layer][page][64][kv_dim] x2) instead of max_batch fixed slots of max_seq_len rows (the reference sizes its
+ * cache statically, infer/infer.c:46-51, and reads it linearly, :850-878).  A sequence slot takes a page when its position
+ * enters a new 64-position block -- taken zero-filled, like the reference's calloc'd rows -- and gives its pages back with
+ * nano_hip_kv_release(); a step that finds no free page fails with NANO_HIP_ENOMEM and changes nothing.  The pool holds
+ * NANO_KV_PAGES pages (environment; default max_batch * ceil(max_seq_len / 64) = what the slots would have held), so more
+ * slots than the memory for full-length sequences can be open when most are short.  Combinable with NANO_HIP_KV_F16; not with
+ * strict mode or LoRA.  nano_hip_model_create() applies it when NANO_KV_PAGED=1 is set in the environment. */
+#define NANO_HIP_KV_PAGED 2u
 int  nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc *desc, const void *params, size_t params_bytes,
                               int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch, uint32_t flags);
 void nano_hip_model_destroy(NanoHipModel *m);
+/* Paged KV cache only: give the pages of sequence slot `slot` back to the pool (the slot's next position is 0 again); pages in
+ * use / in the pool.  Both fail with NANO_HIP_EINVAL on a model without NANO_HIP_KV_PAGED. */
+int  nano_hip_kv_release(NanoHipModel *m, uint32_t slot);
+int  nano_hip_kv_pages(const NanoHipModel *m, uint32_t *in_use, uint32_t *total);
 /* number of parameter-blob bytes the backend expects for `desc` (0 if it cannot be derived
  * without reading the blob, i.e. Q4K whose tensor frames carry their own sizes) */
 size_t nano_hip_params_bytes(const NanoModelDesc *desc);

@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
     fn("nano_hip_op_swiglu", C.c_int, [C.c_int, f32p, f32p, C.c_uint32])
     fn("nano_hip_op_argmax", C.c_int, [C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32)])
     fn("nano_hip_op_fused_gemv", C.c_int, [C.c_int, C.POINTER(NanoFusedGemvDesc)])
+    fn("nano_hip_kv_release", C.c_int, [vp, C.c_uint32])
+    fn("nano_hip_kv_pages", C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
     fn("nano_hip_stamps_begin", C.c_int, [vp])
     fn("nano_hip_stamps_read", C.c_int, [vp, vp, u32p, C.c_uint32, C.POINTER(C.c_uint32)])
     _lib = L
@@ -144,11 +146,16 @@ class DeviceModel:
     """A model resident on one GPU: mirrors what the reference keeps in ``LLM`` (weights + FwdBuffer)."""
 
     def __init__(self, desc: NanoModelDesc, params, params_bytes: int, *, on_device: bool = False,
-                 device: int = 0, max_seq_len: int = 512, max_batch: int = 1, kv_f16: Optional[bool] = None):
+                 device: int = 0, max_seq_len: int = 512, max_batch: int = 1, kv_f16: Optional[bool] = None,
+                 kv_paged: Optional[bool] = None):
         self.desc = desc
         self.h = C.c_void_p(None)
         ptr = params if isinstance(params, int) else params.ctypes.data
-        if kv_f16 is None:           # environment default (NANO_KV_F16)
+        if kv_paged is not None:     # explicit flags: NANO_HIP_KV_F16 = 1, NANO_HIP_KV_PAGED = 2
+            check(lib().nano_hip_model_create_ex(C.byref(self.h), C.byref(desc), C.c_void_p(ptr), params_bytes,
+                                                 1 if on_device else 0, device, max_seq_len, max_batch,
+                                                 (1 if kv_f16 else 0) | (2 if kv_paged else 0)))
+        elif kv_f16 is None:         # environment default (NANO_KV_F16 / NANO_KV_PAGED)
             check(lib().nano_hip_model_create(C.byref(self.h), C.byref(desc), C.c_void_p(ptr), params_bytes,
                                               1 if on_device else 0, device, max_seq_len, max_batch))
         else:
@@ -259,6 +266,16 @@ class DeviceModel:
         check(lib().nano_hip_time_step_masked(self.h, batch, pos, iters, skip_mask, C.byref(ms)))
         return float(ms.value)
 
+    def kv_release(self, slot: int):
+        """paged KV cache: give the slot's pages back to the pool"""
+        check(lib().nano_hip_kv_release(self.h, slot))
+
+    def kv_pages(self):
+        """paged KV cache: (pages in use, pages in the pool)"""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        check(lib().nano_hip_kv_pages(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def stamps_begin(self):
         check(lib().nano_hip_stamps_begin(self.h))
 
@@ -281,7 +298,8 @@ def desc_from_spec(spec) -> NanoModelDesc:
                          spec.group_size)
 
 
-def load_model_file(path: str, *, device: int = 0, max_seq_len: int = 512, max_batch: int = 1, kv_f16: Optional[bool] = None) -> DeviceModel:
+def load_model_file(path: str, *, device: int = 0, max_seq_len: int = 512, max_batch: int = 1, kv_f16: Optional[bool] = None,
+                    kv_paged: Optional[bool] = None) -> DeviceModel:
     """Open a Nano ``.bin`` (header + tokenizer section + parameter blob) and upload it.
     The tokenizer section is skipped: this entry works on token ids."""
     from . import modelfile as mf
@@ -290,7 +308,7 @@ def load_model_file(path: str, *, device: int = 0, max_seq_len: int = 512, max_b
     tok_bytes = int(np.frombuffer(bytes(raw[256:260]), "<u4")[0])
     off = 256 + tok_bytes
     params = np.ascontiguousarray(raw[off:])         # private, aligned copy of the blob
-    m = DeviceModel(desc_from_spec(spec), params, params.size, device=device, max_seq_len=max_seq_len, max_batch=max_batch, kv_f16=kv_f16)
+    m = DeviceModel(desc_from_spec(spec), params, params.size, device=device, max_seq_len=max_seq_len, max_batch=max_batch, kv_f16=kv_f16, kv_paged=kv_paged)
     m.spec = spec
     return m
 

@@ -174,16 +174,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     if constexpr (MODE != 0)
         asm volatile("" :: "s"(a.q), "s"(a.kraw), "s"(a.kcache), "s"(a.vcache), "s"(a.pos), "s"(a.q_norm), "s"(a.k_norm), "s"(a.rope_cur),
                      "s"(a.out), "s"(a.ml), "s"(a.xba_out), "s"(a.nsplit), "s"(a.range_hint), "s"(a.layer), "s"(a.S), "s"(a.q_dim), "s"(a.kv_dim),
-                     "s"(a.cache_bstride_rows), "s"(a.kv_log2), "s"(a.kvmul_log2), "s"(a.vraw), "s"(a.xf_out));
+                     "s"(a.cache_bstride_rows), "s"(a.kv_log2), "s"(a.kvmul_log2), "s"(a.vraw), "s"(a.xf_out), "s"(a.pt_rows), "s"(a.kvrow));
     // the position first: it is waited for before everything else, and vector loads return in issue order
     const uint32_t pos_ld = (MODE == 0 && a.fixed_range) ? 0u : a.pos[blockIdx.y];
+    const bool paged = a.pt_rows != nullptr;                   // paged KV cache: rows are reached through the sequence's page table
+    const uint32_t prow_ld = paged ? a.kvrow[blockIdx.y] : 0u; // pool row of position pos
     // ---- 1. issue every load --------------------------------------------------------------------------------
     constexpr uint32_t ESZ = KVH ? 2u : 4u;                    // bytes per cache element
-    const size_t slot_rows = (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
+    const size_t slot_rows = paged ? (size_t)a.layer * a.pool_rows : (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
     // start of this KV head's rows, in the cache's own element size (typed float* for the FP32 path's arithmetic)
     const float *kc = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.kcache) + (slot_rows * a.kv_dim + (size_t)g * hd) * ESZ);
     const float *vc = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.vcache) + (slot_rows * a.kv_dim + (size_t)g * hd) * ESZ);
-    const uint32_t cache_bytes = (fixed_range ? fixed_range : a.S) * a.kv_dim * ESZ;   // rows >= S: out of range
+    const uint32_t cache_bytes = (paged ? a.pool_rows : fixed_range ? fixed_range : a.S) * a.kv_dim * ESZ;   // rows >= S (paged: beyond the layer plane): out of range
     const __amdgpu_buffer_rsrc_t rk = mkrsrc(kc, cache_bytes - g * hd * ESZ);
     const __amdgpu_buffer_rsrc_t rv = mkrsrc(vc, cache_bytes - g * hd * ESZ);
     const uint32_t sub = (uint32_t)tid / LPR, j = (uint32_t)tid % LPR;
@@ -262,11 +264,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     auto issue_kv = [&](uint32_t round) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const uint32_t t = ((round * NP + p) * nsplit + split) * R + sub;
+            const uint32_t tb = ((round * NP + p) * nsplit + split) * R, t = tb + sub;
+            uint32_t row = t;                                              // row of timestep t inside this sequence's / the pool's layer plane
+            if (paged) {                                                   // (uniform branch; a block of R <= 64 timesteps lies in one page)
+                const uint32_t blk = tb >> 6;
+                const uint32_t rb = (blk < a.pt_stride && tb < range_hint) ? a.pt_rows[(size_t)b * a.pt_bstride + blk] : 0xffffffffu;
+                row = rb == 0xffffffffu ? 0x7fffffu : rb + (t & 63u);      // no page: beyond every plane -> out of range -> 0
+            }
 #pragma unroll
             for (int q = 0; q < QV; q++) {
                 const uint32_t f = j + (uint32_t)LPR * q;                  // float4 index inside the head
-                const uint32_t off = (f * 4u < hd && t < range_hint) ? (t * a.kv_dim + f * 4u) * ESZ : OOB;
+                const uint32_t off = (f * 4u < hd && t < range_hint && row < 0x7fffffu) ? (row * a.kv_dim + f * 4u) * ESZ : OOB;
                 kreg[p][q] = kv_load4<KVH>(rk, off);
                 vreg[p][q] = kv_load4<KVH>(rv, off);
             }
@@ -278,6 +286,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 
     // ---- 2. position, RoPE row, norms ------------------------------------------------------------------------------
     const uint32_t pos = fixed_range ? (fixed_range - 1) : pos_ld;
+    const uint32_t prow = paged ? prow_ld : pos;               // the cache row position pos is written to
     const uint32_t range = fixed_range ? fixed_range : (causal ? (pos + 1) : a.S);
     if constexpr (REGQK) {
         if (MODE == 1) {                         // rmsnorm over the head (infer.c:601-614, 824-835), tree order
@@ -333,8 +342,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
         for (int q = 0; q < QV; q++) { kfresh[q] = kv_round<KVH>(kfresh[q]); if (KVH) vfresh[q] = kv_round<KVH>(vfresh[q]); }   // what the cache holds
         if (split == 0 && sub == 0 && first_of_group) {          // the finished k row (FP16 cache: and the v row) -> cache row pos
-            float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)pos * a.kv_dim * ESZ);
-            float *vrow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)pos * a.kv_dim * ESZ);
+            float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)prow * a.kv_dim * ESZ);
+            float *vrow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)prow * a.kv_dim * ESZ);
 #pragma unroll
             for (int q = 0; q < QV; q++) {
                 const uint32_t f = j + (uint32_t)LPR * q;
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                     if (isk) { y0 = kv_round1<KVH>(y0); y1 = kv_round1<KVH>(y1); }
                     dst[i0] = y0; dst[i1] = y1;
                     if (isk && split == 0 && first_of_group) {
-                        float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)pos * a.kv_dim * ESZ);
+                        float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)prow * a.kv_dim * ESZ);
                         kv_store1<KVH>(krow, i0, y0); kv_store1<KVH>(krow, i1, y1);
                     }
                     if (!isk && split == 0 && q_out) { float *qo = q_out + (size_t)b * a.q_dim + (size_t)(h0 + v) * hd; qo[i0] = y0; qo[i1] = y1; }
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             const bool ok = f * 4u < hd;
             vfresh[q] = kv_round<KVH>(bload_f4(rvr, ok ? g * hd * 4u + f * 16u : OOB));
             if (fresh_v && ok && split == 0 && sub == 0 && first_of_group)
-                kv_store4<KVH>(reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)pos * a.kv_dim * ESZ), 4u * f, vfresh[q]);
+                kv_store4<KVH>(reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)prow * a.kv_dim * ESZ), 4u * f, vfresh[q]);
         }
     }
     __syncthreads();

@@ -110,6 +110,12 @@ struct NanoHipModel {
     uint32_t pending_batch = 0;   // sequences of the step queued by nano_hip_forward_begin
     bool kv_half = false;         // opt-in FP16 KV cache: rows hold __half, v passes through vraw like k through kraw
     float *vraw = nullptr;        // [Bs][KD] fresh v rows (FP16 cache only)
+    // paged KV cache (opt-in): kcache / vcache are pools [L][pages][64][KD]; pt = first pool row of every 64-position block
+    bool kv_paged = false;
+    uint32_t kv_pages = 0, pt_stride = 0;                 // pages in the pool; page-table entries per slot = ceil(S / 64)
+    uint32_t *pt = nullptr, *kvrow = nullptr;             // device: [maxB][pt_stride] (0xffffffff = no page), [Bs] pool row of the step's position
+    uint32_t *h_pt = nullptr;                             // pinned host mirror of pt
+    std::vector<uint32_t> free_pages;
     // strict-parity / per-phase mode (strict.hip): eager, one kernel per reference operator, reference summation order
     bool strict = false;
     float *xn = nullptr, *hb2 = nullptr, *att = nullptr;   // normalised x [Bs][E], W3 output [Bs][H], attention scores [Bs][n_head][S]
@@ -186,9 +192,9 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att, m->vraw, m->gq2, m->gxs2, m->stamps };
+                    m->xn, m->hb2, m->att, m->vraw, m->gq2, m->gxs2, m->stamps, m->pt, m->kvrow };
     for (void *p : dev) if (p) (void)hipFree(p);
-    void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits };
+    void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (m->smp) {
         if (m->smp->block) (void)hipFree(m->smp->block);
@@ -209,13 +215,14 @@ extern "C" int nano_hip_model_create(NanoHipModel **out, const NanoModelDesc *de
                                      int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch) {
     uint32_t flags = 0;
     if (const char *kv = getenv("NANO_KV_F16")) if (*kv && *kv != '0') flags |= NANO_HIP_KV_F16;
+    if (const char *kp = getenv("NANO_KV_PAGED")) if (*kp && *kp != '0') flags |= NANO_HIP_KV_PAGED;
     return nano_hip_model_create_ex(out, desc, params, params_bytes, params_on_device, device, max_seq_len, max_batch, flags);
 }
 
 extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc *desc, const void *params, size_t params_bytes,
                                         int params_on_device, int device, uint32_t max_seq_len, uint32_t max_batch, uint32_t flags) {
     if (!out || !desc || !params) FAIL(NANO_HIP_EINVAL, "null argument");
-    if (flags & ~NANO_HIP_KV_F16) FAIL(NANO_HIP_EINVAL, "unknown flags 0x%x", flags);
+    if (flags & ~(NANO_HIP_KV_F16 | NANO_HIP_KV_PAGED)) FAIL(NANO_HIP_EINVAL, "unknown flags 0x%x", flags);
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(NANO_HIP_ENODEV, "no HIP device visible (this backend has no CPU fallback)");
@@ -245,6 +252,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     m->d = d; m->device = device; m->cus = prop.multiProcessorCount;
     m->S = max_seq_len; m->maxB = max_batch; m->hd = hd; m->QD = QD; m->KD = KD;
     m->kv_half = (flags & NANO_HIP_KV_F16) != 0;
+    m->kv_paged = (flags & NANO_HIP_KV_PAGED) != 0;
     const uint8_t *src = reinterpret_cast<const uint8_t *>(params);
     const size_t L = d.n_layer, E = d.n_embd, H = d.n_hidden, V = d.vocab_size;
     const size_t each[WCOUNT] = { (size_t)QD * E, (size_t)KD * E, (size_t)KD * E, E * QD, H * E, E * H, H * E };
@@ -356,7 +364,15 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     const size_t PF = d.quant_type == NANO_QUANT_Q80 ? 64 : 8;
     const size_t Bs = B > PF ? B : PF;
     m->Bs = (uint32_t)Bs;
-    const size_t kvn = B * L * max_seq_len * KD;
+    size_t kvn = B * L * max_seq_len * KD;
+    if (m->kv_paged) {
+        m->pt_stride = (max_seq_len + 63) / 64;
+        m->kv_pages = (uint32_t)B * m->pt_stride;
+        if (const char *np = getenv("NANO_KV_PAGES")) { const unsigned long v = strtoul(np, nullptr, 0); if (v >= 1 && v <= (1ul << 24)) m->kv_pages = (uint32_t)v; }
+        // a layer plane is addressed with 32-bit byte offsets (buffer descriptors)
+        if ((uint64_t)m->kv_pages * 64 * KD * 4 >= (1ull << 32) - (1u << 20)) { destroy(m); FAIL(NANO_HIP_EINVAL, "paged KV cache: %u pages x 64 rows x %u floats exceed a 4 GB layer plane", m->kv_pages, KD); }
+        kvn = L * (size_t)m->kv_pages * 64 * KD;
+    }
     m->trace_cap = max_seq_len * max_batch;
     m->nsplit_cap = max_seq_len > ATTN_WIDE_FROM ? ATTN_MAX_NSPLIT : 8;     // partial buffers are sized for the maximum
     bool ok = hipMalloc(&m->x, Bs * E * 4) == hipSuccess && hipMalloc(&m->q, Bs * QD * 4) == hipSuccess &&
@@ -375,6 +391,15 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
         size_t nmax = E > QD ? E : QD; if (H > nmax) nmax = H;
         ok = hipMalloc(&m->gq, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, Bs * (nmax / d.group_size) * 4) == hipSuccess &&
              hipMalloc(&m->gq2, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs2, Bs * (nmax / d.group_size) * 4) == hipSuccess;
+    }
+    if (ok && m->kv_paged) {
+        const size_t ptn = B * m->pt_stride;
+        ok = hipMalloc(&m->pt, ptn * 4) == hipSuccess && hipMalloc(&m->kvrow, Bs * 4) == hipSuccess && hipHostMalloc(&m->h_pt, ptn * 4) == hipSuccess &&
+             hipMemset(m->pt, 0xff, ptn * 4) == hipSuccess && hipMemset(m->kvrow, 0, Bs * 4) == hipSuccess;
+        if (ok) {
+            memset(m->h_pt, 0xff, ptn * 4);
+            for (uint32_t pg = m->kv_pages; pg-- > 0;) m->free_pages.push_back(pg);           // pages are handed out in ascending order
+        }
     }
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc for KV cache / scratch failed (batch %zu, seq %u)", B, max_seq_len); }
     // calloc semantics of the reference (infer.c:33,47): non-causal attention reads unwritten rows
@@ -405,6 +430,47 @@ extern "C" uint64_t nano_hip_weight_bytes_per_step(const NanoHipModel *m) { retu
 // one decode step, enqueued on m->st
 // ------------------------------------------------------------------------------------------------
 enum StepMode : uint32_t { MODE_NOCLS = 0, MODE_LOGITS = 1, MODE_ARGMAX = 2, MODE_LOOP = 3 };
+
+// ---- paged KV cache: pages for the positions a call is about to touch ------------------------------------------------------
+// need[i] = last position slot slots[i] will hold after the call.  All or nothing: when the pool cannot cover every missing block
+// the call fails before taking a page.  New pages are zero-filled in every layer plane (the reference callocs its cache,
+// infer.c:33,47) and the slots' table rows go to the device behind everything queued so far.
+static int kv_ensure(NanoHipModel *m, const uint32_t *slots, const uint32_t *need, uint32_t n) {
+    if (!m->kv_paged) return 0;
+    size_t missing = 0;
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t blk = 0; blk <= need[i] >> 6 && blk < m->pt_stride; blk++)
+            if (m->h_pt[(size_t)slots[i] * m->pt_stride + blk] == 0xffffffffu) {
+                bool dup = false;                                  // (the same slot twice in one call: count its block once)
+                for (uint32_t k = 0; k < i && !dup; k++) dup = slots[k] == slots[i] && blk <= need[k] >> 6;
+                if (!dup) missing++;
+            }
+    if (missing > m->free_pages.size())
+        FAIL(NANO_HIP_ENOMEM, "paged KV cache: %zu more pages needed, %zu free of %u (nano_hip_kv_release() returns a finished sequence's pages)", missing, m->free_pages.size(), m->kv_pages);
+    if (!missing) return 0;
+    const size_t esz = m->kv_half ? 2 : 4, page_bytes = (size_t)64 * m->KD * esz, plane_bytes = (size_t)m->kv_pages * page_bytes;
+    for (uint32_t i = 0; i < n; i++) {
+        bool dirty = false;
+        uint32_t *row = m->h_pt + (size_t)slots[i] * m->pt_stride;
+        for (uint32_t blk = 0; blk <= need[i] >> 6 && blk < m->pt_stride; blk++) {
+            if (row[blk] != 0xffffffffu) continue;
+            const uint32_t pg = m->free_pages.back(); m->free_pages.pop_back();
+            HIP_TRY(hipMemset2DAsync(reinterpret_cast<uint8_t *>(m->kcache) + (size_t)pg * page_bytes, plane_bytes, 0, page_bytes, m->d.n_layer, m->st));
+            HIP_TRY(hipMemset2DAsync(reinterpret_cast<uint8_t *>(m->vcache) + (size_t)pg * page_bytes, plane_bytes, 0, page_bytes, m->d.n_layer, m->st));
+            row[blk] = pg * 64u;
+            dirty = true;
+        }
+        if (dirty) HIP_TRY(hipMemcpyAsync(m->pt + (size_t)slots[i] * m->pt_stride, row, (size_t)m->pt_stride * 4, hipMemcpyHostToDevice, m->st));
+    }
+    return 0;
+}
+// sequences 0..batch-1 of a step live in slots 0..batch-1; each needs its pages up to position pos[i] + extra
+static int kv_ensure_batch(NanoHipModel *m, const uint32_t *pos, uint32_t batch, uint32_t extra, bool whole_context) {
+    if (!m->kv_paged) return 0;
+    uint32_t slots[NANO_MAX_BATCH], need[NANO_MAX_BATCH];
+    for (uint32_t i = 0; i < batch; i++) { slots[i] = i; need[i] = whole_context ? m->S - 1 : pos[i] + extra; if (need[i] > m->S - 1) need[i] = m->S - 1; }
+    return kv_ensure(m, slots, need, batch);
+}
 
 static GemvSeg mkseg(const TensorRef &t, float *out, uint32_t rows, uint32_t bstride, uint32_t pstride = 0) {
     GemvSeg s{}; s.w = t.w; s.ws = t.s; s.out = out; s.rows = rows; s.out_bstride = bstride; s.out_pstride = pstride;
@@ -556,7 +622,13 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     // Wo's quantized input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
     const bool wo_frag = m->attn_quant && wo_gemm && d.group_size == 64 && m->hd % 64 == 0;
     EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
-                  m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0 };
+                  m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0, nullptr, nullptr, 0, 0 };
+    // paged KV cache: the step's sequences are slots 0..nb-1 (batched prefill: every token is a position of slot pf_slot); the
+    // embed kernel stages each one's pool row next to its RoPE row, the QKV launch and the attention kernel write there
+    const uint32_t *pt_base = m->kv_paged ? m->pt + (m->pf ? (size_t)m->pf_slot * m->pt_stride : 0) : nullptr;
+    const uint32_t pt_bstride = (m->kv_paged && !m->pf) ? m->pt_stride : 0u;
+    const size_t plane = (size_t)m->kv_pages * 64 * KD;                      // elements of one layer plane of the pool
+    if (m->kv_paged) { ea.pt_rows = pt_base; ea.kvrow = m->kvrow; ea.pt_bstride = pt_bstride; }
     const uint32_t skip = m->skip_mask;
     if (!(skip & 128) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
 
@@ -569,10 +641,11 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.seg[1] = mkseg(m->W[WK][l], m->kraw, KD, KD);
             // v goes straight to its cache row; prefill: every token of the step is a position of KV slot pf_slot
             a.seg[2] = m->kv_half ? mkseg(m->W[WV][l], m->vraw, KD, KD)          // FP16 cache: the attention kernel rounds and stores the row
+                     : m->kv_paged ? mkseg(m->W[WV][l], m->vcache + (size_t)l * plane, KD, 0, KD)      // paged: row kvrow[b] of this layer's plane
                      : m->pf ? mkseg(m->W[WV][l], m->vcache + ((size_t)m->pf_slot * L * S + layer_rows) * KD, KD, 0, KD)
                              : mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_STORE;
-            a.norm_w = m->rms_attn + (size_t)l * E; a.pos = m->pos;
+            a.norm_w = m->rms_attn + (size_t)l * E; a.pos = (m->kv_paged && !m->kv_half) ? m->kvrow : m->pos;     // (the only position-indexed output)
             a.stamps = next_stamps(m, 1);
             if (!(skip & 1) && (e = gemv(m, a)) != hipSuccess) return e;
             if (m->lora_on) {       // q / k / v += (alpha/rank) B (A xb)   reference infer.c:792-808
@@ -599,7 +672,12 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.cache_bstride_rows = L * S; a.fixed_range = 0;
             a.kv_half = m->kv_half ? 1u : 0u; a.vraw = m->kv_half ? m->vraw : nullptr;
             if (wo_frag && nsplit == 1) { a.xf_out = m->gq; a.xsf_out = m->gxs; }
-            if (m->pf) {
+            if (m->kv_paged) { a.pt_rows = pt_base; a.kvrow = m->kvrow; a.pt_stride = m->pt_stride; a.pt_bstride = pt_bstride; a.pool_rows = m->kv_pages * 64u; }
+            if (m->pf && m->kv_paged) {
+                a.prep_only = 1;                                                     // pass 1: every token's k row into its page
+                if ((e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
+                a.prep_only = 0;
+            } else if (m->pf) {
                 // batched prefill: the nb tokens are consecutive positions of ONE sequence.  Pass 1 finishes every k row
                 // (norm + RoPE + cache write, nothing else) so that pass 2 finds the rows of the earlier tokens of the
                 // chunk in the cache; pass 2 is the ordinary decode attention per token (it recomputes its own k row).
@@ -810,6 +888,7 @@ extern "C" int nano_hip_set_phase_hook(NanoHipModel *m, nano_hip_phase_fn fn, vo
 static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t max_pos) {
     uint32_t range_hint = is_causal ? ((max_pos + 1 + 63) / 64) * 64 : m->S;
     if (range_hint > m->S) range_hint = m->S;
+    if (m->kv_paged && (m->strict || m->lora_on)) FAIL(NANO_HIP_EINVAL, "the paged KV cache is served by the fused path only: not with strict mode or the LoRA side branches");
     if (m->strict) {
         const hipError_t e = enqueue_step_strict(m, nb, is_causal, mode, 0);
         if (e == hipErrorNotSupported) FAIL(NANO_HIP_EINVAL, "strict mode covers neither the LoRA side branches nor the FP16 KV cache");
@@ -870,6 +949,7 @@ extern "C" int nano_hip_forward_begin(NanoHipModel *m, const uint32_t *tokens, c
     int rc;
     if ((rc = check_batch(m, tokens, pos, batch, 0))) return rc;
     HIP_TRY(hipSetDevice(m->device));
+    if ((rc = kv_ensure_batch(m, pos, batch, 0, !is_causal))) return rc;
     memcpy(m->h_tokens, tokens, batch * 4); memcpy(m->h_pos, pos, batch * 4);
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
@@ -987,6 +1067,7 @@ extern "C" int nano_hip_forward_sample(NanoHipModel *m, uint32_t token, uint32_t
     if ((rc = check_batch(m, &token, &pos, 1, 0))) return rc;
     HIP_TRY(hipSetDevice(m->device));
     if ((rc = sampler_init(m))) return rc;
+    if ((rc = kv_ensure_batch(m, &pos, 1, 0, false))) return rc;
     m->h_tokens[0] = token; m->h_pos[0] = pos;
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, 4, hipMemcpyHostToDevice, m->st));
@@ -1048,6 +1129,12 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
     if ((uint64_t)pos0 + count > m->rope_rows) FAIL(NANO_HIP_EINVAL, "positions %u..%u exceed the model's RoPE table (%u rows = block_size)", pos0, pos0 + count, m->rope_rows);
     for (uint32_t i = 0; i < count; i++) if (tokens[i] >= m->d.vocab_size) FAIL(NANO_HIP_EINVAL, "token %u out of vocabulary", tokens[i]);
     HIP_TRY(hipSetDevice(m->device));
+    if (m->kv_paged && count) {
+        if (m->strict || m->lora_on) FAIL(NANO_HIP_EINVAL, "the paged KV cache is served by the fused path only: not with strict mode or the LoRA side branches");
+        const uint32_t need = pos0 + count - 1;
+        int rc = kv_ensure(m, &slot, &need, 1);
+        if (rc) return rc;
+    }
     if (m->strict) {                                                        // strict mode: one reference-order forward per prompt token
         for (uint32_t i = 0; i < count; i++) {
             m->h_tokens[0] = tokens[i]; m->h_pos[0] = pos0 + i;
@@ -1122,6 +1209,7 @@ extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, c
     if ((rc = check_batch(m, tokens, pos, batch, steps))) return rc;
     if ((uint64_t)steps * batch > m->trace_cap) FAIL(NANO_HIP_EINVAL, "steps*batch exceeds trace capacity %u", m->trace_cap);
     HIP_TRY(hipSetDevice(m->device));
+    if ((rc = kv_ensure_batch(m, pos, batch, steps - 1, false))) return rc;          // every page the loop will enter, up front
     memcpy(m->h_tokens, tokens, batch * 4); memcpy(m->h_pos, pos, batch * 4);
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
@@ -1174,6 +1262,7 @@ extern "C" int nano_hip_time_classifier_in_step(NanoHipModel *m, uint32_t batch,
     if (!m || !iters || batch == 0 || batch > m->maxB || batch > NANO_MAX_BATCH || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     for (uint32_t i = 0; i < batch; i++) { m->h_tokens[i] = 1 % m->d.vocab_size; m->h_pos[i] = pos; }
+    { const int rc = kv_ensure_batch(m, m->h_pos, batch, 0, false); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
     uint32_t range_hint = ((pos + 1 + 63) / 64) * 64;
@@ -1201,9 +1290,10 @@ extern "C" int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos,
     if (!m || !iters || batch == 0 || batch > m->maxB || batch > NANO_MAX_BATCH || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     for (uint32_t i = 0; i < batch; i++) { m->h_tokens[i] = 1 % m->d.vocab_size; m->h_pos[i] = pos; }
+    int rc;
+    if ((rc = kv_ensure_batch(m, m->h_pos, batch, 0, false))) return rc;
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
-    int rc;
     if ((rc = run_step(m, batch, 1, MODE_ARGMAX, pos))) return rc;       // warm / capture
     HIP_TRY(hipEventRecord(m->ev0, m->st));
     for (uint32_t i = 0; i < iters; i++) if ((rc = run_step(m, batch, 1, MODE_ARGMAX, pos))) return rc;
@@ -1250,7 +1340,13 @@ extern "C" int nano_hip_read_state(NanoHipModel *m, uint32_t slot, int which, ui
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->st));
     const float *src = nullptr; size_t cap = 0;
-    const size_t row = (((size_t)slot * m->d.n_layer + layer) * m->S + pos) * m->KD;
+    size_t row = (((size_t)slot * m->d.n_layer + layer) * m->S + pos) * m->KD;
+    if (m->kv_paged && (which == 5 || which == 6)) {              // paged: the row lives in the slot's page of that 64-position block
+        if (layer >= m->d.n_layer || pos >= m->S) FAIL(NANO_HIP_EINVAL, "bad layer/pos");
+        const uint32_t rb = m->h_pt[(size_t)slot * m->pt_stride + (pos >> 6)];
+        if (rb == 0xffffffffu) { if (n > m->KD) FAIL(NANO_HIP_EINVAL, "n too large"); memset(out, 0, n * 4); return 0; }     // no page yet: a never-written (zero) row
+        row = ((size_t)layer * m->kv_pages * 64 + rb + (pos & 63u)) * m->KD;
+    }
     switch (which) {
     case 0: src = m->x + (size_t)slot * m->d.n_embd; cap = m->d.n_embd; break;
     case 1: src = m->q + (size_t)slot * m->QD; cap = m->QD; break;
@@ -1298,5 +1394,26 @@ extern "C" int nano_hip_stamps_read(NanoHipModel *m, unsigned long long *out, ui
     if (n) HIP_TRY(hipMemcpy(out, m->stamps, (size_t)n * STAMP_WGS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; i++) kinds[i] = m->stamp_kinds[i];
     *n_launches = n;
+    return 0;
+}
+
+
+// ---- paged KV cache: slot life cycle ----------------------------------------------------------------------------------------
+extern "C" int nano_hip_kv_release(NanoHipModel *m, uint32_t slot) {
+    if (!m || !m->kv_paged) FAIL(NANO_HIP_EINVAL, "not a paged-KV model");
+    if (slot >= m->maxB) FAIL(NANO_HIP_EINVAL, "slot %u out of range (max_batch %u)", slot, m->maxB);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->st));                                 // nothing queued may still read the pages
+    uint32_t *row = m->h_pt + (size_t)slot * m->pt_stride;
+    for (uint32_t blk = 0; blk < m->pt_stride; blk++)
+        if (row[blk] != 0xffffffffu) { m->free_pages.push_back(row[blk] / 64u); row[blk] = 0xffffffffu; }
+    HIP_TRY(hipMemcpyAsync(m->pt + (size_t)slot * m->pt_stride, row, (size_t)m->pt_stride * 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    return 0;
+}
+extern "C" int nano_hip_kv_pages(const NanoHipModel *m, uint32_t *in_use, uint32_t *total) {
+    if (!m || !m->kv_paged) FAIL(NANO_HIP_EINVAL, "not a paged-KV model");
+    if (in_use) *in_use = m->kv_pages - (uint32_t)m->free_pages.size();
+    if (total) *total = m->kv_pages;
     return 0;
 }

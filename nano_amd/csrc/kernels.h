@@ -108,6 +108,12 @@ struct AttnArgs {
     // index mod 8 = XCD, each XCD has its own L2): x = sub * n_kv_head + kv head, when n_kv_head is a power of two >= 8;
     // kv_log2 = log2(n_kv_head), else 0xffffffff = plain order (x = first head / heads per workgroup)
     uint32_t kv_log2, kvmul_log2;   // kvmul_log2 = log2(n_head / n_kv_head) (decode modes: both head counts are powers of two)
+    // PAGED KV cache (opt-in): kcache / vcache are pools [layer][page][64 positions][kv_dim]; a sequence's 64-position
+    // block j lives in the page whose first row (page * 64, rows counted inside a layer plane) is pt_rows[slot][j]
+    const uint32_t *pt_rows;        // [slots][pt_stride], 0xffffffff = no page; nullptr = the contiguous cache
+    const uint32_t *kvrow;          // [nb] pool row of position pos[b] (staged by the embed kernel next to the RoPE row)
+    uint32_t pt_stride, pt_bstride; // entries per slot; entries between the sequences of this launch (0: batched prefill, one slot)
+    uint32_t pool_rows, _pad6;      // rows of one layer plane = pages * 64
     unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
@@ -159,6 +165,8 @@ struct EmbedArgs {
     // the step's first kernel also stages the RoPE row of each sequence's position at a FIXED address, so that
     // the attention kernels need no pos-dependent load: rope_cur[b] = { cos[pos[b]][0..half), sin[pos[b]][0..half) }
     const float *rope_cos; const float *rope_sin; const uint32_t *pos; float *rope_cur; uint32_t half, _pad;
+    // paged KV cache: kvrow[b] = pt_rows[b * pt_bstride + pos[b] / 64] + pos[b] % 64 (the pool row the step writes), or nullptr
+    const uint32_t *pt_rows; uint32_t *kvrow; uint32_t pt_bstride, _pad2;
 };
 hipError_t launch_embed(const EmbedArgs &a, uint32_t nb, hipStream_t st);
 

@@ -16,6 +16,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     const uint32_t tok = a.tokens[b];
     float *x = a.x + (size_t)b * a.x_bstride;
     const uint32_t E = a.E;
+    if (a.kvrow && threadIdx.x == 0) {                       // paged KV cache: the pool row of this step's position
+        const uint32_t p = a.pos[b];
+        a.kvrow[b] = a.pt_rows[(size_t)b * a.pt_bstride + (p >> 6)] + (p & 63u);
+    }
     if (a.rope_cur) {
         const uint32_t p = a.pos[b];
         for (uint32_t i = threadIdx.x; i < a.half; i += blockDim.x) {

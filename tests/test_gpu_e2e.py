@@ -438,15 +438,39 @@ def test_sort_model_known_answer_on_gpu():
 @pytest.mark.parametrize("name", ["sample_tiny-nano_f32_rp13", "sample_tiny-nano_f32_t08p09", "sample_tiny-qwen3_q80_rp13", "sample_tiny-qwen3_q4k_t10p05"])
 def test_engine_sampler_ids_vs_reference_golden(model_dir, name):
     """generate_next_token through the C engine (device sampler) with the reference's sampler settings: ids identical to
-    the compiled reference's (FP32, and the two-layer Q80 / Q4K models whose logits agree to ~1e-7)."""
+    the compiled reference's.  FP32 models: on the fast path (its logits agree to ~1e-7, no sampled id depends on that).
+    Quantized models: in STRICT mode, whose logits are the reference's bit for bit, so the sampled ids must be too; the fast
+    path's tree-order sums can flip a last-ulp quantization decision and with it a sampled id far down a free-running
+    sequence -- it is held to the first sampled id here and to the logit tolerances elsewhere."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     path, spec = synth_model(model_dir, str(g["preset"]), str(g["quant"]), int(g["gs"]))
-    e = nb.Engine(path, max_seq_len=int(g["max_seq_len"]), rep_pen=float(g["rep_pen"]), temperature=float(g["temperature"]),
-                  top_p=float(g["top_p"]), top_k=0, seed=int(g["seed"]))
     prompt = g["prompt"]
-    ids = e.generate(prompt, len(g["ids"]) - len(prompt))
-    e.close()
-    assert np.array_equal(ids, g["ids"])
+
+    def run(strict):
+        keep = os.environ.get("NANO_STRICT")
+        if strict:
+            os.environ["NANO_STRICT"] = "1"
+        try:
+            e = nb.Engine(path, max_seq_len=int(g["max_seq_len"]), rep_pen=float(g["rep_pen"]), temperature=float(g["temperature"]),
+                          top_p=float(g["top_p"]), top_k=0, seed=int(g["seed"]))
+            ids = e.generate(prompt, len(g["ids"]) - len(prompt))
+            e.close()
+        finally:
+            if strict:
+                if keep is None:
+                    os.environ.pop("NANO_STRICT", None)
+                else:
+                    os.environ["NANO_STRICT"] = keep
+        return ids
+
+    fast = run(False)
+    if str(g["quant"]) == "f32":
+        assert np.array_equal(fast, g["ids"])
+    else:
+        assert np.array_equal(run(True), g["ids"])
+        assert np.array_equal(fast[:len(prompt) + 1], g["ids"][:len(prompt) + 1])
+        same = int(np.argmin(np.append(fast == g["ids"], False)))
+        print(f"{name}: strict ids == reference; fast path identical for the first {same - len(prompt)} of {len(g['ids']) - len(prompt)} sampled ids")
 
 
 def test_engine_session_api_greedy(model_dir):
