@@ -122,7 +122,8 @@ constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight 
 // MODE resolves the feature flags at compile time for the decode launches (a taken branch costs ~40 cycles and every
 // instruction of the one wave per SIMD is on the critical path): 0 generic (run-time flags), 1 Qwen3 decode (q/k-norm,
 // half-split RoPE, staged RoPE row, fresh k, causal), 2 Nano/Qwen2 decode (adjacent-pair RoPE, staged row, fresh k, causal).
-template <int LPR, int QV, int KVM, int MODE, bool KVH>
+// PG: the paged KV cache (kernels.h AttnArgs::pt_rows) -- a template parameter so that the contiguous cache's code stays as it was
+template <int LPR, int QV, int KVM, int MODE, bool KVH, bool PG>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = 256 / LPR;                 // timesteps per block
@@ -177,8 +178,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                      "s"(a.cache_bstride_rows), "s"(a.kv_log2), "s"(a.kvmul_log2), "s"(a.vraw), "s"(a.xf_out), "s"(a.pt_rows), "s"(a.kvrow));
     // the position first: it is waited for before everything else, and vector loads return in issue order
     const uint32_t pos_ld = (MODE == 0 && a.fixed_range) ? 0u : a.pos[blockIdx.y];
-    const bool paged = a.pt_rows != nullptr;                   // paged KV cache: rows are reached through the sequence's page table
-    const uint32_t prow_ld = paged ? a.kvrow[blockIdx.y] : 0u; // pool row of position pos
+    constexpr bool paged = PG;                                 // paged KV cache: rows are reached through the sequence's page table
+    uint32_t prow_ld = 0u;                                     // pool row of position pos
+    if constexpr (PG) prow_ld = a.kvrow[blockIdx.y];
     // ---- 1. issue every load --------------------------------------------------------------------------------
     constexpr uint32_t ESZ = KVH ? 2u : 4u;                    // bytes per cache element
     const size_t slot_rows = paged ? (size_t)a.layer * a.pool_rows : (size_t)b * a.cache_bstride_rows + (size_t)a.layer * a.S;
@@ -266,9 +268,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         for (int p = 0; p < NP; p++) {
             const uint32_t tb = ((round * NP + p) * nsplit + split) * R, t = tb + sub;
             uint32_t row = t;                                              // row of timestep t inside this sequence's / the pool's layer plane
-            if (paged) {                                                   // (uniform branch; a block of R <= 64 timesteps lies in one page)
+            if constexpr (PG) {                                            // (a block of R <= 64 timesteps lies in one page)
                 const uint32_t blk = tb >> 6;
-                const uint32_t rb = (blk < a.pt_stride && tb < range_hint) ? a.pt_rows[(size_t)b * a.pt_bstride + blk] : 0xffffffffu;
+                uint32_t rb = 0xffffffffu;
+                if (blk < a.pt_stride && tb < range_hint) {                // wave-uniform: a SCALAR load (a vector load here would have to wait for
+                    const uint64_t pa = reinterpret_cast<uint64_t>(a.pt_rows + (size_t)b * a.pt_bstride + blk);   // every K / V load issued before it -- vmcnt counts in order)
+                    const uint64_t pu = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pa);
+                    asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rb) : "s"(pu) : "memory");
+                }
                 row = rb == 0xffffffffu ? 0x7fffffu : rb + (t & 63u);      // no page: beyond every plane -> out of range -> 0
             }
 #pragma unroll
@@ -562,9 +569,10 @@ static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t 
     const uint64_t head_wgs = (uint64_t)a.n_head * nb * a.nsplit;
     uint32_t kvm = (head_wgs <= 256u || kv_mul % 2 != 0) ? 1u : (head_wgs <= 1024u || kv_mul % 4 != 0) ? 2u : 4u;
     if (forced == 1u || (forced == 2u && kv_mul % 2 == 0) || (forced == 4u && kv_mul % 4 == 0)) kvm = forced;
-    if (kvm == 4) hipLaunchKernelGGL((attention_kernel<LPR, QV, 4, MODE, KVH>), dim3(a.n_head / 4, nb, a.nsplit), dim3(256), lds_for(4), st, a);
-    else if (kvm == 2) hipLaunchKernelGGL((attention_kernel<LPR, QV, 2, MODE, KVH>), dim3(a.n_head / 2, nb, a.nsplit), dim3(256), lds_for(2), st, a);
-    else hipLaunchKernelGGL((attention_kernel<LPR, QV, 1, MODE, KVH>), dim3(a.n_head, nb, a.nsplit), dim3(256), lds_for(1), st, a);
+#define ATTN_GO(KVM_) do { if (a.pt_rows) hipLaunchKernelGGL((attention_kernel<LPR, QV, KVM_, MODE, KVH, true>), dim3(a.n_head / KVM_, nb, a.nsplit), dim3(256), lds_for(KVM_), st, a); \
+                         else hipLaunchKernelGGL((attention_kernel<LPR, QV, KVM_, MODE, KVH, false>), dim3(a.n_head / KVM_, nb, a.nsplit), dim3(256), lds_for(KVM_), st, a); } while (0)
+    if (kvm == 4) ATTN_GO(4); else if (kvm == 2) ATTN_GO(2); else ATTN_GO(1);
+#undef ATTN_GO
     return hipGetLastError();
 }
 template <int LPR, int QV, int MODE>

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     float *red = tmp + B * bpl * 16;
     float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);
 
+    NANO_STAMP(a.stamps, 0, tid);
     Staged<B, NV> sx;
     stage_issue<ROLE, B, NV>(a, sx);
 
@@ -428,13 +429,16 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     const bool has_add = epi == GEMV_EPI_RESID && a.resid_add != nullptr;
     if (has_add && fold_live) addv = a.resid_add[(size_t)fb * a.resid_add_bstride + lrow0 + frl];
 
+    NANO_STAMP(a.stamps, 1, tid);                                   // every load issued
     if (has_flag<ROLE>(a, F_PRE)) unpack_q4k_wg(a, xg);
     else {
         const bool regq = NV > 0 && (n & 255u) == 0u;                // whole blocks: quantize from registers, wave-local
         stage_xn<ROLE, B, NV>(a, sx, xn, red, n4, regq);
+        NANO_STAMP(a.stamps, 2, red[0]);                            // the activation arrived and is normalised
         if (regq) quantize_q4k_regs<B, NV>(a, sx, xg);
         else quantize_q4k_wg(a, xn, xg, tmp, n4, (int)a.nb);
     }
+    NANO_STAMP(a.stamps, 3, xg[0].sq);                              // block-quantized activation staged in LDS
 
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
@@ -474,7 +478,9 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
             }
         }
     }
+    NANO_STAMP(a.stamps, 4, (float)nibv[IPT - 1].x);                // this thread's weights arrived, its products are in the table
     __syncthreads();
+    NANO_STAMP(a.stamps, 5, P[0]);
 
     // ordered fold (groups inside a block, then blocks along the row; reference tensor.c:359-434, 438-471).  The eight group
     // values of a block are two 16-byte LDS reads; the reads of four blocks go out together and the block sums (independent
@@ -510,6 +516,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
             res[mat] = line;
         }
         if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, has_add ? res[0] + addv : res[0], res[1], oldv);
+        NANO_STAMP(a.stamps, 6, res[0]);
     }
 }
 

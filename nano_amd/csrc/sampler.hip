@@ -21,6 +21,7 @@
 #include "exact_math.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <atomic>
 
 namespace nano {
 using namespace nano_exact;
@@ -139,6 +140,27 @@ __device__ __attribute__((noinline)) uint32_t samp_walk_chunk(const float *e, ui
     return __builtin_amdgcn_readfirstlane(__float_as_uint(s));
 }
 
+// Inclusive scan of chunk functions over the 64 lanes (lane i <- chunk cur .. cur + i composed in order), VALU only: row shifts
+// inside the 16-lane rows, then row_bcast 15 / 31 across them.  Lanes without a source keep the identity {0, 0} (apply nothing,
+// valid).  (Round 3: the __shfl_up form -- three ds_bpermute per step, 18 per scan -- was ~1 us of each of the ~19 scans.)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t dpp_or_id(uint32_t idv, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)idv, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ void scan_step(ChunkFn &f, uint32_t &valid) {
+    ChunkFn g;
+    g.dE = dpp_or_id<CTRL, ROWMASK>(0u, f.dE); g.dO = dpp_or_id<CTRL, ROWMASK>(0u, f.dO);
+    const uint32_t gv = dpp_or_id<CTRL, ROWMASK>(1u, valid);
+    f = chunk_then(g, f); valid &= gv;
+}
+__device__ __forceinline__ void wave_scan_fn(ChunkFn &f, uint32_t &valid) {
+    scan_step<0x111, 0xF>(f, valid);          // row_shr:1
+    scan_step<0x112, 0xF>(f, valid);          // row_shr:2
+    scan_step<0x114, 0xF>(f, valid);          // row_shr:4
+    scan_step<0x118, 0xF>(f, valid);          // row_shr:8
+    scan_step<0x142, 0xA>(f, valid);          // row_bcast:15 -> rows 1, 3
+    scan_step<0x143, 0xC>(f, valid);          // row_bcast:31 -> rows 2, 3
+}
+
 __global__ __launch_bounds__(64) void samp_propagate_kernel(const SampleArgs a) {
     __shared__ uint32_t s_dE[SAMPLE_MAX_CHUNKS + 64], s_dO[SAMPLE_MAX_CHUNKS + 64], s_spec[SAMPLE_MAX_CHUNKS + 64];
     const uint32_t lane = threadIdx.x;
@@ -155,16 +177,10 @@ __global__ __launch_bounds__(64) void samp_propagate_kernel(const SampleArgs a) 
     while (cur < a.nch) {
         const uint32_t E = sum_exp(sb), M = sum_man(sb);
         ChunkFn f{s_dE[cur + lane], s_dO[cur + lane]};
-        bool valid = s_spec[cur + lane] == E;
-#pragma unroll
-        for (int st = 1; st < 64; st <<= 1) {
-            ChunkFn g;
-            g.dE = __shfl_up(f.dE, st, 64); g.dO = __shfl_up(f.dO, st, 64);
-            const int gv = __shfl_up((int)valid, st, 64);
-            if (lane >= (uint32_t)st) { f = chunk_then(g, f); valid = valid && gv; }
-        }
+        uint32_t valid = s_spec[cur + lane] == E ? 1u : 0u;
+        wave_scan_fn(f, valid);
         const uint32_t tot = M + ((M & 1u) ? f.dO : f.dE);
-        const unsigned long long ok = __ballot(valid && tot < (1u << 24));
+        const unsigned long long ok = __ballot(valid != 0u && tot < (1u << 24));
         const uint32_t n = ok == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ok);         // ok is a prefix of the lanes
         if (n) { sb = ((E - 1u) << 23) + (uint32_t)__builtin_amdgcn_readlane((int)tot, (int)n - 1); cur += n; }
         if (n < 64 && cur < a.nch) { sb = samp_walk_chunk(a.e, cur, lane, sb); walks++; cur++; }
@@ -239,7 +255,10 @@ __global__ __launch_bounds__(256) void samp_filter_kernel(const SampleArgs a) {
 
 // K6: sort the candidates, cut the nucleus, draw.  Also re-arms the two cells the next call's K1/K5 accumulate into.
 __global__ __launch_bounds__(1024) void samp_pick_kernel(const SampleArgs a) {
-    __shared__ unsigned long long key[SAMPLE_MAX_CANDIDATES];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long pick_lds[];     // keys [SAMPLE_MAX_CANDIDATES] + four scalars
+    unsigned long long *key = pick_lds;
+    float *s_rp = reinterpret_cast<float *>(pick_lds + SAMPLE_MAX_CANDIDATES);
+    uint32_t *s_u = reinterpret_cast<uint32_t *>(s_rp + 1);
     const uint32_t tid = threadIdx.x;
     const uint32_t n0 = *a.ncand, ndrop = *a.ndrop;
     const float dropmax = __uint_as_float(*a.dropmax);
@@ -261,41 +280,66 @@ __global__ __launch_bounds__(1024) void samp_pick_kernel(const SampleArgs a) {
             }
             __syncthreads();
         }
-    if (tid != 0) return;
-    // the two sequential loops of sample_top_p.  Probabilities are >= 0, so the running sums never decrease: eight
-    // additions at a time, one test per block.
-    const uint32_t *kw = reinterpret_cast<const uint32_t *>(key);      // probability bits = high word of key i
-    auto prob = [&](uint32_t i) { return __uint_as_float(kw[2 * i + 1]); };
-    auto first_above = [&](float thr, uint32_t n, float &run, uint32_t &where) {     // first i < n whose running sum > thr
+    // The two sequential loops of sample_top_p (infer.c:1078-1106).  The cut: one thread adds the sorted probabilities in
+    // order (they are >= 0, the running sum never decreases: sixteen additions per test) and leaves every running sum in place
+    // of the probability it consumed.  The draw adds the SAME numbers in the same order, so its running sums are those bits:
+    // instead of a second sequential pass all threads look for the first stored sum above r (round 3: the second pass was a
+    // third of this kernel at a nucleus of thousands).
+    float &s_r = s_rp[0];
+    uint32_t &s_last = s_u[0], &s_pick = s_u[1], &s_ok = s_u[2];
+    uint32_t *kw = reinterpret_cast<uint32_t *>(key);                  // probability bits = high word of key i
+    if (tid == 0) {
+        auto prob = [&](uint32_t i) { return __uint_as_float(kw[2 * i + 1]); };
+        float probe5 = n0 > 5 ? prob(5) : 0.0f;                       // (index 5 may be overwritten below)
+        float cum = 0.0f, plast = 0.0f;
+        uint32_t last = n0 - 1;
+        bool cut = false;
         uint32_t i = 0;
-        for (; i + 8 <= n; i += 8) {
-            float cs[8];
-            cs[0] = run + prob(i);
+        for (; i + 16 <= n0 && !cut; i += 16) {
+            float pv[16], cs[16];
 #pragma unroll
-            for (int k = 1; k < 8; k++) cs[k] = cs[k - 1] + prob(i + k);
-            if (cs[7] > thr) {
+            for (int k = 0; k < 16; k++) pv[k] = prob(i + k);
+            cs[0] = cum + pv[0];
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (cs[k] > thr) { run = cs[k]; where = i + k; return true; }
-            }
-            run = cs[7];
+            for (int k = 1; k < 16; k++) cs[k] = cs[k - 1] + pv[k];
+            if (cs[15] > a.top_p) {                                    // cumulative_prob > top_p (infer.c:1078-1084)
+#pragma unroll
+                for (int k = 15; k >= 0; k--) if (cs[k] > a.top_p) { last = i + k; cum = cs[k]; plast = pv[k]; }
+                cut = true;
+            } else cum = cs[15];
+#pragma unroll
+            for (int k = 0; k < 16; k++) kw[2 * (i + k) + 1] = __float_as_uint(cs[k]);      // (sums past `last` are never read)
         }
-        for (; i < n; i++) { run += prob(i); if (run > thr) { where = i; return true; } }
-        return false;
-    };
-    float cum = 0.0f;
-    uint32_t last = n0 - 1;
-    const bool cut = first_above(a.top_p, n0, cum, last);        // cumulative_prob > top_p (infer.c:1078-1084)
-    // tokens were dropped: the sorted list is the reference's only down to the largest dropped probability
-    // (and so are the six most probable tokens reported to the observation hook)
-    const uint32_t deepest = last > 5 ? last : 5;             // n0 >= 6 whenever ndrop != 0
-    if (ndrop && !(cut && prob(deepest) > dropmax)) { a.res->status = NANO_SAMPLE_FALLBACK; a.res->token = 0; return; }
-    const float r = a.coin * cum;
-    float cdf = 0.0f;
-    uint32_t pick = last;
-    (void)first_above(r, last + 1, cdf, pick);                   // r < cdf (infer.c:1100-1106); else probindex[last_idx]
-    a.res->token = 0xffffffffu - (uint32_t)key[pick];
+        for (; i < n0 && !cut; i++) {
+            const float pv = prob(i);
+            cum += pv; kw[2 * i + 1] = __float_as_uint(cum);
+            if (cum > a.top_p) { last = i; plast = pv; cut = true; }
+        }
+        if (!cut) plast = 0.0f;                                        // (only read when cut)
+        // tokens were dropped: the sorted list is the reference's only down to the largest dropped probability
+        // (and so are the six most probable tokens reported to the observation hook)
+        const float pdeep = last > 5 ? plast : probe5;                 // probability of entry max(last, 5); n0 >= 6 whenever ndrop != 0
+        const bool ok = !(ndrop && !(cut && pdeep > dropmax));
+        s_ok = ok ? 1u : 0u; s_last = last; s_pick = last;             // r >= every running sum: probindex[last_idx] (infer.c:1108)
+        s_r = a.coin * cum;
+        if (!ok) { a.res->status = NANO_SAMPLE_FALLBACK; a.res->token = 0; }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    {
+        const float r = s_r;
+        const uint32_t last = s_last;
+        for (uint32_t i = tid; i <= last; i += 1024) {                  // r < cdf (infer.c:1100-1106): the first running sum above r
+            const float c = __uint_as_float(kw[2 * i + 1]);
+            const float before = i ? __uint_as_float(kw[2 * i - 1]) : -1.0f;
+            if (c > r && !(before > r)) s_pick = i;                    // (nondecreasing sums: exactly one such i, or none)
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    a.res->token = 0xffffffffu - (uint32_t)key[s_pick];
     a.res->status = NANO_SAMPLE_OK;
-    a.res->nucleus = last + 1;
+    a.res->nucleus = s_last + 1;
     for (uint32_t i = 0; i < 6; i++) a.res->top[i] = i < n0 ? 0xffffffffu - (uint32_t)key[i] : 0u;
 }
 
@@ -317,7 +361,14 @@ hipError_t launch_sample(const SampleArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(samp_chunkfn_kernel, dim3(a.nch / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(samp_propagate_kernel, dim3(1), dim3(64), 0, st, a);
     hipLaunchKernelGGL(samp_filter_kernel, dim3(wgs), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(samp_pick_kernel, dim3(1), dim3(1024), 0, st, a);
+    constexpr size_t pick_lds_bytes = (size_t)SAMPLE_MAX_CANDIDATES * 8 + 64;
+    static std::atomic<unsigned long long> armed{0};                  // bit per device: the attribute call is a host round trip
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !((armed.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(samp_pick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pick_lds_bytes);
+        if (dev >= 0 && dev < 64) armed.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(samp_pick_kernel, dim3(1), dim3(1024), pick_lds_bytes, st, a);
     return hipGetLastError();
 }
 

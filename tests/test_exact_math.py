@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLD, ROOT
-from nano_amd import sampler_cases as sc
+import sampler_cases as sc
 
 
 def _build(tmp_path, name, extra=()):

@@ -7,7 +7,7 @@ import pytest
 
 from conftest import GOLD, synth_model
 from nano_amd import binding as nb
-from nano_amd import sampler_cases as sc
+import sampler_cases as sc
 
 pytestmark = pytest.mark.gpu
 CAP = 8192          # NANO_SAMPLE_MAX_CANDIDATES

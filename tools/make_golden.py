@@ -130,7 +130,8 @@ def make_e2e(tmpdir, only=None):
 def make_sampler_logits(tmpdir):
     """The reference's sampler (softmax / sample_top_p / sample_argmax of the compiled reference) on seeded logits of
     Qwen3's vocabulary size: tokens for several coins, candidate counts, softmax denominators."""
-    from nano_amd import sampler_cases as sc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sampler_cases as sc
     ref, orc = ob.load_ref(), ob.load_oracle()
     spec = mf.preset("tiny-nano", "f32")
     path = os.path.join(tmpdir, "tiny-nano-f32.bin")

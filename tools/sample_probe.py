@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from nano_amd import binding as nb
 from nano_amd import modelfile as mf
-from nano_amd import sampler_cases as sc
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sampler_cases as sc                    # the test suite's logit / history generators
 
 spec = mf.preset("bigvocab-qwen3", "f32")
 path = "/tmp/bigvocab-qwen3-f32.bin"
