@@ -111,9 +111,14 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
         }
     };
     issue_w(kw);
-    // the first half chunk's weight scales and first activation fragments do not depend on the weights: they go out at kernel
-    // entry, behind them in the load queue (round 3: they used to wait for the weights, one exposed L2 round trip per wave);
-    // inside the loop the NEXT half chunk's are issued as soon as the last token tile's fragments are consumed
+    if (kw == 0u && lane < (uint32_t)TT) flag[lane] = 0u;
+    if (wid == 0u && lane < (uint32_t)TT) gcnt[lane] = 0u;
+    __syncthreads();                                                   // the only workgroup barrier: the counters are armed
+    if (!live) return;
+
+    // (Round 3 tried issuing the first half chunk's weight scales and activation fragments at kernel entry, ahead of the weights'
+    // arrival, and the next half chunk's at the end of each turn: the fragments held across the chain link push the kernel past
+    // the 168 registers of three waves per SIMD -- 10 to 12 spilled registers, Qwen3-4B 8 sequences 2.16 -> 3.79 ms.  Dropped.)
     auto load_ws = [&](float4 &wsv, uint32_t h) {                       // lanes 0..31: row l/2, groups 8h + 4 (l%2) .. +3
         const uint32_t sg = h * 8u + (lane & 1u) * 4u;
         wsv = bload_f4(rs, (lane < 32u && (lane >> 1) < trw && sg < ng && h < nhc) ? ((lrow0 + (lane >> 1)) * ng + sg) * 4u : OOB);
@@ -125,22 +130,17 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
         const uint32_t xg = g0 + (lane >> 2);                           // lanes 0..31: group g0 + l/4, tokens 4 (l%4) .. +3
         xsv = bload_f4(rxs, (lane < 32u && xg < ng && t < tt) ? ((t * ng + xg) * 16u + (lane & 3u) * 4u) * 4u : OOB);
     };
-    i32x4 fb[8]; float4 xsv, wsv;
-    load_ws(wsv, kw);
-    load_fb(fb, xsv, kw * 8u, 0u);
-    if (kw == 0u && lane < (uint32_t)TT) flag[lane] = 0u;
-    if (wid == 0u && lane < (uint32_t)TT) gcnt[lane] = 0u;
-    __syncthreads();                                                   // the only workgroup barrier: the counters are armed
-    if (!live) return;
 
     for (uint32_t h = kw; h < nhc; h += nkw) {
         const uint32_t g0 = h * 8u;
         // 1. the half chunk's weight pieces: registers -> the transposition buffer
 #pragma unroll
         for (int r = 0; r < 8; r++) *reinterpret_cast<int4 *>(wbuf + (size_t)(2 * r + wrow) * G5_PITCH + wcol) = wA[r];
-        // 2. the weight scales and the first fragments of this half chunk are already on their way (issued at kernel entry / by
-        //    the previous turn); the next half chunk's weights follow them in the load queue (loads return in issue order)
-        issue_w(h + nkw);
+        // 2. what this half chunk needs now: weight scales (lanes 0..31: row l/2, groups g0 + 4 (l%2) .. +3), first fragments
+        float4 wsv; load_ws(wsv, h);
+        i32x4 fb[8]; float4 xsv;
+        load_fb(fb, xsv, g0, 0u);
+        issue_w(h + nkw);                                               // prefetch; behind the fragments in the load queue (loads return in issue order)
         if (lane < 32u) {
             const uint32_t r = lane >> 1, gq = (lane & 1u) * 4u;
             wsl[(gq + 0u) * 16u + r] = wsv.x; wsl[(gq + 1u) * 16u + r] = wsv.y; wsl[(gq + 2u) * 16u + r] = wsv.z; wsl[(gq + 3u) * 16u + r] = wsv.w;
@@ -161,13 +161,9 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                     p[j][2] = ((float)cv[2] * wv.z) * xsc; p[j][3] = ((float)cv[3] * wv.w) * xsc;
                 }
                 // 4. the next token tile's fragments, once this tile's are consumed (none left: out-of-range addresses)
-                if (t + 1u < tt) {
+                if (t + 1u < (uint32_t)TT) {
                     __builtin_amdgcn_sched_barrier(0);
                     load_fb(fb, xsv, g0, t + 1u);
-                } else if (h + nkw < nhc) {                              // last token tile: the NEXT half chunk's scales and first fragments
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_ws(wsv, h + nkw);
-                    load_fb(fb, xsv, (h + nkw) * 8u, 0u);
                 }
                 // 5. the chain link of (half chunk h, token tile t): the running values so far, this half chunk's groups in
                 //    ascending order, on to the owner of h + 1 -- or out through the epilogue

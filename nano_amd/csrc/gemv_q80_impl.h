@@ -175,6 +175,25 @@ __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r,
 }
 
 
+// ordered fold of one row's group products (infer.c:668-674): NQ float4 = 4 NQ groups, all LDS reads first, then the chain
+template <int NQ> __device__ __forceinline__ float fold_row(const float *p) {
+    float4 t[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) t[q] = *reinterpret_cast<const float4 *>(p + 4 * q);
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { v += t[q].x; v += t[q].y; v += t[q].z; v += t[q].w; }
+    return v;
+}
+template <int NQ> __device__ __forceinline__ void fold_row2(const float *p0, const float *p1, float &v0, float &v1) {
+    float4 t[NQ], u[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { t[q] = *reinterpret_cast<const float4 *>(p0 + 4 * q); u[q] = *reinterpret_cast<const float4 *>(p1 + 4 * q); }
+    v0 = 0.0f; v1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { v0 += t[q].x; v1 += u[q].x; v0 += t[q].y; v1 += u[q].y; v0 += t[q].z; v1 += u[q].z; v0 += t[q].w; v1 += u[q].w; }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // SLAB kernel
 // ------------------------------------------------------------------------------------------------------------
@@ -206,7 +225,9 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
 
     // ---- 2. all weight / scale loads of this wave; the workgroup's rows lie inside ONE segment ------------
     const uint32_t bid = blockIdx.x;
-    const int sel = swiglu ? 0 : (int)(bid >= a.wg_c0) + (int)(bid >= a.wg_c1);
+    // (the residual and SwiGLU launches of a decode step have ONE weight segment: their roles skip the selection chains)
+    constexpr bool ONESEG = ROLE == R_RESID || ROLE == R_RESID_COMBINE || ROLE == R_NORM_SWIGLU;
+    const int sel = (ONESEG || swiglu) ? 0 : (int)(bid >= a.wg_c0) + (int)(bid >= a.wg_c1);
     const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
     const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
     float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
@@ -307,7 +328,11 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         float v0 = 0.0f, v1 = 0.0f;
         const float *p0 = P + (((size_t)fb * nmat) * RWP + frl) * PITCH;
         const float *p1 = p0 + (size_t)RWP * PITCH;
-        if ((ng & 15u) == 0) {              // whole 16-group batches (every BASELINE shape): no per-element selects
+        if (!swiglu && ng == 48u) v0 = fold_row<12>(p0);        // the row lengths of Qwen3-0.6B at group size 64 (3072 / 2048 / 1024): every
+        else if (!swiglu && ng == 32u) v0 = fold_row<8>(p0);    // LDS read of the row goes out before the dependent add chain starts (round 3:
+        else if (ng == 16u) {                                   // the batch-by-batch loop below exposes one LDS round trip per 16 groups)
+            if (swiglu) fold_row2<4>(p0, p1, v0, v1); else v0 = fold_row<4>(p0);
+        } else if ((ng & 15u) == 0) {       // whole 16-group batches (every BASELINE shape): no per-element selects
             for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
                 float4 t[4], u[4];
 #pragma unroll
