@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                 uint32_t rb = 0xffffffffu;
                 if (blk < a.pt_stride && tb < range_hint) {                // wave-uniform: a SCALAR load (a vector load here would have to wait for
                     const uint64_t pa = reinterpret_cast<uint64_t>(a.pt_rows + (size_t)b * a.pt_bstride + blk);   // every K / V load issued before it -- vmcnt counts in order)
-                    const uint64_t pu = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pa);
+                    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa);   // (readfirstlane returns int: no sign extension into the high word)
                     asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rb) : "s"(pu) : "memory");
                 }
                 row = rb == 0xffffffffu ? 0x7fffffu : rb + (t & 63u);      // no page: beyond every plane -> out of range -> 0

@@ -603,7 +603,7 @@ static uint32_t xba_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_hi
     return (ns > 1 && (wo_takes_gemm(m, nb) || ns > 8)) ? 1u : ns;
 }
 
-// range_hint: host-side upper bound of the attended range of every sequence (decode: a multiple of 16, prefill: of 64; <= S)
+// range_hint: host-side upper bound of the attended range of every sequence (a multiple of 64, <= S)
 static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t range_hint) {
     const NanoModelDesc &d = m->d;
     const uint32_t E = d.n_embd, H = d.n_hidden, QD = m->QD, KD = m->KD, L = d.n_layer, S = m->S;
@@ -887,11 +887,11 @@ extern "C" int nano_hip_set_phase_hook(NanoHipModel *m, nano_hip_phase_fn fn, vo
 // max_pos: largest position among the sequences of this step (host knowledge; the device reads the exact pos[b])
 static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t mode, uint32_t max_pos) {
     // The attention kernel issues its K / V loads before it knows pos (one memory round trip saved): it loads the rows below
-    // range_hint and masks those beyond pos.  The hint is rounded up to 16 positions, not to the 64 of a split's range (round
-    // 3): the last block's rows beyond the hint are not fetched -- at positions 20..39 half of a 64-row block -- and the
-    // attention kernel is bound by what one CU can pull through its L1.  Same split count (ceil(hint / 64)), same arithmetic,
-    // four times as many graphs of a step (keyed by the hint).  NANO_RANGE_STEP=64 restores the coarse hint (A/B runs).
-    static const uint32_t hint_step = [] { const char *e = getenv("NANO_RANGE_STEP"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return (v == 16u || v == 32u || v == 64u) ? v : 16u; }();
+    // range_hint and masks those beyond pos.  The hint is rounded up to the 64 positions of a split's range.  Round 3 measured
+    // a hint rounded to 16 (the last block's rows beyond it are not fetched; four times as many graphs): 1845.9 vs 1846.0 tok/s
+    // at positions 20..39, 1709.6 vs 1707.8 over 31..510 -- an out-of-range load still costs its issue slot, and that, not
+    // the bytes, is what the kernel's load phase pays for.  NANO_RANGE_STEP=16|32 keeps the finer hint for A/B runs.
+    static const uint32_t hint_step = [] { const char *e = getenv("NANO_RANGE_STEP"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return (v == 16u || v == 32u || v == 64u) ? v : 64u; }();
     uint32_t range_hint = is_causal ? ((max_pos + hint_step) / hint_step) * hint_step : m->S;
     if (range_hint > m->S) range_hint = m->S;
     if (m->kv_paged && (m->strict || m->lora_on)) FAIL(NANO_HIP_EINVAL, "the paged KV cache is served by the fused path only: not with strict mode or the LoRA side branches");

@@ -535,13 +535,16 @@ static Q4kPlan plan_q4k(const GemvArgs &a, int B) {
     // 28.0 -> 19.9, Wo 10.4 -> 7.5); Qwen3-0.6B's are fastest at 512 (1024: -3 %).  NANO_Q4K_ITEMS overrides the former.
     const bool large = (uint64_t)rows * a.n >= (8u << 20);
     uint32_t cap = large ? 4096u : rows >= 16384 ? 2048u : 512u;
-    static const char *cap_env = getenv("NANO_Q4K_ITEMS");
+    static const char *cap_env = getenv("NANO_Q4K_ITEMS");           // measurement knobs: items per workgroup (large matrices),
     if (cap_env && large) cap = (uint32_t)strtoul(cap_env, nullptr, 0);
+    static const uint32_t cap_small = getenv("NANO_Q4K_ITEMS_SMALL") ? (uint32_t)strtoul(getenv("NANO_Q4K_ITEMS_SMALL"), nullptr, 0) : 0u;   // ... (per-layer matrices of small models),
+    static const uint32_t nthr_max = getenv("NANO_Q4K_NTHR") ? (uint32_t)strtoul(getenv("NANO_Q4K_NTHR"), nullptr, 0) : 512u;                 // ... threads per workgroup
+    if (cap_small && !large && rows < 16384) cap = cap_small;
     while (rw < 64 && (align % (rw * 2)) == 0 && (rw * 2) * GT * nmat <= cap && rows / (rw * 2) >= 128) rw *= 2;
     for (;; rw /= 2) {
         const uint32_t items = rw * GT * nmat;
         uint32_t nthr = ((items + 63) / 64) * 64;
-        if (nthr > 512) nthr = 512;
+        if (nthr > nthr_max) nthr = nthr_max;
         if (nthr < 256) nthr = 256;
         uint32_t want = ((a.n / 4 + 63) / 64) * 64;        // the block quantizer is one thread per element: ~4 elements per thread
         if (want > 1024) want = 1024;
