@@ -366,7 +366,12 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
                 }
             }
         }
-        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
+        if (fold_live) {
+            float *dst = out0 + (size_t)fb * obs + (size_t)opos * ops + lrow0 + frl;
+            const float val = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
+            // experiment (NANO_DBG bit 4): write-through (sc1) store of the result -- the next kernel's first loads are these bytes
+            if (a.dbg & 4u) __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = val;
+        }
         NANO_STAMP(a.stamps, 6, v0);                                // folded and stored
     }
 }
