@@ -214,7 +214,8 @@ __global__ __launch_bounds__(1024) void gemv_f32_slab_kernel(const GemvDev a) {
         const float *p0 = P + (((size_t)fb * nmat) * RW + frl) * PC;
         const float *p1 = p0 + (size_t)RW * PC;
         for (uint32_t c = 0; c < nchunk; c++) { v0 += p0[c]; if (swiglu) v1 += p1[c]; }
-        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
+        // write-through (sc1) store, see gemv_q80_impl.h: nothing is left for the write-back at the end of the kernel
+        if (fold_live) __hip_atomic_store(out0 + (size_t)fb * obs + (size_t)opos * ops + lrow0 + frl, finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -7,25 +7,25 @@
 //     order-free (min/max, elementwise divides, magic-number rounding) -> BIT-EXACT for equal inputs.
 //     The reference's partial-block source offset j*d (tensor.c:307) is kept.
 //   * dot_two_blocks_q4k / matmul_q4k (reference infer/tensor.c:359-434,438-471): three integer sums
-//     per group (v_dot4_u32_u8 on split nibbles), the four-term float combine in the reference's
+//     per group (v_dot8_u32_u4 on the packed nibbles), the four-term float combine in the reference's
 //     operation order, groups summed in order inside a block and blocks summed in order along the
 //     row -> bit-identical fp32 results for equal quantized inputs.
 //
 // Block layout in HBM (160 B, reference infer/tensor.h:116-135), blocks 16-byte aligned after upload:
 //   +0 u32 0x42 | +4 u32 length | +8 u32 meta | +12 f32 s_scale | +16 f32 s_bias | +20 u8 sb[12] | +32 u8 value[128]
 //
-// LDS staging of the activation (per sequence, per group): the 32 nibbles pre-split into
-// "even elements" / "odd elements" byte lanes (the same split `& 0x0F0F0F0F`, `>> 4 & 0x0F0F0F0F`
-// applied to a weight dword yields), the dequantized 6-bit scale/bias floats and the nibble sum.
+// LDS staging of the activation (per sequence, per group): the 32 nibbles packed exactly like a weight group's 16 value
+// bytes (element 2i in the low nibble of byte i), so that ONE v_dot8_u32_u4 per dword gives the eight products of
+// matching elements (round 3; rounds 1-2 split both operands into even / odd byte lanes for v_dot4_u32_u8: 24 instead of
+// 8 instructions per group and sequence); the dequantized 6-bit scale / bias floats and the nibble sum.
 #include <float.h>
 
 #include "gemv_common.h"
 
 namespace nano {
 
-struct XGroup {            // 48 bytes per (sequence, group), 16-byte aligned
-    uint32_t lo[4];        // even-index nibbles of dword m as 4 bytes
-    uint32_t hi[4];        // odd-index nibbles
+struct XGroup {            // 32 bytes per (sequence, group), 16-byte aligned
+    uint32_t pk[4];        // the group's 32 nibbles, packed like value[16 g .. 16 g + 15] of a block
     float sq, bq;          // (float)s6 * s_scale, (float)b6 * s_bias
     int sumq;
     int _pad;
@@ -268,10 +268,9 @@ __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged
                 if (valid) {
                     const uint32_t tg = tid & 7u;
                     XGroup *o = xg + (size_t)b * GT + (i >> 5);
-                    // split-nibble byte lanes: elements 8m .. 8m+7 live in dword m; even elements -> lo[m], odd -> hi[m], byte (e & 7) >> 1
-                    uint8_t *ob = reinterpret_cast<uint8_t *>(o) + (tg >> 1) * 4 + (tg & 1) * 2;
-                    *reinterpret_cast<uint16_t *>(ob) = (uint16_t)(n0 | (n2 << 8));
-                    *reinterpret_cast<uint16_t *>(ob + 16) = (uint16_t)(n1 | (n3 << 8));
+                    // this thread's four elements 4 tg .. 4 tg + 3 are two bytes of the packed group
+                    uint8_t *ob = reinterpret_cast<uint8_t *>(o) + tg * 2;
+                    *reinterpret_cast<uint16_t *>(ob) = (uint16_t)(n0 | (n1 << 4) | (n2 << 8) | (n3 << 12));
                     if (tg == 0) { o->sq = (float)s6 * s_scale; o->bq = (float)b6 * s_bias; o->sumq = sum; o->_pad = 0; }   // sq / bq: what get_group_scale_and_bias() reads back (tensor.c:137-140)
                 }
             }
@@ -313,10 +312,9 @@ __device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *x
         }
         const int g = t4 >> 3, tg = t4 & 7;                               // group of the block, thread inside the group
         XGroup *o = xg + (size_t)b * GT + j * 8 + g;
-        // split-nibble byte lanes: elements 8m .. 8m+7 live in dword m; even elements -> lo[m], odd -> hi[m], byte (e & 7) >> 1
-        uint8_t *ob = reinterpret_cast<uint8_t *>(o) + (tg >> 1) * 4 + (tg & 1) * 2;
-        *reinterpret_cast<uint16_t *>(ob) = (uint16_t)(n0 | (n2 << 8));
-        *reinterpret_cast<uint16_t *>(ob + 16) = (uint16_t)(n1 | (n3 << 8));
+        // this thread's four elements 4 tg .. 4 tg + 3 are two bytes of the packed group
+        uint8_t *ob = reinterpret_cast<uint8_t *>(o) + tg * 2;
+        *reinterpret_cast<uint16_t *>(ob) = (uint16_t)(n0 | (n1 << 4) | (n2 << 8) | (n3 << 12));
         const int sum = dpp_group_sum<8>((int)(n0 + n1 + n2 + n3));
         if (tg == 0) { o->sumq = sum; o->_pad = 0; float *tp = tmp + ((size_t)b * bpl + j) * 16; tp[g] = gsc; tp[8 + g] = gbi; }
     }
@@ -354,8 +352,8 @@ __device__ __forceinline__ void unpack_q4k_wg(const GemvDev &a, XGroup *xg) {
         XGroup o; int sum = 0;
         for (int m = 0; m < 4; m++) {
             const uint32_t w = *reinterpret_cast<const uint32_t *>(blk + 32 + g * 16 + m * 4);
-            o.lo[m] = w & 0x0f0f0f0fu; o.hi[m] = (w >> 4) & 0x0f0f0f0fu;
-            sum += (int)__builtin_amdgcn_udot4(o.lo[m], 0x01010101u, 0u, false) + (int)__builtin_amdgcn_udot4(o.hi[m], 0x01010101u, 0u, false);
+            o.pk[m] = w;
+            sum += (int)__builtin_amdgcn_udot8(w, 0x11111111u, 0u, false);
         }
         o.sq = (float)s6 * s_scale; o.bq = (float)b6 * s_bias; o.sumq = sum; o._pad = 0;
         xg[gg] = o;
@@ -452,24 +450,17 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
             q4k_unpack6(h1v[k].y, h1v[k].z, h1v[k].w, (int)g, s6, b6);
             const float sp = (float)s6 * s_scale, bp = (float)b6 * __uint_as_float(h1v[k].x);
             const int glen = (len >= (int)(g + 1) * 32) ? 32 : (len - 32 * (int)g);
-            const uint32_t wl[4] = { nib.x & 0x0f0f0f0fu, nib.y & 0x0f0f0f0fu, nib.z & 0x0f0f0f0fu, nib.w & 0x0f0f0f0fu };
-            const uint32_t wh[4] = { (nib.x >> 4) & 0x0f0f0f0fu, (nib.y >> 4) & 0x0f0f0f0fu, (nib.z >> 4) & 0x0f0f0f0fu, (nib.w >> 4) & 0x0f0f0f0fu };
-            uint32_t sump = 0;
+            const uint32_t wn[4] = { nib.x, nib.y, nib.z, nib.w };
+            uint32_t sump = 0;                                           // sum of the weight nibbles: v_dot8_u32_u4 against eight ones
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                sump = __builtin_amdgcn_udot4(wl[m], 0x01010101u, sump, false);
-                sump = __builtin_amdgcn_udot4(wh[m], 0x01010101u, sump, false);
-            }
+            for (int m = 0; m < 4; m++) sump = __builtin_amdgcn_udot8(wn[m], 0x11111111u, sump, false);
 #pragma unroll
             for (int b = 0; b < B; b++) {
                 if (b < (int)a.nb) {
                     const XGroup &xq = xg[(size_t)b * GT + gg];
                     uint32_t spq = 0;
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        spq = __builtin_amdgcn_udot4(wl[m], xq.lo[m], spq, false);
-                        spq = __builtin_amdgcn_udot4(wh[m], xq.hi[m], spq, false);
-                    }
+                    for (int m = 0; m < 4; m++) spq = __builtin_amdgcn_udot8(wn[m], xq.pk[m], spq, false);      // nibble k of both dwords = element 8 m + k
                     const float sq = xq.sq, bq = xq.bq;
                     // reference tensor.c:425-428, same association
                     const float grp = sp * sq * (float)(int)spq - sp * bq * (float)(int)sump - sq * bp * (float)xq.sumq + glen * bp * bq;
@@ -515,7 +506,8 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
             }
             res[mat] = line;
         }
-        if (fold_live) out0[(size_t)fb * obs + (size_t)opos * ops + lrow0 + frl] = finish_epi(epi, has_add ? res[0] + addv : res[0], res[1], oldv);
+        // write-through (sc1) store, see gemv_q80_impl.h: nothing is left for the write-back at the end of the kernel
+        if (fold_live) __hip_atomic_store(out0 + (size_t)fb * obs + (size_t)opos * ops + lrow0 + frl, finish_epi(epi, has_add ? res[0] + addv : res[0], res[1], oldv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         NANO_STAMP(a.stamps, 6, res[0]);
     }
 }

@@ -369,8 +369,10 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         if (fold_live) {
             float *dst = out0 + (size_t)fb * obs + (size_t)opos * ops + lrow0 + frl;
             const float val = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
-            // experiment (NANO_DBG bit 4): write-through (sc1) store of the result -- the next kernel's first loads are these bytes
-            if (a.dbg & 4u) __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = val;
+            // WRITE-THROUGH (sc1) store: the result leaves the XCD's L2 now instead of in the write-back at the end of the kernel, which
+            // the next kernel's start waits for (round 3, measured: 1807 -> 1836 tok/s at positions 20..39, 1681 -> 1718 over 31..510;
+            // NANO_DBG bit 4 restores the plain store for A/B runs)
+            if (a.dbg & 4u) *dst = val; else __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         NANO_STAMP(a.stamps, 6, v0);                                // folded and stored
     }
