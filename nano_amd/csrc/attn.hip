@@ -524,8 +524,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         const uint32_t h = h0 + m;
         if (nsplit == 1) {
             const float val = o / L;                                                                  // softmax normalisation (infer.c:631-633)
-            // write-through (sc1) like the GEMV outputs: nothing of this kernel is left for the end-of-kernel write-back
-            __hip_atomic_store(a.xba_out + (size_t)b * a.q_dim + (size_t)h * hd + i, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (plain store: write-through stores, which pay for the GEMVs' few results per workgroup, cost this kernel's 128 lanes
+            // per head +0.3 us in round 3's A/B run)
+            a.xba_out[(size_t)b * a.q_dim + (size_t)h * hd + i] = val;
             if (a.xf_out) {
                 // Q80 group of 64 = the 64 lanes of this wave (head_dim % 64 == 0): quantize (infer/tensor.c:21-46) and store in
                 // fragment order xf[token tile][group][kq * 16 + token % 16][16 bytes], byte j of a group at kq = j / 16
@@ -539,11 +540,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                 if (jj == 0) a.xsf_out[gb * 16u + (b & 15u)] = scale;
             }
         } else {
-            __hip_atomic_store(a.out + ((size_t)b * nsplit + split) * a.q_dim + (size_t)h * hd + i, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i == 0) {
-                float *ml = a.ml + (((size_t)b * a.n_head + h) * nsplit + split) * 2;
-                __hip_atomic_store(ml, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(ml + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            a.out[((size_t)b * nsplit + split) * a.q_dim + (size_t)h * hd + i] = o;
+            if (i == 0) { float *ml = a.ml + (((size_t)b * a.n_head + h) * nsplit + split) * 2; ml[0] = M; ml[1] = L; }
         }
     }
     NANO_STAMP(a.stamps, 5, mrun[0]);                          // combined and stored

@@ -36,7 +36,7 @@ struct G5Dev {
     const int8_t *w[3]; const float *ws[3]; float *out[3];
     uint32_t rows[3], out_bstride[3], out_pstride[3];
     uint32_t n, ng, epi, nb, nhc, ntiles, tt, nkw, cpw, teams, nmat;
-    uint32_t trw, tc0, tc1, sc1;        // rows per tile (even, <= 16: balanced tiles), tiles up to the end of segment 0 / 1; sc1: write-through output stores
+    uint32_t trw, tc0, tc1, _padt;      // rows per tile (even, <= 16: balanced tiles), tiles up to the end of segment 0 / 1
     const int8_t *xf; const float *xsf; const uint32_t *pos;
     // SwiGLU launches, optional (4 row-tile pairs per workgroup): the outputs also leave as Q80 groups of 64 in fragment order,
     // i.e. the next GEMM's activation operand (what quant_rows_frag_kernel would make of them); ng2 = rows / 64
@@ -206,9 +206,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                         float *o = orow + (size_t)opos * ops;
 #pragma unroll
                         for (int i = 0; i < 4; i++)
-                            if (kq * 4u + i < trw && lrow0 + kq * 4u + i < rows0) {
-                                if (a.sc1) __hip_atomic_store(o + i, val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else o[i] = val[i];   // (NANO_G5_SC1: write-through, A/B)
-                            }
+                            if (kq * 4u + i < trw && lrow0 + kq * 4u + i < rows0) o[i] = val[i];      // (write-through stores measured slower here: 2.19 -> 2.22 ms at 8 sequences)
                     }
                     if constexpr (TT == 1) if (a.xf2) {               // (one token tile only: measured slower with more, and its registers would cost the other instantiations)
                         // ---- the 64-row Q80 group of these outputs (infer/tensor.c:21-46): this wave holds rows 16 rt .. +15 of
@@ -290,7 +288,6 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
     d.tt = (a.nb + 15) / 16;
     d.nmat = sw ? 2u : 1u;
     d.xf = a.xq_in; d.xsf = a.xs_in; d.pos = a.pos;
-    { static const uint32_t sc1 = getenv("NANO_G5_SC1") ? (uint32_t)atoi(getenv("NANO_G5_SC1")) : 0u; d.sc1 = sc1; }
     // The split.  A workgroup = one row tile (SwiGLU: the W1/W3 pair) x nkw waves; a CU holds 12 waves (3 per SIMD at
     // <= 168 VGPRs).  Take the deepest split whose workgroups are ALL resident at once (no second round of workgroups, whose
     // tail would run on a mostly idle chip); matrices too tall for that (the classifier) get one wave per tile, 4 per group.
