@@ -111,6 +111,9 @@ struct NanoHipModel {
     bool kv_half = false;         // opt-in FP16 KV cache: rows hold __half, v passes through vraw like k through kraw
     float *vraw = nullptr;        // [Bs][KD] fresh v rows (FP16 cache only)
     // paged KV cache (opt-in): kcache / vcache are pools [L][pages][64][KD]; pt = first pool row of every 64-position block
+    // greedy loop (nano_hip_decode_greedy): from the second step on the previous step's arg-max kernel has already embedded this
+    // step's token (misc.hip argmax_kernel) -- the step then starts at layer 0's QKV launch
+    bool skip_embed = false;
     bool kv_paged = false;
     uint32_t kv_pages = 0, pt_stride = 0;                 // pages in the pool; page-table entries per slot = ceil(S / 64)
     uint32_t *pt = nullptr, *kvrow = nullptr;             // device: [maxB][pt_stride] (0xffffffff = no page), [Bs] pool row of the step's position
@@ -630,7 +633,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     const size_t plane = (size_t)m->kv_pages * 64 * KD;                      // elements of one layer plane of the pool
     if (m->kv_paged) { ea.pt_rows = pt_base; ea.kvrow = m->kvrow; ea.pt_bstride = pt_bstride; }
     const uint32_t skip = m->skip_mask;
-    if (!(skip & 128) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
+    if (!(skip & 128) && !(m->skip_embed && mode == MODE_LOOP) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
 
     for (uint32_t l = 0; l < L; l++) {
         const size_t layer_rows = (size_t)l * S;                    // cache row offset of this layer within a slot
@@ -751,7 +754,10 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     if (sample) {
         ArgmaxArgs aa{ m->logits, d.vocab_size, d.vocab_size, m->amax, nullptr, m->pos, nullptr, m->pos0, nb,
                        ntiles ? m->tile_max : nullptr, ntiles };
-        if (mode == MODE_LOOP) { aa.tokens = m->tokens; aa.trace = m->trace; }
+        if (mode == MODE_LOOP) {
+            aa.tokens = m->tokens; aa.trace = m->trace;
+            if (!m->pf && !(skip & (64 | 128))) { aa.emb = ea; aa.rope_rows = m->rope_rows; }      // ... and embeds the token it picked for the next step
+        }
         if (!(skip & 64) && (e = launch_argmax(aa, nb, m->st)) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -903,7 +909,8 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
     }
     if (m->kv_half && m->lora_on) FAIL(NANO_HIP_EINVAL, "the LoRA side branches write FP32 v rows: not available with the FP16 KV cache");
     if (!m->use_graph || m->stamps_on) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); m->nsplit = xba_nsplit(m, nb, range_hint); return 0; }
-    const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) | ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
+    const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)((m->skip_embed && mode == MODE_LOOP) ? 1 : 0) << 49) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) |
+                         ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         // first use: THIS step runs eagerly (the launchers set their kernel attributes and validate their arguments outside
@@ -1222,8 +1229,12 @@ extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, c
     HIP_TRY(hipMemcpyAsync(m->pos0, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
     uint32_t max_pos = 0;
     for (uint32_t i = 0; i < batch; i++) if (pos[i] > max_pos) max_pos = pos[i];
-    for (uint32_t s = 0; s < steps; s++)
-        if ((rc = run_step(m, batch, 1, MODE_LOOP, max_pos + s))) return rc;
+    for (uint32_t s = 0; s < steps; s++) {
+        m->skip_embed = s > 0 && !m->strict;          // the fused path's arg-max kernel of step s - 1 embedded this step's token
+        rc = run_step(m, batch, 1, MODE_LOOP, max_pos + s);
+        m->skip_embed = false;
+        if (rc) return rc;
+    }
     if (out_ids) {
         HIP_TRY(hipMemcpyAsync(m->h_amax, m->trace, (size_t)steps * batch * 4, hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));

@@ -177,6 +177,10 @@ struct ArgmaxArgs {
     uint32_t *out;
     uint32_t *tokens; uint32_t *pos; uint32_t *trace; const uint32_t *pos0; uint32_t nb;   // trace[(pos-pos0)*nb + b]
     const float *tile_max; uint32_t ntiles;     // optional (max, row) partials from the classifier GEMV
+    // greedy loop only (tokens != nullptr): the SAME kernel then embeds the token it picked at its next position -- the next
+    // step's first kernel (embed) and its launch boundary are gone.  emb.x == nullptr: not fused.  rope_rows: rows of the RoPE
+    // tables (the position after the last one has no row: nothing is staged for it)
+    EmbedArgs emb; uint32_t rope_rows, _pade;
 };
 hipError_t launch_argmax(const ArgmaxArgs &a, uint32_t nb, hipStream_t st);
 

@@ -11,17 +11,13 @@ namespace nano {
 // The reference dequantizes the whole table to fp32 at load (infer/infer.c:126-127,147-149) and
 // memcpy's one row per token (infer.c:987-988).  Here the row is dequantized when it is needed; the
 // floats are the same: Q80 q[i]*s[i/gs] (tensor.c:15-19), Q4K (float)nibble*s - b (tensor.c:253-278).
-__global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
-    const int b = blockIdx.x;
-    const uint32_t tok = a.tokens[b];
+// sequence b: token `tok` at position `p` -> x[b] (and the staged RoPE row / pool row of p); the calling workgroup's threads share the work
+__device__ __forceinline__ void embed_row(const EmbedArgs &a, uint32_t b, uint32_t tok, uint32_t p, bool stage_pos) {
     float *x = a.x + (size_t)b * a.x_bstride;
     const uint32_t E = a.E;
-    if (a.kvrow && threadIdx.x == 0) {                       // paged KV cache: the pool row of this step's position
-        const uint32_t p = a.pos[b];
+    if (stage_pos && a.kvrow && threadIdx.x == 0)            // paged KV cache: the pool row of this step's position
         a.kvrow[b] = a.pt_rows[(size_t)b * a.pt_bstride + (p >> 6)] + (p & 63u);
-    }
-    if (a.rope_cur) {
-        const uint32_t p = a.pos[b];
+    if (stage_pos && a.rope_cur) {
         for (uint32_t i = threadIdx.x; i < a.half; i += blockDim.x) {
             a.rope_cur[(size_t)b * 2 * a.half + i] = a.rope_cos[(size_t)p * a.half + i];
             a.rope_cur[(size_t)b * 2 * a.half + a.half + i] = a.rope_sin[(size_t)p * a.half + i];
@@ -62,6 +58,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
+    const int b = blockIdx.x;
+    embed_row(a, (uint32_t)b, a.tokens[b], a.pos ? a.pos[b] : 0u, true);
+}
+
 hipError_t launch_embed(const EmbedArgs &a, uint32_t nb, hipStream_t st) {
     hipLaunchKernelGGL(embed_kernel, dim3(nb), dim3(256), 0, st, a);
     return hipGetLastError();
@@ -71,6 +72,7 @@ hipError_t launch_embed(const EmbedArgs &a, uint32_t nb, hipStream_t st) {
 __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
     __shared__ float sval[16];
     __shared__ uint32_t sidx[16];
+    __shared__ uint32_t s_next[2];                            // greedy loop, fused embedding: the picked token and its position
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *x = a.logits + (size_t)b * a.bstride;
     float best = -INFINITY;
@@ -123,7 +125,12 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
         a.out[b] = bi;
         if (a.tokens) a.tokens[b] = bi;
         if (a.trace) a.trace[(size_t)(a.pos[b] - a.pos0[b]) * a.nb + b] = bi;
-        if (a.tokens) a.pos[b] = a.pos[b] + 1;
+        if (a.tokens) { const uint32_t np = a.pos[b] + 1; a.pos[b] = np; s_next[0] = bi; s_next[1] = np; }
+    }
+    if (a.tokens && a.emb.x) {                                // greedy loop: embed the picked token at its next position right here
+        __syncthreads();
+        const uint32_t np = s_next[1];
+        embed_row(a.emb, (uint32_t)b, s_next[0], np, np < a.rope_rows);
     }
 }
 
