@@ -539,6 +539,9 @@ static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
             if (e != hipSuccess) return e;
         }
         a.xq_in = a.frag_ready == 2u ? m->gq2 : m->gq; a.xs_in = a.frag_ready == 2u ? m->gxs2 : m->gxs;
+        // the classifier of a batched step: GC (persistent waves, the activation fragments staged in LDS once per workgroup)
+        static const bool use_cls = !(getenv("NANO_GEMM_CLS") && *getenv("NANO_GEMM_CLS") == '0');
+        if (use_cls && !a.frag_out && gemm_q80_cls_supports(a)) return launch_gemm_q80_cls(a, m->st);
         if (m->use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, a.frag_out, a.frag_scale_out, m->st);
         if (a.frag_out) return hipErrorInvalidValue;               // the caller checked gemm_q80_g5_can_quantize_outputs()
         return launch_gemm_q80_g2(a, m->st);

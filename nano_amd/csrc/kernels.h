@@ -68,6 +68,9 @@ hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st);
 bool gemm_q80_g5_supports(const GemvArgs &a);
 bool gemm_q80_g5_can_quantize_outputs(const GemvArgs &a);           // SwiGLU launches: the outputs also as Q80 fragments (xf2 / xsf2)
 hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipStream_t st);
+// GC, tall matrices with short rows (the classifier): persistent waves, activation fragments staged in LDS (gemm_q80_cls.hip)
+bool gemm_q80_cls_supports(const GemvArgs &a);
+hipError_t launch_gemm_q80_cls(const GemvArgs &a, hipStream_t st);
 hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                                   int8_t *xf, float *xsf, hipStream_t st);
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,

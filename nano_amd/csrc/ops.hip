@@ -230,7 +230,7 @@ extern "C" int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *dp) {
         OP_CHECK(xf && xsf, "device alloc failed");
         OP_HIP(launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, xf, xsf, 0));
         a.xq_in = xf; a.xs_in = xsf;
-        e = gemm_q80_g5_supports(a) ? launch_gemm_q80_g5(a, nullptr, nullptr, 0) : launch_gemm_q80_g2(a, 0);
+        e = gemm_q80_cls_supports(a) ? launch_gemm_q80_cls(a, 0) : gemm_q80_g5_supports(a) ? launch_gemm_q80_g5(a, nullptr, nullptr, 0) : launch_gemm_q80_g2(a, 0);
     } else if (d.nb > 8) {
         nano_hip_set_error_("more than 8 sequences need use_gemm"); return NANO_HIP_EINVAL;
     } else {

@@ -141,7 +141,10 @@ def test_batched_gemv_roles_q80_bit_exact(oracle, nb_, kind):
 
 
 GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (9, 1, 3072, (1024,)), (40, 1, 2048, (1024,)), (64, 0, 1024, (2048, 1024, 1024)),
-              (8, 1, 9728, (2560,)), (16, 0, 2560, (4096, 1024, 1024)), (33, 1, 4096, (2560,))]
+              (8, 1, 9728, (2560,)), (16, 0, 2560, (4096, 1024, 1024)), (33, 1, 4096, (2560,)),
+              # tall matrices (>= 16384 rows): the classifier's kernel GC (gemm_q80_cls.hip) -- every token tile staged in LDS /
+              # two staged + two from L2 (64 tokens at row length 2560), a ragged last row tile, group counts 16 / 40 / 12
+              (16, 0, 1024, (16400,)), (64, 0, 1024, (16391,)), (8, 0, 2560, (16512,)), (64, 0, 2560, (16390,)), (33, 0, 768, (16384,))]
 
 
 def gemm_route_case(oracle, nb_, kind, n, rows):
