@@ -24,6 +24,8 @@
 
 namespace nano {
 
+typedef unsigned int u32x2_q __attribute__((ext_vector_type(2)));
+
 struct XGroup {            // 32 bytes per (sequence, group), 16-byte aligned
     uint32_t pk[4];        // the group's 32 nibbles, packed like value[16 g .. 16 g + 15] of a block
     float sq, bq;          // (float)s6 * s_scale, (float)b6 * s_bias
@@ -257,10 +259,23 @@ __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged
                 const int sum = dpp_group_sum<8>((int)(n0 + n1 + n2 + n3));
                 // the block's 8 groups are the 8 lane-octets of this wave
                 float smax = (gsc > FLT_TRUE_MIN) ? gsc : FLT_TRUE_MIN, bmax = (gbi > FLT_TRUE_MIN) ? gbi : FLT_TRUE_MIN;   // the reference's strict comparisons
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    const float so = __shfl_xor(smax, o, 64), bo = __shfl_xor(bmax, o, 64);
+                // across the wave's eight lane-octets: lane ^ 8 by a DPP row rotate, lane ^ 16 / ^ 32 by v_permlane16/32_swap (VALU only;
+                // round 3: the three ds_bpermute pairs this replaces were ~0.25 us of every Q4K launch's prologue)
+                {
+                    const float so = DPP_F(smax, 0x128), bo = DPP_F(bmax, 0x128);
                     smax = (so > smax) ? so : smax; bmax = (bo > bmax) ? bo : bmax;
+                }
+                {
+                    const u32x2_q rs_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(smax), __float_as_uint(smax), false, false);
+                    const u32x2_q rb_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(bmax), __float_as_uint(bmax), false, false);
+                    const float s0 = __uint_as_float(rs_[0]), s1 = __uint_as_float(rs_[1]), b0 = __uint_as_float(rb_[0]), b1 = __uint_as_float(rb_[1]);
+                    smax = (s1 > s0) ? s1 : s0; bmax = (b1 > b0) ? b1 : b0;
+                }
+                {
+                    const u32x2_q rs_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(smax), __float_as_uint(smax), false, false);
+                    const u32x2_q rb_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(bmax), __float_as_uint(bmax), false, false);
+                    const float s0 = __uint_as_float(rs_[0]), s1 = __uint_as_float(rs_[1]), b0 = __uint_as_float(rb_[0]), b1 = __uint_as_float(rb_[1]);
+                    smax = (s1 > s0) ? s1 : s0; bmax = (b1 > b0) ? b1 : b0;
                 }
                 const float s_scale = smax / 63.0f, s_bias = bmax / 63.0f;
                 const uint32_t s6 = (s_scale == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(gsc / s_scale) & 0x3f);
