@@ -652,6 +652,39 @@ def test_engine_replicas_serve_a_batch_concurrently(model_dir):
     m1.close()
 
 
+def test_replicas_apply_the_lora_module_too(model_dir):
+    """Round-2 advice: a LoRA module belongs to the context, so EVERY replica's forwards apply it (reference: one LLM, every
+    forward of the context takes ctx->lora, infer.c:721).  Replicas made AFTER the module was loaded get it attached too; a
+    batch of identical sequences dealt over two replicas returns identical logits, and they are the single-device LoRA ones."""
+    import ctypes as C
+    from nano_amd import modelfile as mf
+    path, spec = synth_model(model_dir, "tiny-nano", "f32", 0)
+    lpath = os.path.join(model_dir, "tiny-nano-lora-replicas.bin")
+    mf.write_lora(lpath, spec, rank=4, alpha=8, seed=5)
+    ids = mf.prompt_ids(77, 6, spec.vocab_size)
+    e = nb.Engine(path, max_seq_len=16, max_batch=2, lora_path=lpath)
+    e.L.nano_context_replicate.restype = C.c_int
+    e.L.nano_context_replicate.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    assert e.L.nano_context_replicate(e.ctx, (C.c_int * 1)(0), 1) == 0
+    got = []
+    for pos in range(6):
+        lg = np.empty((4, spec.vocab_size), np.float32)
+        t = np.full(4, int(ids[pos]), np.uint32); p = np.full(4, pos, np.uint32)
+        assert e.L.nano_forward_batch(e.ctx, t, p, 4, lg.ctypes.data, None) == 0
+        for b in range(1, 4):                                  # sequences 1 and 3 ran on the replica
+            assert np.array_equal(lg[b].view(np.uint32), lg[0].view(np.uint32)), (pos, b)
+        got.append(lg[0].copy())
+    e.close()
+    m = nb.load_model_file(path, max_seq_len=16, max_batch=1)
+    base = [m.forward([int(ids[pos])], [pos])[0][0].copy() for pos in range(6)]
+    m.lora_attach_file(lpath)
+    for pos in range(6):
+        lg, _ = m.forward([int(ids[pos])], [pos])
+        assert np.array_equal(lg[0].view(np.uint32), got[pos].view(np.uint32)), pos
+    assert not np.array_equal(base[5].view(np.uint32), got[5].view(np.uint32))      # the module does change the logits
+    m.close()
+
+
 def test_bench_replicas_mode_runs_without_torch(tmp_path):
     """bench.py --replicas 2: two weight replicas in ONE process (both on the one GPU of this box), driven only through the
     C engine (nano_context_replicate + nano_forward_batch); the process never imports torch.  Same tokens as one replica."""
