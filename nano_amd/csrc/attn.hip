@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             if (i == 0) { float *ml = a.ml + (((size_t)b * a.n_head + h) * nsplit + split) * 2; ml[0] = M; ml[1] = L; }
         }
     }
-    NANO_STAMP(a.stamps, 5, mrun[0]);                          // combined and stored
+    NANO_STAMP_END(a.stamps, 5);                               // combined and stored: the workgroup's last wave ends
 }
 
 template <int LPR, int QV, int MODE, bool KVH>

@@ -577,7 +577,8 @@ static GemvArgs classifier_args(const NanoHipModel *m, uint32_t nb) {
 
 static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
     GemvArgs a = classifier_args(m, nb);
-    if (ntiles_out && m->d.quant_type != NANO_QUANT_Q4K && nb <= 8 && !(takes_mfma(m, a) && gemm_q80_g2_supports(a))) {      // per-tile arg-max partials for the sampler
+    if (ntiles_out && nb <= 8 && !(takes_mfma(m, a) && gemm_q80_g2_supports(a)) &&
+        (m->d.quant_type != NANO_QUANT_Q4K || nb <= (nb > 1 ? gemv_q4k_fit_batch(a) : 1u))) {      // per-tile arg-max partials for the sampler (Q4K: not for sliced launches)
         a.tile_max = m->tile_max;
         *ntiles_out = gemv_tiles(m->d.quant_type, a);
     }
@@ -911,8 +912,10 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
         return 0;
     }
     if (m->kv_half && m->lora_on) FAIL(NANO_HIP_EINVAL, "the LoRA side branches write FP32 v rows: not available with the FP16 KV cache");
-    if (!m->use_graph || m->stamps_on) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); m->nsplit = xba_nsplit(m, nb, range_hint); return 0; }
-    const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)((m->skip_embed && mode == MODE_LOOP) ? 1 : 0) << 49) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) |
+    // (measurement builds: NANO_STAMPS_GRAPH=1 captures the stamped step too -- the stamp slots are baked into a graph of its own key)
+    static const bool stamps_graph = getenv("NANO_STAMPS_GRAPH") && *getenv("NANO_STAMPS_GRAPH") == '1';
+    if (!m->use_graph || (m->stamps_on && !stamps_graph)) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); m->nsplit = xba_nsplit(m, nb, range_hint); return 0; }
+    const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)(m->stamps_on ? 1 : 0) << 50) | ((uint64_t)((m->skip_embed && mode == MODE_LOOP) ? 1 : 0) << 49) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) |
                          ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {

@@ -22,9 +22,16 @@
 #if NANO_STAMPS
 #define NANO_STAMP(buf, k, dep) do { if ((buf) && threadIdx.x < 64) { unsigned long long t_; \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); \
-        if (threadIdx.x == 0) (buf)[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (k)] = t_; } } while (0)
+        if (threadIdx.x == 0) (buf)[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (k)] = t_; \
+        if ((k) == 0) { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); /* slot 7: the device-wide 100 MHz clock at entry */ \
+            if (threadIdx.x == 0) (buf)[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 7] = t_; } } } while (0)
+// the last instruction of a kernel, every wave: slot k = the latest shader clock at which a wave of the workgroup ended
+#define NANO_STAMP_END(buf, k) do { if (buf) { unsigned long long t_; \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if ((threadIdx.x & 63) == 0) atomicMax((buf) + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (k), t_); } } while (0)
 #else
 #define NANO_STAMP(buf, k, dep) do { } while (0)
+#define NANO_STAMP_END(buf, k) do { } while (0)
 #endif
 
 namespace nano {

@@ -16,6 +16,7 @@ hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t
 // 0 = none written, the arg-max kernel scans the logits)
 uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a) {
     if (quant == 0x80u) return gemv_q80_partials(a);
+    if (quant == 0x42u) return gemv_q4k_partials(a);
     return 0;
 }
 

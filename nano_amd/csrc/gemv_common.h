@@ -56,6 +56,11 @@ __device__ __forceinline__ float bload_f(__amdgpu_buffer_rsrc_t r, uint32_t off)
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
 
+// A kernel argument the compiler would fetch (s_load) right before its first use -- in the middle of the dependent chain, one
+// scalar-cache round trip each -- is asked for at the top of the kernel instead: every argument load is issued together and
+// waited for once, while nothing else could run anyway.
+template <class T> __device__ __forceinline__ void karg_touch(const T &v) { asm volatile("" :: "s"(v)); }
+
 enum : uint32_t { F_NORM = 1u, F_PRE = 2u, F_COMBINE = 4u };
 
 // Kernel roles.  A taken branch costs ~40 cycles and every instruction of the single wave a SIMD runs is on the
@@ -76,7 +81,7 @@ struct GemvDev {
     // wg_c0 / wg_c1 = workgroups up to the end of segment 0 / 1 (a workgroup's rows lie inside one segment)
     uint32_t tpw, magic_rw, wg_c0, wg_c1;
     const float *xin; const float *norm_w; const uint32_t *pos;
-    uint32_t xin_bstride, _pad0;
+    uint32_t xin_bstride, nthr;     // nthr = threads per workgroup (blockDim.x lives in the dispatch packet: one more scalar-cache line, read late)
     const int8_t *xq_in; const float *xs_in;
     const float *attn_part; const float *attn_ml;
     uint32_t attn_nsplit, attn_n_head, attn_hd, ntiles;
@@ -120,7 +125,7 @@ struct Staged<B, 0> {};          // NV == 0: nothing is kept in registers, stage
 template <int ROLE, int B, int NV>
 __device__ __forceinline__ void stage_issue(const GemvDev &a, Staged<B, NV> &r) {
     if constexpr (NV == 0) { (void)a; (void)r; return; } else {
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n;
+    const uint32_t tid = threadIdx.x, nthr = a.nthr, n = a.n;
     const bool plain = !has_flag<ROLE>(a, F_PRE) && !has_flag<ROLE>(a, F_COMBINE);
     const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xin, plain ? ((a.nb - 1) * a.xin_bstride + n) * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rn = mkrsrc(a.norm_w, has_flag<ROLE>(a, F_NORM) ? n * 4u : 0u);
@@ -155,15 +160,18 @@ __device__ __forceinline__ void stage_issue(const GemvDev &a, Staged<B, NV> &r) 
 }
 
 // x[b][i] = sum_s part[b][s][i] * wgt[b][head(i)][s]  (attn.hip split partials), wgt from (max, sum) pairs
-template <int B>
-__device__ __forceinline__ void combine_weights(const GemvDev &a, float *wgt /* LDS [B][n_head][8] */, bool preloaded, float pm, float pl) {
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+// PRE: the (max, sum) pair of thread (head, split) came with the kernel's first loads (pm, pl) -- one pass, no load in the
+// loop (a runtime flag left a load on the other path, and the wait the compiler put at the join was for EVERY load in flight,
+// the weights included)
+template <int B, bool PRE>
+__device__ __forceinline__ void combine_weights(const GemvDev &a, float *wgt /* LDS [B][n_head][8] */, float pm, float pl) {
+    const uint32_t tid = threadIdx.x, nthr = a.nthr;
     const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
     // thread (b, h, s<8): e_s = exp(m_s - M) / sum_s l_s exp(m_s - M); the 8 lanes of a head are one DPP half-row
     for (uint32_t t = tid; t < (uint32_t)B * nh * 8u; t += nthr) {
         const uint32_t s = t & 7u, h = (t >> 3) % nh, b = (t >> 3) / nh;
         float m = -INFINITY, l = 0.0f;
-        if (preloaded) { m = pm; l = pl; }
+        if constexpr (PRE) { m = pm; l = pl; (void)s; (void)h; (void)b; (void)ns; }
         else if (s < ns && b < a.nb) { const float *ml = a.attn_ml + (((size_t)b * nh + h) * ns + s) * 2; m = ml[0]; l = ml[1]; }
         const bool live = l > 0.0f;
         float M = live ? m : -INFINITY;
@@ -172,6 +180,7 @@ __device__ __forceinline__ void combine_weights(const GemvDev &a, float *wgt /* 
         float L = l * e;
         L += DPP_F(L, 0xB1); L += DPP_F(L, 0x4E); L += DPP_F(L, 0x141);
         wgt[t] = e / L;
+        if constexpr (PRE) break;       // every (head, split) pair has its own thread
     }
     __syncthreads();
 }

@@ -15,12 +15,12 @@ namespace {
 
 template <int ROLE, int B, int NV>
 __device__ __forceinline__ void stage_finish_f32(const GemvDev &a, Staged<B, NV> &r, float *xf, float *red, uint32_t n4) {
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n;
+    const uint32_t tid = threadIdx.x, nthr = a.nthr, n = a.n;
     const uint32_t lane = tid & 63u, wid = tid >> 6, NW = nthr >> 6;
     const bool norm = has_flag<ROLE>(a, F_NORM), comb = has_flag<ROLE>(a, F_COMBINE);
     float *wgt = red + B * 16;
     if constexpr (NV == 0) {
-        if (comb) combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+        if (comb) combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
         for (uint32_t b = 0; b < a.nb; b++) {
             const float *x = a.xin + (size_t)b * a.xin_bstride;
             float ss = 1.0f;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void stage_finish_f32(const GemvDev &a, Staged<B, NV>
         if (comb) {
             if constexpr (B == 1) {
                 const bool pre_ml = a.attn_n_head * 8u <= nthr;
-                combine_weights<B>(a, wgt, pre_ml, r.ml_m, r.ml_l);
+                if (pre_ml) combine_weights<B, true>(a, wgt, r.ml_m, r.ml_l); else combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
                     const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
@@ -67,7 +67,7 @@ __device__ __forceinline__ void stage_finish_f32(const GemvDev &a, Staged<B, NV>
                     r.x[0][j] = acc;
                 }
             } else {
-                combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+                combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
 #pragma unroll
                 for (int b = 0; b < B; b++)
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void gemv_f32_slab_kernel(const GemvDev a) {
     constexpr int TR = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = blockDim.x >> 6;
+    const int NW = (int)(a.nthr >> 6);
     const uint32_t n = a.n, n4 = (n + 3) & ~3u;
     const uint32_t nchunk = a.nchunk, PC = (nchunk + 3) & ~3u;      // a.nchunk: 256-float chunks per row
     const uint32_t RW = a.rw;
@@ -248,7 +248,8 @@ static hipError_t launch_f32_t(const GemvDev &d, const F32Plan &p, uint32_t rows
     const size_t lds = (B * n4 + B * 16 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 8 : 0) + (size_t)B * nmat * p.rw * pc) * 4;
     auto kern = &gemv_f32_slab_kernel<ROLE, B, NV, UPW>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(64 * p.nw), lds, st, d);
+    GemvDev dd = d; dd.nthr = 64 * p.nw;
+    hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(64 * p.nw), lds, st, dd);
     return hipGetLastError();
 }
 template <int ROLE, int B>

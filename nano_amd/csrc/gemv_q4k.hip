@@ -122,12 +122,12 @@ namespace {
 template <int ROLE, int B, int NV>
 __device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, float *xn, float *red, uint32_t n4, bool keep) {
     // rmsnorm / split-attention combine of the activation into xn[B][n4] (same code path as the FP32 GEMV's staging)
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n;
+    const uint32_t tid = threadIdx.x, nthr = a.nthr, n = a.n;
     const uint32_t lane = tid & 63u, wid = tid >> 6, NW = nthr >> 6;
     const bool norm = has_flag<ROLE>(a, F_NORM), comb = has_flag<ROLE>(a, F_COMBINE);
     float *wgt = red + B * 16;
     if constexpr (NV == 0) {
-        if (comb) combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+        if (comb) combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
         for (uint32_t b = 0; b < a.nb; b++) {
             const float *x = a.xin + (size_t)b * a.xin_bstride;
             float ss = 1.0f;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, flo
         if (comb) {
             if constexpr (B == 1) {
                 const bool pre_ml = a.attn_n_head * 8u <= nthr;
-                combine_weights<B>(a, wgt, pre_ml, r.ml_m, r.ml_l);
+                if (pre_ml) combine_weights<B, true>(a, wgt, r.ml_m, r.ml_l); else combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
                     const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
@@ -174,7 +174,7 @@ __device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, flo
                     r.x[0][j] = acc;
                 }
             } else {
-                combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+                combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
 #pragma unroll
                 for (int b = 0; b < B; b++)
 #pragma unroll
@@ -234,7 +234,7 @@ __device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, flo
 template <int B, int NV>
 __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged<B, NV> &r, XGroup *xg) {
     if constexpr (NV == 0) { (void)a; (void)r; (void)xg; } else {
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n, GT = (n >> 8) * 8u;
+    const uint32_t tid = threadIdx.x, nthr = a.nthr, n = a.n, GT = (n >> 8) * 8u;
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
@@ -299,7 +299,7 @@ __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged
 // tensor.c:281-310 + 144-242), all blocks at once: phase 1 = one thread per element, phase 2 = one thread per group.
 // tmp: [B][bpl][16] floats (group scales, group biases).  Ends with a barrier.
 __device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *xn, XGroup *xg, float *tmp, uint32_t n4, int nbq) {
-    const int n = (int)a.n, tid = threadIdx.x, nthr = blockDim.x;
+    const int n = (int)a.n, tid = threadIdx.x, nthr = (int)a.nthr;
     const int bpl = (n + 255) / 256, GT = bpl * 8;
     // phase 1: a thread owns FOUR consecutive elements (one 16-byte LDS read; the four divisions are independent), a
     // 32-element group = 8 consecutive lanes (three DPP steps for min / max / nibble sum)
@@ -357,7 +357,7 @@ __device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *x
 __device__ __forceinline__ void unpack_q4k_wg(const GemvDev &a, XGroup *xg) {
     const int n = (int)a.n, GT = ((n + 255) / 256) * 8;
     const uint8_t *x4 = reinterpret_cast<const uint8_t *>(a.xq_in);
-    for (int gg = threadIdx.x; gg < GT; gg += blockDim.x) {
+    for (int gg = threadIdx.x; gg < GT; gg += (int)a.nthr) {
         const uint8_t *blk = x4 + (size_t)(gg >> 3) * 160;
         const int g = gg & 7;
         const float s_scale = *reinterpret_cast<const float *>(blk + 12), s_bias = *reinterpret_cast<const float *>(blk + 16);
@@ -385,7 +385,7 @@ __device__ __forceinline__ uint4 bload_u4(__amdgpu_buffer_rsrc_t r, uint32_t off
 template <int ROLE, int B, int NV, int IPT>
 __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x, nthr = (int)a.nthr;
     const uint32_t n = a.n, n4 = (n + 3) & ~3u;
     const uint32_t bpl = (n + 255) / 256, GT = bpl * 8, GTP = GT + 4;        // row pitch of the product table: 16-byte aligned rows
     const uint32_t RW = a.rw;
@@ -399,6 +399,11 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     float *red = tmp + B * bpl * 16;
     float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);
 
+    // late-read arguments are fetched with the first ones (karg_touch, gemv_common.h)
+    karg_touch(a.out[0]); karg_touch(a.out_bstride[0]); karg_touch(a.out_pstride[0]); karg_touch(a.nb); karg_touch(a.magic_nchunk); karg_touch(a.log2_tiles);
+    if (!swiglu) { karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.out_bstride[1]); karg_touch(a.out_bstride[2]); karg_touch(a.out_pstride[1]); karg_touch(a.out_pstride[2]); }
+    karg_touch(a.pos);
+    if (ROLE == R_GENERIC || ROLE == R_RESID || ROLE == R_RESID_COMBINE) { karg_touch(a.resid_add); karg_touch(a.resid_add_bstride); }
     NANO_STAMP(a.stamps, 0, tid);
     Staged<B, NV> sx;
     stage_issue<ROLE, B, NV>(a, sx);
@@ -421,15 +426,24 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
         const uint32_t it = (uint32_t)tid + (uint32_t)k * nthr;
-        const uint32_t gg = it % GT, rr = it / GT;                    // rr = mat * RW + local row
-        const uint32_t mat = rr >= RW ? 1u : 0u, rl = rr - mat * RW;
-        const uint32_t boff = (it < items) ? ((lrow0 + rl) * bpl + (gg >> 3)) * 160u : OOB;   // rows beyond the segment: out of range -> 0
-        const bool m1 = mat != 0;
-        nibv[k] = m1 ? bload_u4(rw1, boff == OOB ? OOB : boff + 32u + (gg & 7u) * 16u, true) : bload_u4(rw0, boff == OOB ? OOB : boff + 32u + (gg & 7u) * 16u, true);
-        h0v[k] = m1 ? bload_u4(rw1, boff, false) : bload_u4(rw0, boff, false);
-        h1v[k] = m1 ? bload_u4(rw1, boff == OOB ? OOB : boff + 16u, false) : bload_u4(rw0, boff == OOB ? OOB : boff + 16u, false);
+        const uint32_t rr = __umulhi(it, a.magic_nchunk), gg = it - rr * GT;   // it / GT, it % GT (magic_nchunk = ceil(2^32 / GT) here); rr = mat * RW + local row
+        // Which matrix: only the SwiGLU launch has two, and when a matrix's items fill whole waves (RW x GT a multiple of 64:
+        // a.units = 1, set by the launcher) the choice is wave-uniform.  Said to the compiler (readfirstlane), the descriptor
+        // is picked with scalar selects; left per-lane it becomes a waterfall loop around each of the three loads -- and the
+        // register reuse between them put a full s_waitcnt vmcnt(0) in the middle of the issue phase (round 3: ~1 us per launch).
+        auto issue_item = [&](const uint32_t mat) __attribute__((always_inline)) {
+            const uint32_t rl = rr - mat * RW;
+            const uint32_t boff = (it < items) ? ((lrow0 + rl) * bpl + (gg >> 3)) * 160u : OOB;   // rows beyond the segment: out of range -> 0
+            const bool m1 = mat != 0;
+            nibv[k] = m1 ? bload_u4(rw1, boff == OOB ? OOB : boff + 32u + (gg & 7u) * 16u, true) : bload_u4(rw0, boff == OOB ? OOB : boff + 32u + (gg & 7u) * 16u, true);
+            h0v[k] = m1 ? bload_u4(rw1, boff, false) : bload_u4(rw0, boff, false);
+            h1v[k] = m1 ? bload_u4(rw1, boff == OOB ? OOB : boff + 16u, false) : bload_u4(rw0, boff == OOB ? OOB : boff + 16u, false);
+        };
+        if (!swiglu) issue_item(0u);
+        else if (a.units) issue_item((uint32_t)__builtin_amdgcn_readfirstlane((int)(rr >= RW ? 1u : 0u)));
+        else issue_item(rr >= RW ? 1u : 0u);
     }
-    uint32_t lrw = 0; while ((1u << lrw) < RW) lrw++;
+    const uint32_t lrw = a.log2_tiles;                                // log2(RW) here
     const int fb = tid >> lrw, frl = tid & ((int)RW - 1);
     const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
     // the position of a pos-indexed output (v-cache row) is fetched now and used only by the final store: no wait
@@ -457,8 +471,11 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     for (int k = 0; k < IPT; k++) {
         const uint32_t it = (uint32_t)tid + (uint32_t)k * nthr;
         if (it < items) {
-            const uint32_t gg = it % GT, rr = it / GT, g = gg & 7u;
+            const uint32_t rr = __umulhi(it, a.magic_nchunk), gg = it - rr * GT, g = gg & 7u;
             const uint4 nib = nibv[k];
+            // the header words nobody reads stay "live" up to here: declared dead at the load, their registers were handed to the
+            // next load's address -- which then had to wait (s_waitcnt vmcnt(0)) for the load in flight to write them
+            asm volatile("" :: "v"(h0v[k].x), "v"(h0v[k].z));
             const float s_scale = __uint_as_float(h0v[k].w);
             const int len = (int)h0v[k].y;
             uint32_t s6, b6;
@@ -522,9 +539,25 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
             res[mat] = line;
         }
         // write-through (sc1) store, see gemv_q80_impl.h: nothing is left for the write-back at the end of the kernel
-        if (fold_live) __hip_atomic_store(out0 + (size_t)fb * obs + (size_t)opos * ops + lrow0 + frl, finish_epi(epi, has_add ? res[0] + addv : res[0], res[1], oldv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        NANO_STAMP(a.stamps, 6, res[0]);
+        const float val = finish_epi(epi, has_add ? res[0] + addv : res[0], res[1], oldv);
+        if (fold_live) __hip_atomic_store(out0 + (size_t)fb * obs + (size_t)opos * ops + lrow0 + frl, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // classifier launches (one STORE segment): this workgroup's (max, first row) arg-max partial per sequence, so that the
+        // arg-max kernel scans gridDim.x pairs instead of every logit (the Q80 STREAM kernel's tile_max, gemv_q80_impl.h)
+        if (a.tile_max) {
+            float bv = fold_live ? val : -INFINITY;
+            uint32_t bi = fold_live ? lrow0 + (uint32_t)frl : 0xffffffffu;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                if (o < (int)RW) {                                       // the RW fold threads of a sequence are RW consecutive lanes
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const uint32_t oi = __shfl_xor(bi, o, 64);
+                    if (oi != 0xffffffffu && (bi == 0xffffffffu || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                }
+            }
+            if (frl == 0 && fb < (int)a.nb) { float *tm = a.tile_max + ((size_t)fb * a.ntiles + blockIdx.x) * 2; tm[0] = bv; tm[1] = __uint_as_float(bi); }
+        }
     }
+    NANO_STAMP_END(a.stamps, 6);
 }
 
 struct Q4kPlan { uint32_t rw, nthr, ipt, nv; };
@@ -547,6 +580,8 @@ static Q4kPlan plan_q4k(const GemvArgs &a, int B) {
     static const uint32_t cap_small = getenv("NANO_Q4K_ITEMS_SMALL") ? (uint32_t)strtoul(getenv("NANO_Q4K_ITEMS_SMALL"), nullptr, 0) : 0u;   // ... (per-layer matrices of small models),
     static const uint32_t nthr_max = getenv("NANO_Q4K_NTHR") ? (uint32_t)strtoul(getenv("NANO_Q4K_NTHR"), nullptr, 0) : 512u;                 // ... threads per workgroup
     if (cap_small && !large && rows < 16384) cap = cap_small;
+    static const uint32_t cap_swiglu = getenv("NANO_Q4K_ITEMS_SWIGLU") ? (uint32_t)strtoul(getenv("NANO_Q4K_ITEMS_SWIGLU"), nullptr, 0) : 0u;   // ... of the two-matrix launch alone
+    if (!large && nmat == 2 && rows < 16384) cap = cap_swiglu ? cap_swiglu : 1024u;     // measured (Qwen3-0.6B W1|W3): 384 workgroups of 512 items 1542 tok/s, 192 of 1024: 1595
     while (rw < 64 && (align % (rw * 2)) == 0 && (rw * 2) * GT * nmat <= cap && rows / (rw * 2) >= 128) rw *= 2;
     for (;; rw /= 2) {
         const uint32_t items = rw * GT * nmat;
@@ -575,7 +610,10 @@ static hipError_t launch_q4k_t(const GemvDev &d, const Q4kPlan &p, uint32_t rows
     if (lds > 160 * 1024) return hipErrorInvalidValue;                 // gemv_q4k_fit_batch() tells the caller how many sequences fit
     auto kern = &gemv_q4k_slab_kernel<ROLE, B, NV, IPT>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(p.nthr), lds, st, d);
+    GemvDev dd = d; dd.nthr = p.nthr;
+    { const uint32_t GT = ((d.n + 255) / 256) * 8; dd.magic_nchunk = (uint32_t)(((1ull << 32) + GT - 1) / GT); dd.log2_tiles = 0; while ((1u << dd.log2_tiles) < p.rw) dd.log2_tiles++;
+      dd.units = ((p.rw * GT) % 64u == 0u && p.nthr % 64u == 0u) ? 1u : 0u; }   // kernel: item -> (row, group), thread -> (sequence, row)
+    hipLaunchKernelGGL(kern, dim3((rows + p.rw - 1) / p.rw), dim3(p.nthr), lds, st, dd);
     return hipGetLastError();
 }
 template <int ROLE, int B>
@@ -594,15 +632,26 @@ static hipError_t launch_q4k_r(const GemvDev &d, const Q4kPlan &p, uint32_t rows
     return hipErrorInvalidValue;
 #undef Q4K_GO
 }
+}  // namespace
+// (max, row) arg-max partials a STORE launch with tile_max writes per sequence: one per workgroup of a one-segment launch
+// (the classifier); 0 = none, the arg-max kernel scans the logits
+uint32_t gemv_q4k_partials(const GemvArgs &a) {
+    if (!a.tile_max || a.epi != GEMV_EPI_STORE || a.nseg != 1 || a.nb == 0 || a.nb > 8 || a.seg[0].out_pstride) return 0;
+    const int B = a.nb <= 1 ? 1 : a.nb <= 2 ? 2 : a.nb <= 4 ? 4 : 8;
+    const Q4kPlan p = plan_q4k(a, B);
+    return (a.seg[0].rows + p.rw - 1) / p.rw;
+}
+namespace {
 template <int B>
 static hipError_t launch_q4k_b(const GemvArgs &a, hipStream_t st) {
     GemvDev d = to_dev(a);
-    d.tile_max = nullptr;
     if (a.x4_in) { d.flags |= F_PRE; d.xq_in = reinterpret_cast<const int8_t *>(a.x4_in); }
     const Q4kPlan p = plan_q4k(a, B);
     d.rw = p.rw;
     uint32_t rows = 0;
     if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
+    d.ntiles = gemv_q4k_partials(a);                                // arg-max partials: one per workgroup (0: none)
+    if (!d.ntiles || d.ntiles != (rows + p.rw - 1) / p.rw) { d.tile_max = nullptr; d.ntiles = 0; }
     if constexpr (B == 1) {
         const uint32_t f = d.flags;
         if (f == F_NORM && d.epi == GEMV_EPI_STORE) return launch_q4k_r<R_NORM_STORE, B>(d, p, rows, st);

@@ -50,7 +50,7 @@ __device__ __forceinline__ void quant_store4(float4 v, float scale, int8_t *dst)
 
 template <int ROLE, int GS, int B, int NV>
 __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r, int8_t *xq, float *xs, float *red, uint32_t n16, uint32_t ng4) {
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, n = a.n, ng = a.ng;
+    const uint32_t tid = threadIdx.x, nthr = a.nthr, n = a.n, ng = a.ng;
     const uint32_t lane = tid & 63u, wid = tid >> 6, NW = nthr >> 6;
     if (has_flag<ROLE>(a, F_PRE)) { // the activations arrive quantized: xq_in[nb][n16], xs_in[nb][ng] (operator tests; large
                                     // batch x row-length products, where quant_rows_kernel quantizes ONCE instead of once per workgroup)
@@ -64,7 +64,7 @@ __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r,
     const bool norm = has_flag<ROLE>(a, F_NORM), comb = has_flag<ROLE>(a, F_COMBINE);
     float *wgt = red + B * 16;
     if constexpr (NV == 0) {
-        if (comb) combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+        if (comb) combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
         // generic path (large n x B): two passes over memory per sequence
         for (uint32_t b = 0; b < a.nb; b++) {
             const float *x = a.xin + (size_t)b * a.xin_bstride;
@@ -102,7 +102,7 @@ __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r,
         if (comb) {
             if constexpr (B == 1) {
                 const bool pre_ml = a.attn_n_head * 8u <= nthr;       // every (head, split) pair has its own thread
-                combine_weights<B>(a, wgt, pre_ml, r.ml_m, r.ml_l);
+                if (pre_ml) combine_weights<B, true>(a, wgt, r.ml_m, r.ml_l); else combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
 #pragma unroll
                 for (int j = 0; j < NV; j++) {
                     const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r,
                     r.x[0][j] = acc;
                 }
             } else {
-                combine_weights<B>(a, wgt, false, 0.0f, 0.0f);
+                combine_weights<B, false>(a, wgt, 0.0f, 0.0f);
 #pragma unroll
                 for (int b = 0; b < B; b++)
 #pragma unroll
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     constexpr int NS = (TR + LPG - 1) / LPG;               // rows a lane owns after the group reduction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = blockDim.x >> 6;
+    const int NW = (int)(a.nthr >> 6);
     const uint32_t n = a.n, ng = a.ng;
     const uint32_t n16 = (n + 15) & ~15u, ng4 = (ng + 3) & ~3u;
     const uint32_t PITCH = (GC == 16) ? (((ng + 47) / 64) * 64 + 16) : (ng4 + 4);
@@ -218,6 +218,15 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     float *red = xs + B * ng4;                                     // [B][16] (+ combine weights [B][n_head][8])
     float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);   // [B][nmat][RWP][PITCH]
 
+    // every argument the chain below reads late (output slots, strides, positions, the residual addend) is fetched NOW, with
+    // the first ones (karg_touch, gemv_common.h)
+    karg_touch(a.out[0]); karg_touch(a.out_bstride[0]); karg_touch(a.out_pstride[0]); karg_touch(a.rows[0]); karg_touch(a.magic_rw); karg_touch(a.nb);
+    if (!(ROLE == R_RESID || ROLE == R_RESID_COMBINE || ROLE == R_NORM_SWIGLU)) {
+        karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.out_bstride[1]); karg_touch(a.out_bstride[2]);
+        karg_touch(a.out_pstride[1]); karg_touch(a.out_pstride[2]); karg_touch(a.rows[1]); karg_touch(a.rows[2]);
+    }
+    karg_touch(a.pos);
+    if (ROLE == R_GENERIC || ROLE == R_RESID || ROLE == R_RESID_COMBINE) { karg_touch(a.resid_add); karg_touch(a.resid_add_bstride); }
     NANO_STAMP(a.stamps, 0, tid);
     // ---- 1. activation loads (critical path) ------------------------------------------------------------
     Staged<B, NV> sx;
@@ -371,11 +380,11 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
             const float val = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
             // WRITE-THROUGH (sc1) store: the result leaves the XCD's L2 now instead of in the write-back at the end of the kernel, which
             // the next kernel's start waits for (round 3, measured: 1807 -> 1836 tok/s at positions 20..39, 1681 -> 1718 over 31..510;
-            // NANO_DBG bit 4 restores the plain store for A/B runs)
-            if (a.dbg & 4u) *dst = val; else __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // measurement builds: NANO_DBG bit 4 restores the plain store for A/B runs)
+            if (NANO_STAMPS && (a.dbg & 4u)) *dst = val; else __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        NANO_STAMP(a.stamps, 6, v0);                                // folded and stored
     }
+    NANO_STAMP_END(a.stamps, 6);                                    // folded and stored: the workgroup's last wave ends
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -607,7 +616,8 @@ static hipError_t launch_slab_t(const GemvDev &d, const SlabPlan &p, uint32_t nw
     const size_t lds = B * n16 + B * ng4 * 4 + B * 64 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 32 : 0) + (size_t)B * nmat * (d.tpw * 4) * pitch * 4;
     auto kern = &gemv_q80_slab_kernel<ROLE, GS, B, NV, UPW>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * p.nw), lds, st, d);
+    GemvDev dd = d; dd.nthr = 64 * p.nw;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * p.nw), lds, st, dd);
     return hipGetLastError();
 }
 template <int ROLE, int GS, int B>
@@ -654,7 +664,7 @@ static hipError_t launch_slab_b(GemvDev &d, const GemvArgs &a, hipStream_t st) {
 
 template <int ROLE, int GS, int B>
 static hipError_t launch_stream_r(GemvDev &d, hipStream_t st) {
-    d.ntiles = STREAM_WGS * 4;
+    d.ntiles = STREAM_WGS * 4; d.nthr = 256;
     const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u;
     const size_t lds = B * n16 + B * ng4 * 4 + B * 64 + 4 * 16 * (1024 / GS) * 4;
     const uint32_t nv = (d.n + 1023) / 1024;

@@ -76,6 +76,7 @@ hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const floa
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                              int8_t *xq, float *xs, hipStream_t st);
 uint32_t gemv_q80_partials(const GemvArgs &a);
+uint32_t gemv_q4k_partials(const GemvArgs &a);   // Q4K: one (max, row) partial per workgroup of a one-segment STORE launch with tile_max
 
 // ---- attention ------------------------------------------------------------------------------------
 constexpr uint32_t ATTN_MAX_NSPLIT = 32, ATTN_WIDE_FROM = 2048;   // up to 32 splits of a range beyond 2048 positions (<= 8 below: attention_nsplit())

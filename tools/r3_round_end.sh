@@ -38,6 +38,7 @@ prof() {   # prof TAG bench-args... : eager kernel-trace stats of a short bench 
 pmc() {    # pmc TAG "COUNTERS" cmd... : counters in a pass of their own (kernel-trace only), mean per kernel + mean duration
   tag=$1; ctr=$2; shift; shift
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_$tag && NANO_HIP_NO_GRAPH=1 timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$tag -o p -- "$@" > /tmp/pmc_$tag.log 2>&1 ) || tail -3 /tmp/pmc_$tag.log
+  grep -v "rocprofv3\|^[EWI][0-9]" /tmp/pmc_$tag.log | tail -8 > $O/${T}_${tag}_pmc_log.txt
   f=$(find /tmp/pmc_$tag -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" > $O/${T}_${tag}_pmc.txt <<'PY'
 import csv, sys, collections

@@ -6,8 +6,11 @@ launch of ONE eager decode step, from the measurement build of the library:
     NANO_LIB=nano_amd/lib/libnano_mi355x_stamps.so python tools/stamp_probe.py [model] [quant] [batch] [pos]
 
 Prints, per launch kind (averaged over the layers): workgroups and the mean / max over workgroups of each phase of a
-workgroup's first wave, in microseconds at an assumed 2.1 GHz shader clock (NANO_STAMP_GHZ).  The clock is per XCD, so only
-differences inside one workgroup are meaningful."""
+workgroup's first wave, in microseconds at an assumed 2.1 GHz shader clock (NANO_STAMP_GHZ).  The shader clock is per XCD, so only
+differences inside one workgroup are meaningful; the last phase ends when the workgroup's LAST wave ends.  A second line per
+kind places the launch on the device-wide 100 MHz clock (s_memrealtime at a workgroup's entry, 10 ns steps): ramp = first ->
+last workgroup entry, span = first entry -> last workgroup end, gap = this launch's last end -> the next launch's first entry
+(eager launches: the gap of a graph replay is shorter)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,11 +34,20 @@ for p in range(0, pos):                                     # some KV history (v
 names = {1: "qkv", 2: "attention", 3: "wo", 4: "w1w3", 5: "w2"}
 phases = {1: ["issue", "x arrives(+norm sum)", "quantize", "w arrive+dots", "barrier", "fold+store"], 2: ["issue", "q/k norm+rope", "KV+softmax", "partials", "combine+store"]}
 agg = {}
-for rep in range(3):
+tl = {}
+GRAPH = os.environ.get("NANO_STAMPS_GRAPH") == "1"          # stamp a graph replay instead of eager launches
+for rep in range(1 if GRAPH else 3):
     m.stamps_begin()
-    m.forward([1] * B, [pos] * B, want_logits=False)
-    st, kinds = m.stamps_read()
-    if rep == 0:
+    if GRAPH:
+        for _ in range(2):                                  # eager first use + capture, then ONE replay into the captured slots (the
+                                                            # end stamps are maxima and a workgroup's XCD, hence its clock, changes per replay)
+            m.forward([1] * B, [pos] * B, want_logits=False)
+        st, kinds = m.stamps_read()
+        st, kinds = st[len(kinds) // 2:], kinds[len(kinds) // 2:]
+    else:
+        m.forward([1] * B, [pos] * B, want_logits=False)
+        st, kinds = m.stamps_read()
+    if rep == 0 and not GRAPH:
         continue                                            # first eager step: warm-up
     for i in range(len(kinds)):
         k = int(kinds[i]); s = st[i].astype(np.int64)
@@ -50,11 +62,20 @@ for rep in range(3):
         d = np.diff(s[:, :nph + 1], axis=1)[ok] / (GHZ * 1e3)
         tot = (ends[ok] - s[ok, 0]) / (GHZ * 1e3)
         agg.setdefault(k, []).append((live.sum(), d.mean(axis=0), d.max(axis=0), tot.mean(), tot.max()))
-print(f"{model} {quant} batch {B} position {pos}: phase stamps, microseconds at {GHZ} GHz (mean over workgroups / max), averaged over layers and 2 steps")
+        rt0 = s[ok, 7] / 100.0                              # us, device-wide clock
+        rt1 = rt0 + tot
+        nxt = None
+        for j in range(i + 1, len(kinds)):                  # the next stamped launch's first entry
+            sj = st[j].astype(np.int64); lj = sj[:, 0] > 0
+            if lj.any():
+                nxt = sj[lj, 7].min() / 100.0; break
+        tl.setdefault(k, []).append((rt0.max() - rt0.min(), rt1.max() - rt0.min(), (nxt - rt1.max()) if nxt is not None else np.nan))
+print(f"{model} {quant} batch {B} position {pos} ({'graph replay' if GRAPH else 'eager launches'}): phase stamps, microseconds at {GHZ} GHz (mean over workgroups / max), averaged over layers and 2 steps")
 for k in sorted(agg):
     rows = agg[k]
     wg = np.mean([r[0] for r in rows])
     mean = np.mean([r[1] for r in rows], axis=0); mx = np.mean([r[2] for r in rows], axis=0)
     print(f"{names.get(k, k):10s} wgs {wg:6.0f}  entry -> end of a workgroup's first wave: mean {np.mean([r[3] for r in rows]):5.2f}  max {np.mean([r[4] for r in rows]):5.2f}")
     print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(phases[1 if k != 2 else 2], mean, mx)))
+    t = np.array(tl[k]); print(f"           device clock: entry ramp {t[:, 0].mean():.2f}  span {t[:, 1].mean():.2f}  gap to the next launch {np.nanmean(t[:, 2]):.2f}")
 m.close()
