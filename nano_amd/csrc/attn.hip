@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
                 float mx = fabsf(val);
 #pragma unroll
                 for (int o2 = 1; o2 < 64; o2 <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
-                const float scale = mx / 127.0f;
+                const float scale = div_const<127>(mx);
                 const uint32_t e = h * hd + i, g = e >> 6, jj = e & 63u, ng = a.q_dim >> 6;
                 const size_t gb = (size_t)(b >> 4) * ng + g;
                 a.xf_out[gb * 1024u + (size_t)((jj >> 4) * 16u + (b & 15u)) * 16u + (jj & 15u)] = (int8_t)q80_quant1(val, scale);
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(128) void attn_combine_tokens_kernel(const float *p
             float mx = fabsf(acc);
 #pragma unroll
             for (int o2 = 1; o2 < 64; o2 <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
-            const float scale = mx / 127.0f;
+            const float scale = div_const<127>(mx);
             const uint32_t el = h * hd + i, g = el >> 6, jj = el & 63u, ng = q_dim >> 6;
             const size_t gb = (size_t)(b >> 4) * ng + g;
             xf_out[gb * 1024u + (size_t)((jj >> 4) * 16u + (b & 15u)) * 16u + (jj & 15u)] = (int8_t)q80_quant1(acc, scale);

@@ -16,11 +16,12 @@
 // Phase stamps (measurement builds only: make stamps -> libnano_mi355x_stamps.so, tools/stamp_probe.py).  In the product build
 // NANO_STAMPS is 0 and every stamp site compiles to nothing.  A stamp is the shader clock (s_memtime) read by the first wave
 // of a workgroup; `dep` ties the read behind the value it is meant to follow (the compiler cannot hoist it above the wait).
+// NANO_STAMPS == 2 keeps only the entry stamp (slots 0 and 7) and the end stamp: the product's own schedule, timed.
 #ifndef NANO_STAMPS
 #define NANO_STAMPS 0
 #endif
 #if NANO_STAMPS
-#define NANO_STAMP(buf, k, dep) do { if ((buf) && threadIdx.x < 64) { unsigned long long t_; \
+#define NANO_STAMP(buf, k, dep) do { if ((NANO_STAMPS == 1 || (k) == 0) && (buf) && threadIdx.x < 64) { unsigned long long t_; \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); \
         if (threadIdx.x == 0) (buf)[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (k)] = t_; \
         if ((k) == 0) { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); /* slot 7: the device-wide 100 MHz clock at entry */ \
@@ -35,6 +36,20 @@
 #endif
 
 namespace nano {
+
+// ---- x / C for the quantizers' constant divisors (15, 63, 127) -----------------------------------------
+// Three operations (multiply by RN(1/C), exact remainder by FMA, one correction) instead of the ~12 of the IEEE division
+// expansion.  The result is the correctly rounded quotient -- bit-identical to x / C -- for EVERY finite float x (denormals
+// included; kernels run with denormals on) except x = -0, which gives +0: checked exhaustively over all 2^32 bit patterns on
+// the host for C = 15, 63, 127 (tools/div_const_check.c; the quantizers only divide maxima, which are never -0).
+template <int C>
+__device__ __forceinline__ float div_const(float x) {
+    static_assert(C == 15 || C == 63 || C == 127, "checked constants only");
+    constexpr float rc = 1.0f / (float)C;
+    const float q0 = x * rc;
+    const float r = __builtin_fmaf(-q0, (float)C, x);
+    return __builtin_fmaf(r, rc, q0);
+}
 
 // ---- cross-lane --------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const float *x, uint32_
         }
         float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         m = dpp_group_max<GS / 4>(m);
-        const float scale = m / 127.0f;
+        const float scale = div_const<127>(m);
         const int q0 = q80_quant1(v.x, scale), q1 = q80_quant1(v.y, scale), q2 = q80_quant1(v.z, scale), q3 = q80_quant1(v.w, scale);
         *reinterpret_cast<uint32_t *>(xq + (size_t)t * n16 + i) =
             (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void quant_rows_frag_kernel(const float *x, ui
     float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     mx = dpp_group_max<GS / 4>(mx);                       // n % GS == 0 and 1024 % GS == 0: groups are whole
     if (!live) return;
-    const float scale = mx / 127.0f;
+    const float scale = div_const<127>(mx);
     const int q0 = q80_quant1(v.x, scale), q1 = q80_quant1(v.y, scale), q2 = q80_quant1(v.z, scale), q3 = q80_quant1(v.w, scale);
     const uint32_t g = i / GS, j = i % GS;                                  // byte j of group g
     const uint32_t ks = GS >= 64 ? j / 64u : 0u, jj = GS >= 64 ? j % 64u : j, kq = jj / KB, b = jj % KB;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                         while (lds_load_acq(gcnt + t) != 4u) __builtin_amdgcn_s_sleep(1);
                         const float g4 = fmaxf(fmaxf(gmax[(t * 4u + 0u) * 16u + m], gmax[(t * 4u + 1u) * 16u + m]),
                                                fmaxf(gmax[(t * 4u + 2u) * 16u + m], gmax[(t * 4u + 3u) * 16u + m]));
-                        const float scale = g4 / 127.0f;
+                        const float scale = div_const<127>(g4);
                         const uint32_t packed = (uint32_t)(q80_quant1(val[0], scale) & 0xff) | ((uint32_t)(q80_quant1(val[1], scale) & 0xff) << 8) |
                                                 ((uint32_t)(q80_quant1(val[2], scale) & 0xff) << 16) | ((uint32_t)(q80_quant1(val[3], scale) & 0xff) << 24);
                         if (tok < a.nb) {

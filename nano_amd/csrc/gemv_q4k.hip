@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t q4k_quantize_block_coop(float v, bool valid,
         lo = fminf(lo, __shfl_xor(lo, o, 64));
         hi = fmaxf(hi, __shfl_xor(hi, o, 64));
     }
-    const float gsc = (lo <= 0.0f) ? ((hi - lo) / 15.0f) : (hi / 15.0f);
+    const float gsc = (lo <= 0.0f) ? div_const<15>(hi - lo) : div_const<15>(hi);
     const float gbi = (lo <= 0.0f) ? (-lo) : 0.0f;
     uint32_t nib = 0;
     if (valid && gsc != 0.0f) nib = (uint32_t)(nearest_int_magic((v + gbi) / gsc) & 0x0f);
@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t q4k_quantize_block_coop(float v, bool valid,
     float smax = FLT_TRUE_MIN, bmax = FLT_TRUE_MIN;
 #pragma unroll
     for (int k = 0; k < 8; k++) { if (tmp[k] > smax) smax = tmp[k]; if (tmp[8 + k] > bmax) bmax = tmp[8 + k]; }
-    const float s_scale = smax / 63.0f, s_bias = bmax / 63.0f;
+    const float s_scale = div_const<63>(smax), s_bias = div_const<63>(bmax);
     uint32_t s6[8], b6[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -249,7 +249,7 @@ __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged
                 lo = fminf(lo, DPP_F(lo, 0xB1)); hi = fmaxf(hi, DPP_F(hi, 0xB1));
                 lo = fminf(lo, DPP_F(lo, 0x4E)); hi = fmaxf(hi, DPP_F(hi, 0x4E));
                 lo = fminf(lo, DPP_F(lo, 0x141)); hi = fmaxf(hi, DPP_F(hi, 0x141));
-                const float gsc = (lo <= 0.0f) ? ((hi - lo) / 15.0f) : (hi / 15.0f);
+                const float gsc = (lo <= 0.0f) ? div_const<15>(hi - lo) : div_const<15>(hi);
                 const float gbi = (lo <= 0.0f) ? (-lo) : 0.0f;
                 uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
                 if (gsc != 0.0f) {
@@ -277,7 +277,7 @@ __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged
                     const float s0 = __uint_as_float(rs_[0]), s1 = __uint_as_float(rs_[1]), b0 = __uint_as_float(rb_[0]), b1 = __uint_as_float(rb_[1]);
                     smax = (s1 > s0) ? s1 : s0; bmax = (b1 > b0) ? b1 : b0;
                 }
-                const float s_scale = smax / 63.0f, s_bias = bmax / 63.0f;
+                const float s_scale = div_const<63>(smax), s_bias = div_const<63>(bmax);
                 const uint32_t s6 = (s_scale == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(gsc / s_scale) & 0x3f);
                 const uint32_t b6 = (s_bias == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(gbi / s_bias) & 0x3f);
                 if (valid) {
@@ -318,7 +318,7 @@ __device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *x
         lo = fminf(lo, DPP_F(lo, 0xB1)); hi = fmaxf(hi, DPP_F(hi, 0xB1));
         lo = fminf(lo, DPP_F(lo, 0x4E)); hi = fmaxf(hi, DPP_F(hi, 0x4E));
         lo = fminf(lo, DPP_F(lo, 0x141)); hi = fmaxf(hi, DPP_F(hi, 0x141));
-        const float gsc = (lo <= 0.0f) ? ((hi - lo) / 15.0f) : (hi / 15.0f);
+        const float gsc = (lo <= 0.0f) ? div_const<15>(hi - lo) : div_const<15>(hi);
         const float gbi = (lo <= 0.0f) ? (-lo) : 0.0f;
         uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
         if (valid && gsc != 0.0f) {
@@ -343,7 +343,7 @@ __device__ __forceinline__ void quantize_q4k_wg(const GemvDev &a, const float *x
         float smax = FLT_TRUE_MIN, bmax = FLT_TRUE_MIN, sg = sv[0], bg = bv[0];
 #pragma unroll
         for (int k = 0; k < 8; k++) { if (sv[k] > smax) smax = sv[k]; if (bv[k] > bmax) bmax = bv[k]; sg = (k == g) ? sv[k] : sg; bg = (k == g) ? bv[k] : bg; }
-        const float s_scale = smax / 63.0f, s_bias = bmax / 63.0f;
+        const float s_scale = div_const<63>(smax), s_bias = div_const<63>(bmax);
         const uint32_t s6 = (s_scale == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(sg / s_scale) & 0x3f);
         const uint32_t b6 = (s_bias == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(bg / s_bias) & 0x3f);
         XGroup *o = xg + (size_t)b * GT + gg;

@@ -92,7 +92,7 @@ __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r,
                 }
                 float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                 m = dpp_group_max<GS / 4>(m);
-                const float scale = m / 127.0f;
+                const float scale = div_const<127>(m);
                 quant_store4(v, scale, xq + b * n16 + i);
                 if ((tid % (GS / 4)) == 0) xs[b * ng4 + i / GS] = scale;
             }
@@ -163,7 +163,7 @@ __device__ __forceinline__ void stage_finish(const GemvDev &a, Staged<B, NV> &r,
                 }
                 float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                 m = dpp_group_max<GS / 4>(m);
-                const float scale = m / 127.0f;
+                const float scale = div_const<127>(m);
                 if (i < n) {
                     quant_store4(v, scale, xq + b * n16 + i);
                     if ((tid % (GS / 4)) == 0) xs[b * ng4 + i / GS] = scale;

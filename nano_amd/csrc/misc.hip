@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void quantize_q80_kernel(const float *x, uint3
         float4 v = act ? *reinterpret_cast<const float4 *>(x + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         m = group_max(m, tpg);
-        const float scale = m / 127.0f;
+        const float scale = div_const<127>(m);
         if (act) {
             q[i] = (int8_t)q80_quant1(v.x, scale); q[i + 1] = (int8_t)q80_quant1(v.y, scale);
             q[i + 2] = (int8_t)q80_quant1(v.z, scale); q[i + 3] = (int8_t)q80_quant1(v.w, scale);

@@ -36,6 +36,7 @@ phases = {1: ["issue", "x arrives(+norm sum)", "quantize", "w arrive+dots", "bar
 agg = {}
 tl = {}
 GRAPH = os.environ.get("NANO_STAMPS_GRAPH") == "1"          # stamp a graph replay instead of eager launches
+LIGHT = os.environ.get("NANO_STAMPS_LIGHT") == "1"          # library built with STAMPS=2: entry / end stamps only
 for rep in range(1 if GRAPH else 3):
     m.stamps_begin()
     if GRAPH:
@@ -59,6 +60,8 @@ for rep in range(1 if GRAPH else 3):
         ends = s[:, nph]
         ok = ends > 0                                       # (fold threads exist in every workgroup)
         # (the shader clock is per XCD: only differences INSIDE a workgroup mean anything)
+        if LIGHT:
+            s[:, 1:nph] = s[:, :1]                          # no phase stamps in this build: everything is "the last phase"
         d = np.diff(s[:, :nph + 1], axis=1)[ok] / (GHZ * 1e3)
         tot = (ends[ok] - s[ok, 0]) / (GHZ * 1e3)
         agg.setdefault(k, []).append((live.sum(), d.mean(axis=0), d.max(axis=0), tot.mean(), tot.max()))
@@ -76,6 +79,7 @@ for k in sorted(agg):
     wg = np.mean([r[0] for r in rows])
     mean = np.mean([r[1] for r in rows], axis=0); mx = np.mean([r[2] for r in rows], axis=0)
     print(f"{names.get(k, k):10s} wgs {wg:6.0f}  entry -> end of a workgroup's first wave: mean {np.mean([r[3] for r in rows]):5.2f}  max {np.mean([r[4] for r in rows]):5.2f}")
-    print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(phases[1 if k != 2 else 2], mean, mx)))
+    if not LIGHT:
+        print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(phases[1 if k != 2 else 2], mean, mx)))
     t = np.array(tl[k]); print(f"           device clock: entry ramp {t[:, 0].mean():.2f}  span {t[:, 1].mean():.2f}  gap to the next launch {np.nanmean(t[:, 2]):.2f}")
 m.close()
