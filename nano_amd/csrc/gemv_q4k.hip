@@ -239,6 +239,9 @@ __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged
     for (int j = 0; j < NV; j++) {
         const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
         const bool valid = i < n;                                     // whole waves: n % 256 == 0
+        // a wave past the end of the row (512 threads on a 1024-value row: half of them) skips the ~170 instructions: it would
+        // share its SIMD's issue slots with a wave that has a block to quantize
+        if (!valid) continue;
 #pragma unroll
         for (int b = 0; b < B; b++) {
             if (b < (int)a.nb) {

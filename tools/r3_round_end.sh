@@ -78,6 +78,8 @@ elif [ "$1" = "b" ]; then
   timeout 300 python tools/long_ctx_probe.py 2>&1 | tail -10 > $O/${T}_long_ctx_probe.txt; head -5 $O/${T}_long_ctx_probe.txt
   for x in 1 0; do NANO_ATTN_XCD=$x pmc long_ctx_xcd$x FETCH_SIZE python $R/tools/long_ctx_one.py 4095; done
   timeout 400 python tools/sample_decode_probe.py 2>&1 | tee $O/${T}_sample_decode_probe.txt
+elif [ "$1" = "e" ]; then
+  for x in 1 0; do NANO_ATTN_XCD=$x pmc long_ctx_xcd$x FETCH_SIZE python $R/tools/long_ctx_one.py 4095; cat $O/${T}_long_ctx_xcd${x}_pmc_log.txt; done
 elif [ "$1" = "c" ]; then
   timeout 1200 python bench.py --all-configs --no-cpu-baseline 2>/dev/null > $O/${T}_bench_all_configs.jsonl; python3 -c "
 import json
