@@ -403,7 +403,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
     float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);
 
     // late-read arguments are fetched with the first ones (karg_touch, gemv_common.h)
-    karg_touch(a.out[0]); karg_touch(a.out_bstride[0]); karg_touch(a.out_pstride[0]); karg_touch(a.nb); karg_touch(a.magic_nchunk); karg_touch(a.log2_tiles);
+    karg_touch(a.out[0]); karg_touch(a.out_bstride[0]); karg_touch(a.out_pstride[0]); karg_touch(a.nb); karg_touch(a.magic_nchunk); karg_touch(a.log2_tiles); karg_touch(a.tile_max); karg_touch(a.ntiles);
     if (!swiglu) { karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.out_bstride[1]); karg_touch(a.out_bstride[2]); karg_touch(a.out_pstride[1]); karg_touch(a.out_pstride[2]); }
     karg_touch(a.pos);
     if (ROLE == R_GENERIC || ROLE == R_RESID || ROLE == R_RESID_COMBINE) { karg_touch(a.resid_add); karg_touch(a.resid_add_bstride); }
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
         const uint32_t it = (uint32_t)tid + (uint32_t)k * nthr;
         const uint32_t rr = __umulhi(it, a.magic_nchunk), gg = it - rr * GT;   // it / GT, it % GT (magic_nchunk = ceil(2^32 / GT) here); rr = mat * RW + local row
         // Which matrix: only the SwiGLU launch has two, and when a matrix's items fill whole waves (RW x GT a multiple of 64:
-        // a.units = 1, set by the launcher) the choice is wave-uniform.  Said to the compiler (readfirstlane), the descriptor
+        // the launcher gives the R_NORM_SWIGLU role to such plans only, others run R_GENERIC) the choice is wave-uniform.  Said to the compiler (readfirstlane), the descriptor
         // is picked with scalar selects; left per-lane it becomes a waterfall loop around each of the three loads -- and the
         // register reuse between them put a full s_waitcnt vmcnt(0) in the middle of the issue phase (round 3: ~1 us per launch).
         auto issue_item = [&](const uint32_t mat) __attribute__((always_inline)) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_slab_kernel(const GemvDev a) {
             h1v[k] = m1 ? bload_u4(rw1, boff == OOB ? OOB : boff + 16u, false) : bload_u4(rw0, boff == OOB ? OOB : boff + 16u, false);
         };
         if (!swiglu) issue_item(0u);
-        else if (a.units) issue_item((uint32_t)__builtin_amdgcn_readfirstlane((int)(rr >= RW ? 1u : 0u)));
+        else if (ROLE == R_NORM_SWIGLU) issue_item((uint32_t)__builtin_amdgcn_readfirstlane((int)(rr >= RW ? 1u : 0u)));   // the launcher checked: whole waves per matrix
         else issue_item(rr >= RW ? 1u : 0u);
     }
     const uint32_t lrw = a.log2_tiles;                                // log2(RW) here
@@ -660,7 +660,8 @@ static hipError_t launch_q4k_b(const GemvArgs &a, hipStream_t st) {
         if (f == F_NORM && d.epi == GEMV_EPI_STORE) return launch_q4k_r<R_NORM_STORE, B>(d, p, rows, st);
         if (f == 0 && d.epi == GEMV_EPI_RESID) return launch_q4k_r<R_RESID, B>(d, p, rows, st);
         if (f == F_COMBINE && d.epi == GEMV_EPI_RESID) return launch_q4k_r<R_RESID_COMBINE, B>(d, p, rows, st);
-        if (f == F_NORM && d.epi == GEMV_EPI_SWIGLU) return launch_q4k_r<R_NORM_SWIGLU, B>(d, p, rows, st);
+        const uint32_t GT = ((d.n + 255) / 256) * 8;
+        if (f == F_NORM && d.epi == GEMV_EPI_SWIGLU && (p.rw * GT) % 64u == 0u && p.nthr % 64u == 0u) return launch_q4k_r<R_NORM_SWIGLU, B>(d, p, rows, st);
     }
     return launch_q4k_r<R_GENERIC, B>(d, p, rows, st);
 }

@@ -543,6 +543,12 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
         while (rw > 4 && (size_t)B * nmat * rw * pitch * 4 > 64 * 1024) rw /= 2;
         while (rw > 4 && (rw / 4) * nchunk * nmat > 64) rw /= 2;          // <= 16 waves x 4 units
     }
+    // One workgroup per CU when the power of two leaves CUs idle (round 3, Qwen3-0.6B's W1|W3: 3072 rows as 192 slabs of 16 ->
+    // 256 slabs of 12: 1871-1879 -> 1896 tok/s; the slab kernel takes any row count).  One-segment launches only.
+    if (B == 1 && nseg == 1) {
+        const uint32_t cus = a.cus ? a.cus : 256u, c = (rows + cus - 1) / cus;
+        if (c >= 5 && c < rw && rows / rw < cus && ((c + 3) / 4) * nchunk * nmat <= 64) rw = c;
+    }
     // Large matrices (Qwen3-4B's layers: 10-50 MB each) are bandwidth rather than latency bound, and a CU pulls ~25 GB/s whatever
     // it runs: the launch ends when the CU with the most rows ends.  BALANCED slabs (round 3): rw = ANY row count, chosen to
     // minimise (rounds of `cus` workgroups) x rw = the rows the busiest CU streams; a power-of-two slab left 160 of 256 CUs
