@@ -37,6 +37,11 @@
 
 namespace nano {
 
+// A kernel argument the compiler would fetch (s_load) right before its first use -- in the middle of the dependent chain, one
+// scalar-cache round trip each -- is asked for at the top of the kernel instead: every argument load is issued together and
+// waited for once, while nothing else could run anyway.
+template <class T> __device__ __forceinline__ void karg_touch(const T &v) { asm volatile("" :: "s"(v)); }
+
 // ---- x / C for the quantizers' constant divisors (15, 63, 127) -----------------------------------------
 // Three operations (multiply by RN(1/C), exact remainder by FMA, one correction) instead of the ~12 of the IEEE division
 // expansion.  The result is the correctly rounded quotient -- bit-identical to x / C -- for EVERY finite float x (denormals

@@ -335,6 +335,7 @@ template <int GS>
 __global__ __launch_bounds__(256) void quant_rows_frag_kernel(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n,
                                                               int8_t *xf, float *xsf, uint32_t ng) {
     __shared__ float red[8];
+    karg_touch(xf); karg_touch(xsf); karg_touch(ng);                  // the output pointers come with the first arguments, not after the quantizer
     constexpr uint32_t FR = GS >= 64 ? GS / 64 : 1, FB = GS == 32 ? 512u : 1024u, KB = GS == 32 ? 8u : 16u;
     const uint32_t t = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t tt = t >> 4, nn = t & 15u;

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_cls_kernel(const GCDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    karg_touch(a.out); karg_touch(a.out_bstride); karg_touch(a.rows); karg_touch(a.xf); karg_touch(a.xsf);      // (late-read arguments with the first batch)
     const uint32_t nw = blockDim.x >> 6;
     const uint32_t n = a.n, ng = a.ng, nhc = a.nhc, tt = a.tt, lt = a.lt;
     const uint32_t m = lane & 15u, kq = lane >> 4;

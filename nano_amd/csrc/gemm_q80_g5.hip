@@ -55,6 +55,9 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the arguments first read inside the tile loop (activation fragments, positions, the fragment outputs) come with the first batch
+    karg_touch(a.xf); karg_touch(a.xsf); karg_touch(a.pos); karg_touch(a.xf2); karg_touch(a.xsf2); karg_touch(a.ng2);
+    karg_touch(a.out[0]); karg_touch(a.out[1]); karg_touch(a.out[2]);
     const uint32_t nkw = a.nkw, nmat = a.nmat;
     const uint32_t team = wid / nkw, kw = wid % nkw;
     const uint32_t unit = blockIdx.x * a.teams + team;                  // (row tile, matrix)

@@ -56,11 +56,6 @@ __device__ __forceinline__ float bload_f(__amdgpu_buffer_rsrc_t r, uint32_t off)
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
 
-// A kernel argument the compiler would fetch (s_load) right before its first use -- in the middle of the dependent chain, one
-// scalar-cache round trip each -- is asked for at the top of the kernel instead: every argument load is issued together and
-// waited for once, while nothing else could run anyway.
-template <class T> __device__ __forceinline__ void karg_touch(const T &v) { asm volatile("" :: "s"(v)); }
-
 enum : uint32_t { F_NORM = 1u, F_PRE = 2u, F_COMBINE = 4u };
 
 // Kernel roles.  A taken branch costs ~40 cycles and every instruction of the single wave a SIMD runs is on the

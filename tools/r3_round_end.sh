@@ -72,14 +72,15 @@ elif [ "$1" = "b" ]; then
   prof q06_q80_b1 --steps 100 --warmup 4
   pmc q06_q80_b1 FETCH_SIZE python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-table
   prof q06_q4k_b1 --quant q4k --steps 60 --warmup 4
-  S=$R/nano_amd/lib/libnano_mi355x_stamps.so
-  { for a in "qwen3-0.6b q80 1 30" "qwen3-0.6b q80 1 300" "qwen3-0.6b q4k 1 30" "wide-qwen3 q80 1 30"; do NANO_LIB=$S timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -11; done; } > $O/${T}_phase_stamps.txt; head -12 $O/${T}_phase_stamps.txt
+  S=$R/nano_amd/lib/libnano_mi355x_stamps.so; S2=$R/nano_amd/lib/libnano_mi355x_stamps2.so
+  { for a in "qwen3-0.6b q80 1 30" "qwen3-0.6b q80 1 300" "qwen3-0.6b q4k 1 30" "wide-qwen3 q80 1 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done; } > $O/${T}_phase_stamps.txt; head -12 $O/${T}_phase_stamps.txt
+  { for a in "qwen3-0.6b q80 1 30" "qwen3-0.6b q80 1 300" "qwen3-0.6b q4k 1 30"; do NANO_STAMPS_LIGHT=1 NANO_STAMPS_GRAPH=1 NANO_LIB=$S2 timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -11; done; } > $O/${T}_timeline_light_stamps.txt
   timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -6 | tee $O/${T}_prefill_probe.txt
   timeout 300 python tools/long_ctx_probe.py 2>&1 | tail -10 > $O/${T}_long_ctx_probe.txt; head -5 $O/${T}_long_ctx_probe.txt
-  for x in 1 0; do NANO_ATTN_XCD=$x pmc long_ctx_xcd$x FETCH_SIZE python $R/tools/long_ctx_one.py 4095; done
+  pmc long_ctx_4095_fetch FETCH_SIZE python $R/tools/long_ctx_one.py 4095
   timeout 400 python tools/sample_decode_probe.py 2>&1 | tee $O/${T}_sample_decode_probe.txt
 elif [ "$1" = "e" ]; then
-  for x in 1 0; do NANO_ATTN_XCD=$x pmc long_ctx_xcd$x FETCH_SIZE python $R/tools/long_ctx_one.py 4095; cat $O/${T}_long_ctx_xcd${x}_pmc_log.txt; done
+  pmc long_ctx_4095_fetch FETCH_SIZE python $R/tools/long_ctx_one.py 4095; cat $O/${T}_long_ctx_4095_fetch_pmc_log.txt
 elif [ "$1" = "c" ]; then
   timeout 1200 python bench.py --all-configs --no-cpu-baseline 2>/dev/null > $O/${T}_bench_all_configs.jsonl; python3 -c "
 import json
