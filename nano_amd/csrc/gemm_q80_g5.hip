@@ -41,6 +41,8 @@ struct G5Dev {
     // SwiGLU launches, optional (4 row-tile pairs per workgroup): the outputs also leave as Q80 groups of 64 in fragment order,
     // i.e. the next GEMM's activation operand (what quant_rows_frag_kernel would make of them); ng2 = rows / 64
     int8_t *xf2; float *xsf2; uint32_t ng2;
+    uint32_t hoist_ws;                  // 1: every wave fetches the weight scales of its first half chunk at kernel entry (TT == 1 launches)
+    unsigned long long *stamps;         // measurement builds only (NANO_STAMPS): [workgroup][8] stamps of the workgroup's first wave, or nullptr
 };
 
 constexpr uint32_t G5_PITCH = 528, G5_WBUF = 16 * G5_PITCH;           // transposition buffer of one wave: 16 rows x 512 B
@@ -113,7 +115,17 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
             wA[r] = make_int4(v.x, v.y, v.z, v.w);
         }
     };
+    NANO_STAMP(a.stamps, 0, lane);
     issue_w(kw);
+    // The weight scales of the first half chunk come from HBM like the weights; asked for only when the weights have landed
+    // (the loop below) they cost a second memory round trip before the first matrix instruction.  Four registers per lane:
+    // the TT == 1 instantiation has the room (140 of 168), the wider ones spill already.
+    float4 ws_first = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool hoist = TT == 1 && a.hoist_ws != 0u;
+    if (hoist) {
+        const uint32_t sg = kw * 8u + (lane & 1u) * 4u;
+        ws_first = bload_f4(rs, (lane < 32u && (lane >> 1) < trw && sg < ng && kw < nhc) ? ((lrow0 + (lane >> 1)) * ng + sg) * 4u : OOB);
+    }
     if (kw == 0u && lane < (uint32_t)TT) flag[lane] = 0u;
     if (wid == 0u && lane < (uint32_t)TT) gcnt[lane] = 0u;
     __syncthreads();                                                   // the only workgroup barrier: the counters are armed
@@ -139,11 +151,14 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
         // 1. the half chunk's weight pieces: registers -> the transposition buffer
 #pragma unroll
         for (int r = 0; r < 8; r++) *reinterpret_cast<int4 *>(wbuf + (size_t)(2 * r + wrow) * G5_PITCH + wcol) = wA[r];
+        if (h == kw) NANO_STAMP(a.stamps, 1, (float)wA[7].x);          // the first half chunk's weights arrived
         // 2. what this half chunk needs now: weight scales (lanes 0..31: row l/2, groups g0 + 4 (l%2) .. +3), first fragments
-        float4 wsv; load_ws(wsv, h);
+        float4 wsv;
+        if (hoist) wsv = ws_first; else load_ws(wsv, h);               // hoisted: fetched at entry / behind the previous half chunk's prefetch
         i32x4 fb[8]; float4 xsv;
         load_fb(fb, xsv, g0, 0u);
         issue_w(h + nkw);                                               // prefetch; behind the fragments in the load queue (loads return in issue order)
+        if (hoist) load_ws(ws_first, h + nkw);                          // ... and the next half chunk's weight scales behind its weights
         if (lane < 32u) {
             const uint32_t r = lane >> 1, gq = (lane & 1u) * 4u;
             wsl[(gq + 0u) * 16u + r] = wsv.x; wsl[(gq + 1u) * 16u + r] = wsv.y; wsl[(gq + 2u) * 16u + r] = wsv.z; wsl[(gq + 3u) * 16u + r] = wsv.w;
@@ -163,6 +178,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                     p[j][0] = ((float)cv[0] * wv.x) * xsc; p[j][1] = ((float)cv[1] * wv.y) * xsc;                 // infer.c:672
                     p[j][2] = ((float)cv[2] * wv.z) * xsc; p[j][3] = ((float)cv[3] * wv.w) * xsc;
                 }
+                if (h == kw && t == 0u) NANO_STAMP(a.stamps, 2, p[7][3]);      // scales + fragments arrived, products of the first half chunk done
                 // 4. the next token tile's fragments, once this tile's are consumed (none left: out-of-range addresses)
                 if (t + 1u < (uint32_t)TT) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -189,6 +205,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                 // x + (+0.0f) only differ for x == -0.0f
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) { acc[0] += p[j][0]; acc[1] += p[j][1]; acc[2] += p[j][2]; acc[3] += p[j][3]; }
+                if (h == kw && t == 0u) NANO_STAMP(a.stamps, 3, acc[0]);       // the first wave's first chain link folded (h = 0: no wait before it)
                 if (!fin) {
                     *reinterpret_cast<float4 *>(slot + t * 256 + lane * 4u) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                     lds_store_rel(flag + t, h + 1u);
@@ -236,6 +253,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
             }
         }
     }
+    NANO_STAMP_END(a.stamps, 6);                                       // the workgroup's last wave (the finisher of the chain) ends
 }
 
 static uint32_t total_rows5(const GemvArgs &a) {
@@ -291,6 +309,8 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
     d.tt = (a.nb + 15) / 16;
     d.nmat = sw ? 2u : 1u;
     d.xf = a.xq_in; d.xsf = a.xs_in; d.pos = a.pos;
+    d.stamps = a.stamps;
+    { static const bool hoist = !(getenv("NANO_G5_HOIST") && *getenv("NANO_G5_HOIST") == '0'); d.hoist_ws = hoist ? 1u : 0u; }   // A/B knob
     // The split.  A workgroup = one row tile (SwiGLU: the W1/W3 pair) x nkw waves; a CU holds 12 waves (3 per SIMD at
     // <= 168 VGPRs).  Take the deepest split whose workgroups are ALL resident at once (no second round of workgroups, whose
     // tail would run on a mostly idle chip); matrices too tall for that (the classifier) get one wave per tile, 4 per group.
@@ -329,7 +349,24 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
     const uint32_t maxkw = G5_MAX_WAVES / d.nmat;
     uint32_t nkw = 1, groups = 1;                                      // groups: row tiles (pairs) per workgroup
     bool fits = false;
-    for (uint32_t k = maxkw < d.nhc ? maxkw : d.nhc; k >= 1; k--) {
+    // Measured with the phase stamps (round 3, `profiles/r03_g5_stamps.txt`): two workgroups of 5 or 8 waves do NOT share a CU
+    // (Qwen3-4B's QKV, 384 tiles as 384 five-wave workgroups: the last workgroup entered 3.9 us after the first, the launch was
+    // two rounds of ~5 us).  So when the tiles outnumber the CUs, a workgroup takes `groups` tiles -- one team of waves each --
+    // and the whole launch is one round again.  NANO_G5_GROUPS=0 restores the one-tile workgroups.
+    static const bool group_tiles = !(getenv("NANO_G5_GROUPS") && *getenv("NANO_G5_GROUPS") == '0');
+    if (group_tiles && !xf2 && d.ntiles > (uint32_t)cus) {
+        for (uint32_t gsz = 2; gsz <= 4 && !fits; gsz++) {
+            if ((d.ntiles + gsz - 1) / gsz > (uint32_t)cus) continue;
+            for (uint32_t k = G5_MAX_WAVES / (gsz * d.nmat); k >= 1; k--) {
+                if (k > d.nhc) continue;
+                const uint32_t cpw = (d.nhc + k - 1) / k, kk = (d.nhc + cpw - 1) / cpw;
+                const uint32_t wg_waves = gsz * d.nmat * kk;
+                const size_t wg_lds = (size_t)wg_waves * G5_LDS_WAVE + (size_t)gsz * d.nmat * TTc * 1040u + 1024u;
+                if (wg_waves <= G5_MAX_WAVES && wg_lds <= 160u * 1024u) { nkw = kk; groups = gsz; fits = true; break; }
+            }
+        }
+    }
+    for (uint32_t k = maxkw < d.nhc ? maxkw : d.nhc; k >= 1 && !fits; k--) {
         const uint32_t cpw = (d.nhc + k - 1) / k, kk = (d.nhc + cpw - 1) / cpw;            // balanced: no wave owns more than cpw half chunks
         const uint32_t wg_waves = kk * d.nmat;
         const size_t wg_lds = (size_t)wg_waves * G5_LDS_WAVE + (size_t)d.nmat * TTc * 1040u;

@@ -33,6 +33,9 @@ for p in range(0, pos):                                     # some KV history (v
     m.forward([1] * B, [p] * B, want_logits=False)
 names = {1: "qkv", 2: "attention", 3: "wo", 4: "w1w3", 5: "w2"}
 phases = {1: ["issue", "x arrives(+norm sum)", "quantize", "w arrive+dots", "barrier", "fold+store"], 2: ["issue", "q/k norm+rope", "KV+softmax", "partials", "combine+store"]}
+G5 = B > 1 and quant == "q80"          # batched Q80 steps of large matrices run the G5 GEMM: its first wave stamps entry, weights of its first half chunk
+                                        # landed, scales + fragments landed and products done, its first chain link folded; the last phase = the rest of the chain
+g5_phases = ["first weights land", "scales+fragments land, products", "first link folded", "-", "-", "rest of the chain + epilogue"]
 agg = {}
 tl = {}
 GRAPH = os.environ.get("NANO_STAMPS_GRAPH") == "1"          # stamp a graph replay instead of eager launches
@@ -60,6 +63,8 @@ for rep in range(1 if GRAPH else 3):
         ends = s[:, nph]
         ok = ends > 0                                       # (fold threads exist in every workgroup)
         # (the shader clock is per XCD: only differences INSIDE a workgroup mean anything)
+        if G5 and k != 2:
+            s[:, 4] = s[:, 3]; s[:, 5] = s[:, 3]            # G5 stamps slots 0..3 and the end
         if LIGHT:
             s[:, 1:nph] = s[:, :1]                          # no phase stamps in this build: everything is "the last phase"
         d = np.diff(s[:, :nph + 1], axis=1)[ok] / (GHZ * 1e3)
@@ -80,6 +85,6 @@ for k in sorted(agg):
     mean = np.mean([r[1] for r in rows], axis=0); mx = np.mean([r[2] for r in rows], axis=0)
     print(f"{names.get(k, k):10s} wgs {wg:6.0f}  entry -> end of a workgroup's first wave: mean {np.mean([r[3] for r in rows]):5.2f}  max {np.mean([r[4] for r in rows]):5.2f}")
     if not LIGHT:
-        print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(phases[1 if k != 2 else 2], mean, mx)))
+        print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(g5_phases if (G5 and k != 2) else phases[1 if k != 2 else 2], mean, mx)))
     t = np.array(tl[k]); print(f"           device clock: entry ramp {t[:, 0].mean():.2f}  span {t[:, 1].mean():.2f}  gap to the next launch {np.nanmean(t[:, 2]):.2f}")
 m.close()
