@@ -41,6 +41,7 @@ struct G5Dev {
     // SwiGLU launches, optional (4 row-tile pairs per workgroup): the outputs also leave as Q80 groups of 64 in fragment order,
     // i.e. the next GEMM's activation operand (what quant_rows_frag_kernel would make of them); ng2 = rows / 64
     int8_t *xf2; float *xsf2; uint32_t ng2;
+    uint32_t stage_x;                   // 1 (nkw == 1, TT == 1): the tile's activation fragments [ng][1 KiB] are copied to LDS once per workgroup; every wave reads them there
     uint32_t hoist_ws;                  // 1: every wave fetches the weight scales of its first half chunk at kernel entry (TT == 1 launches)
     unsigned long long *stamps;         // measurement builds only (NANO_STAMPS): [workgroup][8] stamps of the workgroup's first wave, or nullptr
 };
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
     uint32_t *flag = flags + team * TT;
     float *gmax = reinterpret_cast<float *>(flags + ((a.teams * TT + 3u) & ~3u));          // [TT][4 row tiles][16 tokens] (fused group quantizer)
     uint32_t *gcnt = reinterpret_cast<uint32_t *>(gmax + TT * 64);                         // [TT] finishers arrived
+    unsigned char *xstage = reinterpret_cast<unsigned char *>(gcnt) + 256;                 // [ng][1024] (stage_x launches; 16-byte aligned: everything before it is)
 
     // ---- which segment (q | k | v share a launch; SwiGLU: matrix 0 = W1, matrix 1 = W3 over the same rows) -----------------
     // A tile is trw <= 16 rows of ONE segment (balanced tiles: trw is fitted so that the tiles spread evenly over the CUs; the
@@ -128,20 +130,48 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
     }
     if (kw == 0u && lane < (uint32_t)TT) flag[lane] = 0u;
     if (wid == 0u && lane < (uint32_t)TT) gcnt[lane] = 0u;
-    __syncthreads();                                                   // the only workgroup barrier: the counters are armed
+    // Workgroups whose waves all walk the whole row (nkw == 1: the W1|W3 launch with fused output quantizer, eight waves) read
+    // the SAME fragments eight times from L2 -- as many bytes through the CU's vector memory path as the weights themselves, and a
+    // ~1.1-1.8 us L2 / Infinity Cache round trip exposed in every one of a wave's five half chunks (the stamps).  Copied to LDS
+    // once here (ng KiB, 40 for Qwen3-4B's hidden size), the loop reads them with ds_read_b128.
+    if constexpr (TT == 1) {
+        if (a.stage_x) {
+            const uint32_t units = ng * 64u, nthr = nwaves * 64u;     // 16-byte units
+            for (uint32_t i = threadIdx.x; i < units; i += nthr) {
+                const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)(i * 16u), 0, 0);
+                *reinterpret_cast<i32x4 *>(xstage + (size_t)i * 16u) = v;
+            }
+        }
+    }
+    __syncthreads();                                                   // the only workgroup barrier: the counters are armed (and the fragments staged)
     if (!live) return;
 
     // (Round 3 tried issuing the first half chunk's weight scales and activation fragments at kernel entry, ahead of the weights'
     // arrival, and the next half chunk's at the end of each turn: the fragments held across the chain link push the kernel past
-    // the 168 registers of three waves per SIMD -- 10 to 12 spilled registers, Qwen3-4B 8 sequences 2.16 -> 3.79 ms.  Dropped.)
+    // the 168 registers of three waves per SIMD -- 10 to 12 spilled registers, Qwen3-4B 8 sequences 2.16 -> 3.79 ms.  Dropped.
+    // Second try with the registers solved -- first call peeled, an 8-wave instantiation with 256 registers for the prefetch --:
+    // no spills, bit-identical, and SLOWER, 8 sequences 2.103 -> 2.192 ms, 16: 2.159 -> 2.250: every wave of the chip asking for
+    // the same fragment lines at the same moment delays the weights behind them (first weights land after 3.4-3.8 us instead of
+    // 2.3, profiles/r03_g5_stamps_fragments_at_entry_dropped.txt).  Only the weight SCALES are fetched early: + 1.1 ... 1.5 %.
+    // Third: two weight buffers per wave (two half chunks in flight) in that 8-wave instantiation: 2.083 -> 2.096 ... 2.130 ms --
+    // the loop of a wave that owns five half chunks (W1|W3) is not short of bytes in flight
+    // (profiles/r03_g5_stamps_two_weight_buffers_dropped.txt).)
     auto load_ws = [&](float4 &wsv, uint32_t h) {                       // lanes 0..31: row l/2, groups 8h + 4 (l%2) .. +3
         const uint32_t sg = h * 8u + (lane & 1u) * 4u;
         wsv = bload_f4(rs, (lane < 32u && (lane >> 1) < trw && sg < ng && h < nhc) ? ((lrow0 + (lane >> 1)) * ng + sg) * 4u : OOB);
     };
     auto load_fb = [&](i32x4 (&fb)[8], float4 &xsv, uint32_t g0, uint32_t t) {
+        bool staged = false;
+        if constexpr (TT == 1) staged = a.stage_x != 0u;
+        if (staged) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++)
+                fb[j] = (g0 + j < ng) ? *reinterpret_cast<const i32x4 *>(xstage + (size_t)(g0 + j) * 1024u + lane * 16u) : i32x4{0, 0, 0, 0};
+        } else {
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++)
             fb[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)((g0 + j < ng && t < tt) ? lane * 16u : OOB), (int)((t * ng + g0 + j) * 1024u), 0);   // uniform part in the scalar offset; the range check is on the lane part
+        }
         const uint32_t xg = g0 + (lane >> 2);                           // lanes 0..31: group g0 + l/4, tokens 4 (l%4) .. +3
         xsv = bload_f4(rxs, (lane < 32u && xg < ng && t < tt) ? ((t * ng + xg) * 16u + (lane & 3u) * 4u) * 4u : OOB);
     };
@@ -380,7 +410,13 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
     d.teams = groups * d.nmat;
     const uint32_t waves = d.teams * d.nkw;
     const uint32_t nwg = (d.ntiles + groups - 1) / groups;
-    const size_t lds = (size_t)waves * G5_LDS_WAVE + (size_t)d.teams * TTc * 1024u + (((size_t)d.teams * TTc * 4u + 15u) & ~(size_t)15u) + (size_t)TTc * 256u + 16u;
+    size_t lds = (size_t)waves * G5_LDS_WAVE + (size_t)d.teams * TTc * 1024u + (((size_t)d.teams * TTc * 4u + 15u) & ~(size_t)15u) + (size_t)TTc * 256u + 16u;
+    {   // fragments staged in LDS: one token tile, every wave walks the whole row, more than one wave to share them, and room
+        static const bool stage = !(getenv("NANO_G5_STAGE") && *getenv("NANO_G5_STAGE") == '0');     // A/B knob
+        const size_t need = (size_t)waves * G5_LDS_WAVE + (size_t)d.teams * 1024u + (((size_t)d.teams * 4u + 15u) & ~(size_t)15u) + 64u * 4u + 256u + (size_t)d.ng * 1024u + 64u;
+        d.stage_x = (stage && TTc == 1 && nkw == 1 && waves >= 4 && need <= 160u * 1024u) ? 1u : 0u;
+        if (d.stage_x) lds = need;
+    }
     if (TTc == 1) launch_tt<1>(d, nwg, waves, lds, st);
     else if (TTc == 2) launch_tt<2>(d, nwg, waves, lds, st);
     else launch_tt<4>(d, nwg, waves, lds, st);
