@@ -1,0 +1,44 @@
+"""Regression guard for what round 3's disassembly scan found (tools/isa_scan.py): the batch-1 GEMV kernels must
+not contain waterfall loops (a divergent buffer descriptor) or a full `s_waitcnt vmcnt(0)` in their issue phase (before the first
+workgroup barrier, with vector loads still to be issued behind it) -- either one is a whole memory round trip per launch, which is
+what made every Q4K launch ~1 us slower than it had to be.  Needs hipcc (cross-compiles without a GPU); about two minutes."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None, reason="needs hipcc")
+
+
+def hot(records, must_contain):
+    ks = [k for k in records if all(s in k["name"] for s in must_contain)]
+    assert ks, must_contain
+    return ks
+
+
+def check(k):
+    assert k["waterfall_compares"] == 0, (k["name"], "waterfall loop")
+    early = [w for w in k["full_waits_before_later_loads"] if w < k["first_barrier"]]
+    assert not early, (k["name"], "s_waitcnt vmcnt(0) inside the issue phase at instruction", early)
+
+
+def test_q4k_batch1_roles_issue_their_loads_without_waterfalls_or_full_waits():
+    import isa_scan
+    recs = isa_scan.scan(isa_scan.compile_to_asm(os.path.join(ROOT, "nano_amd", "csrc", "gemv_q4k.hip")), "gemv_q4k_slab_kernel")
+    for role in (1, 2, 4):                                   # QKV / Wo, W2 / W1|W3 at batch 1, one activation vector per thread
+        for ipt in (1, 2, 4):
+            for k in hot(recs, [f"gemv_q4k_slab_kernelILi{role}ELi1ELi1ELi{ipt}E"]):
+                check(k)
+
+
+def test_q80_batch1_roles_fetch_their_arguments_up_front():
+    import isa_scan
+    recs = isa_scan.scan(isa_scan.compile_to_asm(os.path.join(ROOT, "nano_amd", "csrc", "gemv_q80_gs64.hip")), "gemv_q80_slab_kernel")
+    for sig in ("ILi1ELi64ELi1ELi1ELi1E", "ILi2ELi64ELi1ELi2ELi1E", "ILi4ELi64ELi1ELi1ELi2E"):     # the launches of the Qwen3-0.6B step
+        for k in hot(recs, ["gemv_q80_slab_kernel" + sig]):
+            check(k)
+            assert not k["late_scalar_loads"], (k["name"], "kernel arguments fetched after the first batch", k["late_scalar_loads"])

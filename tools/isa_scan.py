@@ -15,7 +15,9 @@ FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32
 
 
 def scan(asm: str, pat: str = ""):
+    """-> one dict per kernel whose mangled name contains `pat`"""
     lines = asm.split("\n")
+    out = []
     i = 0
     while i < len(lines):
         m = re.match(r"^(_Z\S+):", lines[i])
@@ -33,17 +35,24 @@ def scan(asm: str, pat: str = ""):
                     if "s_barrier" in t: bars.append(n)
                     if "v_cmp_eq_u64" in t: wf += 1
                 j += 1
-            mid = [w for w in waits if any(l > w for l in loads)]
-            short = re.sub(r"^_ZN4nano\d*(_GLOBAL__N_1)?\d*", "", name)[:64]
-            print(f"{short:64s} instr {n:5d}  vector loads {len(loads):3d}  first barrier @{bars[0] if bars else 0:4d}  "
-                  f"late scalar loads {late_s[:6]}  vmcnt(0) before later loads @{mid[:6]}  waterfall compares {wf}")
+            out.append({"name": name, "instr": n, "loads": loads, "first_barrier": bars[0] if bars else 0, "late_scalar_loads": late_s,
+                        "full_waits_before_later_loads": [w for w in waits if any(l > w for l in loads)], "waterfall_compares": wf})
             i = j
         i += 1
+    return out
+
+
+def compile_to_asm(src: str) -> str:
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-o", out, src], check=True, stderr=subprocess.DEVNULL)
+        return open(out).read()
 
 
 if __name__ == "__main__":
     src = sys.argv[1]; pat = sys.argv[2] if len(sys.argv) > 2 else ""
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-o", out, src], check=True, stderr=subprocess.DEVNULL)
-        scan(open(out).read(), pat)
+    for k in scan(compile_to_asm(src), pat):
+        short = re.sub(r"^_ZN4nano\d*(_GLOBAL__N_1)?\d*", "", k["name"])[:64]
+        print(f"{short:64s} instr {k['instr']:5d}  vector loads {len(k['loads']):3d}  first barrier @{k['first_barrier']:4d}  "
+              f"late scalar loads {k['late_scalar_loads'][:6]}  vmcnt(0) before later loads @{k['full_waits_before_later_loads'][:6]}  "
+              f"waterfall compares {k['waterfall_compares']}")
