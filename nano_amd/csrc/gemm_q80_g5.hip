@@ -131,9 +131,9 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
     if (kw == 0u && lane < (uint32_t)TT) flag[lane] = 0u;
     if (wid == 0u && lane < (uint32_t)TT) gcnt[lane] = 0u;
     // Workgroups whose waves all walk the whole row (nkw == 1: the W1|W3 launch with fused output quantizer, eight waves) read
-    // the SAME fragments eight times from L2 -- as many bytes through the CU's vector memory path as the weights themselves, and a
-    // ~1.1-1.8 us L2 / Infinity Cache round trip exposed in every one of a wave's five half chunks (the stamps).  Copied to LDS
-    // once here (ng KiB, 40 for Qwen3-4B's hidden size), the loop reads them with ds_read_b128.
+    // the SAME fragments eight times from L2 -- as many bytes through the CU's vector memory path as the weights themselves.
+    // Copied to LDS once here (ng KiB, 40 for Qwen3-4B's hidden size), the loop reads them with ds_read_b128: + 1 ... 3 % at 16
+    // sequences, +-1 % at 8 (the loop stays issue bound, ~2.2 us per half chunk and wave: DESIGN.md section 3, G5 phase stamps).
     if constexpr (TT == 1) {
         if (a.stage_x) {
             const uint32_t units = ng * 64u, nthr = nwaves * 64u;     // 16-byte units
