@@ -217,6 +217,45 @@ def make_fullsize(tmpdir, only=None):
               float(((part[:, 1] - part[:, 0]) / np.abs(logits).max(axis=1)).min()))
 
 
+# BASELINE.json configs[4] as SURVEY 8d specifies it: Qwen3-4B Q80, 64 prompts of 16 ids (seeds 39..102), 128 decode steps
+# each.  The reference decodes one sequence at a time; four of the 64 (the first, the second, one from the middle, the last)
+# are run here from the prompt to position 143 (the prompt's last forward + 128 decode steps = 129 logit vectors each).
+FULLSIZE64_SEEDS = (39, 40, 70, 102)
+FULLSIZE64 = ("qwen3-4b", "q80", 64, 16, 144)
+
+
+def make_fullsize64(tmpdir):
+    """tests/golden/fullsize64_qwen3-4b_q80.npz: per seed and decode step the CRC-32 of the logits, arg-max, top-2 gap,
+    max|logit|; strided logits at the kept steps (the fast path's bar).  The GPU test decodes all 64 prompts as ONE batch and
+    compares these four slots (tests/test_gpu_fullsize.py::test_config4_64_prompts_vs_reference_golden)."""
+    import zlib
+    ref = ob.load_ref()
+    name, quant, gs, n_prompt, S = FULLSIZE64
+    spec = mf.preset(name, quant, group_size=gs)
+    path = os.path.join(tmpdir, f"{name}-{quant}.bin")
+    if not os.path.exists(path):
+        mf.write_model(path, spec, seed=39)
+    n_decode = S - n_prompt + 1
+    keep = fullsize_keep(n_prompt, S)
+    out = dict(preset=name, quant=quant, gs=spec.group_size, model_seed=39, seeds=np.array(FULLSIZE64_SEEDS, np.uint32), max_seq_len=S,
+               n_prompt=n_prompt, stride=FULLSIZE_STRIDE, keep=keep, model_sha256=sha256(path))
+    for seed in FULLSIZE64_SEEDS:
+        prompt = mf.prompt_ids(seed, n_prompt, spec.vocab_size)
+        ctx = ob.OracleCtx(ref, path, max_seq_len=S)
+        ids, logits, secs = ctx.generate(prompt, n_decode, want_logits=True)
+        ctx.close()
+        part = np.partition(logits, -2, axis=1)[:, -2:]
+        out[f"ids_{seed}"] = ids
+        out[f"crc32_{seed}"] = np.array([zlib.crc32(np.ascontiguousarray(logits[i]).tobytes()) for i in range(n_decode)], np.uint32)
+        out[f"argmax_{seed}"] = np.argmax(logits, axis=1).astype(np.uint32)
+        out[f"top2_gap_{seed}"] = (part[:, 1] - part[:, 0]).astype(np.float32)
+        out[f"max_abs_{seed}"] = np.abs(logits).max(axis=1).astype(np.float32)
+        out[f"logits_strided_{seed}"] = logits[keep][:, ::FULLSIZE_STRIDE].copy()
+        print("fullsize64", name, quant, "seed", seed, f"{n_decode} steps to position {S - 1}, {n_decode / secs:.2f} tok/s (strict reference build)",
+              "first ids", ids[n_prompt:n_prompt + 8].tolist(), flush=True)
+    np.savez_compressed(os.path.join(GOLD, f"fullsize64_{name}_{quant}.npz"), **out)
+
+
 LORA_CASES = [("tiny-nano", "f32", 0), ("tiny-nano", "q80", 32), ("tiny-nano-odd", "f32", 0)]
 
 
@@ -319,6 +358,9 @@ if __name__ == "__main__":
     assert ob.load_ref() is not None, "build oracle/_ref first: make -C oracle ref"
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":          # python tools/make_golden.py fullsize [name_quant ...]
         make_fullsize(tmp, set(sys.argv[2:]))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize64":        # python tools/make_golden.py fullsize64   (BASELINE configs[4], ~15 min of CPU)
+        make_fullsize64(tmp)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "e2e":               # python tools/make_golden.py e2e name_quant[_gs128] ...
         make_e2e(tmp, set(sys.argv[2:]))
