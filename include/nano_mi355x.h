@@ -263,6 +263,8 @@ typedef struct NanoFusedGemvDesc {
     const float *attn_ml;       /* [nb][n_head][nsplit][2] (max, exp-sum) per split */
     uint32_t attn_nsplit, attn_n_head, attn_hd;
     uint32_t use_gemm;          /* 1 (Q80): the batched route of a step -- activation quantizer launch + int8 MFMA GEMM */
+    uint32_t ordered;           /* 1: strict mode -- the reference's ascending group order in every kernel (bit-exact fp32); 0: the fast path */
+    uint32_t *route_out;        /* optional: the route the launch took (RouteKind of nano_amd/csrc/kernels.h), or NULL */
     float *out;                 /* [nb][sum of rows] (kind 2: [nb][rows[0]]); kind 1: holds the residual stream on entry */
 } NanoFusedGemvDesc;
 int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *d);

@@ -33,7 +33,11 @@ class NanoFusedGemvDesc(C.Structure):
     _fields_ = [("quant", C.c_uint32), ("gs", C.c_uint32), ("kind", C.c_uint32), ("n", C.c_uint32), ("nb", C.c_uint32), ("nseg", C.c_uint32),
                 ("rows", C.c_uint32 * 3), ("w", C.c_void_p * 3), ("ws", C.c_void_p * 3), ("x", C.c_void_p), ("norm_w", C.c_void_p),
                 ("attn_part", C.c_void_p), ("attn_ml", C.c_void_p), ("attn_nsplit", C.c_uint32), ("attn_n_head", C.c_uint32),
-                ("attn_hd", C.c_uint32), ("use_gemm", C.c_uint32), ("out", C.c_void_p)]
+                ("attn_hd", C.c_uint32), ("use_gemm", C.c_uint32), ("ordered", C.c_uint32), ("route_out", C.c_void_p), ("out", C.c_void_p)]
+
+
+# RouteKind of nano_amd/csrc/kernels.h (what NanoFusedGemvDesc.route_out reports)
+ROUTE_NAMES = ("gemv", "gemv_preq", "gemv_sliced", "q4k", "g6p", "frag_g6", "frag_old")
 
 
 class NanoHipError(RuntimeError):
@@ -347,12 +351,15 @@ def op_matmul_q4k(x_blocks, w_blocks, n, d, device=0):
     check(lib().nano_hip_op_matmul_q4k(device, out, np.ascontiguousarray(x_blocks), np.ascontiguousarray(w_blocks), n, d)); return out
 
 
-def op_fused_gemv(quant, kind, n, weights, x=None, norm_w=None, *, gs=0, nb=1, resid=None, attn=None, use_gemm=False, device=0):
+def op_fused_gemv(quant, kind, n, weights, x=None, norm_w=None, *, gs=0, nb=1, resid=None, attn=None, use_gemm=False, ordered=False,
+                  want_route=False, device=0):
     """One fused decode GEMV launch exactly as a decode step issues it (nano_hip_op_fused_gemv).
     quant: 0x00 F32 / 0x80 Q80 / 0x42 Q4K; kind: 0 store, 1 residual add, 2 SwiGLU.
     weights: list of (w, ws_or_None, rows) -- F32 float[rows, n]; Q80 int8[rows*n] + float scales; Q4K uint8 blocks (no frame).
     x: [nb, n] fp32; resid: [nb, rows] old residual values (kind 1); attn = (part[nb, nsplit, n], ml[nb, n_head, nsplit, 2], n_head, hd).
-    Returns out[nb, rows_total]."""
+    ordered: strict mode (the reference's ascending group order; bit-exact fp32 against the oracle); default: the fast path, whose
+    Q80 kernels of group size 64 fold canonically (unit sums of 8 groups, units ascending -- tests/canon.py restates it).
+    Returns out[nb, rows_total] (want_route: (out, route name))."""
     d = NanoFusedGemvDesc()
     d.quant, d.gs, d.kind, d.n, d.nb, d.nseg = quant, gs, kind, n, nb, len(weights)
     keep = []
@@ -373,8 +380,13 @@ def op_fused_gemv(quant, kind, n, weights, x=None, norm_w=None, *, gs=0, nb=1, r
         d.attn_nsplit, d.attn_n_head, d.attn_hd = part.shape[-2], n_head, hd
     out = np.zeros((nb, rows_total), np.float32) if resid is None else np.array(resid, np.float32, copy=True).reshape(nb, rows_total)
     d.use_gemm = 1 if use_gemm else 0
+    d.ordered = 1 if ordered else 0
+    route = C.c_uint32(0xffffffff)
+    d.route_out = C.cast(C.pointer(route), C.c_void_p)
     d.out = out.ctypes.data
     check(lib().nano_hip_op_fused_gemv(device, C.byref(d)))
+    if want_route:
+        return out, (ROUTE_NAMES[route.value] if route.value < len(ROUTE_NAMES) else "?")
     return out
 
 

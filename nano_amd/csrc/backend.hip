@@ -104,6 +104,7 @@ struct NanoHipModel {
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
     bool attn_quant = true;                               // batched steps: the attention kernel also writes the Wo GEMM's quantized input (NANO_ATTN_QUANT=0: quantizer launch)
     bool use_g5 = true;                                   // batched Q80 launches of group size 64 take gemm_q80_g5.hip's chained K-split kernel (NANO_GEMM_G5=0: G2 everywhere)
+    bool use_g6 = true;                                   // fast path, group size 64: gemm_q80_g6.hip's split-K kernel (<= 16 tokens; MODE P for 1..8 sequences on wide matrices); NANO_GEMM_G6=0: round 3's routes
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
@@ -419,6 +420,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
     if (const char *g5 = getenv("NANO_GEMM_G5")) m->use_g5 = *g5 && *g5 != '0';
+    if (const char *g6 = getenv("NANO_GEMM_G6")) m->use_g6 = *g6 && *g6 != '0';
     if (const char *aq = getenv("NANO_ATTN_QUANT")) m->attn_quant = *aq && *aq != '0';
     if (const char *wq = getenv("NANO_W2_QUANT")) m->w2_quant = *wq && *wq != '0';
     HIP_TRY(hipDeviceSynchronize());
@@ -480,91 +482,20 @@ static GemvSeg mkseg(const TensorRef &t, float *out, uint32_t rows, uint32_t bst
     return s;
 }
 
-// every workgroup of a multi-sequence GEMV launch re-quantizes the nb x n activations: ~ workgroups x elements of redundant work
-static bool gemv_is_heavy(const GemvArgs &a) {
-    uint32_t rows = 0;
-    if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
-    return (uint64_t)(rows / 16) * a.nb * a.n > (4u << 20);
+// the router's view of the model (route.hip): which kernel a projection launch goes to
+static Q80Route route_of(const NanoHipModel *m) {
+    static const bool use_cls = !(getenv("NANO_GEMM_CLS") && *getenv("NANO_GEMM_CLS") == '0');
+    Q80Route r{};
+    r.quant = m->d.quant_type; r.cus = m->cus; r.mfma_min_nb = m->mfma_min_nb;
+    r.use_g5 = m->use_g5; r.use_g6 = m->use_g6; r.use_cls = use_cls;
+    r.gq = m->gq; r.gxs = m->gxs; r.gq2 = m->gq2; r.gxs2 = m->gxs2;
+    return r;
 }
-// Q80 launches that go to the int8 MFMA GEMM (gemm_q80.hip): 9..64 sequences always; 8 sequences when the matrix is
-// large (measured on Qwen3-4B's matrices: 152 vs 183 us per layer; on Qwen3-0.6B's the GEMV kernels win up to 8)
-static bool takes_mfma(const NanoHipModel *m, const GemvArgs &a) {
-    if (m->d.quant_type != NANO_QUANT_Q80 || !m->gq || !m->gxs) return false;
-    if (a.nb >= m->mfma_min_nb) return true;
-    if (m->mfma_min_nb != 9) return false;                           // (NANO_MFMA_MIN_NB != 9 disables the rules below: A/B runs)
-    if (a.nb == 8 && gemv_is_heavy(a)) return true;
-    // per-layer matrices of >= 8 M weights (Qwen3-4B's): from 2 sequences on (measured on its row lengths, one layer +
-    // classifier per step, tools/wide_batch.sh: 2 sequences 88 vs 111 us, 4: 94 vs 134, 6: 91 vs 166); the classifier
-    // keeps its STREAM GEMV up to 7 sequences
-    uint32_t rows = 0;
-    if (a.epi == GEMV_EPI_SWIGLU) rows = a.seg[0].rows; else for (uint32_t s = 0; s < a.nseg; s++) rows += a.seg[s].rows;
-    return a.nb >= 2 && rows < 65536u && (uint64_t)rows * a.n >= (8u << 20);
-}
-
-// the sequences [b0, b0 + cnt) of a launch, as a launch of their own (every per-sequence pointer advanced)
-static GemvArgs gemv_slice(const GemvArgs &a, uint32_t b0, uint32_t cnt) {
-    GemvArgs s = a;
-    s.nb = cnt;
-    for (uint32_t i = 0; i < a.nseg; i++) if (s.seg[i].out) s.seg[i].out += (size_t)b0 * a.seg[i].out_bstride;
-    if (a.xin) s.xin += (size_t)b0 * a.xin_bstride;
-    if (a.pos) s.pos += b0;
-    if (a.xq_in) s.xq_in += (size_t)b0 * ((a.n + 15) & ~15u);
-    if (a.xs_in) s.xs_in += (size_t)b0 * (a.n / a.gs);
-    if (a.attn_part) { s.attn_part += (size_t)b0 * a.attn_nsplit * a.n; s.attn_ml += (size_t)b0 * a.attn_n_head * a.attn_nsplit * 2; }
-    if (a.resid_add) s.resid_add += (size_t)b0 * a.resid_add_bstride;
-    s.tile_max = nullptr;
-    return s;
-}
+static RouteKind kind_of(const NanoHipModel *m, GemvArgs a) { a.ordered = m->strict ? 1u : 0u; a.cus = (uint32_t)m->cus; return route_kind(route_of(m), a); }
 
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
-    const uint32_t max_wg = (uint32_t)m->cus * 8;
-    a.cus = (uint32_t)m->cus;
-    if (m->d.quant_type == NANO_QUANT_Q4K) {
-        // every workgroup stages the whole quantized activation of each sequence in LDS: long rows (Qwen3-4B's hidden size)
-        // take fewer sequences per launch
-        const uint32_t fit = a.nb > 1 ? gemv_q4k_fit_batch(a) : 1u;
-        if (a.nb <= fit) return launch_gemv_q4k(a, max_wg, m->st);
-        for (uint32_t b0 = 0; b0 < a.nb; b0 += fit) {
-            GemvArgs s = gemv_slice(a, b0, a.nb - b0 < fit ? a.nb - b0 : fit);
-            const hipError_t e = launch_gemv_q4k(s, max_wg, m->st);
-            if (e != hipSuccess) return e;
-        }
-        return hipSuccess;
-    }
-    if (takes_mfma(m, a) && !a.attn_part && !a.resid_add && gemm_q80_g2_supports(a)) {
-        // quantize every sequence's activation once, straight into MFMA fragment order, then the GEMM: G5 (group size 64: the
-        // row length split over a chained team of waves, gemm_q80_g5.hip) or the general G2 kernel.  One arithmetic, same bits.
-        if (!a.frag_ready) {
-            const hipError_t e = launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
-            if (e != hipSuccess) return e;
-        }
-        a.xq_in = a.frag_ready == 2u ? m->gq2 : m->gq; a.xs_in = a.frag_ready == 2u ? m->gxs2 : m->gxs;
-        // the classifier of a batched step: GC (persistent waves, the activation fragments staged in LDS once per workgroup)
-        static const bool use_cls = !(getenv("NANO_GEMM_CLS") && *getenv("NANO_GEMM_CLS") == '0');
-        if (use_cls && !a.frag_out && gemm_q80_cls_supports(a)) return launch_gemm_q80_cls(a, m->st);
-        if (m->use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, a.frag_out, a.frag_scale_out, m->st);
-        if (a.frag_out) return hipErrorInvalidValue;               // the caller checked gemm_q80_g5_can_quantize_outputs()
-        return launch_gemm_q80_g2(a, m->st);
-    }
-    if (a.nb > 8) {
-        // More sequences than a GEMV launch takes and a launch the GEMM does not take (row length / group size not a
-        // multiple of 4 groups, segment rows not multiples of 16, the LoRA o-branch addend): groups of 8 through the
-        // GEMV kernels.  Same arithmetic per sequence, the weights are read once per group.
-        for (uint32_t b0 = 0; b0 < a.nb; b0 += 8) {
-            GemvArgs s = gemv_slice(a, b0, a.nb - b0 < 8 ? a.nb - b0 : 8u);
-            const hipError_t e = launch_gemv(m->d.quant_type, s, max_wg, m->st);
-            if (e != hipSuccess) return e;
-        }
-        return hipSuccess;
-    }
-    if (m->d.quant_type == NANO_QUANT_Q80 && a.nb > 1 && !a.attn_part && !a.xq_in && m->gq && m->gxs && gemv_is_heavy(a)) {
-        // when the redundant quantization outweighs a launch (~3 us) the activations are quantized once
-        // (quant_rows_kernel) and the GEMV reads them back
-        hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, m->gq, m->gxs, m->st);
-        if (e != hipSuccess) return e;
-        a.xq_in = m->gq; a.xs_in = m->gxs; a.norm_w = nullptr;
-    }
-    return launch_gemv(m->d.quant_type, a, max_wg, m->st);
+    a.ordered = m->strict ? 1u : 0u;                                   // strict mode: the reference's group order in every kernel
+    return route_projection(route_of(m), a, m->st);
 }
 
 static GemvArgs classifier_args(const NanoHipModel *m, uint32_t nb) {
@@ -577,7 +508,7 @@ static GemvArgs classifier_args(const NanoHipModel *m, uint32_t nb) {
 
 static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
     GemvArgs a = classifier_args(m, nb);
-    if (ntiles_out && nb <= 8 && !(takes_mfma(m, a) && gemm_q80_g2_supports(a)) &&
+    if (ntiles_out && nb <= 8 && !route_takes_fragments(kind_of(m, a)) &&
         (m->d.quant_type != NANO_QUANT_Q4K || nb <= (nb > 1 ? gemv_q4k_fit_batch(a) : 1u))) {      // per-tile arg-max partials for the sampler (Q4K: not for sliced launches)
         a.tile_max = m->tile_max;
         *ntiles_out = gemv_tiles(m->d.quant_type, a);
@@ -596,18 +527,25 @@ static uint32_t step_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_h
     return ns ? ns : 1;
 }
 
-// the Wo launch of a step of nb sequences goes to the batched GEMM
-static bool wo_takes_gemm(const NanoHipModel *m, uint32_t nb) {
-    if (m->lora_on || m->d.quant_type != NANO_QUANT_Q80) return false;
+// the Wo launch of a step of nb sequences: with the plain (combined, normalised) attention output as its input, and -- a split
+// attention -- with the splits' partials as its input (combined in its prologue: SLAB GEMV / G6 MODE P of one sequence)
+static GemvArgs wo_args(const NanoHipModel *m, uint32_t nb, uint32_t nsplit) {
     GemvArgs wa{};
     wa.nseg = 1; wa.seg[0] = mkseg(m->W[WO][0], m->x, m->d.n_embd, m->d.n_embd); wa.n = m->QD; wa.gs = m->d.group_size; wa.nb = nb;
     wa.xin = m->xba; wa.xin_bstride = m->QD; wa.epi = GEMV_EPI_RESID;
-    return takes_mfma(m, wa) && gemm_q80_g2_supports(wa);
+    if (m->lora_on) { wa.resid_add = m->lora_o1; wa.resid_add_bstride = m->d.n_embd; }
+    if (nsplit > 1) { wa.attn_part = m->attn_part; wa.attn_ml = m->attn_ml; wa.attn_nsplit = nsplit; wa.attn_n_head = m->d.n_head; wa.attn_hd = m->hd; }
+    return wa;
+}
+// does the Wo launch combine the `nsplit` partials itself?  (else: a combine kernel of its own in front of it)
+static bool wo_takes_parts(const NanoHipModel *m, uint32_t nb, uint32_t nsplit) {
+    if (nsplit <= 1 || nsplit > 8 || m->pf) return false;
+    return route_takes_attn_parts(kind_of(m, wo_args(m, nb, nsplit)));
 }
 // splits nano_hip_read_state still has to combine xba from after a decode step (1: the step left it final)
 static uint32_t xba_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_hint) {
     const uint32_t ns = step_nsplit(m, nb, range_hint);
-    return (ns > 1 && (wo_takes_gemm(m, nb) || ns > 8)) ? 1u : ns;
+    return (ns > 1 && !wo_takes_parts(m, nb, ns)) ? 1u : ns;
 }
 
 // range_hint: host-side upper bound of the attended range of every sequence (a multiple of 64, <= S)
@@ -622,8 +560,8 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     // Does this step's Wo launch go to the batched GEMM (plain activations only), or is the range split wider than the Wo
     // GEMV's prologue combines?  Then a split attention is combined by a kernel of its own (as in batched prefill) -- for
     // <= 8 splits the same arithmetic, same bits.
-    const bool wo_gemm = wo_takes_gemm(m, nb);
-    const bool pf_combine = nsplit > 1 && (m->pf || wo_gemm || nsplit > 8);
+    const bool pf_combine = nsplit > 1 && !wo_takes_parts(m, nb, nsplit);
+    const bool wo_gemm = route_takes_fragments(kind_of(m, wo_args(m, nb, pf_combine ? 1u : nsplit)));
     m->nsplit = pf_combine ? 1 : nsplit;
     // Single-split attention (or the combine kernel) of a step whose Wo launch goes to the batched GEMM: that kernel writes
     // Wo's quantized input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
@@ -723,10 +661,11 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_SWIGLU;
             a.norm_w = m->rms_ffn + (size_t)l * E; a.pos = m->pos;
             // both FFN launches on the batched GEMM path and this one on G5: its epilogue quantizes hb for W2 (64-row groups)
-            if (m->w2_quant && m->use_g5 && m->gq2 && !(skip & 8) && takes_mfma(m, a) && gemm_q80_g5_can_quantize_outputs(a)) {
+            // (the older batched route only: G6 quantizes nothing in its epilogue -- its tiles are fitted to the CUs, not to 64-row groups)
+            if (m->w2_quant && m->use_g5 && m->gq2 && !(skip & 8) && kind_of(m, a) == ROUTE_FRAG_OLD && gemm_q80_g5_can_quantize_outputs(a)) {
                 GemvArgs w2{};
                 w2.nseg = 1; w2.seg[0] = mkseg(m->W[W2][l], m->x, E, E); w2.n = H; w2.gs = d.group_size; w2.nb = nb; w2.xin = m->hb; w2.xin_bstride = H; w2.epi = GEMV_EPI_RESID;
-                if (takes_mfma(m, w2) && gemm_q80_g2_supports(w2)) { w2_frag = true; a.frag_out = m->gq2; a.frag_scale_out = m->gxs2; }
+                if (kind_of(m, w2) == ROUTE_FRAG_OLD) { w2_frag = true; a.frag_out = m->gq2; a.frag_scale_out = m->gxs2; }
             }
             a.stamps = next_stamps(m, 4);
             if (!(skip & 8) && (e = gemv(m, a)) != hipSuccess) return e;
@@ -745,7 +684,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     uint32_t ntiles = 0;
     // probe: Q80 STREAM classifier (batch <= 8) -> the kernel's own start / stop timestamps (hipExtLaunchKernelGGL);
     // other classifiers -> events recorded around the launch (ev1..ev2 = an empty pair, the event overhead)
-    const bool probe_ext = m->probe_cls && d.quant_type == NANO_QUANT_Q80 && nb <= 8 && d.vocab_size >= 16384 && !takes_mfma(m, classifier_args(m, nb));
+    const bool probe_ext = m->probe_cls && d.quant_type == NANO_QUANT_Q80 && nb <= 8 && d.vocab_size >= 16384 && !route_takes_fragments(kind_of(m, classifier_args(m, nb)));
     if (probe_ext) { g_q80_probe_start = m->ev0; g_q80_probe_stop = m->ev1; }
     else if (m->probe_cls && (e = hipEventRecord(m->ev0, m->st)) != hipSuccess) return e;
     if (!(skip & 32) && (e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;

@@ -333,7 +333,7 @@ g2_done:
 //   xsf [tt][g][16 tokens]
 template <int GS>
 __global__ __launch_bounds__(256) void quant_rows_frag_kernel(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n,
-                                                              int8_t *xf, float *xsf, uint32_t ng) {
+                                                              int8_t *xf, float *xsf, uint32_t ng, uint32_t order512) {
     __shared__ float red[8];
     karg_touch(xf); karg_touch(xsf); karg_touch(ng);                  // the output pointers come with the first arguments, not after the quantizer
     constexpr uint32_t FR = GS >= 64 ? GS / 64 : 1, FB = GS == 32 ? 512u : 1024u, KB = GS == 32 ? 8u : 16u;
@@ -347,6 +347,27 @@ __global__ __launch_bounds__(256) void quant_rows_frag_kernel(const float *x, ui
     float4 v = live ? *reinterpret_cast<const float4 *>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 w = (live && norm_w) ? *reinterpret_cast<const float4 *>(norm_w + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     float ss = 1.0f;
+    if (norm_w && order512) {           // rmsnorm scale in the tree order of gemm_q80_g6.hip's MODE P prologue (512 threads: thread T adds the float4
+        // items T, T + 512, ...; eight wave sums added in order): this thread plays T = tid and T = tid + 256 -- the same additions,
+        // so 1..8 sequences (quantized in that prologue) and 9..64 (quantized here) see the same bits
+        float acc0 = 0.0f, acc1 = 0.0f;
+        for (uint32_t k0 = tid * 4u; k0 < n; k0 += 2048u) {
+            const uint32_t k1 = k0 + 1024u;
+            const float4 u0 = *reinterpret_cast<const float4 *>(xr + k0);
+            const float4 u1 = k1 < n ? *reinterpret_cast<const float4 *>(xr + k1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc0 += u0.x * u0.x; acc0 += u0.y * u0.y; acc0 += u0.z * u0.z; acc0 += u0.w * u0.w;
+            if (k1 < n) { acc1 += u1.x * u1.x; acc1 += u1.y * u1.y; acc1 += u1.z * u1.z; acc1 += u1.w * u1.w; }
+        }
+        acc0 = dpp_wave_sum(acc0); acc1 = dpp_wave_sum(acc1);
+        if (lane == 0) { red[wid] = acc0; red[4 + wid] = acc1; }
+        __syncthreads();
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += red[k];
+        s /= (float)n; s += 1e-5f;
+        ss = 1.0f / sqrtf(s);
+        v.x = w.x * (ss * v.x); v.y = w.y * (ss * v.y); v.z = w.z * (ss * v.z); v.w = w.w * (ss * v.w);
+    } else
     if (norm_w) {                       // rmsnorm scale (infer.c:603-609), the GEMV prologue's tree order for 256 threads
         // four row pieces per trip, all four loads in flight before the first is used (a load per trip would cost a memory
         // round trip per 1024 elements); the additions keep their order: k ascending, x y z w
@@ -450,14 +471,14 @@ hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st) {
 // bytes of the fragment-order activation scratch for up to `tokens` tokens of row length n
 size_t gemm_q80_frag_bytes(uint32_t tokens, uint32_t n) { return (size_t)((tokens + 15) / 16) * 16 * ((n + 15) & ~15u); }
 hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
-                                  int8_t *xf, float *xsf, hipStream_t st) {
-    if (!nb || gs == 0 || n % gs || n % 4) return hipErrorInvalidValue;
-    const uint32_t ng = n / gs;
+                                  int8_t *xf, float *xsf, hipStream_t st, uint32_t order) {
+    if (!nb || gs == 0 || n % gs || n % 4 || (order != 256u && order != 512u)) return hipErrorInvalidValue;
+    const uint32_t ng = n / gs, o5 = order == 512u ? 1u : 0u;
     switch (gs) {
-    case 32: hipLaunchKernelGGL((quant_rows_frag_kernel<32>), dim3((n + 1023) / 1024, nb), dim3(256), 0, st, x, x_bstride, norm_w, n, xf, xsf, ng); break;
-    case 64: hipLaunchKernelGGL((quant_rows_frag_kernel<64>), dim3((n + 1023) / 1024, nb), dim3(256), 0, st, x, x_bstride, norm_w, n, xf, xsf, ng); break;
-    case 128: hipLaunchKernelGGL((quant_rows_frag_kernel<128>), dim3((n + 1023) / 1024, nb), dim3(256), 0, st, x, x_bstride, norm_w, n, xf, xsf, ng); break;
-    case 256: hipLaunchKernelGGL((quant_rows_frag_kernel<256>), dim3((n + 1023) / 1024, nb), dim3(256), 0, st, x, x_bstride, norm_w, n, xf, xsf, ng); break;
+    case 32: hipLaunchKernelGGL((quant_rows_frag_kernel<32>), dim3((n + 1023) / 1024, nb), dim3(256), 0, st, x, x_bstride, norm_w, n, xf, xsf, ng, o5); break;
+    case 64: hipLaunchKernelGGL((quant_rows_frag_kernel<64>), dim3((n + 1023) / 1024, nb), dim3(256), 0, st, x, x_bstride, norm_w, n, xf, xsf, ng, o5); break;
+    case 128: hipLaunchKernelGGL((quant_rows_frag_kernel<128>), dim3((n + 1023) / 1024, nb), dim3(256), 0, st, x, x_bstride, norm_w, n, xf, xsf, ng, o5); break;
+    case 256: hipLaunchKernelGGL((quant_rows_frag_kernel<256>), dim3((n + 1023) / 1024, nb), dim3(256), 0, st, x, x_bstride, norm_w, n, xf, xsf, ng, o5); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -36,7 +36,9 @@ struct G5Dev {
     const int8_t *w[3]; const float *ws[3]; float *out[3];
     uint32_t rows[3], out_bstride[3], out_pstride[3];
     uint32_t n, ng, epi, nb, nhc, ntiles, tt, nkw, cpw, teams, nmat;
-    uint32_t trw, tc0, tc1, _padt;      // rows per tile (even, <= 16: balanced tiles), tiles up to the end of segment 0 / 1
+    uint32_t trw, tc0, tc1;             // rows per tile (even, <= 16: balanced tiles), tiles up to the end of segment 0 / 1
+    uint32_t canon;                     // 1: the fast path's canonical fold (kernels.h q80_canonical()): the half chunk's 8 products are summed on
+                                        // their own (= the unit sum S_u), then added to the running value; 0 (strict mode): group by group
     const int8_t *xf; const float *xsf; const uint32_t *pos;
     // SwiGLU launches, optional (4 row-tile pairs per workgroup): the outputs also leave as Q80 groups of 64 in fragment order,
     // i.e. the next GEMM's activation operand (what quant_rows_frag_kernel would make of them); ng2 = rows / 64
@@ -233,8 +235,16 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                 // groups beyond ng (the last half chunk when ng % 8 == 4) contribute products +0.0f: exact, because a running
                 // value that started at +0.0f (here as in the reference, infer.c:668) is never -0.0f -- x + (-0.0f) and
                 // x + (+0.0f) only differ for x == -0.0f
+                if (a.canon) {                                           // S_u = ((p_0 + p_1) + ...) + p_7, then running + S_u (gemm_q80_g6.hip's shape)
+                    float su[4] = {p[0][0], p[0][1], p[0][2], p[0][3]};
+#pragma unroll
+                    for (uint32_t j = 1; j < 8; j++) if (g0 + j < ng) { su[0] += p[j][0]; su[1] += p[j][1]; su[2] += p[j][2]; su[3] += p[j][3]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[i] = h != 0u ? acc[i] + su[i] : su[i];
+                } else {
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) { acc[0] += p[j][0]; acc[1] += p[j][1]; acc[2] += p[j][2]; acc[3] += p[j][3]; }
+                }
                 if (h == kw && t == 0u) NANO_STAMP(a.stamps, 3, acc[0]);       // the first wave's first chain link folded (h = 0: no wait before it)
                 if (!fin) {
                     *reinterpret_cast<float4 *>(slot + t * 256 + lane * 4u) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -340,6 +350,7 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
     d.nmat = sw ? 2u : 1u;
     d.xf = a.xq_in; d.xsf = a.xs_in; d.pos = a.pos;
     d.stamps = a.stamps;
+    d.canon = q80_canonical(a) ? 1u : 0u;
     { static const bool hoist = !(getenv("NANO_G5_HOIST") && *getenv("NANO_G5_HOIST") == '0'); d.hoist_ws = hoist ? 1u : 0u; }   // A/B knob
     // The split.  A workgroup = one row tile (SwiGLU: the W1/W3 pair) x nkw waves; a CU holds 12 waves (3 per SIMD at
     // <= 168 VGPRs).  Take the deepest split whose workgroups are ALL resident at once (no second round of workgroups, whose

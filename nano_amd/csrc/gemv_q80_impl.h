@@ -194,6 +194,48 @@ template <int NQ> __device__ __forceinline__ void fold_row2(const float *p0, con
     for (int q = 0; q < NQ; q++) { v0 += t[q].x; v1 += u[q].x; v0 += t[q].y; v1 += u[q].y; v0 += t[q].z; v1 += u[q].z; v0 += t[q].w; v1 += u[q].w; }
 }
 
+// CANONICAL fold of the fast path (kernels.h q80_canonical(); group size 64): unit sums S_u = the 8 group products of unit u added in
+// ascending order, row = ((S_0 + S_1) + S_2) + ... -- the one reduction shape the split-K kernels (gemm_q80_g6.hip, G5) share, so
+// that a batch stays bit for bit its sequences alone whichever kernel a batch size is routed to.  NQ float4 = 4 NQ groups.
+__device__ __forceinline__ float unit_sum(const float4 &t0, const float4 &t1) {
+    float s = t0.x; s += t0.y; s += t0.z; s += t0.w; s += t1.x; s += t1.y; s += t1.z; s += t1.w;
+    return s;
+}
+template <int NQ> __device__ __forceinline__ float fold_row_canon(const float *p) {
+    static_assert(NQ % 2 == 0, "whole units");
+    float4 t[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) t[q] = *reinterpret_cast<const float4 *>(p + 4 * q);
+    float v = unit_sum(t[0], t[1]);
+#pragma unroll
+    for (int q = 2; q < NQ; q += 2) v += unit_sum(t[q], t[q + 1]);
+    return v;
+}
+// any group count that is a multiple of 4 (the last unit may hold 4 groups); two units per trip, their reads first
+__device__ __forceinline__ float fold_row_canon_any(const float *p, uint32_t ng) {
+    float v = 0.0f;
+    for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
+        float4 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) t[q] = (g0 + 4u * (uint32_t)q < ng) ? *reinterpret_cast<const float4 *>(p + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = t[0].x; s += t[0].y; s += t[0].z; s += t[0].w;
+        if (g0 + 4 < ng) { s += t[1].x; s += t[1].y; s += t[1].z; s += t[1].w; }
+        v = g0 == 0 ? s : v + s;
+        if (g0 + 8 < ng) {
+            s = t[2].x; s += t[2].y; s += t[2].z; s += t[2].w;
+            if (g0 + 12 < ng) { s += t[3].x; s += t[3].y; s += t[3].z; s += t[3].w; }
+            v += s;
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ float fold_row_canon_ng(const float *p, uint32_t ng) {
+    if (ng == 16u) return fold_row_canon<4>(p);
+    if (ng == 32u) return fold_row_canon<8>(p);
+    if (ng == 48u) return fold_row_canon<12>(p);
+    return fold_row_canon_any(p, ng);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // SLAB kernel
 // ------------------------------------------------------------------------------------------------------------
@@ -225,7 +267,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.out_bstride[1]); karg_touch(a.out_bstride[2]);
         karg_touch(a.out_pstride[1]); karg_touch(a.out_pstride[2]); karg_touch(a.rows[1]); karg_touch(a.rows[2]);
     }
-    karg_touch(a.pos);
+    karg_touch(a.pos); karg_touch(a.canon);
     if (ROLE == R_GENERIC || ROLE == R_RESID || ROLE == R_RESID_COMBINE) { karg_touch(a.resid_add); karg_touch(a.resid_add_bstride); }
     NANO_STAMP(a.stamps, 0, tid);
     // ---- 1. activation loads (critical path) ------------------------------------------------------------
@@ -337,6 +379,10 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         float v0 = 0.0f, v1 = 0.0f;
         const float *p0 = P + (((size_t)fb * nmat) * RWP + frl) * PITCH;
         const float *p1 = p0 + (size_t)RWP * PITCH;
+        if (GS == 64 && a.canon) {                              // the fast path's canonical fold (strict mode: the reference's order below)
+            v0 = fold_row_canon_ng(p0, ng);
+            if (swiglu) v1 = fold_row_canon_ng(p1, ng);
+        } else
         if (!swiglu && ng == 48u) v0 = fold_row<12>(p0);        // the row lengths of Qwen3-0.6B at group size 64 (3072 / 2048 / 1024): every
         else if (!swiglu && ng == 32u) v0 = fold_row<8>(p0);    // LDS read of the row goes out before the dependent add chain starts (round 3:
         else if (ng == 16u) {                                   // the batch-by-batch loop below exposes one LDS round trip per 16 groups)

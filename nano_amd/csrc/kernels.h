@@ -50,10 +50,21 @@ struct GemvArgs {
     const float *resid_add; uint32_t resid_add_bstride, _pad3;
     // optional per-tile arg-max partials of a STORE launch: tile_max[b][tile] = (max value, row index bits)
     float *tile_max;
-    uint32_t cus, _pad4;    // compute units of the device the launch goes to (0: assume 256); sizes the work split
+    uint32_t cus;           // compute units of the device the launch goes to (0: assume 256); sizes the work split
+    uint32_t ordered;       // 1: strict mode -- every fp32 group fold in the reference's ascending order (infer.c:668-674); 0: the fast
+                            // path's CANONICAL fold where it applies (q80_canonical(): unit sums of 8 groups, units ascending)
     unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
 
+// The fast path's reduction shape of a Q80 projection (group size 64, row length a multiple of 256; not the classifier-like tall
+// STORE launches, whose kernels hold whole rows per wave and keep the reference's order): row = ((S_0 + S_1) + ...), S_u = the 8
+// group products of unit u added in ascending order.  Every kernel a launch can be routed to (SLAB GEMV, G6, G5) implements this
+// one shape, so a batch stays bit for bit its sequences alone whatever route each size takes.  Strict mode: never.
+inline bool q80_canonical(const GemvArgs &a) {
+    if (a.ordered || a.gs != 64 || a.n % 256u) return false;
+    if (a.nseg == 1 && a.epi == GEMV_EPI_STORE && a.seg[0].rows >= 16384u && a.seg[0].out_pstride == 0) return false;
+    return true;
+}
 uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // tiles launch_gemv() will use (sizes tile_max)
 hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t st);
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
@@ -68,15 +79,45 @@ hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st);
 bool gemm_q80_g5_supports(const GemvArgs &a);
 bool gemm_q80_g5_can_quantize_outputs(const GemvArgs &a);           // SwiGLU launches: the outputs also as Q80 fragments (xf2 / xsf2)
 hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipStream_t st);
+// G6 (gemm_q80_g6.hip): the fast path's split-K kernel, canonical fold, group size 64.  MODE F: fragment-order activations, up to 16
+// tokens; MODE P: fp32 activations of 1..8 sequences, rmsnorm | split-attention combine + quantization in the kernel's prologue
+bool gemm_q80_g6_supports(const GemvArgs &a);
+hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st);
+bool gemm_q80_g6p_supports(const GemvArgs &a);
+hipError_t launch_gemm_q80_g6p(const GemvArgs &a, hipStream_t st);
 // GC, tall matrices with short rows (the classifier): persistent waves, activation fragments staged in LDS (gemm_q80_cls.hip)
 bool gemm_q80_cls_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_cls(const GemvArgs &a, hipStream_t st);
+// order: threads of the rmsnorm sum-of-squares tree -- 256 (the SLAB GEMV prologue's of the small matrices) or 512 (G6 MODE P's)
 hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
-                                  int8_t *xf, float *xsf, hipStream_t st);
+                                  int8_t *xf, float *xsf, hipStream_t st, uint32_t order = 256);
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                              int8_t *xq, float *xs, hipStream_t st);
 uint32_t gemv_q80_partials(const GemvArgs &a);
 uint32_t gemv_q4k_partials(const GemvArgs &a);   // Q4K: one (max, row) partial per workgroup of a one-segment STORE launch with tile_max
+
+// ---- routing (route.hip): which kernel a projection launch goes to ------------------------------------------------------------
+enum RouteKind : uint32_t {
+    ROUTE_GEMV = 0,        // one GEMV launch (FP32 / Q80 SLAB or STREAM), activation quantized in its prologue
+    ROUTE_GEMV_PREQ,       // Q80: row-major quantizer launch + GEMV reading the quantized rows (2..8 sequences on large inputs)
+    ROUTE_GEMV_SLICED,     // more than 8 sequences through the GEMV kernels in groups of 8
+    ROUTE_Q4K,
+    ROUTE_G6P,             // G6 MODE P: fp32 activation (or split-attention partials), quantized in the kernel's prologue
+    ROUTE_FRAG_G6,         // fragment-order activations (quantizer launch unless frag_ready) + G6 MODE F
+    ROUTE_FRAG_OLD,        // fragment-order activations + GC | G5 | G2
+};
+inline bool route_takes_fragments(RouteKind k) { return k == ROUTE_FRAG_G6 || k == ROUTE_FRAG_OLD; }
+inline bool route_takes_attn_parts(RouteKind k) { return k == ROUTE_GEMV || k == ROUTE_G6P || k == ROUTE_Q4K; }
+struct Q80Route {
+    uint32_t quant; int cus;
+    uint32_t mfma_min_nb;  // sequences from which the small Q80 matrices take the batched route (9; measurement: NANO_MFMA_MIN_NB)
+    bool use_g5, use_g6, use_cls;
+    int8_t *gq; float *gxs; int8_t *gq2; float *gxs2;   // fragment-order activation scratch (nullptr: no batched route)
+};
+RouteKind route_kind(const Q80Route &r, const GemvArgs &a);
+hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st);
+uint32_t route_norm_order(const Q80Route &r, const GemvArgs &a);
+bool route_is_wide(const GemvArgs &a);
 
 // ---- attention ------------------------------------------------------------------------------------
 constexpr uint32_t ATTN_MAX_NSPLIT = 32, ATTN_WIDE_FROM = 2048;   // up to 32 splits of a range beyond 2048 positions (<= 8 below: attention_nsplit())

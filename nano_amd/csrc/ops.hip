@@ -94,6 +94,7 @@ extern "C" int nano_hip_op_matmul_q80(int device, float *out, const int8_t *xq, 
     OP_CHECK(dxq && dwq && dxs && dws && dout, "device alloc failed");
     GemvArgs a{}; a.nseg = 1; a.seg[0].w = dwq; a.seg[0].ws = dws; a.seg[0].out = dout; a.seg[0].rows = d; a.seg[0].out_bstride = d;
     a.n = n; a.gs = gs; a.nb = 1; a.epi = GEMV_EPI_STORE; a.xq_in = dxq; a.xs_in = dxs;
+    a.ordered = 1;      // the operator-level certificate: the reference's ascending group order (the fast path's canonical fold is tested through nano_hip_op_fused_gemv)
     if ((rc = run_gemv(NANO_QUANT_Q80, a))) return rc;
     OP_HIP(hipMemcpy(out, dout, (size_t)d * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -222,20 +223,22 @@ extern "C" int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *dp) {
     }
     hipDeviceProp_t prop; OP_HIP(hipGetDeviceProperties(&prop, device));
     a.cus = (uint32_t)prop.multiProcessorCount;
-    hipError_t e;
-    if (d.use_gemm) {
-        if (d.quant != NANO_QUANT_Q80 || a.attn_part || !gemm_q80_g2_supports(a)) { nano_hip_set_error_("the batched GEMM route does not take this launch"); return NANO_HIP_EINVAL; }
+    // the step's own router (route.hip): use_gemm = 1 forces the fragment-order route of batched steps (quantizer launch + G6 MODE F /
+    // G5 / GC / G2); ordered = 1 is strict mode (the reference's group order in every kernel)
+    a.ordered = d.ordered ? 1u : 0u;
+    Q80Route r{};
+    r.quant = d.quant; r.cus = (int)a.cus; r.mfma_min_nb = d.use_gemm ? 1u : 9u;
+    r.use_g5 = !(getenv("NANO_GEMM_G5") && *getenv("NANO_GEMM_G5") == '0');
+    r.use_g6 = !(getenv("NANO_GEMM_G6") && *getenv("NANO_GEMM_G6") == '0');
+    r.use_cls = !(getenv("NANO_GEMM_CLS") && *getenv("NANO_GEMM_CLS") == '0');
+    if (d.quant == NANO_QUANT_Q80) {
         const size_t n16 = (d.n + 15) & ~(size_t)15, tt = (d.nb + 15) / 16;
-        int8_t *xf = B.alloc<int8_t>(tt * 16 * n16); float *xsf = B.alloc<float>(tt * 16 * (d.n / d.gs));
-        OP_CHECK(xf && xsf, "device alloc failed");
-        OP_HIP(launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, xf, xsf, 0));
-        a.xq_in = xf; a.xs_in = xsf;
-        e = gemm_q80_cls_supports(a) ? launch_gemm_q80_cls(a, 0) : gemm_q80_g5_supports(a) ? launch_gemm_q80_g5(a, nullptr, nullptr, 0) : launch_gemm_q80_g2(a, 0);
-    } else if (d.nb > 8) {
-        nano_hip_set_error_("more than 8 sequences need use_gemm"); return NANO_HIP_EINVAL;
-    } else {
-        e = (d.quant == NANO_QUANT_Q4K) ? launch_gemv_q4k(a, 2048, 0) : launch_gemv(d.quant, a, 2048, 0);
+        r.gq = B.alloc<int8_t>(tt * 16 * n16); r.gxs = B.alloc<float>(tt * 16 * (d.n / d.gs));
+        OP_CHECK(r.gq && r.gxs, "device alloc failed");
     }
+    if (d.use_gemm && (d.quant != NANO_QUANT_Q80 || !route_takes_fragments(route_kind(r, a)))) { nano_hip_set_error_("the batched GEMM route does not take this launch"); return NANO_HIP_EINVAL; }
+    if (d.route_out) *d.route_out = (uint32_t)route_kind(r, a);
+    const hipError_t e = route_projection(r, a, 0);
     OP_HIP(e);
     OP_HIP(hipDeviceSynchronize());
     OP_HIP(hipMemcpy(d.out, dout, (size_t)d.nb * rows_total * 4, hipMemcpyDeviceToHost));

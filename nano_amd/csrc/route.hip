@@ -1,0 +1,141 @@
+// route.hip -- which kernel a projection launch (out = W . act, one weight tensor or a run of them sharing the activation) goes to.
+// ONE router for the decode step (backend.hip), batched prefill and the operator entry points (ops.hip), so that the operator tests
+// exercise exactly the launches a step issues.
+//
+//   FP32 / Q4K              the GEMV kernels (gemv_f32.hip, gemv_q4k.hip), more than 8 sequences in groups
+//   Q80, fast path          SLAB GEMV (1..8 sequences on the small per-layer matrices)           gemv_q80_impl.h
+//                           G6 MODE P (1..8 sequences on matrices of >= 8 M weights: Qwen3-4B)    gemm_q80_g6.hip
+//                           G6 MODE F (fragment-order activations, <= 16 tokens)                 gemm_q80_g6.hip
+//                           G5 (17..64 tokens), G2 (group sizes other than 64)                   gemm_q80_g5.hip, gemm_q80.hip
+//                           STREAM GEMV / GC for the classifier                                   gemv_q80_impl.h, gemm_q80_cls.hip
+//   Q80, strict mode        the kernels that keep the reference's ascending group order: SLAB, G5, GC, G2 (a.ordered = 1)
+#include <stdlib.h>
+#include "kernels.h"
+
+namespace nano {
+
+static uint32_t route_rows(const GemvArgs &a) {
+    if (a.epi == GEMV_EPI_SWIGLU) return a.seg[0].rows;
+    uint32_t r = 0;
+    for (uint32_t s = 0; s < a.nseg; s++) r += a.seg[s].rows;
+    return r;
+}
+// every workgroup of a multi-sequence GEMV launch re-quantizes the nb x n activations: ~ workgroups x elements of redundant work
+static bool gemv_is_heavy(const GemvArgs &a) { return (uint64_t)(route_rows(a) / 16) * a.nb * a.n > (4u << 20); }
+// per-layer matrices of >= 8 M weights (Qwen3-4B's): bandwidth rather than latency bound
+bool route_is_wide(const GemvArgs &a) { const uint32_t rows = route_rows(a); return rows < 65536u && (uint64_t)rows * a.n >= (8u << 20); }
+
+// the rmsnorm sum-of-squares tree the activation quantizer launch must repeat for this matrix (launch_quant_rows_frag order)
+// (not a function of the A/B knobs: with NANO_GEMM_G6=0 the batched launches of wide matrices keep MODE P's tree, so that switching
+// G6 off changes kernels, not bits)
+uint32_t route_norm_order(const Q80Route &r, const GemvArgs &a) {
+    (void)r;
+    return (q80_canonical(a) && route_is_wide(a) && a.n <= 10240u) ? 512u : 256u;
+}
+
+// MODE P quantizes nb x n values in EVERY workgroup: taken when the launch needs fp32 processing anyway (a norm or the split-attention
+// combine: the quantizer launch it replaces costs ~3.5 us) or when the activation is small
+static bool p_worthwhile(const GemvArgs &a) { return a.norm_w || a.attn_part || (uint64_t)a.nb * a.n <= 12288u; }
+
+RouteKind route_kind(const Q80Route &r, const GemvArgs &a) {
+    if (r.quant == NANO_QUANT_Q4K) return ROUTE_Q4K;
+    if (r.quant != NANO_QUANT_Q80) return a.nb > 8 ? ROUTE_GEMV_SLICED : ROUTE_GEMV;
+    const bool scratch = r.gq && r.gxs;
+    const bool canon = q80_canonical(a);
+    const bool wide = route_is_wide(a);
+    if (canon && r.use_g6) {
+        if (wide && !a.xq_in && a.nb <= 8 && r.mfma_min_nb == 9 && p_worthwhile(a) && gemm_q80_g6p_supports(a)) return ROUTE_G6P;
+        const bool batched = a.nb >= r.mfma_min_nb || (r.mfma_min_nb == 9 && ((a.nb == 8 && gemv_is_heavy(a)) || (wide && a.nb >= 2)));
+        // (wide, one sequence, MODE P not taken -- a plain activation too long for it: quantizer launch + MODE F beats the SLAB GEMV, whose
+        //  every workgroup would re-quantize the row)
+        const bool wide1 = wide && a.nb == 1 && r.mfma_min_nb == 9 && !a.attn_part && !a.norm_w;
+        if ((batched || wide1) && scratch && !a.attn_part && !a.resid_add && gemm_q80_g6_supports(a)) return ROUTE_FRAG_G6;
+    }
+    // the older batched route: 9..64 sequences always; 8 sequences when the matrix is large; per-layer matrices of >= 8 M weights from 2
+    // sequences on (tools/wide_batch.sh, round 2); the classifier keeps its STREAM GEMV up to 7 sequences
+    bool mfma = false;
+    if (scratch) {
+        if (a.nb >= r.mfma_min_nb) mfma = true;
+        else if (r.mfma_min_nb == 9) mfma = (a.nb == 8 && gemv_is_heavy(a)) || (a.nb >= 2 && wide);
+    }
+    if (mfma && !a.attn_part && !a.resid_add && gemm_q80_g2_supports(a)) return ROUTE_FRAG_OLD;
+    if (a.nb > 8) return ROUTE_GEMV_SLICED;
+    if (a.nb > 1 && !a.attn_part && !a.xq_in && scratch && gemv_is_heavy(a)) return ROUTE_GEMV_PREQ;
+    return ROUTE_GEMV;
+}
+
+// the sequences [b0, b0 + cnt) of a launch, as a launch of their own (every per-sequence pointer advanced)
+static GemvArgs gemv_slice(const GemvArgs &a, uint32_t b0, uint32_t cnt) {
+    GemvArgs s = a;
+    s.nb = cnt;
+    for (uint32_t i = 0; i < a.nseg; i++) if (s.seg[i].out) s.seg[i].out += (size_t)b0 * a.seg[i].out_bstride;
+    if (a.xin) s.xin += (size_t)b0 * a.xin_bstride;
+    if (a.pos) s.pos += b0;
+    if (a.xq_in) s.xq_in += (size_t)b0 * ((a.n + 15) & ~15u);
+    if (a.xs_in) s.xs_in += (size_t)b0 * (a.n / a.gs);
+    if (a.attn_part) { s.attn_part += (size_t)b0 * a.attn_nsplit * a.n; s.attn_ml += (size_t)b0 * a.attn_n_head * a.attn_nsplit * 2; }
+    if (a.resid_add) s.resid_add += (size_t)b0 * a.resid_add_bstride;
+    s.tile_max = nullptr;
+    return s;
+}
+
+hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st) {
+    const uint32_t max_wg = (r.cus ? (uint32_t)r.cus : 256u) * 8u;
+    a.cus = (uint32_t)r.cus;
+    const RouteKind k = route_kind(r, a);
+    switch (k) {
+    case ROUTE_Q4K: {
+        // every workgroup stages the whole quantized activation of each sequence in LDS: long rows (Qwen3-4B's hidden size)
+        // take fewer sequences per launch
+        const uint32_t fit = a.nb > 1 ? gemv_q4k_fit_batch(a) : 1u;
+        if (a.nb <= fit) return launch_gemv_q4k(a, max_wg, st);
+        for (uint32_t b0 = 0; b0 < a.nb; b0 += fit) {
+            GemvArgs s = gemv_slice(a, b0, a.nb - b0 < fit ? a.nb - b0 : fit);
+            const hipError_t e = launch_gemv_q4k(s, max_wg, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    case ROUTE_G6P:
+        return launch_gemm_q80_g6p(a, st);
+    case ROUTE_FRAG_G6:
+    case ROUTE_FRAG_OLD: {
+        // quantize every sequence's activation once, straight into MFMA fragment order (unless the producing kernel already did), then
+        // the GEMM
+        if (!a.frag_ready) {
+            const hipError_t e = launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, r.gq, r.gxs, st, route_norm_order(r, a));
+            if (e != hipSuccess) return e;
+        }
+        a.xq_in = a.frag_ready == 2u ? r.gq2 : r.gq; a.xs_in = a.frag_ready == 2u ? r.gxs2 : r.gxs;
+        if (k == ROUTE_FRAG_G6) return launch_gemm_q80_g6(a, st);
+        // the classifier of a batched step: GC (persistent waves, the activation fragments staged in LDS once per workgroup)
+        if (r.use_cls && !a.frag_out && gemm_q80_cls_supports(a)) return launch_gemm_q80_cls(a, st);
+        if (r.use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, a.frag_out, a.frag_scale_out, st);
+        if (a.frag_out) return hipErrorInvalidValue;               // the caller checked gemm_q80_g5_can_quantize_outputs()
+        return launch_gemm_q80_g2(a, st);
+    }
+    case ROUTE_GEMV_SLICED:
+        // More sequences than a GEMV launch takes and a launch the GEMM does not take (row length / group size not a multiple of 4
+        // groups, segment rows not multiples of 16, the LoRA o-branch addend): groups of 8 through the GEMV kernels.  Same arithmetic
+        // per sequence, the weights are read once per group.
+        for (uint32_t b0 = 0; b0 < a.nb; b0 += 8) {
+            GemvArgs s = gemv_slice(a, b0, a.nb - b0 < 8 ? a.nb - b0 : 8u);
+            const hipError_t e = launch_gemv(r.quant, s, max_wg, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    case ROUTE_GEMV_PREQ: {
+        // when the redundant quantization outweighs a launch (~3 us) the activations are quantized once (quant_rows_kernel) and the GEMV
+        // reads them back
+        const hipError_t e = launch_quant_rows(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, r.gq, r.gxs, st);
+        if (e != hipSuccess) return e;
+        a.xq_in = r.gq; a.xs_in = r.gxs; a.norm_w = nullptr;
+        return launch_gemv(r.quant, a, max_wg, st);
+    }
+    case ROUTE_GEMV:
+    default:
+        return launch_gemv(r.quant, a, max_wg, st);
+    }
+}
+
+}  // namespace nano

@@ -150,7 +150,9 @@ def test_small_batch_on_large_layers_takes_the_gemm_with_a_split_attention(model
         m.close()
         return out
     a = run()
-    for other in (run(NANO_GEMM_G5="0"), run(NANO_ATTN_QUANT="0"), run(NANO_W2_QUANT="0")):
+    # round 3's kernels (G5 with the canonical fold + quantizer launches, NANO_GEMM_G6=0) and a quantizer launch instead of the
+    # attention kernel's fragment output: other kernels, the same arithmetic
+    for other in (run(NANO_GEMM_G6="0"), run(NANO_ATTN_QUANT="0"), run(NANO_GEMM_G6="0", NANO_W2_QUANT="0")):
         for x, y in zip(a, other):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     gemv = run(NANO_MFMA_MIN_NB="65")                          # every launch through the GEMV kernels
@@ -255,7 +257,7 @@ def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
     T = 3
     seqs = [mf.prompt_ids(900 + b, T, spec.vocab_size) for b in range(B)]
 
-    def run(**env):
+    def run(strict=False, **env):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -264,17 +266,24 @@ def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
             for k, v in old.items():
                 if v is None: os.environ.pop(k, None)
                 else: os.environ[k] = v
+        m.set_strict(strict)
         out = [m.forward([int(s[pos]) for s in seqs], [pos] * B)[0].copy() for pos in range(T)]
         kv = m.read_state("v", spec.kv_dim, slot=B - 1, layer=0, pos=T - 1).copy()
         m.close()
         return out, kv
     a, akv = run()
-    # the general G2 kernel everywhere; Wo's / W2's input quantized by a launch of its own instead of by the attention kernel /
-    # the W1|W3 GEMM's epilogue
-    for b, bkv in (run(NANO_GEMM_G5="0"), run(NANO_ATTN_QUANT="0"), run(NANO_W2_QUANT="0")):
+    # FAST path: G6 (<= 16 tokens) / G5 beyond against G5 everywhere (NANO_GEMM_G6=0) -- the canonical fold is one shape whatever
+    # the split; Wo's / W2's input quantized by a launch of its own instead of by the attention kernel / the W1|W3 GEMM's epilogue
+    for b, bkv in (run(NANO_GEMM_G6="0"), run(NANO_ATTN_QUANT="0"), run(NANO_GEMM_G6="0", NANO_W2_QUANT="0")):
         for pos in range(T):
             assert np.array_equal(a[pos].view(np.uint32), b[pos].view(np.uint32)), pos
         assert np.array_equal(akv.view(np.uint32), bkv.view(np.uint32))
+    # STRICT mode (the reference's ascending group order): the chained G5 against the general G2 kernel
+    s5, s5kv = run(strict=True)
+    s2, s2kv = run(strict=True, NANO_GEMM_G5="0")
+    for pos in range(T):
+        assert np.array_equal(s5[pos].view(np.uint32), s2[pos].view(np.uint32)), pos
+    assert np.array_equal(s5kv.view(np.uint32), s2kv.view(np.uint32))
     m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
     worst, exact = 0.0, True
     for bi in (0, B // 2, B - 1):
@@ -282,7 +291,7 @@ def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
             lg, _ = m1.forward([int(seqs[bi][pos])], [pos])
             worst = max(worst, rel_err(a[pos][bi], lg[0])); exact = exact and np.array_equal(lg[0], a[pos][bi])
     m1.close()
-    print(f"wide rows, batch {B}: G5 == G2 bit for bit; vs one-by-one GEMV worst {worst:.3e}, bit-identical {exact}")
+    print(f"wide rows, batch {B}: G6/G5 == G5 (fast), G5 == G2 (strict) bit for bit; vs one-by-one decoding worst {worst:.3e}, bit-identical {exact}")
     assert worst < TOL["q80"]
 
 

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-4 GPU cycles (one script, modes by name): usage tools/r4_cycle.sh MODE [args]
+exec < /dev/null
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4; mkdir -p $O; cd $R
+one() { python3 -c "import json;d=json.loads(open('$1').read().strip().splitlines()[-1]);k=d.get('roofline',{}).get('kernels') or [];print('$2', d['value'], 'tok/s', d['ms_per_step'], 'ms |', '  '.join(f\"{x['kernel'].split('_')[0]} {x['us_per_launch']}\" for x in k))" 2>/dev/null || { echo "$2 FAILED"; tail -3 $1.err 2>/dev/null; }; }
+bench() { tag=$1; shift; timeout 400 python bench.py "$@" --no-cpu-baseline > $O/$tag.json 2> $O/$tag.json.err; one $O/$tag.json "$tag"; }
+case "$1" in
+g6a)   # first light of G6: operator tests, then A/B against round 3's routes on Qwen3-4B
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py -m gpu -x -q -k "q80" 2>&1 | tail -6
+  for b in 1 2 8 16; do
+    bench 4b_b${b}_g6 --model qwen3-4b --batch $b --steps 32 --warmup 4
+    NANO_GEMM_G6=0 bench 4b_b${b}_old --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-kernel-table
+  done
+  ;;
+*) echo "unknown mode $1";;
+esac
