@@ -30,328 +30,11 @@
 //       MODE F  (fragment-order activations from quant_rows_frag_kernel / the attention kernel): each item's 8 KB of B fragments
 //               are requested right before its weights.
 // MFMA operand layout as in gemm_q80.hip (verified on gfx950, tools/kbench/mfma_probe.hip).
-#include <atomic>
-#include <type_traits>
-#include "gemv_common.h"
+#include "gemm_q80_g6_impl.h"
 
 namespace nano {
 
 namespace {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-enum : int { G6_F = 0, G6_P = 1 };
-constexpr uint32_t G6_PITCH = 528, G6_WBUF = 16 * G6_PITCH;
-constexpr uint32_t G6_LDS_WAVE = G6_WBUF + 512 + 512;          // + weight scales [8 groups][16 rows] + (F) activation scales [8][16 tokens]
-constexpr uint32_t G6_NW = 8;                                   // waves of a workgroup (launches with fewer items use fewer)
-
-struct G6Dev {
-    GemvDev g;                          // segments, n, ng, epi, flags, nb, the fp32 activation / norm weight / attention partials (MODE P)
-    const int8_t *xf; const float *xsf; // MODE F: activations in MFMA B-fragment order [group][lane][16 B], scales [group][16 tokens]
-    uint32_t hh;                        // live rows per half tile (1..8)
-    uint32_t nu, magic_nu;              // units per row; (it * magic_nu) >> 16 == it / nu for every item index of a workgroup
-    uint32_t ntiles, tc0, tc1;          // tiles; tiles up to the end of segment 0 / 1
-    uint32_t grid, tpw;                 // workgroups; tiles per workgroup (max)
-    uint32_t nw, _pad;                  // waves per workgroup
-};
-
-__device__ __forceinline__ uint32_t g6_lds_load_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// the fp32 activation items of a thread (MODE P): float4 item q = tid + j * 512 of every sequence
-template <int NBC, int NV, bool COMB>
-struct G6X {
-    float4 x[NBC][NV];
-    float4 nw[NV];
-    float4 pv[COMB ? NV : 1][COMB ? 8 : 1];     // split-attention partials (one sequence): all splits of this thread's items
-    float ml_m, ml_l;
-};
-
-template <int MODE, bool COMB, int NBC, int NV>
-__global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int D = MODE == G6_P ? 3 : 2;                             // items in flight per wave
-    const GemvDev &a = d.g;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t m = lane & 15u, kq = lane >> 4;
-    karg_touch(a.out[0]); karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.pos); karg_touch(d.xf); karg_touch(d.xsf);
-    karg_touch(a.out_bstride[0]); karg_touch(a.out_pstride[2]); karg_touch(d.tc0); karg_touch(d.magic_nu);
-    const uint32_t n = a.n, ng = a.ng, nu = d.nu, hh = d.hh, NW = d.nw, nb = a.nb;
-    const uint32_t epi = a.epi;
-    const bool sw = epi == GEMV_EPI_SWIGLU;
-    const uint32_t halfoff = sw ? 0u : hh;                              // rows between the two halves of a tile
-
-    // ---- LDS ---------------------------------------------------------------------------------------------------------------
-    int8_t *wbuf = reinterpret_cast<int8_t *>(smem) + (size_t)wid * G6_LDS_WAVE;
-    float *wsl = reinterpret_cast<float *>(wbuf + G6_WBUF);            // [8 groups][16 rows]
-    float *xslw = wsl + 128;                                           // MODE F: [8 groups][16 tokens]
-    float *T = reinterpret_cast<float *>(smem + (size_t)NW * G6_LDS_WAVE);          // [tpw][nu - 1][256] unit sums
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(T + (size_t)d.tpw * (nu - 1u) * 256u);   // [tpw] units arrived
-    unsigned char *pbase = reinterpret_cast<unsigned char *>(cnt + ((d.tpw + 3u) & ~3u));
-    int8_t *xqc = reinterpret_cast<int8_t *>(pbase);                   // MODE P: [ng][4 k-quarters][NBC][16 B]
-    float *xs_l = reinterpret_cast<float *>(pbase + (size_t)ng * 64u * NBC);        // MODE P: [ng][16] activation scales (slots >= NBC unused)
-    float *red = xs_l + (size_t)ng * 16u;                              // [NBC][8] wave partials of the sums of squares
-    float *wgt = red + NBC * 8;                                        // COMB: [n_head][8] combine weights
-
-    // ---- the workgroup's items -----------------------------------------------------------------------------------------------
-    const uint32_t bid = blockIdx.x;
-    const uint32_t ntl = bid < d.ntiles ? (d.ntiles - bid + d.grid - 1u) / d.grid : 0u;   // tiles of this workgroup
-    const uint32_t nitems = ntl * nu;
-
-    struct TI { uint32_t tl, u, lrow0, rows0, obs, ops; const int8_t *wA, *wB; const float *sA, *sB; float *out; bool live; };
-    auto decode = [&](uint32_t it) -> TI {
-        TI t;
-        t.live = it < nitems;
-        t.tl = (it * d.magic_nu) >> 16; t.u = it - t.tl * nu;
-        const uint32_t tile = bid + t.tl * d.grid;
-        const int sel = sw ? 0 : (int)(tile >= d.tc0) + (int)(tile >= d.tc1);
-        t.wA = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
-        t.sA = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
-        t.wB = sw ? a.w[1] : t.wA; t.sB = sw ? a.ws[1] : t.sA;
-        t.out = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
-        t.rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
-        t.obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
-        t.ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
-        t.lrow0 = (tile - (sel == 0 ? 0u : sel == 1 ? d.tc0 : d.tc1)) * (sw ? hh : 2u * hh);
-        return t;
-    };
-
-    // ---- the ring: D items of this wave in flight ---------------------------------------------------------------------------------
-    struct Slot { int4 w[8]; float4 s0, s1; i32x4 b[MODE == G6_F ? 8 : 1]; float4 xs; };
-    Slot ring[D];
-    const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf, MODE == G6_F ? ng * 1024u : 0u);
-    const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf, MODE == G6_F ? ng * 64u : 0u);
-    auto issue = [&](auto J, uint32_t it) {
-        constexpr int sl = decltype(J)::value;
-        const TI t = decode(it);
-        const uint32_t g0 = t.u * 8u;
-        if constexpr (MODE == G6_F) {               // the item's activation fragments FIRST (loads return in issue order)
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++)
-                ring[sl].b[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)((t.live && g0 + j < ng) ? lane * 16u : OOB), (int)((g0 + j) * 1024u), 0);
-            const uint32_t xg = g0 + (lane >> 2);                       // lanes 0..31: group g0 + l/4, tokens 4 (l%4) .. +3
-            ring[sl].xs = bload_f4(rxs, (t.live && lane < 32u && xg < ng) ? (xg * 16u + (lane & 3u) * 4u) * 4u : OOB);
-        }
-        const __amdgpu_buffer_rsrc_t rA = mkrsrc(t.wA, t.live ? t.rows0 * n : 0u), rB = mkrsrc(t.wB, t.live ? t.rows0 * n : 0u);
-        const __amdgpu_buffer_rsrc_t qA = mkrsrc(t.sA, t.live ? t.rows0 * ng * 4u : 0u), qB = mkrsrc(t.sB, t.live ? t.rows0 * ng * 4u : 0u);
-        const uint32_t col = t.u * 512u + (lane & 31u) * 16u;
-#pragma unroll
-        for (int r8 = 0; r8 < 8; r8++) {            // tile row 2 r8 + l/32: half r8 / 4 (compile time: one descriptor per instruction)
-            const uint32_t r = 2u * ((uint32_t)r8 & 3u) + (lane >> 5);
-            const uint32_t row = t.lrow0 + (r8 >= 4 ? halfoff : 0u) + r;
-            const bool ok = r < hh && row < t.rows0 && col < n;
-            ring[sl].w[r8] = bload_w(r8 >= 4 ? rB : rA, ok ? row * n + col : OOB);
-        }
-        {                                           // weight scales: lanes 0..15: row l/2 of the half, groups g0 + 4 (l%2) .. +3
-            const uint32_t r = lane >> 1, g = g0 + (lane & 1u) * 4u;
-            const uint32_t rowA = t.lrow0 + r, rowB = t.lrow0 + halfoff + r;
-            const bool okl = lane < 16u && r < hh && g < ng;
-            ring[sl].s0 = bload_f4(qA, (okl && rowA < t.rows0) ? (rowA * ng + g) * 4u : OOB);
-            ring[sl].s1 = bload_f4(qB, (okl && rowB < t.rows0) ? (rowB * ng + g) * 4u : OOB);
-        }
-    };
-
-    // ---- MODE P: the fp32 activation is asked for before any weight --------------------------------------------------------------
-    G6X<NBC, NV, COMB> sx;
-    const bool norm = (a.flags & F_NORM) != 0;
-    if constexpr (MODE == G6_P) {
-        const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xin, COMB ? 0u : ((nb - 1u) * a.xin_bstride + n) * 4u);
-        const __amdgpu_buffer_rsrc_t rn = mkrsrc(a.norm_w, norm ? n * 4u : 0u);
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
-            const uint32_t off = (i < n) ? i * 4u : OOB;
-            if constexpr (!COMB) {
-#pragma unroll
-                for (int b = 0; b < NBC; b++) sx.x[b][j] = bload_f4(rx, (b < (int)nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
-            }
-            sx.nw[j] = bload_f4(rn, off);
-        }
-        if constexpr (COMB) {
-            const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
-            const __amdgpu_buffer_rsrc_t rp = mkrsrc(a.attn_part, ns * n * 4u);
-            const __amdgpu_buffer_rsrc_t rm = mkrsrc(a.attn_ml, nh * ns * 8u);
-#pragma unroll
-            for (int j = 0; j < NV; j++) {
-                const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
-#pragma unroll
-                for (int sp = 0; sp < 8; sp++) sx.pv[j][sp] = bload_f4(rp, (i < n && (uint32_t)sp < ns) ? ((uint32_t)sp * n + i) * 4u : OOB);
-            }
-            const uint32_t sp = tid & 7u, h = tid >> 3;
-            const uint32_t mo = (h < nh && sp < ns) ? (h * ns + sp) * 8u : OOB;
-            sx.ml_m = bload_f(rm, mo);
-            sx.ml_l = bload_f(rm, mo == OOB ? OOB : mo + 4u);
-        }
-    }
-    // ---- every wave's first D items ---------------------------------------------------------------------------------------------
-    issue(std::integral_constant<int, 0>{}, wid);
-    issue(std::integral_constant<int, 1>{}, wid + NW);
-    if constexpr (D == 3) issue(std::integral_constant<int, 2>{}, wid + 2u * NW);
-    if (tid < d.tpw) cnt[tid] = 0u;
-
-    // ---- MODE P prologue: combine | rmsnorm, Q80 quantization (tensor.c:21-46) into the compact fragment layout ---------------------
-    if constexpr (MODE == G6_P) {
-        if constexpr (COMB) {
-            const bool pre_ml = a.attn_n_head * 8u <= 512u;           // every (head, split) pair has its own thread
-            if (pre_ml) combine_weights<1, true>(a, wgt, sx.ml_m, sx.ml_l); else combine_weights<1, false>(a, wgt, 0.0f, 0.0f);
-#pragma unroll
-            for (int j = 0; j < NV; j++) {
-                const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
-                const float *wg = wgt + (size_t)((i < n ? i : 0u) / a.attn_hd) * 8u;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int sp = 0; sp < 8; sp++) {                      // splits >= nsplit: partial read as 0, weight 0 (gemv_q80_impl.h)
-                    const float w = wg[sp];
-                    acc.x += sx.pv[j][sp].x * w; acc.y += sx.pv[j][sp].y * w; acc.z += sx.pv[j][sp].z * w; acc.w += sx.pv[j][sp].w * w;
-                }
-                sx.x[0][j] = acc;
-            }
-        }
-        float ss[NBC];
-#pragma unroll
-        for (int b = 0; b < NBC; b++) ss[b] = 1.0f;
-        if (norm) {                     // rmsnorm scale (infer.c:603-609): the 512-thread tree (quant_rows_frag_kernel repeats it for batches > 8)
-#pragma unroll
-            for (int b = 0; b < NBC; b++) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < NV; j++) {
-                    acc += sx.x[b][j].x * sx.x[b][j].x; acc += sx.x[b][j].y * sx.x[b][j].y;
-                    acc += sx.x[b][j].z * sx.x[b][j].z; acc += sx.x[b][j].w * sx.x[b][j].w;
-                }
-                acc = dpp_wave_sum(acc);
-                if (lane == 0) red[b * 8 + wid] = acc;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < NBC; b++) {
-                float t = 0.0f;
-#pragma unroll
-                for (int w = 0; w < 8; w++) t += red[b * 8 + w];
-                t /= (float)n; t += 1e-5f;
-                ss[b] = 1.0f / sqrtf(t);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
-            const uint32_t g = i >> 6, q4 = (i >> 4) & 3u, e = i & 15u;
-#pragma unroll
-            for (int b = 0; b < NBC; b++) {
-                float4 v = sx.x[b][j];
-                if (norm) {
-                    v.x = sx.nw[j].x * (ss[b] * v.x); v.y = sx.nw[j].y * (ss[b] * v.y);
-                    v.z = sx.nw[j].z * (ss[b] * v.z); v.w = sx.nw[j].w * (ss[b] * v.w);
-                }
-                float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-                mx = dpp_group_max<16>(mx);                           // a group of 64 = 16 consecutive threads
-                const float scale = div_const<127>(mx);
-                if (i < n) {
-                    const int q0 = q80_quant1(v.x, scale), q1 = q80_quant1(v.y, scale), q2 = q80_quant1(v.z, scale), q3 = q80_quant1(v.w, scale);
-                    *reinterpret_cast<uint32_t *>(xqc + (size_t)g * 64u * NBC + (size_t)q4 * 16u * NBC + (size_t)b * 16u + e) =
-                        (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-                    if ((tid & 15u) == 0u) xs_l[g * 16u + (uint32_t)b] = scale;
-                }
-            }
-        }
-    }
-    __syncthreads();                                                   // counters armed, (P) the quantized activation is in LDS
-
-    // ---- the items of this wave ---------------------------------------------------------------------------------------------------
-    auto consume = [&](auto J, uint32_t it) {
-        constexpr int sl = decltype(J)::value;
-        const TI t = decode(it);
-        const uint32_t g0 = t.u * 8u;
-        // 1. weight pieces -> transposition buffer; weight scales (and, F, activation scales) -> LDS
-#pragma unroll
-        for (int r8 = 0; r8 < 8; r8++) *reinterpret_cast<int4 *>(wbuf + (size_t)(2 * r8 + (int)(lane >> 5)) * G6_PITCH + (lane & 31u) * 16u) = ring[sl].w[r8];
-        if (lane < 16u) {
-            const uint32_t r = lane >> 1, gq = (lane & 1u) * 4u;
-            wsl[(gq + 0u) * 16u + r] = ring[sl].s0.x; wsl[(gq + 1u) * 16u + r] = ring[sl].s0.y; wsl[(gq + 2u) * 16u + r] = ring[sl].s0.z; wsl[(gq + 3u) * 16u + r] = ring[sl].s0.w;
-            wsl[(gq + 0u) * 16u + 8u + r] = ring[sl].s1.x; wsl[(gq + 1u) * 16u + 8u + r] = ring[sl].s1.y; wsl[(gq + 2u) * 16u + 8u + r] = ring[sl].s1.z; wsl[(gq + 3u) * 16u + 8u + r] = ring[sl].s1.w;
-        }
-        if constexpr (MODE == G6_F) { if (lane < 32u) *reinterpret_cast<float4 *>(xslw + lane * 4u) = ring[sl].xs; }
-        // 2. the finisher of the tile (owner of its last unit) asks for what its epilogue needs now
-        const bool fin = t.u == nu - 1u;
-        const uint32_t half = kq >> 1, rr0 = (kq & 1u) * 4u;
-        const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;          // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
-        float oldv[4] = {0.f, 0.f, 0.f, 0.f};
-        uint32_t opos = 0;
-        if (fin && m < nb) {
-            if (t.ops) opos = a.pos[m];
-            if (epi == GEMV_EPI_RESID) {
-                const float *o = t.out + (size_t)m * t.obs + orow0;     // the residual stream is never position indexed
-#pragma unroll
-                for (int i = 0; i < 4; i++) if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) oldv[i] = o[i];
-            }
-        }
-        // (P: the slot's registers are free once the pieces are in LDS -- the next item of this wave goes out now)
-        if constexpr (MODE == G6_P) issue(J, it + (uint32_t)D * NW);
-        // 3. eight groups: A fragment from LDS, one MFMA, products, the unit sum in ascending group order
-        float S[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const i32x4 fa = *reinterpret_cast<const i32x4 *>(wbuf + (size_t)m * G6_PITCH + j * 64u + kq * 16u);
-            i32x4 fb; float xsc;
-            if constexpr (MODE == G6_F) { fb = ring[sl].b[j]; xsc = xslw[j * 16u + m]; }
-            else {
-                const bool okb = m < (uint32_t)NBC && g0 + j < ng;
-                fb = okb ? *reinterpret_cast<const i32x4 *>(xqc + (size_t)(g0 + j) * 64u * NBC + (size_t)kq * 16u * NBC + (size_t)m * 16u) : i32x4{0, 0, 0, 0};
-                xsc = okb ? xs_l[(g0 + j) * 16u + m] : 0.0f;
-            }
-            const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
-            const float4 wv = *reinterpret_cast<const float4 *>(wsl + j * 16u + kq * 4u);
-            const float p0 = ((float)cv[0] * wv.x) * xsc, p1 = ((float)cv[1] * wv.y) * xsc;      // infer.c:672
-            const float p2 = ((float)cv[2] * wv.z) * xsc, p3 = ((float)cv[3] * wv.w) * xsc;
-            if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
-            else if (g0 + j < ng) { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }           // (wave-uniform: a row's last unit may hold 4 groups)
-        }
-        // 4. arrive, or fold the tile and finish it
-        if (!fin) {
-            *reinterpret_cast<float4 *>(T + ((size_t)t.tl * (nu - 1u) + t.u) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
-            if (lane == 0u) __hip_atomic_fetch_add(cnt + t.tl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            float tot[4] = {S[0], S[1], S[2], S[3]};
-            if (nu > 1u) {
-                // (bounded: a miscounted tile must not hang the device -- 2^24 naps are ~0.5 s, the results are then wrong and the tests say so)
-                for (uint32_t spin = 0; g6_lds_load_acq(cnt + t.tl) != nu - 1u && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
-                const float *tp = T + (size_t)t.tl * (nu - 1u) * 256u + lane * 4u;
-                float4 acc = *reinterpret_cast<const float4 *>(tp);
-                for (uint32_t u0 = 1; u0 < nu - 1u; u0 += 4) {          // units ascending; the reads of four units go out together
-                    float4 q[4];
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) q[k] = (u0 + k < nu - 1u) ? *reinterpret_cast<const float4 *>(tp + (size_t)(u0 + k) * 256u) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) if (u0 + k < nu - 1u) { acc.x += q[k].x; acc.y += q[k].y; acc.z += q[k].z; acc.w += q[k].w; }
-                }
-                tot[0] = acc.x + S[0]; tot[1] = acc.y + S[1]; tot[2] = acc.z + S[2]; tot[3] = acc.w + S[3];
-            }
-            float v3[4] = {0.f, 0.f, 0.f, 0.f};
-            if (sw) {                                                  // W3's values live 32 lanes up (rows 8..15 of the tile)
-#pragma unroll
-                for (int i = 0; i < 4; i++) v3[i] = __shfl_xor(tot[i], 32, 64);
-            }
-            if (t.live && m < nb && (!sw || kq < 2u)) {
-                float *o = t.out + (size_t)m * t.obs + (size_t)opos * t.ops + orow0;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) o[i] = finish_epi(epi, tot[i], v3[i], oldv[i]);
-            }
-        }
-        if constexpr (MODE == G6_F) issue(J, it + (uint32_t)D * NW);  // (F: the fragments were read by the MFMAs above)
-    };
-    for (uint32_t s = 0;; s += (uint32_t)D) {
-        const uint32_t it = wid + s * NW;
-        if (it >= nitems) break;
-        consume(std::integral_constant<int, 0>{}, it);
-        if (it + NW >= nitems) break;
-        consume(std::integral_constant<int, 1>{}, it + NW);
-        if constexpr (D == 3) {
-            if (it + 2u * NW >= nitems) break;
-            consume(std::integral_constant<int, 2>{}, it + 2u * NW);
-        }
-    }
-}
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 static uint32_t g6_rows(const GemvArgs &a) {
@@ -361,7 +44,7 @@ static uint32_t g6_rows(const GemvArgs &a) {
     return r;
 }
 
-struct G6Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nw, nu; size_t lds_common; };
+struct G6Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nw, nu, rounds; bool ms; size_t lds_common; };
 
 // tile height fitted to the chip: minimise the rows the busiest workgroup streams (+ a per-tile overhead worth ~2 rows)
 static bool g6_plan(const GemvArgs &a, G6Plan &p) {
@@ -385,10 +68,13 @@ static bool g6_plan(const GemvArgs &a, G6Plan &p) {
     p.ntiles = tiles; p.tc0 = nseg > 1 ? tc[0] : 0xffffffffu; p.tc1 = nseg > 2 ? tc[1] : 0xffffffffu;
     p.grid = tiles < cus ? tiles : cus; p.tpw = (tiles + p.grid - 1) / p.grid;
     const uint32_t items = p.tpw * p.nu;
-    p.nw = items < G6_NW ? items : G6_NW;
-    p.lds_common = (size_t)p.nw * G6_LDS_WAVE + (size_t)p.tpw * (p.nu - 1u) * 1024u + (size_t)((p.tpw + 3u) & ~3u) * 4u;
+    p.nw = G6_NW;
+    while (p.nw > items) p.nw >>= 1;                                   // a power of two (the kernel finds a tile's finisher with a mask)
+    p.rounds = (items + p.nw - 1u) / p.nw;                             // the most items a wave owns
+    p.ms = !sw && a.nseg > 1;
+    p.lds_common = (size_t)p.nw * G6_LDS_WAVE + (size_t)p.tpw * p.nu * 1024u + (size_t)((p.tpw + 3u) & ~3u) * 4u;
     const uint32_t magic = (65536u + p.nu - 1u) / p.nu;
-    for (uint32_t it = 0; it < items + 4u * G6_NW; it++) if (((it * magic) >> 16) != it / p.nu) return false;
+    for (uint32_t it = 0; it < items + 8u * G6_NW; it++) if (((it * magic) >> 16) != it / p.nu) return false;
     return true;
 }
 
@@ -401,35 +87,29 @@ static bool g6_common_ok(const GemvArgs &a) {
     return true;
 }
 
-template <int MODE, bool COMB, int NBC, int NV>
-static hipError_t g6_launch_t(const G6Dev &d, size_t lds, hipStream_t st) {
-    auto kern = &gemm_q80_g6_kernel<MODE, COMB, NBC, NV>;
-    static std::atomic<bool> armed[64];
-    int dev = 0; (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !armed[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (dev >= 0 && dev < 64) armed[dev].store(true, std::memory_order_release);
-    }
-    hipLaunchKernelGGL(kern, dim3(d.grid), dim3(d.nw * 64u), lds, st, d);
-    return hipGetLastError();
-}
-
 static G6Dev g6_dev(const GemvArgs &a, const G6Plan &p) {
     G6Dev d{};
     d.g = to_dev(a);
     d.g.nthr = p.nw * 64u;
     d.hh = p.hh; d.nu = p.nu; d.magic_nu = (65536u + p.nu - 1u) / p.nu;
     d.ntiles = p.ntiles; d.tc0 = p.tc0; d.tc1 = p.tc1; d.grid = p.grid; d.tpw = p.tpw; d.nw = p.nw;
+    d.full = p.ntiles - (p.tpw - 1u) * p.grid;
     return d;
 }
 
 }  // namespace
 
-// MODE F: activations already quantized, MFMA B-fragment order (a.xq_in / a.xs_in), up to 16 tokens
+// MODE F: activations already quantized, MFMA B-fragment order (a.xq_in / a.xs_in), up to 16 tokens; up to 4 items per wave
 bool gemm_q80_g6_supports(const GemvArgs &a) {
     if (!g6_common_ok(a) || a.nb > 16 || a.attn_part) return false;
     G6Plan p;
-    return g6_plan(a, p) && p.lds_common + 64 <= 160u * 1024u;
+    return g6_plan(a, p) && p.rounds <= 4u && p.lds_common + 64 <= 160u * 1024u;
+}
+// MODE S where the activation fits LDS next to everything else (one 1 KB block per group + scales), else MODE F
+static size_t g6s_lds(const G6Plan &p) { const size_t ngp = (size_t)p.nu * 8u; return p.lds_common + ngp * 1024u + 64u + ngp * 64u + 64u; }
+static bool g6s_ok(const GemvArgs &a, const G6Plan &p) {
+    static const bool on = !(getenv("NANO_G6_STAGE") && *getenv("NANO_G6_STAGE") == '0');       // A/B knob
+    return on && p.nw == G6_NW && a.n <= 4096u && g6s_lds(p) <= 160u * 1024u;
 }
 hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
     if (!a.xq_in || !a.xs_in || !gemm_q80_g6_supports(a)) return hipErrorInvalidValue;
@@ -437,26 +117,50 @@ hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
     if (!g6_plan(a, p)) return hipErrorInvalidValue;
     G6Dev d = g6_dev(a, p);
     d.xf = a.xq_in; d.xsf = a.xs_in;
-    return g6_launch_t<G6_F, false, 1, 1>(d, p.lds_common + 64, st);
+    if (g6s_ok(a, p)) {             // NV = 16-byte units per thread: 5 (rows up to 2560 values) or 8 (up to 4096)
+        const size_t lds = g6s_lds(p);
+#define G6S_GO(NV_, R_) do { return p.ms ? g6_launch_t<G6_S, false, 1, NV_, R_, true>(d, lds, st) : g6_launch_t<G6_S, false, 1, NV_, R_, false>(d, lds, st); } while (0)
+#define G6S_R(NV_) do { if (p.rounds <= 1) G6S_GO(NV_, 1); if (p.rounds == 2) G6S_GO(NV_, 2); G6S_GO(NV_, 4); } while (0)
+        if (a.n <= 2560u) G6S_R(5);
+        G6S_R(8);
+#undef G6S_R
+#undef G6S_GO
+    }
+    const size_t lds = p.lds_common + 64;
+#define G6F_GO(R_) do { return p.ms ? g6_launch_t<G6_F, false, 1, 1, R_, true>(d, lds, st) : g6_launch_t<G6_F, false, 1, 1, R_, false>(d, lds, st); } while (0)
+    if (p.rounds <= 1) G6F_GO(1);
+    if (p.rounds == 2) G6F_GO(2);
+    if (p.rounds == 3) G6F_GO(3);
+    G6F_GO(4);
+#undef G6F_GO
 }
 
 // MODE P: fp32 activations (a.xin | the split-attention partials), 1..8 sequences; rmsnorm / combine + quantization in the prologue
+static size_t g6p_lds(const GemvArgs &a, const G6Plan &p, uint32_t nbc) {       // the kernel's carve-up: xqc | zero block | xs_l | red | wgt
+    const size_t ngp = (size_t)p.nu * 8u;
+    return p.lds_common + ngp * 64u * nbc + 64u + ngp * 64u + (size_t)nbc * 32u + (a.attn_part ? (size_t)a.attn_n_head * 32u : 0u) + 64u;
+}
 static bool g6p_shape(const GemvArgs &a, uint32_t &nbc, uint32_t &nv) {
-    nbc = a.nb <= 1 ? 1u : a.nb <= 2 ? 2u : a.nb <= 4 ? 4u : 8u;
+    if (a.nb > 2) return false;
+    nbc = a.nb <= 1 ? 1u : 2u;
     nv = a.n <= 4096u ? 2u : a.n <= 10240u ? 5u : 0u;
     if (!nv || nbc * nv > 16u) return false;
     if (a.attn_part && (a.nb != 1 || nv != 2u || a.norm_w || a.attn_nsplit > 8 || a.attn_hd % 4 || a.attn_n_head > 128)) return false;
     return true;
 }
+// the instantiated round counts of a (NV, multi-segment, combine) family: the smallest one that covers `need`, or 0
+static uint32_t g6p_rounds(uint32_t nv, uint32_t nbc, uint32_t need, bool ms, bool comb) {
+    for (uint32_t r = need; r <= 4u; r++) if (g6p_has(nv, nbc, r, ms, comb)) return r;
+    return 0u;
+}
 bool gemm_q80_g6p_supports(const GemvArgs &a) {
-    if (!g6_common_ok(a) || a.nb > 8 || a.xq_in || (!a.xin && !a.attn_part)) return false;
+    if (!g6_common_ok(a) || a.nb > 2 || a.xq_in || (!a.xin && !a.attn_part)) return false;
     uint32_t nbc, nv;
     if (!g6p_shape(a, nbc, nv)) return false;
     G6Plan p;
     if (!g6_plan(a, p) || p.nw != G6_NW) return false;               // the prologue's tree is the 512-thread one
-    const uint32_t ng = a.n / 64u;
-    const size_t lds = p.lds_common + (size_t)ng * 64u * nbc + (size_t)ng * 64u + (size_t)nbc * 32u + (a.attn_part ? (size_t)a.attn_n_head * 32u : 0u) + 64u;
-    return lds <= 160u * 1024u;
+    if (!g6p_rounds(nv, nbc, p.rounds, p.ms, a.attn_part != nullptr)) return false;
+    return g6p_lds(a, p, nbc) <= 160u * 1024u;
 }
 hipError_t launch_gemm_q80_g6p(const GemvArgs &a, hipStream_t st) {
     if (!gemm_q80_g6p_supports(a)) return hipErrorInvalidValue;
@@ -464,18 +168,11 @@ hipError_t launch_gemm_q80_g6p(const GemvArgs &a, hipStream_t st) {
     G6Plan p;
     if (!g6p_shape(a, nbc, nv) || !g6_plan(a, p)) return hipErrorInvalidValue;
     G6Dev d = g6_dev(a, p);
-    const uint32_t ng = a.n / 64u;
-    const size_t lds = p.lds_common + (size_t)ng * 64u * nbc + (size_t)ng * 64u + (size_t)nbc * 32u + (a.attn_part ? (size_t)a.attn_n_head * 32u : 0u) + 64u;
-    if (a.attn_part) return g6_launch_t<G6_P, true, 1, 2>(d, lds, st);
-    if (nv == 2u) {
-        if (nbc == 1) return g6_launch_t<G6_P, false, 1, 2>(d, lds, st);
-        if (nbc == 2) return g6_launch_t<G6_P, false, 2, 2>(d, lds, st);
-        if (nbc == 4) return g6_launch_t<G6_P, false, 4, 2>(d, lds, st);
-        return g6_launch_t<G6_P, false, 8, 2>(d, lds, st);
-    }
-    if (nbc == 1) return g6_launch_t<G6_P, false, 1, 5>(d, lds, st);
-    if (nbc == 2) return g6_launch_t<G6_P, false, 2, 5>(d, lds, st);
-    return hipErrorInvalidValue;
+    const size_t lds = g6p_lds(a, p, nbc);
+    const bool comb = a.attn_part != nullptr;
+    const uint32_t r = g6p_rounds(nv, nbc, p.rounds, p.ms, comb);
+    if (nv == 2u) return g6p_launch_nv2(&d, lds, nbc, r, p.ms, comb, st);
+    return g6p_launch_nv5(&d, lds, nbc, r, p.ms, st);
 }
 
 }  // namespace nano

@@ -1,0 +1,418 @@
+// gemm_q80_g6_impl.h -- the G6 kernel (see gemm_q80_g6.hip for the design); included by the translation units that instantiate it
+// (gemm_q80_g6.hip: MODE F and the host side; gemm_q80_g6_p*.hip: MODE P) so that the instantiations build in parallel.
+#pragma once
+#include <atomic>
+#include <type_traits>
+#include "gemv_common.h"
+
+namespace nano {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+enum : int { G6_F = 0, G6_P = 1, G6_S = 2 };
+constexpr uint32_t G6_PITCH = 528, G6_WBUF = 16 * G6_PITCH;
+constexpr uint32_t G6_LDS_WAVE = G6_WBUF + 512 + 512;          // + weight scales [8 groups][16 rows] + (F) activation scales [8][16 tokens]
+constexpr uint32_t G6_NW = 8;                                   // waves of a workgroup (launches with fewer items use fewer)
+
+struct G6Dev {
+    GemvDev g;                          // segments, n, ng, epi, flags, nb, the fp32 activation / norm weight / attention partials (MODE P)
+    const int8_t *xf; const float *xsf; // MODE F: activations in MFMA B-fragment order [group][lane][16 B], scales [group][16 tokens]
+    uint32_t hh;                        // live rows per half tile (1..8)
+    uint32_t nu, magic_nu;              // units per row; (it * magic_nu) >> 16 == it / nu for every item index of a workgroup
+    uint32_t ntiles, tc0, tc1;          // tiles; tiles up to the end of segment 0 / 1
+    uint32_t grid, tpw;                 // workgroups; tiles per workgroup (max)
+    uint32_t nw, full;                  // waves per workgroup (a power of two); workgroups that own tpw tiles (the others: tpw - 1)
+};
+
+__device__ __forceinline__ uint32_t g6_lds_load_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// the fp32 activation items of a thread (MODE P): float4 item q = tid + j * 512 of every sequence
+template <int NBC, int NV, bool COMB>
+struct G6X {
+    float4 x[NBC][NV];
+    float4 nw[NV];
+    float4 pv[COMB ? NV : 1][COMB ? 8 : 1];     // split-attention partials (one sequence): all splits of this thread's items
+    float ml_m, ml_l;
+};
+
+template <int R0, int R1, class F> __device__ __forceinline__ void g6_static_for(F &&f) {
+    if constexpr (R0 < R1) { f(std::integral_constant<int, R0>{}); g6_static_for<R0 + 1, R1>(f); }
+}
+
+// R  = rounds: the most items a wave of the launch owns (compile time: R issues and R consumes in straight-line code, nothing dead)
+// MS = several weight segments share the launch (q | k | v): a tile looks its segment up; single-segment launches skip that
+template <int MODE, bool COMB, int NBC, int NV, int R, bool MS>
+__global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int D = MODE == G6_F ? 2 : 4;                             // items in flight per wave (F: a slot also holds the item's 8 KB of B fragments)
+    const GemvDev &a = d.g;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t m = lane & 15u, kq = lane >> 4;
+    karg_touch(a.out[0]); karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.pos); karg_touch(d.xf); karg_touch(d.xsf);
+    karg_touch(a.out_bstride[0]); karg_touch(a.out_pstride[2]); karg_touch(d.tc0); karg_touch(d.magic_nu);
+    NANO_STAMP(a.stamps, 0, tid);
+    const uint32_t n = a.n, ng = a.ng, nu = d.nu, hh = d.hh, NW = d.nw, nb = a.nb;
+    const uint32_t epi = a.epi;
+    const bool sw = epi == GEMV_EPI_SWIGLU;
+    const uint32_t halfoff = sw ? 0u : hh;                              // rows between the two halves of a tile
+    const uint32_t ngp = nu * 8u;                                       // groups incl. the padding of a row's last unit (ng % 8 == 4)
+
+    // ---- LDS ---------------------------------------------------------------------------------------------------------------
+    int8_t *wbuf = reinterpret_cast<int8_t *>(smem) + (size_t)wid * G6_LDS_WAVE;
+    float *wsl = reinterpret_cast<float *>(wbuf + G6_WBUF);            // [8 groups][16 rows]
+    float *xslw = wsl + 128;                                           // MODE F: [8 groups][16 tokens]
+    float *T = reinterpret_cast<float *>(smem + (size_t)NW * G6_LDS_WAVE);          // [tpw][nu][256] unit sums
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(T + (size_t)d.tpw * nu * 256u);   // [tpw] units arrived
+    unsigned char *pbase = reinterpret_cast<unsigned char *>(cnt + ((d.tpw + 3u) & ~3u));
+    // MODE P: the quantized activation [ngp][4 k-quarters][NBC][16 B] (groups >= ng zero), a 64-byte zero block (what the lanes of
+    // token slots >= NBC read), the activation scales [ngp][16] (slots >= NBC unused, groups >= ng zero)
+    // MODE S: the fragment-order activation itself [ngp][64 lanes][16 B] (NBC = 16 token slots), scales [ngp][16]
+    constexpr uint32_t SLOTS = MODE == G6_S ? 16u : (uint32_t)NBC;     // token slots of a group's 64-byte k-quarter
+    int8_t *xqc = reinterpret_cast<int8_t *>(pbase);
+    unsigned char *zblk = pbase + (size_t)ngp * 64u * SLOTS;
+    float *xs_l = reinterpret_cast<float *>(zblk + 64);
+    float *red = xs_l + (size_t)ngp * 16u;                             // [NBC][8] wave partials of the sums of squares
+    float *wgt = red + NBC * 8;                                        // COMB: [n_head][8] combine weights
+
+    // ---- lane parts of every address of the item loop (item-invariant) --------------------------------------------------------------
+    // weight pieces of an item: 16 rows x 512 B, two rows per load instruction: load k (and k + 4, the other half) reads row
+    // 2k + l/32 of its half, bytes 16 (l % 32) .. +15.  Rows >= hh: out of range -> 0.  Everything item dependent (tile row, unit,
+    // the end of the segment) sits in the descriptor's base and size, which are scalars.
+    const uint32_t r_lo = lane >> 5, c16 = (lane & 31u) * 16u;
+    uint32_t voff[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { const uint32_t r = 2u * k + r_lo; voff[k] = r < hh ? r * n + c16 : OOB; }
+    const uint32_t svoff = (lane < 16u && (lane >> 1) < hh) ? ((lane >> 1) * ng + (lane & 1u) * 4u) * 4u : OOB;   // weight scales: row l/2, 4 groups
+    int8_t *wb_w = wbuf + (size_t)r_lo * G6_PITCH + c16;               // + 2 r8 rows
+    const int8_t *wb_r = wbuf + (size_t)m * G6_PITCH + kq * 16u;       // + 64 j
+    float *wsl_w = wsl + ((lane & 1u) * 4u) * 16u + (lane >> 1);       // lanes 0..15: [4 (l%2) + k][row l/2], half 1: + 8
+    const float *wsl_r = wsl + kq * 4u;                                // + 16 j
+    // MODE P: token slot m of the compact layout, or the zero block
+    const uint32_t pb_off = m < SLOTS ? kq * 16u * SLOTS + m * 16u : (uint32_t)(zblk - reinterpret_cast<unsigned char *>(xqc));
+    const uint32_t pb_str = m < SLOTS ? 64u * SLOTS : 0u;
+    const uint32_t px_off = m < SLOTS ? m : 15u, px_str = 16u;       // (slot 15 of a group's scales is never written when NBC < 16: zero-filled)
+
+    // ---- the workgroup's items -----------------------------------------------------------------------------------------------
+    const uint32_t bid = blockIdx.x;
+    const uint32_t ntl = bid < d.full ? d.tpw : d.tpw - 1u;              // tiles of this workgroup
+    const uint32_t nitems = ntl * nu;
+
+    struct TI { uint32_t lrow0, rows0, obs, ops; const int8_t *wA, *wB; const float *sA, *sB; float *out; };
+    auto decode = [&](uint32_t tl) -> TI {
+        TI t;
+        const uint32_t tile = bid + tl * d.grid;
+        const int sel = !MS ? 0 : (int)(tile >= d.tc0) + (int)(tile >= d.tc1);
+        t.wA = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
+        t.sA = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
+        t.wB = sw ? a.w[1] : t.wA; t.sB = sw ? a.ws[1] : t.sA;
+        t.out = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
+        t.rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
+        t.obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
+        t.ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
+        t.lrow0 = (tile - (sel == 0 ? 0u : sel == 1 ? d.tc0 : d.tc1)) * (sw ? hh : 2u * hh);
+        return t;
+    };
+
+    // ---- the ring: D items of this wave in flight ---------------------------------------------------------------------------------
+    struct Slot { int4 w[8]; float4 s0, s1; i32x4 b[MODE == G6_F ? 8 : 1]; float4 xs; };
+    Slot ring[D];
+    auto issue = [&](auto J, uint32_t it) {
+        constexpr int sl = decltype(J)::value;
+        const bool live = it < nitems;
+        const uint32_t tl = (it * d.magic_nu) >> 16, u = it - tl * nu;
+        const TI t = decode(tl);
+        if constexpr (MODE == G6_F) {               // the item's activation fragments FIRST (loads return in issue order)
+            const uint32_t g0 = u * 8u;
+            const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf + (size_t)g0 * 1024u, live ? (ng - g0) * 1024u : 0u);     // groups >= ng: out of range -> 0
+            const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf + (size_t)g0 * 16u, live ? (ng - g0) * 64u : 0u);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) ring[sl].b[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)(lane * 16u + j * 1024u), 0, 0);
+            ring[sl].xs = bload_f4(rxs, lane < 32u ? lane * 16u : OOB);             // lanes 0..31: group g0 + l/4, tokens 4 (l%4) .. +3
+        }
+        // descriptors of the two halves: base = first row of the half, this unit's 512 bytes; size = what is left of the segment (a row
+        // beyond it, i.e. a dead item or the ragged last tile, reads 0).  A row's last unit may be half a unit (ng % 8 == 4): its upper
+        // 256 bytes then belong to the next row -- finite int8 values that meet activation bytes which are zero there.
+        const uint32_t rowA = t.lrow0, rowB = t.lrow0 + halfoff;
+        const uint32_t offA = rowA * n + u * 512u, offB = rowB * n + u * 512u, end = t.rows0 * n;
+        const __amdgpu_buffer_rsrc_t rA = mkrsrc(t.wA + offA, (live && rowA < t.rows0) ? end - offA : 0u);
+        const __amdgpu_buffer_rsrc_t rB = mkrsrc(t.wB + offB, (live && rowB < t.rows0) ? end - offB : 0u);
+#pragma unroll
+        for (int r8 = 0; r8 < 8; r8++) ring[sl].w[r8] = bload_w(r8 >= 4 ? rB : rA, voff[r8 & 3]);
+        const uint32_t sofA = rowA * ng + u * 8u, sofB = rowB * ng + u * 8u, send = t.rows0 * ng;
+        const __amdgpu_buffer_rsrc_t qA = mkrsrc(t.sA + sofA, (live && rowA < t.rows0) ? (send - sofA) * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t qB = mkrsrc(t.sB + sofB, (live && rowB < t.rows0) ? (send - sofB) * 4u : 0u);
+        ring[sl].s0 = bload_f4(qA, svoff);
+        ring[sl].s1 = bload_f4(qB, svoff);
+    };
+
+    // ---- MODE P: the fp32 activation is asked for before any weight --------------------------------------------------------------
+    G6X<NBC, NV, COMB> sx;
+    const bool norm = (a.flags & F_NORM) != 0;
+    if constexpr (MODE == G6_P) {
+        const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xin, COMB ? 0u : ((nb - 1u) * a.xin_bstride + n) * 4u);
+        const __amdgpu_buffer_rsrc_t rn = mkrsrc(a.norm_w, norm ? n * 4u : 0u);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
+            const uint32_t off = (i < n) ? i * 4u : OOB;
+            if constexpr (!COMB) {
+#pragma unroll
+                for (int b = 0; b < NBC; b++) sx.x[b][j] = bload_f4(rx, (b < (int)nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
+            }
+            sx.nw[j] = bload_f4(rn, off);
+        }
+        if constexpr (COMB) {
+            const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
+            const __amdgpu_buffer_rsrc_t rp = mkrsrc(a.attn_part, ns * n * 4u);
+            const __amdgpu_buffer_rsrc_t rm = mkrsrc(a.attn_ml, nh * ns * 8u);
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
+#pragma unroll
+                for (int sp = 0; sp < 8; sp++) sx.pv[j][sp] = bload_f4(rp, (i < n && (uint32_t)sp < ns) ? ((uint32_t)sp * n + i) * 4u : OOB);
+            }
+            const uint32_t sp = tid & 7u, h = tid >> 3;
+            const uint32_t mo = (h < nh && sp < ns) ? (h * ns + sp) * 8u : OOB;
+            sx.ml_m = bload_f(rm, mo);
+            sx.ml_l = bload_f(rm, mo == OOB ? OOB : mo + 4u);
+        }
+    }
+    // ---- MODE S: the workgroup's copy of the fragment-order activation (quant_rows_frag_kernel / the attention kernel wrote it): thread
+    //      t fetches the 16-byte units t, t + 512, ... (NV of them; a group is 64 units) and one float4 of the scales -- asked for before
+    //      any weight, parked in LDS behind the first barrier, read by every item of every tile of the workgroup -------------------------
+    i32x4 sb[MODE == G6_S ? NV : 1]; float4 sxs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MODE == G6_S) {
+        const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf, ng * 1024u);
+        const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf, ng * 64u);
+#pragma unroll
+        for (int j = 0; j < NV; j++) sb[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)((tid + (uint32_t)j * 512u) * 16u), 0, 0);   // beyond ng groups: 0
+        sxs = bload_f4(rxs, tid * 16u);
+    }
+    // ---- what the first tile this wave FINISHES needs for its epilogue (the old residual values, the position of a position-indexed
+    //      output): asked for first, tiny, and only by launches that need them -- nothing at the end waits for a cold load of its own ---
+    // tile tl is finished by the wave that owns its last unit, item tl * nu + nu - 1
+    uint32_t ftl = 0xffffffffu;
+    for (uint32_t tl = 0; tl < ntl; tl++) if (((tl * nu + nu - 1u) & (NW - 1u)) == wid) { ftl = tl; break; }
+    const uint32_t half = kq >> 1, rr0 = (kq & 1u) * 4u;              // this lane's four output rows: rows rr0 .. rr0 + 3 of half `half`
+    float oldv0[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t opos0 = 0;
+    if (epi == GEMV_EPI_RESID || (a.out_pstride[0] | a.out_pstride[1] | a.out_pstride[2]) != 0u) {
+        const TI t = decode(ftl == 0xffffffffu ? 0u : ftl);
+        const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;
+        const bool lv = ftl != 0xffffffffu && m < nb;
+        const __amdgpu_buffer_rsrc_t ro = mkrsrc(t.out, (ftl != 0xffffffffu && epi == GEMV_EPI_RESID) ? ((nb - 1u) * t.obs + t.rows0) * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rp = mkrsrc(a.pos, (ftl != 0xffffffffu && t.ops) ? nb * 4u : 0u);
+        opos0 = __builtin_amdgcn_raw_buffer_load_b32(rp, (int)(lv ? m * 4u : OOB), 0, 0);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)                               // (the residual stream is never position indexed)
+            oldv0[i] = bload_f(ro, (lv && rr0 + i < hh && orow0 + i < t.rows0) ? (m * t.obs + orow0 + i) * 4u : OOB);
+    }
+    // ---- the first items go out.  MODE F: every round that has a slot, right away (its one barrier -- arming the counters -- is behind
+    //      it: nothing waits on a wave that the memory pipeline holds up while it issues).  MODE P: ROUND 0 ONLY -- the prologue below has
+    //      barriers, and a wave stuck issuing 30 KB into a full memory pipeline keeps the whole workgroup from its first multiply
+    //      (measured, round 4: W1|W3 of Qwen3-4B multiplied its first item 8.3 us after entry, when the stream was nearly over) -----------
+    if (tid < d.tpw) cnt[tid] = 0u;
+    if constexpr (MODE == G6_F) __syncthreads();
+    g6_static_for<0, (MODE == G6_F ? (R < D ? R : D) : 1)>([&](auto K) { issue(K, wid + (uint32_t)decltype(K)::value * NW); });
+    NANO_STAMP(a.stamps, 1, opos0);                                 // the loads of the first round(s) issued
+
+    // ---- MODE P prologue: combine | rmsnorm, Q80 quantization (tensor.c:21-46) into the compact fragment layout ---------------------
+    if constexpr (MODE == G6_P) {
+        // what no quantizer thread writes: the zero block, the padding groups of a row's last unit, the unused scale slots
+        if (tid < 16u) reinterpret_cast<uint32_t *>(zblk)[tid] = 0u;
+        for (uint32_t i = tid * 4u; i < ngp * 16u; i += 2048u) *reinterpret_cast<float4 *>(xs_l + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t i = ng * 64u * NBC + tid * 16u; i < ngp * 64u * NBC; i += 8192u) *reinterpret_cast<int4 *>(xqc + i) = make_int4(0, 0, 0, 0);
+        if constexpr (COMB) {
+            const bool pre_ml = a.attn_n_head * 8u <= 512u;           // every (head, split) pair has its own thread
+            if (pre_ml) combine_weights<1, true>(a, wgt, sx.ml_m, sx.ml_l); else combine_weights<1, false>(a, wgt, 0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
+                const float *wg = wgt + (size_t)((i < n ? i : 0u) / a.attn_hd) * 8u;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int sp = 0; sp < 8; sp++) {                      // splits >= nsplit: partial read as 0, weight 0 (gemv_q80_impl.h)
+                    const float w = wg[sp];
+                    acc.x += sx.pv[j][sp].x * w; acc.y += sx.pv[j][sp].y * w; acc.z += sx.pv[j][sp].z * w; acc.w += sx.pv[j][sp].w * w;
+                }
+                sx.x[0][j] = acc;
+            }
+        } else __syncthreads();                                        // (the zero fills above precede the quantizer's scale stores)
+        float ss[NBC];
+#pragma unroll
+        for (int b = 0; b < NBC; b++) ss[b] = 1.0f;
+        if (norm) {                     // rmsnorm scale (infer.c:603-609): the 512-thread tree (quant_rows_frag_kernel repeats it for batches > 8)
+#pragma unroll
+            for (int b = 0; b < NBC; b++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    acc += sx.x[b][j].x * sx.x[b][j].x; acc += sx.x[b][j].y * sx.x[b][j].y;
+                    acc += sx.x[b][j].z * sx.x[b][j].z; acc += sx.x[b][j].w * sx.x[b][j].w;
+                }
+                acc = dpp_wave_sum(acc);
+                if (lane == 0) red[b * 8 + wid] = acc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < NBC; b++) {
+                float t = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; w++) t += red[b * 8 + w];
+                t /= (float)n; t += 1e-5f;
+                ss[b] = 1.0f / sqrtf(t);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
+            const uint32_t g = i >> 6, q4 = (i >> 4) & 3u, e = i & 15u;
+#pragma unroll
+            for (int b = 0; b < NBC; b++) {
+                float4 v = sx.x[b][j];
+                if (norm) {
+                    v.x = sx.nw[j].x * (ss[b] * v.x); v.y = sx.nw[j].y * (ss[b] * v.y);
+                    v.z = sx.nw[j].z * (ss[b] * v.z); v.w = sx.nw[j].w * (ss[b] * v.w);
+                }
+                float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+                mx = dpp_group_max<16>(mx);                           // a group of 64 = 16 consecutive threads
+                const float scale = div_const<127>(mx);
+                if (i < n) {
+                    const int q0 = q80_quant1(v.x, scale), q1 = q80_quant1(v.y, scale), q2 = q80_quant1(v.z, scale), q3 = q80_quant1(v.w, scale);
+                    *reinterpret_cast<uint32_t *>(xqc + (size_t)g * 64u * NBC + (size_t)q4 * 16u * NBC + (size_t)b * 16u + e) =
+                        (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+                    if ((tid & 15u) == 0u) xs_l[g * 16u + (uint32_t)b] = scale;
+                }
+            }
+        }
+    }
+    if constexpr (MODE == G6_S) {                                      // (loads beyond the ng groups returned 0: the padding groups of a row's last unit)
+#pragma unroll
+        for (int j = 0; j < NV; j++) { const uint32_t un = tid + (uint32_t)j * 512u; if (un < ngp * 64u) *reinterpret_cast<i32x4 *>(xqc + (size_t)un * 16u) = sb[j]; }
+        if (tid < ngp * 4u) *reinterpret_cast<float4 *>(xs_l + tid * 4u) = sxs;
+    }
+    if constexpr (MODE != G6_F) {
+        __syncthreads();                                               // counters armed, the quantized activation is in LDS
+        g6_static_for<1, (R < D ? R : D)>([&](auto K) { issue(K, wid + (uint32_t)decltype(K)::value * NW); });     // the other rounds that have a slot
+    }
+    NANO_STAMP(a.stamps, 2, cnt[0]);                                // (P) the activation arrived, normalised + quantized
+
+    // ---- the items of this wave ---------------------------------------------------------------------------------------------------
+    // consume: slot registers -> LDS, eight MFMAs, the unit sum into the table, the tile's counter.  No load, no store, no wait for
+    // another wave: straight-line code whose s_waitcnt counts the compiler gets exactly right (round 4's first build looped over the
+    // slots -- at the loop header the compiler's counter merged to "wait for everything", and every wave multiplied only after ALL
+    // its weights had landed: 21 us for a launch whose stream lasts 8).
+    auto consume = [&](auto J, auto FIRST, uint32_t it) {
+        constexpr int sl = decltype(J)::value;
+        constexpr bool first = decltype(FIRST)::value;
+        const uint32_t tl = (it * d.magic_nu) >> 16, u = it - tl * nu;
+        const uint32_t g0 = u * 8u;
+        // 1. weight pieces -> transposition buffer; weight scales (and, F, activation scales) -> LDS
+#pragma unroll
+        for (int r8 = 0; r8 < 8; r8++) *reinterpret_cast<int4 *>(wb_w + (size_t)(2 * r8) * G6_PITCH) = ring[sl].w[r8];
+        if (lane < 16u) {
+            wsl_w[0] = ring[sl].s0.x; wsl_w[16] = ring[sl].s0.y; wsl_w[32] = ring[sl].s0.z; wsl_w[48] = ring[sl].s0.w;
+            wsl_w[8] = ring[sl].s1.x; wsl_w[24] = ring[sl].s1.y; wsl_w[40] = ring[sl].s1.z; wsl_w[56] = ring[sl].s1.w;
+        }
+        if constexpr (MODE == G6_F) { if (lane < 32u) *reinterpret_cast<float4 *>(xslw + lane * 4u) = ring[sl].xs; }
+        if constexpr (first) NANO_STAMP(a.stamps, 3, (float)ring[sl].w[7].x + ring[sl].s1.x);     // this wave's first weights (and scales) arrived
+        // 2. eight groups: A fragment from LDS, one MFMA, products, the unit sum in ascending group order (groups >= ng of a row's last
+        //    unit: zero activation bytes and scales -> products +0.0f)
+        float S[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const i32x4 fa = *reinterpret_cast<const i32x4 *>(wb_r + j * 64u);
+            i32x4 fb; float xsc;
+            if constexpr (MODE == G6_F) { fb = ring[sl].b[j]; xsc = xslw[j * 16u + m]; }
+            else {
+                fb = *reinterpret_cast<const i32x4 *>(xqc + pb_off + (g0 + j) * pb_str);
+                xsc = xs_l[px_off + (g0 + j) * px_str];
+            }
+            const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
+            const float4 wv = *reinterpret_cast<const float4 *>(wsl_r + j * 16u);
+            const float p0 = ((float)cv[0] * wv.x) * xsc, p1 = ((float)cv[1] * wv.y) * xsc;      // infer.c:672
+            const float p2 = ((float)cv[2] * wv.z) * xsc, p3 = ((float)cv[3] * wv.w) * xsc;
+            if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
+            else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
+        }
+        if constexpr (first) NANO_STAMP(a.stamps, 4, S[3]);             // ... multiplied
+        // 3. arrive
+        *reinterpret_cast<float4 *>(T + ((size_t)tl * nu + u) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
+        if (lane == 0u) __hip_atomic_fetch_add(cnt + tl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // R rounds in straight-line code; the item of round r + D is requested as soon as round r's slot is free
+    g6_static_for<0, R>([&](auto K) {
+        constexpr int r = decltype(K)::value;
+        const uint32_t it = wid + (uint32_t)r * NW;
+        if (it < nitems) consume(std::integral_constant<int, r % D>{}, std::integral_constant<bool, r == 0>{}, it);
+        if constexpr (r + D < R) issue(std::integral_constant<int, r % D>{}, it + (uint32_t)D * NW);
+    });
+    NANO_STAMP(a.stamps, 5, oldv0[0]);                                // this wave's items done
+    // ---- the tiles this wave finishes: wait for the tile's units, add them in ascending order, epilogue ---------------------------
+    for (uint32_t tl = ftl; tl < ntl; tl++) {
+        if (((tl * nu + nu - 1u) & (NW - 1u)) != wid) continue;
+        const TI t = decode(tl);
+        const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;        // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
+        float oldv[4] = {oldv0[0], oldv0[1], oldv0[2], oldv0[3]};
+        uint32_t opos = opos0;
+        if (tl != ftl && m < nb) {                                     // (a wave that finishes several tiles: only the first one's were fetched up front)
+            if (t.ops) opos = a.pos[m];
+            if (epi == GEMV_EPI_RESID) {
+                const float *o = t.out + (size_t)m * t.obs + orow0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) oldv[i] = o[i];
+            }
+        }
+        // (bounded: a miscounted tile must not hang the device -- 2^24 naps are ~0.5 s, the results are then wrong and the tests say so)
+        for (uint32_t spin = 0; g6_lds_load_acq(cnt + tl) != nu && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
+        const float *tp = T + (size_t)tl * nu * 256u + lane * 4u;
+        float4 acc = *reinterpret_cast<const float4 *>(tp);
+        for (uint32_t u0 = 1; u0 < nu; u0 += 4) {                      // units ascending; the reads of four units go out together
+            float4 q[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) q[k] = (u0 + k < nu) ? *reinterpret_cast<const float4 *>(tp + (size_t)(u0 + k) * 256u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) if (u0 + k < nu) { acc.x += q[k].x; acc.y += q[k].y; acc.z += q[k].z; acc.w += q[k].w; }
+        }
+        const float tot[4] = {acc.x, acc.y, acc.z, acc.w};
+        float v3[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sw) {                                                      // W3's values live 32 lanes up (rows 8..15 of the tile)
+#pragma unroll
+            for (int i = 0; i < 4; i++) v3[i] = __shfl_xor(tot[i], 32, 64);
+        }
+        if (m < nb && (!sw || kq < 2u)) {
+            float *o = t.out + (size_t)m * t.obs + (size_t)opos * t.ops + orow0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) o[i] = finish_epi(epi, tot[i], v3[i], oldv[i]);
+        }
+    }
+    NANO_STAMP_END(a.stamps, 6);                                    // the workgroup's last wave ends
+}
+
+
+// ---- launch plumbing shared by the translation units ---------------------------------------------------------------------------------
+template <int MODE, bool COMB, int NBC, int NV, int R, bool MS>
+static hipError_t g6_launch_t(const G6Dev &d, size_t lds, hipStream_t st) {
+    auto kern = &gemm_q80_g6_kernel<MODE, COMB, NBC, NV, R, MS>;
+    static std::atomic<bool> armed[64];
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !armed[dev].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (dev >= 0 && dev < 64) armed[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(d.grid), dim3(d.nw * 64u), lds, st, d);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// MODE P launchers by (NV, rounds, multi-segment); defined in gemm_q80_g6_p*.hip.  nbc = sequence capacity 1 | 2 | 4 | 8
+hipError_t g6p_launch_nv2(const void *dv, size_t lds, uint32_t nbc, uint32_t rounds, bool ms, bool comb, hipStream_t st);
+hipError_t g6p_launch_nv5(const void *dv, size_t lds, uint32_t nbc, uint32_t rounds, bool ms, hipStream_t st);
+bool g6p_has(uint32_t nv, uint32_t nbc, uint32_t rounds, bool ms, bool comb);
+
+}  // namespace nano

@@ -35,7 +35,12 @@ uint32_t route_norm_order(const Q80Route &r, const GemvArgs &a) {
 
 // MODE P quantizes nb x n values in EVERY workgroup: taken when the launch needs fp32 processing anyway (a norm or the split-attention
 // combine: the quantizer launch it replaces costs ~3.5 us) or when the activation is small
-static bool p_worthwhile(const GemvArgs &a) { return a.norm_w || a.attn_part || (uint64_t)a.nb * a.n <= 12288u; }
+// -- up to two sequences: measured (round 4, Qwen3-4B's QKV at 8 sequences) the prologue of 8 x 2560 values per workgroup lasts 9.7 us
+// where the quantizer launch it replaces costs 3.5
+static bool p_worthwhile(const GemvArgs &a) {
+    static const uint32_t pmax = [] { const char *e = getenv("NANO_G6P_MAX_NB"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v ? v : 2u; }();
+    return a.nb <= pmax && (a.norm_w || a.attn_part || (uint64_t)a.nb * a.n <= 12288u);
+}
 
 RouteKind route_kind(const Q80Route &r, const GemvArgs &a) {
     if (r.quant == NANO_QUANT_Q4K) return ROUTE_Q4K;
@@ -44,12 +49,12 @@ RouteKind route_kind(const Q80Route &r, const GemvArgs &a) {
     const bool canon = q80_canonical(a);
     const bool wide = route_is_wide(a);
     if (canon && r.use_g6) {
-        if (wide && !a.xq_in && a.nb <= 8 && r.mfma_min_nb == 9 && p_worthwhile(a) && gemm_q80_g6p_supports(a)) return ROUTE_G6P;
+        // one sequence: the SLAB GEMV is the leaner kernel (measured, round 4, Qwen3-4B: 1.48 ms per step against MODE P's 1.77;
+        // NANO_G6P_B1=1 routes it through MODE P for A/B runs)
+        static const bool p_b1 = getenv("NANO_G6P_B1") && *getenv("NANO_G6P_B1") == '1';
+        if (wide && !a.xq_in && a.nb <= 8 && (a.nb >= 2 || p_b1) && r.mfma_min_nb == 9 && p_worthwhile(a) && gemm_q80_g6p_supports(a)) return ROUTE_G6P;
         const bool batched = a.nb >= r.mfma_min_nb || (r.mfma_min_nb == 9 && ((a.nb == 8 && gemv_is_heavy(a)) || (wide && a.nb >= 2)));
-        // (wide, one sequence, MODE P not taken -- a plain activation too long for it: quantizer launch + MODE F beats the SLAB GEMV, whose
-        //  every workgroup would re-quantize the row)
-        const bool wide1 = wide && a.nb == 1 && r.mfma_min_nb == 9 && !a.attn_part && !a.norm_w;
-        if ((batched || wide1) && scratch && !a.attn_part && !a.resid_add && gemm_q80_g6_supports(a)) return ROUTE_FRAG_G6;
+        if (batched && scratch && !a.attn_part && !a.resid_add && gemm_q80_g6_supports(a)) return ROUTE_FRAG_G6;
     }
     // the older batched route: 9..64 sequences always; 8 sequences when the matrix is large; per-layer matrices of >= 8 M weights from 2
     // sequences on (tools/wide_batch.sh, round 2); the classifier keeps its STREAM GEMV up to 7 sequences

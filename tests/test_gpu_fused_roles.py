@@ -60,6 +60,8 @@ def ref_q80(oracle, act, segs, n, gs, canon=False):
 
 
 ROUTES_FREE = os.environ.get("NANO_GEMM_G6") == "0"        # round 3's routes (A/B knob): the expected-route assertions do not apply
+# one sequence on Qwen3-4B's matrices: the SLAB GEMV (leaner, measured faster); NANO_G6P_B1=1 sends it through G6 MODE P
+W1 = "g6p" if os.environ.get("NANO_G6P_B1") == "1" else "gemv"
 
 
 def check_q80(oracle, kind, n, segs, x, nw, old, nb_, *, attn=None, act_of=None, use_gemm=False, routes=None, strict_too=True):
@@ -88,10 +90,10 @@ def silu_mul(a, b):
 
 
 # (name, n, rows of the weight tensors, the fast path's route): Qwen3-0.6B (SLAB GEMV) and Qwen3-4B (G6 MODE P) per-layer shapes
-K1_SHAPES = [("q06", 1024, (2048, 1024, 1024), "gemv"), ("4b", 2560, (4096, 1024, 1024), "g6p")]
-K3_SHAPES = [("q06", 2048, 1024, "gemv"), ("4b", 4096, 2560, "g6p")]
-K4_SHAPES = [("q06", 1024, 3072, "gemv"), ("4b", 2560, 9728, "g6p")]
-K5_SHAPES = [("q06", 3072, 1024, "gemv"), ("4b", 9728, 2560, "g6p")]
+K1_SHAPES = [("q06", 1024, (2048, 1024, 1024), "gemv"), ("4b", 2560, (4096, 1024, 1024), W1)]
+K3_SHAPES = [("q06", 2048, 1024, "gemv"), ("4b", 4096, 2560, W1)]
+K4_SHAPES = [("q06", 1024, 3072, "gemv"), ("4b", 2560, 9728, W1)]
+K5_SHAPES = [("q06", 3072, 1024, "gemv"), ("4b", 9728, 2560, W1)]
 
 
 @pytest.mark.parametrize("name,n,rows,route", K1_SHAPES)
@@ -112,7 +114,7 @@ def test_k3_k5_residual_q80(oracle, name, n, rows, route):
     check_q80(oracle, 1, n, [seg], x[None], None, old[None], 1, routes=(route,))
 
 
-@pytest.mark.parametrize("n_head,n,rows,route", [(16, 2048, 1024, "gemv"), (32, 4096, 2560, "g6p")])
+@pytest.mark.parametrize("n_head,n,rows,route", [(16, 2048, 1024, "gemv"), (32, 4096, 2560, W1)])
 @pytest.mark.parametrize("nsplit,ls", [(2, (3, 5)), (4, (1, 3, 2, 2)), (8, (1, 1, 2, 4, 2, 2, 1, 3))])
 def test_k3_split_attention_combine_q80(oracle, nsplit, ls, n_head, n, rows, route):
     """Wo launch whose prologue combines split-attention partials (gemv_common.h combine_weights; G6 MODE P at Qwen3-4B's shape):
@@ -168,24 +170,24 @@ def test_batched_gemv_roles_q80(oracle, nb_, kind):
 @pytest.mark.parametrize("nb_", [2, 3, 4, 8])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_batched_g6_prologue_roles_q80(oracle, nb_, kind):
-    """Qwen3-4B's shapes, 2..8 sequences: the norm launches quantize in G6's prologue (MODE P, capacity templates 2 / 4 / 8); the
-    plain ones (Wo, W2) take fragment-order activations from a quantizer launch unless the activation is small"""
+    """Qwen3-4B's shapes, 2..8 sequences: two sequences quantize in G6's prologue (MODE P, capacity 2), more take fragment-order
+    activations from a quantizer launch (MODE F)"""
     n, rows = [(2560, (4096, 1024, 1024)), (4096, (2560,)), (2560, (9728, 9728))][kind]
     rng = np.random.default_rng(nb_ * 7 + kind)
     x = order_free(rng, (nb_, n))
     nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32) if kind != 1 else None
     segs = [(*q80_weights(rng, r, n, 64), r) for r in rows]
     if kind == 2:                                          # SwiGLU: the pair's store form pins the bits, the fused form the epilogue
-        check_q80(oracle, 0, n, segs, x, nw, None, nb_, routes=("g6p",))
+        check_q80(oracle, 0, n, segs, x, nw, None, nb_, routes=("g6p",) if nb_ <= 2 else ("frag_g6",))
         out, r = nb.op_fused_gemv(Q80, 2, n, segs, x, nw, gs=64, nb=nb_, want_route=True)
-        assert r == "g6p"
+        assert r == ("g6p" if nb_ <= 2 else "frag_g6")
         for b in range(nb_):
             xn = oracle.rmsnorm(x[b], nw)
             want = silu_mul(ref_q80(oracle, xn, segs[:1], n, 64, canon=True), ref_q80(oracle, xn, segs[1:], n, 64, canon=True))
             assert np.allclose(out[b], want, rtol=3e-6, atol=1e-9), b
         return
     old = rng.standard_normal((nb_, sum(rows))).astype(np.float32)
-    check_q80(oracle, kind, n, segs, x, nw, old, nb_, routes=("g6p",) if kind == 0 or nb_ <= 3 else ("frag_g6",))
+    check_q80(oracle, kind, n, segs, x, nw, old, nb_, routes=("g6p",) if nb_ <= 2 else ("frag_g6",))
 
 
 GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (9, 1, 3072, (1024,)), (40, 1, 2048, (1024,)), (64, 0, 1024, (2048, 1024, 1024)),
@@ -222,7 +224,7 @@ def test_g6_ragged_segments(oracle):
     nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
     segs = [(*q80_weights(rng, r, n, 64), r) for r in rows]
     check_q80(oracle, 0, n, segs, x, nw, None, nb_, use_gemm=True, routes=("frag_g6",), strict_too=False)
-    check_q80(oracle, 0, n, segs, x[:5], nw, None, 5, routes=("g6p",))
+    check_q80(oracle, 0, n, segs, x[:2], nw, None, 2, routes=("g6p",))
 
 
 @pytest.mark.parametrize("nb_,kind,n,rows", GEMM_CASES)
@@ -230,6 +232,14 @@ def test_mfma_gemm_route_q80(oracle, nb_, kind, n, rows):
     """the batched route of a step: quant_rows_frag_kernel (fragment-order activations) + the int8 MFMA GEMM (G6 MODE F up to 16
     tokens, G5 beyond, GC for tall matrices; strict mode: G5 / GC in the reference's order)"""
     gemm_route_case(oracle, nb_, kind, n, rows)
+
+
+def test_one_sequence_through_g6_mode_p():
+    """NANO_G6P_B1=1: the one-sequence launches of Qwen3-4B's shapes through G6 MODE P (capacity 1, the split-attention combine in its
+    prologue) instead of the SLAB GEMV -- same bits (the knob is read once per process)"""
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k", "test_k1 or test_k3 or test_k4"],
+                       env=dict(os.environ, NANO_G6P_B1="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:]
 
 
 def test_mfma_gemm_route_older_kernels():

@@ -12,5 +12,17 @@ g6a)   # first light of G6: operator tests, then A/B against round 3's routes on
     NANO_GEMM_G6=0 bench 4b_b${b}_old --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-kernel-table
   done
   ;;
+g6b)   # leaner G6 (compile-time rounds): operator tests, Qwen3-4B at 1 / 8 / 16 sequences, phase stamps of its launches
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py -m gpu -x -q -k "q80" 2>&1 | tail -4
+  for b in 1 2 4 8 16; do bench 4b_b${b}_g6 --model qwen3-4b --batch $b --steps 32 --warmup 4; done
+  for b in 1 8; do NANO_STAMPS_GRAPH=1 NANO_LIB=$R/nano_amd/lib/libnano_mi355x_stamps.so timeout 200 python tools/stamp_probe.py wide-qwen3 q80 $b 30 2>&1 | tail -14 | tee $O/g6_stamps_b$b.txt; done
+  ;;
+g6c)   # routing settled (1 sequence: SLAB with the activation-first barrier; 2..16: G6): tests, Qwen3-4B 1..16, A/B of the barrier, small model
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py -m gpu -x -q -k "q80 or g6" 2>&1 | tail -4
+  for b in 1 2 8 16; do bench 4b_b${b} --model qwen3-4b --batch $b --steps 32 --warmup 4; done
+  NANO_SLAB_ACTFIRST=0 bench 4b_b1_noactfirst --model qwen3-4b --batch 1 --steps 32 --warmup 4
+  NANO_G6_STAGE=0 bench 4b_b8_nostage --model qwen3-4b --batch 8 --steps 32 --warmup 4 --no-kernel-table
+  for b in 1 16 64; do bench q06_b${b} --batch $b --steps 64 --warmup 4 --no-kernel-table; NANO_GEMM_G6=0 bench q06_b${b}_old --batch $b --steps 64 --warmup 4 --no-kernel-table; done
+  ;;
 *) echo "unknown mode $1";;
 esac
