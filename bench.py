@@ -94,9 +94,17 @@ def usable_cores(cap=32):
 
 
 def cpu_baseline(path, spec, budget_s=20.0, timeout_s=150):
+    """The reference's CPU engine beside the GPU number (OMP_NUM_THREADS = nproc AND 1): all usable host cores
+    is the headline of the object, `single_thread` the same build with one thread on a smaller sample."""
+    out = cpu_baseline_run(path, spec, usable_cores(), budget_s, timeout_s)
+    one = cpu_baseline_run(path, spec, 1, 8.0, 90)
+    out["single_thread"] = {k: one.get(k) for k in ("value", "unit", "cores", "kind", "sample", "GBps")}
+    return out
+
+
+def cpu_baseline_run(path, spec, cores, budget_s, timeout_s):
     """Run the CPU baseline in a child process (own OpenMP runtime, hard time limit)."""
     import subprocess
-    cores = usable_cores()
     env = dict(os.environ, OMP_NUM_THREADS=str(cores))
     code = ("import json, sys; sys.path.insert(0, %r); import bench; from nano_amd import modelfile as mf; "
             "print(json.dumps(bench.cpu_baseline_worker(%r, mf.read_header(%r), %r, %d)))" % (ROOT, path, path, budget_s, cores))
@@ -243,6 +251,52 @@ def parse_pmc_csv(path, kernel_substr="stream_kernel"):
     return int(s / n * 1024 * 2) if n else None
 
 
+def measure_traffic(args, timeout_s=240):
+    """HBM bytes of one decode step from the PMC counters: a child run of THIS command (20 eager steps -- rocprofv3 cannot follow HIP
+    graph replays in this image) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (a counter pass of its own, run from /tmp with
+    TMPDIR=/tmp, as MI355X_MICROARCH.md prescribes), FETCH_SIZE (KB) x 1024 x 2 (gfx950 counts 64 B per 128-B request).  Returns
+    None when rocprofv3 is missing or the pass fails -- the bench line never depends on it."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("NANO_BENCH_NO_TRAFFIC") == "1":
+        return None
+    steps = 24
+    d = tempfile.mkdtemp(prefix="nano_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+           "--pmc-child", "--steps", str(steps), "--batch", str(args.batch), "--model", args.model, "--quant", args.quant, "--gs", str(args.gs)]
+    env = dict(os.environ, NANO_HIP_NO_GRAPH="1", TMPDIR="/tmp", NANO_BENCH_NO_TRAFFIC="1")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            log(f"[bench] PMC pass failed (rc {r.returncode}); traffic stays null")
+            return None
+        per_kernel, calls = {}, {}
+        for row in csv.DictReader(open(files[0])):
+            if row.get("Counter_Name") != "FETCH_SIZE":
+                continue
+            k = row.get("Kernel_Name", "?").replace("void nano::(anonymous namespace)::", "").replace("nano::(anonymous namespace)::", "").replace("nano::", "")
+            per_kernel[k] = per_kernel.get(k, 0.0) + float(row["Counter_Value"]) * 1024 * 2
+            calls[k] = calls.get(k, 0) + 1
+        if not per_kernel:
+            return None
+        top = sorted(per_kernel, key=lambda kk: -per_kernel[kk])[:8]
+        return {"bytes_per_step": int(sum(per_kernel.values()) / steps),
+                "kernels": [{"kernel": k[:110], "launches_per_step": round(calls[k] / steps, 2), "bytes_per_launch": int(per_kernel[k] / calls[k])} for k in top],
+                "how": f"child run of {steps} eager decode steps (positions 0..{steps - 1}: the KV rows are a fraction of a percent of the bytes) under rocprofv3 --pmc "
+                       "FETCH_SIZE --kernel-trace, a counter pass of its own; FETCH_SIZE is in KB: x 1024, x 2 on gfx950 (64 B counted per 128-B request, "
+                       "MI355X_MICROARCH.md); every kernel of the steps summed / the steps"}
+    except Exception as e:                                  # noqa: BLE001 -- the counter pass must never take the bench line down
+        log(f"[bench] PMC pass failed: {e}")
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def all_configs(args):
     """One JSON line per BASELINE.json config that runs here, each from a child run of this file; the default line last."""
     import subprocess
@@ -351,7 +405,16 @@ def main():
     ap.add_argument("--all-configs", action="store_true", help="one JSON line per BASELINE config, the default line last")
     ap.add_argument("--replicas", type=int, default=0, help="N weight replicas in ONE process through the C engine (no torch)")
     ap.add_argument("--min-window-s", type=float, default=0.25, help="repeat the K-step window until this much time is covered; report the median window")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) nothing but --steps eager decode steps: what measure_traffic() profiles")
     args = ap.parse_args()
+    if args.pmc_child:
+        from nano_amd import binding as nb
+        gs_ = args.gs if args.quant == "q80" else 0
+        path_, spec_ = ensure_model(args.model, args.quant, gs_)
+        m_ = nb.load_model_file(path_, device=0, max_seq_len=SEQ_LEN, max_batch=args.batch)
+        m_.decode_greedy([1] * args.batch, [0] * args.batch, int(args.steps or 24))
+        m_.sync(); m_.close()
+        return
 
     if args.all_configs:
         return all_configs(args)
@@ -461,6 +524,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wins = [float(v) for v in t.cpu().numpy()]
     elapsed = float(np.median(wins))
+    # the seq_len-512 number next to a short driver window: one more window from the same start state to the LAST position of the context
+    full_win = None
+    K_full = SEQ_LEN - pos0
+    if not strong and K_full > K and os.environ.get("NANO_BENCH_NO_FULL_WINDOW") != "1":
+        barrier()
+        t0 = time.perf_counter()
+        m.decode_greedy(tok, [pos0] * B, K_full)
+        m.sync()
+        barrier()
+        e_full = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([e_full], dtype=torch.float64, device=f"cuda:{local}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e_full = float(t.item())
+        full_win = {"value": round(n_seq * K_full / e_full, 2), "unit": "tokens/s", "steps": K_full, "ms_per_step": round(e_full / K_full * 1e3, 4),
+                    "positions": f"{pos0}..{pos0 + K_full - 1}", "what": "one contiguous window from the same start state to the last position of the 512-token context"}
     log(f"[bench] rank {rank}: timed region done, {elapsed * 1e3 / K:.3f} ms/step (median of {len(wins)} windows of {K} steps, "
         f"min {min(wins) * 1e3 / K:.3f} max {max(wins) * 1e3 / K:.3f})")
 
@@ -497,19 +577,43 @@ def main():
     kv_mid = 8 * spec.n_layer * spec.kv_dim * (pos_mid + 1)
     alg_bytes = step_bytes + B * kv_mid                    # per GPU and step: every weight byte once + each sequence's KV rows
     achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
+    # the dominant launch kind BY TIME: the per-layer weight projections (QKV, Wo, W1|W3, W2: one kernel family, 4 x n_layer launches per
+    # step) from the in-situ table; the classifier launch is the BEST kernel (its own start / stop events), not the dominant one
+    dominant = None
+    if table:
+        fam = [r for r in table if r["kernel"] in ("qkv_gemv", "wo_gemv", "w1w3_gemv", "w2_gemv")]
+        us = sum(r["us_per_step"] for r in fam); by = sum(r["bytes_per_step"] for r in fam)
+        if us > 0:
+            dominant = {"kernel": "per-layer weight projections (QKV, Wo, W1|W3, W2 launches: SLAB GEMV at 1..8 sequences, G6 / G5 GEMM beyond)",
+                        "launches_per_step": 4 * spec.n_layer, "bytes_per_step": int(by), "us_per_step": round(us, 2), "share_of_step": round(us / full_us, 3),
+                        "us_per_launch": round(us / (4 * spec.n_layer), 3), "GBps": round(by / (us * 1e-6) / 1e9, 1), "frac": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "how": "sum of the four kinds' in-situ marginals (kernels table): a LOWER bound of their time, so this fraction is an upper bound"}
+    traffic = None
+    if args.pmc_csv:
+        traffic = parse_pmc_csv(args.pmc_csv)
+    elif n_gpus == 1 and not use_dist:
+        traffic = measure_traffic(args)
     roofline = {"bound": "hbm", "what": "whole decode step on one GPU: algorithmic bytes per step (weights once + KV rows at the mid-run position) / measured ms_per_step",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "peak_measured": peak_measured, "peak_measured_how": "non-temporal 16-byte streaming read of a 2 GiB buffer on this GPU (nano_hip_membw, 2048 x 256 threads), GB/s",
                 "frac_of_measured": round(achieved / peak_measured, 4) if peak_measured else None,
-                "traffic": parse_pmc_csv(args.pmc_csv) if args.pmc_csv else None,
+                "traffic": traffic["bytes_per_step"] if isinstance(traffic, dict) else traffic,
+                "traffic_over_algorithmic": round(traffic["bytes_per_step"] / alg_bytes, 4) if isinstance(traffic, dict) else None,
+                "traffic_detail": traffic if isinstance(traffic, dict) else None,
                 "bytes_per_step": int(alg_bytes), "weight_bytes_per_step": int(step_bytes), "kv_bytes_per_step": int(B * kv_mid),
                 "kernels": table, "kernels_how": None if table is None else
-                f"in-situ: graph replays of the step at position {pos_mid} minus replays with the launch kind left out; full step {full_us:.1f} us, sum of the kinds {sum_us:.1f} us",
-                "dominant_kernel": cls}
+                f"in-situ: graph replays of the step at position {pos_mid} minus replays with the launch kind left out; full step {full_us:.1f} us, sum of the kinds {sum_us:.1f} us. "
+                "The marginals are LOWER bounds of a kind's time (leaving a launch out also removes its boundary and lets its neighbours' weights stay cached): a row's "
+                "GB/s is an upper bound and can exceed peak_measured",
+                "dominant_kernel": dominant, "best_kernel": cls}
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tokens / elapsed, 2), "unit": "tokens/s",
         "n_gpus": n_gpus, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4),
-        "windows": len(wins), "window_ms": {"min": round(min(wins) * 1e3, 4), "median": round(elapsed * 1e3, 4), "max": round(max(wins) * 1e3, 4)},
+        "windows": len(wins), "window_ms": {"min": round(min(wins) * 1e3, 4), "median": round(elapsed * 1e3, 4), "max": round(max(wins) * 1e3, 4), "first": round(first * 1e3, 4)},
+        "value_first_window": round(tokens / first, 2),
+        "value_how": "median of `windows` repeats of the same K-step window (same start token and positions: later repeats re-touch the same KV rows; the first window also pays "
+                     "the first use of the position buckets' HIP graphs -- value_first_window); value_full_window = one contiguous run to the end of the context",
+        "value_full_window": full_win,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": {"q80": "i8", "q4k": "u4", "f32": "f32"}[args.quant], "data": "synthetic",
         "config": {"workload": f"{args.model} {args.quant.upper()}" + (f" gs={spec.group_size}" if args.quant == "q80" else "") +

@@ -215,6 +215,8 @@ int nano_forward_batch(Nano_Context *ctx, const uint32_t *tokens, const uint32_t
  * shares concurrently -- independent sequences shard trivially, no collective.  The one-process-per-GPU
  * route with an RCCL broadcast of the weights is nano_amd/dist.py + bench.py.  Returns 0 or a NANO_HIP_E* code. */
 int nano_context_replicate(Nano_Context *ctx, const int *devices, int n_devices);
+/* how the last nano_context_replicate moved the weights (one host upload + an RCCL broadcast / peer copies over xGMI, replicate.hip) */
+int nano_replicate_stats(Nano_Context *ctx, double *upload_s, double *share_s, char *how, size_t how_cap);
 /* Session over token ids (no tokenizer needed): like llm_session_init but the prompt is given as ids. */
 Nano_Session *nano_session_init_ids(Nano_Context *ctx, const uint32_t *prompt_ids, uint32_t n_prompt, uint32_t max_seq_len);
 /* Like llm_session_step but never touches the tokenizer (output_text stays NULL). */

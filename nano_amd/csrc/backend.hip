@@ -429,6 +429,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     return NANO_HIP_OK;
 }
 
+extern "C" int nano_hip_model_device(const NanoHipModel *m) { return m ? m->device : -1; }
 extern "C" uint64_t nano_hip_weight_bytes_per_step(const NanoHipModel *m) { return m ? m->weight_bytes_per_step : 0; }
 
 // ------------------------------------------------------------------------------------------------

@@ -267,13 +267,12 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
         karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.out_bstride[1]); karg_touch(a.out_bstride[2]);
         karg_touch(a.out_pstride[1]); karg_touch(a.out_pstride[2]); karg_touch(a.rows[1]); karg_touch(a.rows[2]);
     }
-    karg_touch(a.pos); karg_touch(a.canon); karg_touch(a.log2_tiles);
+    karg_touch(a.pos); karg_touch(a.canon);
     if (ROLE == R_GENERIC || ROLE == R_RESID || ROLE == R_RESID_COMBINE) { karg_touch(a.resid_add); karg_touch(a.resid_add_bstride); }
     NANO_STAMP(a.stamps, 0, tid);
     // ---- 1. activation loads (critical path) ------------------------------------------------------------
     Staged<B, NV> sx;
     if (!(NANO_STAMPS && (a.dbg & 2u))) stage_issue<ROLE, B, NV>(a, sx);
-    if (a.log2_tiles) __builtin_amdgcn_s_barrier();                 // act_first (plan_slab): every wave's activation loads are in the queue before any weight load
 
     // ---- 2. all weight / scale loads of this wave; the workgroup's rows lie inside ONE segment ------------
     const uint32_t bid = blockIdx.x;
@@ -572,7 +571,7 @@ __global__ __launch_bounds__(256) void gemv_q80_stream_kernel(const GemvDev a) {
 
 // rows per workgroup / waves per workgroup of a slab launch (tuned on Qwen3-0.6B with tools/kbench: the chain
 // time is flat within 3 % around these choices -- the kernels are latency bound)
-struct SlabPlan { uint32_t rw, nw, upw, nv, act_first; };
+struct SlabPlan { uint32_t rw, nw, upw, nv; };
 static SlabPlan plan_slab(const GemvArgs &a, int B) {
     const uint32_t nchunk = (a.n + 1023) / 1024, nmat = a.epi == GEMV_EPI_SWIGLU ? 2 : 1;
     const uint32_t nseg = a.epi == GEMV_EPI_SWIGLU ? 1u : a.nseg;
@@ -657,12 +656,11 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     while (upw > 4 && nw < 16) { nw++; upw = (units + nw - 1) / nw; }
     if (large_nw) { nw = large_nw; upw = (units + nw - 1) / nw; while (upw > 4 && nw < 16) { nw++; upw = (units + nw - 1) / nw; } }
     if (force_nw) { nw = force_nw; upw = (units + nw - 1) / nw; }
-    // Large slabs (64-200 KB of weights per workgroup, every load issued at entry): round 3 measured the activation of Qwen3-4B's W1|W3
-    // "arriving" with the end of the 52.9 MB burst.  act_first (NANO_SLAB_ACTFIRST=1): a raw barrier between the activation loads and the
-    // weight loads, so that every wave's activation is asked for before any weight.  MEASURED (round 4, Qwen3-4B, one box): 1.4707 ms per
-    // step with it, 1.4594 without -- the launch is bound by latency + stream + tail, not by where the activation sits in the queue.  Off.
-    static const bool act_first_on = getenv("NANO_SLAB_ACTFIRST") && *getenv("NANO_SLAB_ACTFIRST") == '1';
-    SlabPlan p{rw, nw, upw, (a.n + 256 * nw - 1) / (256 * nw), (large_nw && act_first_on) ? 1u : 0u};
+    // (Round 4 tried a raw barrier between the activation loads and the weight loads of the large slabs, so that every wave's activation
+    // is asked for before any weight -- round 3 had measured the activation of Qwen3-4B's W1|W3 "arriving" with the end of the 52.9 MB
+    // burst.  Measured on one box: 1.4707 ms per step with it, 1.4594 without.  The launch is bound by latency + stream + tail, not by
+    // where the activation sits in the queue.  Removed.)
+    SlabPlan p{rw, nw, upw, (a.n + 256 * nw - 1) / (256 * nw)};
     return p;
 }
 
@@ -700,7 +698,7 @@ static hipError_t launch_slab_b(GemvDev &d, const GemvArgs &a, hipStream_t st) {
     d.rw = p.rw;
     d.tpw = (p.rw + 3) / 4;
     d.magic_rw = 65536u / p.rw + 1u;                                   // (tid * magic_rw) >> 16 == tid / rw for tid < 1024 <= 65536 / rw
-    d.log2_tiles = p.act_first;                                        // (Q80 slab launches: the act_first flag)
+    d.log2_tiles = 0;
     const bool sw = d.epi == GEMV_EPI_SWIGLU;
     d.units = d.tpw * d.nchunk * (sw ? 2 : 1);
     // workgroups per segment (a workgroup's rows lie inside one segment; the last one of a segment may be ragged)

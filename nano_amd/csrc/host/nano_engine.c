@@ -69,6 +69,8 @@ typedef struct ModelEntry {
     NanoHipModel *replica[NANO_MAX_REPLICAS]; int n_replica;       /* replica[0] == dev */
     /* the LoRA module attached to the model (load_lora*): later replicas get it too */
     const float *lora_params; size_t lora_floats; uint32_t lora_rank, lora_alpha;
+    const void *lora_owner;                          /* the LoRA object those parameters belong to (free_lora of another module leaves them) */
+    double rep_upload_s, rep_share_s; char rep_how[48];   /* how the last nano_context_replicate moved the weights */
 } ModelEntry;
 static ModelEntry g_reg[MAX_MODELS];
 
@@ -248,7 +250,9 @@ static LoRA *lora_from_buffer(LLM *llm, uint8_t *buffer, int owns) {
         NanoHipModel *d = (me && me->n_replica > 0) ? me->replica[r] : dev;
         if (nano_hip_lora_attach(d, c->lora_rank, c->lora_alpha, (const float *)(buffer + 256), n_floats) != NANO_HIP_OK) die_hip("load_lora");
     }
-    if (me) { me->lora_params = (const float *)(buffer + 256); me->lora_floats = n_floats; me->lora_rank = c->lora_rank; me->lora_alpha = c->lora_alpha; }
+    /* (what later replicas are given: the LAST module loaded, owned by this LoRA object.  load_lora_from_buffer: the caller's buffer must
+     * stay readable until free_lora of this object -- the replicas made in between are attached from it) */
+    if (me) { me->lora_params = (const float *)(buffer + 256); me->lora_floats = n_floats; me->lora_rank = c->lora_rank; me->lora_alpha = c->lora_alpha; me->lora_owner = p; }
     return p;
 }
 LoRA *load_lora_from_buffer(LLM *llm, uint8_t *buffer) { return lora_from_buffer(llm, buffer, 0); }
@@ -267,10 +271,11 @@ LoRA *load_lora(LLM *llm, char *lora_path) {
 void free_lora(LLM *llm, LoRA *lora) {
     if (!lora) return;
     ModelEntry *me = llm ? reg_entry(llm) : NULL;
-    if (me) {
+    if (me && me->lora_owner == lora) {                         /* the module the devices hold (a module loaded later replaced an earlier one there:
+                                                                 * freeing the EARLIER object must not drop the later module's bookkeeping) */
         for (int r = 0; r < me->n_replica; r++) (void)nano_hip_lora_enable(me->replica[r], 0);
         if (me->n_replica == 0 && me->dev) (void)nano_hip_lora_enable(me->dev, 0);
-        me->lora_params = NULL; me->lora_floats = 0;                /* the buffer below may be the module's storage */
+        me->lora_params = NULL; me->lora_floats = 0; me->lora_owner = NULL;   /* the buffer below may be the module's storage */
     }
     free(lora->data);                                        /* the loader's buffer (NULL for _from_buffer) */
     free(lora);
@@ -382,16 +387,37 @@ float *llm_forward(Nano_Context *ctx, uint32_t token, uint32_t pos, uint32_t max
 int nano_context_replicate(Nano_Context *ctx, const int *devices, int n_devices) {
     ModelEntry *me = ctx ? reg_entry(ctx->llm) : NULL;
     if (!me || !devices || n_devices < 0 || me->n_replica + n_devices > NANO_MAX_REPLICAS) return NANO_HIP_EINVAL;
+    if (n_devices == 0) return NANO_HIP_OK;
+    /* ONE upload of the parameter bytes to the context's own device, then device to device (RCCL broadcast over xGMI, or peer copies):
+     * replicate.hip.  Each replica is built from the copy on its own device. */
+    size_t bytes = nano_hip_params_bytes(&me->desc);
+    if (!bytes || bytes > me->params_avail) bytes = me->params_avail;
+    NanoBlobShare *sh = NULL;
+    int rc0 = nano_hip_blob_share(&sh, me->params, bytes, nano_hip_model_device(me->dev), devices, n_devices);
+    if (rc0 != NANO_HIP_OK) return rc0;
+    nano_hip_blob_stats(sh, &me->rep_upload_s, &me->rep_share_s, me->rep_how, sizeof me->rep_how);
     for (int i = 0; i < n_devices; i++) {
         NanoHipModel *r = NULL;
-        int rc = nano_hip_model_create(&r, &me->desc, me->params, me->params_avail, 0, devices[i], me->max_seq_len, me->max_batch);
-        if (rc != NANO_HIP_OK) return rc;
+        int rc = nano_hip_model_create(&r, &me->desc, nano_hip_blob_ptr(sh, i), bytes, 1, devices[i], me->max_seq_len, me->max_batch);
+        if (rc != NANO_HIP_OK) { nano_hip_blob_release(sh); return rc; }
         if (me->lora_params) {                                      /* a module loaded before the replicas were made */
             rc = nano_hip_lora_attach(r, me->lora_rank, me->lora_alpha, me->lora_params, me->lora_floats);
-            if (rc != NANO_HIP_OK) { nano_hip_model_destroy(r); return rc; }
+            if (rc != NANO_HIP_OK) { nano_hip_model_destroy(r); nano_hip_blob_release(sh); return rc; }
         }
         me->replica[me->n_replica++] = r;
     }
+    nano_hip_blob_release(sh);
+    return NANO_HIP_OK;
+}
+
+/* how the last nano_context_replicate moved the weights: seconds of the host upload, seconds of the device-to-device share, and
+ * "rccl broadcast over N device(s)" | "hipMemcpyPeer per device" | "host upload per device" | "single device" */
+int nano_replicate_stats(Nano_Context *ctx, double *upload_s, double *share_s, char *how, size_t cap) {
+    ModelEntry *me = ctx ? reg_entry(ctx->llm) : NULL;
+    if (!me) return NANO_HIP_EINVAL;
+    if (upload_s) *upload_s = me->rep_upload_s;
+    if (share_s) *share_s = me->rep_share_s;
+    if (how && cap) { strncpy(how, me->rep_how, cap - 1); how[cap - 1] = 0; }
     return NANO_HIP_OK;
 }
 

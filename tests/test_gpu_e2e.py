@@ -631,7 +631,8 @@ def test_engine_per_phase_observation(model_dir):
     assert np.array_equal(ids, g["ids"][:len(prompt) + 3])
 
 
-def test_engine_replicas_serve_a_batch_concurrently(model_dir):
+@pytest.mark.parametrize("via,want_how", [("", "single device"), ("rccl", "rccl broadcast over 1 device"), ("peer", "single device"), ("host", "single device")])
+def test_engine_replicas_serve_a_batch_concurrently(model_dir, via, want_how):
     """nano_context_replicate: replicas of the model (here a second one on the same GPU -- a 1-GPU box) share a prompt
     batch, sequence i on replica i mod G, steps begun on all replicas before any is waited for; every sequence's logits
     and arg-max are those of decoding it alone."""
@@ -643,8 +644,23 @@ def test_engine_replicas_serve_a_batch_concurrently(model_dir):
     e = nb.Engine(path, max_seq_len=16, max_batch=3)
     e.L.nano_context_replicate.restype = C.c_int
     e.L.nano_context_replicate.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    e.L.nano_replicate_stats.restype = C.c_int
+    e.L.nano_replicate_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
     devs = (C.c_int * 1)(0)
-    assert e.L.nano_context_replicate(e.ctx, devs, 1) == 0
+    old_via = os.environ.get("NANO_REPLICATE_VIA")
+    if via: os.environ["NANO_REPLICATE_VIA"] = via
+    try:
+        assert e.L.nano_context_replicate(e.ctx, devs, 1) == 0, nb.last_error()
+    finally:
+        if via: os.environ.pop("NANO_REPLICATE_VIA")
+        if old_via is not None: os.environ["NANO_REPLICATE_VIA"] = old_via
+    up, sh, how = C.c_double(-1), C.c_double(-1), C.create_string_buffer(64)
+    assert e.L.nano_replicate_stats(e.ctx, C.byref(up), C.byref(sh), how, 64) == 0
+    # the replica's weights came from ONE host upload + a device-side hand-over (replicate.hip): with the one GPU of this box the
+    # default finds nothing to send ("single device": the replica is built from the root's copy); NANO_REPLICATE_VIA=rccl pushes the
+    # bytes through a 1-rank RCCL communicator (ncclCommInitAll + ncclBroadcast from librccl.so, opened with dlopen)
+    assert how.value.decode().startswith(want_how), how.value
+    assert up.value > 0.0
     got = []
     for pos in range(T):
         lg = np.empty((B, spec.vocab_size), np.float32); am = np.empty(B, np.uint32)

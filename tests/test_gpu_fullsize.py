@@ -182,3 +182,67 @@ def test_fullsize_vs_reference_golden(model_dir, name, quant, gs, tol, tol1):
     assert worst < tol and one < tol1
     if quant == "f32":
         assert np.array_equal(out, ids[n_prompt:])
+
+
+def test_config4_64_prompts_vs_reference_golden(model_dir):
+    """BASELINE.json configs[4] as SURVEY 8d specifies it: Qwen3-4B Q80, 64 prompts of 16 ids (seeds 39 .. 102), 128 decode steps each,
+    decoded as ONE batch of 64 sequences.  The compiled reference ran four of them alone (seeds 39, 40, 70, 102: the first, the
+    second, one from the middle, the last; tests/golden/fullsize64_qwen3-4b_q80.npz, tools/make_golden.py fullsize64):
+      strict mode   those four slots reproduce the reference's logits BIT FOR BIT (CRC-32 over the vocabulary) and its greedy ids at
+                    every one of the 129 steps (positions 15 .. 143), while the other 60 slots decode their own prompts in the same
+                    launches (the reference's matmul_quant order through the batched GEMM kernels, infer/infer.c:654-679, 971-1018);
+      fast path     the same batch, the four slots teacher-forced with the reference's ids: strided logits within 2 x the reference's
+                    own inter-build floor at the kept steps, arg-max agreement over all 129 steps recorded (profiles/r04_parity.txt)."""
+    import os
+    import zlib
+    from conftest import GOLD, file_sha256
+    if os.environ.get("NANO_SKIP_4B") == "1":
+        pytest.skip("NANO_SKIP_4B=1")
+    g = np.load(os.path.join(GOLD, "fullsize64_qwen3-4b_q80.npz"))
+    path, spec = synth_model(model_dir, "qwen3-4b", "q80", 64)
+    assert file_sha256(path) == str(g["model_sha256"]), "the synthetic model writer does not reproduce the golden file"
+    S, n_prompt, stride = int(g["max_seq_len"]), int(g["n_prompt"]), int(g["stride"])
+    seeds = list(range(39, 103))
+    B = len(seeds)
+    gold = {int(s): seeds.index(int(s)) for s in g["seeds"]}
+    prompts = [mf.prompt_ids(s, n_prompt, spec.vocab_size) for s in seeds]
+    for s, slot in gold.items():
+        assert np.array_equal(prompts[slot], g[f"ids_{s}"][:n_prompt])
+    n_decode = S - n_prompt + 1
+    keep = {int(k): j for j, k in enumerate(g["keep"])}
+    floor = FULLSIZE[3][3]                                        # 2 x the inter-build floor of qwen3-4b/q80
+    m = nb.load_model_file(path, max_seq_len=S, max_batch=B)
+
+    def run(strict):
+        m.set_strict(strict)
+        for p in range(n_prompt - 1):
+            m.forward([int(pr[p]) for pr in prompts], [p] * B, want_logits=False)
+        cur = [int(pr[n_prompt - 1]) for pr in prompts]
+        worst, agree = 0.0, 0
+        for i in range(n_decode):
+            pos = n_prompt - 1 + i
+            logits, am = m.forward(cur, [pos] * B, want_argmax=True)
+            nxt = [int(t) for t in am]
+            for s, slot in gold.items():
+                same = int(am[slot]) == int(g[f"argmax_{s}"][i])
+                if strict:
+                    assert zlib.crc32(logits[slot].tobytes()) == int(g[f"crc32_{s}"][i]), f"strict logits of seed {s} differ from the reference at position {pos}"
+                    assert same and int(am[slot]) == int(g[f"ids_{s}"][pos + 1])
+                else:
+                    agree += same
+                    if i in keep:
+                        err = float(np.abs(logits[slot, ::stride].astype(np.float64) - g[f"logits_strided_{s}"][keep[i]]).max())
+                        worst = max(worst, err / float(g[f"max_abs_{s}"][i]))
+                        if float(g[f"top2_gap_{s}"][i]) > 4.0 * err:
+                            assert same, (s, i)
+                    nxt[slot] = int(g[f"ids_{s}"][pos + 1])                 # teacher-forced: the reference's own continuation
+            cur = nxt
+        return worst, agree
+
+    run(True)
+    worst, agree = run(False)
+    m.close()
+    print(f"qwen3-4b/q80, 64 prompts x {n_decode} steps as one batch: strict == reference bit for bit in the 4 reference-run slots at every step "
+          f"(positions {n_prompt - 1}..{S - 1}); fast path: worst max|dlogit|/max|logit| over {len(keep)} kept steps x 4 slots = {worst:.3e}, "
+          f"arg-max agrees on {agree}/{4 * n_decode} steps")
+    assert worst < floor

@@ -24,5 +24,10 @@ g6c)   # routing settled (1 sequence: SLAB with the activation-first barrier; 2.
   NANO_G6_STAGE=0 bench 4b_b8_nostage --model qwen3-4b --batch 8 --steps 32 --warmup 4 --no-kernel-table
   for b in 1 16 64; do bench q06_b${b} --batch $b --steps 64 --warmup 4 --no-kernel-table; NANO_GEMM_G6=0 bench q06_b${b}_old --batch $b --steps 64 --warmup 4 --no-kernel-table; done
   ;;
+full)  # the whole GPU suite + the bench line as the driver runs it
+  timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 | tee $O/pytest_gpu.txt
+  timeout 600 python bench.py --steps 20 --warmup 5 2> $O/bench_driver.err | tee $O/bench_driver.json | cut -c1-600
+  tail -5 $O/bench_driver.err
+  ;;
 *) echo "unknown mode $1";;
 esac
