@@ -120,6 +120,7 @@ struct NanoHipModel {
     uint32_t *pt = nullptr, *kvrow = nullptr;             // device: [maxB][pt_stride] (0xffffffff = no page), [Bs] pool row of the step's position
     uint32_t *h_pt = nullptr;                             // pinned host mirror of pt
     std::vector<uint32_t> free_pages;
+    std::vector<std::vector<uint32_t>> pt_stage;           // staging copies of page-table rows whose upload may still be queued (kv_ensure)
     // strict-parity / per-phase mode (strict.hip): eager, one kernel per reference operator, reference summation order
     bool strict = false;
     float *xn = nullptr, *hb2 = nullptr, *att = nullptr;   // normalised x [Bs][E], W3 output [Bs][H], attention scores [Bs][n_head][S]
@@ -372,9 +373,16 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (m->kv_paged) {
         m->pt_stride = (max_seq_len + 63) / 64;
         m->kv_pages = (uint32_t)B * m->pt_stride;
+        // a layer plane is addressed with 32-bit byte offsets (buffer descriptors): pages x 64 rows x kv_dim x element size < 4 GB.  The
+        // DEFAULT pool (every slot's whole context) is clamped to that with a log line; an explicit NANO_KV_PAGES beyond it is refused.
+        const uint64_t esz_kv = m->kv_half ? 2 : 4, page_b = 64ull * KD * esz_kv, max_pages = (((1ull << 32) - (1u << 20)) / page_b);
+        if (m->kv_pages > max_pages) {
+            fprintf(stderr, "nano_hip: paged KV cache: default pool of %u pages clamped to %llu (a layer plane is limited to 4 GB: 64 rows x %u x %llu B per page); set NANO_KV_PAGES to choose\n",
+                    m->kv_pages, (unsigned long long)max_pages, KD, (unsigned long long)esz_kv);
+            m->kv_pages = (uint32_t)max_pages;
+        }
         if (const char *np = getenv("NANO_KV_PAGES")) { const unsigned long v = strtoul(np, nullptr, 0); if (v >= 1 && v <= (1ul << 24)) m->kv_pages = (uint32_t)v; }
-        // a layer plane is addressed with 32-bit byte offsets (buffer descriptors)
-        if ((uint64_t)m->kv_pages * 64 * KD * 4 >= (1ull << 32) - (1u << 20)) { destroy(m); FAIL(NANO_HIP_EINVAL, "paged KV cache: %u pages x 64 rows x %u floats exceed a 4 GB layer plane", m->kv_pages, KD); }
+        if ((uint64_t)m->kv_pages > max_pages) { destroy(m); FAIL(NANO_HIP_EINVAL, "paged KV cache: %u pages x 64 rows x %u elements of %llu B exceed a 4 GB layer plane (at most %llu pages)", m->kv_pages, KD, (unsigned long long)esz_kv, (unsigned long long)max_pages); }
         kvn = L * (size_t)m->kv_pages * 64 * KD;
     }
     m->trace_cap = max_seq_len * max_batch;
@@ -455,18 +463,45 @@ static int kv_ensure(NanoHipModel *m, const uint32_t *slots, const uint32_t *nee
         FAIL(NANO_HIP_ENOMEM, "paged KV cache: %zu more pages needed, %zu free of %u (nano_hip_kv_release() returns a finished sequence's pages)", missing, m->free_pages.size(), m->kv_pages);
     if (!missing) return 0;
     const size_t esz = m->kv_half ? 2 : 4, page_bytes = (size_t)64 * m->KD * esz, plane_bytes = (size_t)m->kv_pages * page_bytes;
-    for (uint32_t i = 0; i < n; i++) {
-        bool dirty = false;
-        uint32_t *row = m->h_pt + (size_t)slots[i] * m->pt_stride;
-        for (uint32_t blk = 0; blk <= need[i] >> 6 && blk < m->pt_stride; blk++) {
-            if (row[blk] != 0xffffffffu) continue;
-            const uint32_t pg = m->free_pages.back(); m->free_pages.pop_back();
-            HIP_TRY(hipMemset2DAsync(reinterpret_cast<uint8_t *>(m->kcache) + (size_t)pg * page_bytes, plane_bytes, 0, page_bytes, m->d.n_layer, m->st));
-            HIP_TRY(hipMemset2DAsync(reinterpret_cast<uint8_t *>(m->vcache) + (size_t)pg * page_bytes, plane_bytes, 0, page_bytes, m->d.n_layer, m->st));
-            row[blk] = pg * 64u;
-            dirty = true;
-        }
-        if (dirty) HIP_TRY(hipMemcpyAsync(m->pt + (size_t)slots[i] * m->pt_stride, row, (size_t)m->pt_stride * 4, hipMemcpyHostToDevice, m->st));
+    // Take the pages, zero them, send the table rows; COMMIT (host table, free list) only when every call succeeded -- a failing memset or
+    // copy gives the pages back and leaves the host table as it was (round-3 advice: pages leaked / host and device tables diverged).
+    // Each changed row goes to the device from a staging copy of its own: a later kv_ensure may rewrite the pinned mirror before an
+    // earlier queued copy has run.
+    struct Take { uint32_t slot, blk, page; };
+    std::vector<Take> takes;
+    size_t avail = m->free_pages.size();
+    auto has = [&](uint32_t slot, uint32_t blk) { for (const Take &t : takes) if (t.slot == slot && t.blk == blk) return true; return false; };
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t blk = 0; blk <= need[i] >> 6 && blk < m->pt_stride; blk++)
+            if (m->h_pt[(size_t)slots[i] * m->pt_stride + blk] == 0xffffffffu && !has(slots[i], blk)) takes.push_back(Take{slots[i], blk, m->free_pages[--avail]});
+    hipError_t err = hipSuccess;
+    for (const Take &t : takes) {
+        if (err == hipSuccess) err = hipMemset2DAsync(reinterpret_cast<uint8_t *>(m->kcache) + (size_t)t.page * page_bytes, plane_bytes, 0, page_bytes, m->d.n_layer, m->st);
+        if (err == hipSuccess) err = hipMemset2DAsync(reinterpret_cast<uint8_t *>(m->vcache) + (size_t)t.page * page_bytes, plane_bytes, 0, page_bytes, m->d.n_layer, m->st);
+    }
+    std::vector<uint32_t> rows_done;
+    for (size_t k = 0; k < takes.size() && err == hipSuccess; k++) {
+        const uint32_t slot = takes[k].slot;
+        bool seen = false;
+        for (uint32_t r : rows_done) seen = seen || r == slot;
+        if (seen) continue;
+        rows_done.push_back(slot);
+        m->pt_stage.emplace_back(m->h_pt + (size_t)slot * m->pt_stride, m->h_pt + (size_t)(slot + 1) * m->pt_stride);
+        std::vector<uint32_t> &row = m->pt_stage.back();
+        for (const Take &t : takes) if (t.slot == slot) row[t.blk] = t.page * 64u;
+        err = hipMemcpyAsync(m->pt + (size_t)slot * m->pt_stride, row.data(), (size_t)m->pt_stride * 4, hipMemcpyHostToDevice, m->st);
+    }
+    if (err != hipSuccess) {
+        char b[256];
+        snprintf(b, sizeof b, "paged KV cache: preparing %zu page(s) failed: %s (nothing taken)", takes.size(), hipGetErrorString(err));
+        g_err = b;
+        return NANO_HIP_ERUNTIME;
+    }
+    for (const Take &t : takes) m->h_pt[(size_t)t.slot * m->pt_stride + t.blk] = t.page * 64u;
+    m->free_pages.resize(avail);
+    if (m->pt_stage.size() > 256) {                                    // staging rows of copies long done: drop them behind a sync
+        HIP_TRY(hipStreamSynchronize(m->st));
+        m->pt_stage.clear();
     }
     return 0;
 }
@@ -574,7 +609,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     const uint32_t *pt_base = m->kv_paged ? m->pt + (m->pf ? (size_t)m->pf_slot * m->pt_stride : 0) : nullptr;
     const uint32_t pt_bstride = (m->kv_paged && !m->pf) ? m->pt_stride : 0u;
     const size_t plane = (size_t)m->kv_pages * 64 * KD;                      // elements of one layer plane of the pool
-    if (m->kv_paged) { ea.pt_rows = pt_base; ea.kvrow = m->kvrow; ea.pt_bstride = pt_bstride; }
+    if (m->kv_paged) { ea.pt_rows = pt_base; ea.kvrow = m->kvrow; ea.pt_bstride = pt_bstride; ea.pt_entries = m->pt_stride; }
     const uint32_t skip = m->skip_mask;
     if (!(skip & 128) && !(m->skip_embed && mode == MODE_LOOP) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
 

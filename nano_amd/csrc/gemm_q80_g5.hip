@@ -37,6 +37,7 @@ struct G5Dev {
     uint32_t rows[3], out_bstride[3], out_pstride[3];
     uint32_t n, ng, epi, nb, nhc, ntiles, tt, nkw, cpw, teams, nmat;
     uint32_t trw, tc0, tc1;             // rows per tile (even, <= 16: balanced tiles), tiles up to the end of segment 0 / 1
+    uint32_t t_off;                     // canonical fold without the chain: byte offset in LDS of the unit-sum table [team][TT][nhc][256] (0: none -- chained)
     uint32_t canon;                     // 1: the fast path's canonical fold (kernels.h q80_canonical()): the half chunk's 8 products are summed on
                                         // their own (= the unit sum S_u), then added to the running value; 0 (strict mode): group by group
     const int8_t *xf; const float *xsf; const uint32_t *pos;
@@ -55,7 +56,8 @@ constexpr uint32_t G5_MAX_WAVES = 12;
 __device__ __forceinline__ uint32_t lds_load_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store_rel(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <int TT>
+// TAB: the fast path's table fold (t_off != 0) instead of the chain -- a template parameter: the two forms do not share registers
+template <int TT, bool TAB>
 __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const G5Dev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -227,6 +229,25 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                     for (int i = 0; i < 4; i++) if (kq * 4u + i < trw && lrow0 + kq * 4u + i < rows0) oldv[i] = orow[i];
                 }
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                // (round 4) fast path: unit sums to a table, ONE wait per (tile, token tile) instead of a link per half chunk
+                if constexpr (TAB) {
+                    float su[4] = {p[0][0], p[0][1], p[0][2], p[0][3]};
+#pragma unroll
+                    for (uint32_t j = 1; j < 8; j++) if (g0 + j < ng) { su[0] += p[j][0]; su[1] += p[j][1]; su[2] += p[j][2]; su[3] += p[j][3]; }
+                    float *tb = reinterpret_cast<float *>(smem + a.t_off) + ((size_t)(team * TT + t) * nhc) * 256u;
+                    if (h != hlast) {
+                        *reinterpret_cast<float4 *>(tb + (size_t)h * 256u + lane * 4u) = make_float4(su[0], su[1], su[2], su[3]);
+                        if (lane == 0u) __hip_atomic_fetch_add(flag + t, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        continue;                                       // (the W3 team's last owner and every last owner fall through to the fold below)
+                    }
+                    for (uint32_t spin = 0; lds_load_acq(flag + t) != hlast && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
+                    if (hlast == 0u) { acc[0] = su[0]; acc[1] = su[1]; acc[2] = su[2]; acc[3] = su[3]; }
+                    else {
+                        float4 r = *reinterpret_cast<const float4 *>(tb + lane * 4u);
+                        for (uint32_t u = 1; u < hlast; u++) { const float4 q = *reinterpret_cast<const float4 *>(tb + (size_t)u * 256u + lane * 4u); r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+                        acc[0] = r.x + su[0]; acc[1] = r.y + su[1]; acc[2] = r.z + su[2]; acc[3] = r.w + su[3];
+                    }
+                } else {
                 if (h != 0u) {
                     while (lds_load_acq(flag + t) != h) __builtin_amdgcn_s_sleep(1);
                     const float4 in = *reinterpret_cast<const float4 *>(slot + t * 256 + lane * 4u);
@@ -244,6 +265,7 @@ __global__ __launch_bounds__(G5_MAX_WAVES * 64, 3) void gemm_q80_g5_kernel(const
                 } else {
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) { acc[0] += p[j][0]; acc[1] += p[j][1]; acc[2] += p[j][2]; acc[3] += p[j][3]; }
+                }
                 }
                 if (h == kw && t == 0u) NANO_STAMP(a.stamps, 3, acc[0]);       // the first wave's first chain link folded (h = 0: no wait before it)
                 if (!fin) {
@@ -302,9 +324,9 @@ static uint32_t total_rows5(const GemvArgs &a) {
     return rows;
 }
 
-template <int TT>
+template <int TT, bool TAB>
 static void launch_tt(const G5Dev &d, uint32_t nwg, uint32_t waves, size_t lds, hipStream_t st) {
-    auto kern = &gemm_q80_g5_kernel<TT>;
+    auto kern = &gemm_q80_g5_kernel<TT, TAB>;
     static std::atomic<bool> armed[64];                                // once per instantiation and device: a host call per launch costs microseconds
     int dev = 0; (void)hipGetDevice(&dev);                             // (two threads arming the same device twice is harmless)
     if (dev < 0 || dev >= 64 || !armed[dev].load(std::memory_order_acquire)) {
@@ -428,9 +450,25 @@ hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipSt
         d.stage_x = (stage && TTc == 1 && nkw == 1 && waves >= 4 && need <= 160u * 1024u) ? 1u : 0u;
         if (d.stage_x) lds = need;
     }
-    if (TTc == 1) launch_tt<1>(d, nwg, waves, lds, st);
-    else if (TTc == 2) launch_tt<2>(d, nwg, waves, lds, st);
-    else launch_tt<4>(d, nwg, waves, lds, st);
+    // Fast path (canonical fold), round 4: the unit sums of a row tile can go to a TABLE [team][token tile][half chunk][256] whose last
+    // owner adds them in order -- one wait per (tile, token tile) instead of one chain link per half chunk.  MEASURED (one box, Qwen3-4B,
+    // whole steps): 32 sequences 2.921 ms with the table, 2.910 with the chain; 64 sequences 4.260 vs 4.230; Qwen3-0.6B at 64: 1.975 vs
+    // 1.992.  Neutral: at 2..4 token tiles the launch is bound by the serial MFMA -> scale work of a wave walking every token tile and by
+    // the fragment traffic, not by the chain's links.  Off by default (NANO_G5_TABLE=1), kept because it is the same bits.
+    d.t_off = 0;
+    if (d.canon && d.nkw > 1u && getenv("NANO_G5_TABLE") && *getenv("NANO_G5_TABLE") == '1') {
+        const size_t off = (lds + 15u) & ~(size_t)15u, tab = (size_t)d.teams * TTc * d.nhc * 1024u;
+        if (off + tab <= 160u * 1024u) { d.t_off = (uint32_t)off; lds = off + tab; }
+    }
+    if (d.t_off) {
+        if (TTc == 1) launch_tt<1, true>(d, nwg, waves, lds, st);
+        else if (TTc == 2) launch_tt<2, true>(d, nwg, waves, lds, st);
+        else launch_tt<4, true>(d, nwg, waves, lds, st);
+    } else {
+        if (TTc == 1) launch_tt<1, false>(d, nwg, waves, lds, st);
+        else if (TTc == 2) launch_tt<2, false>(d, nwg, waves, lds, st);
+        else launch_tt<4, false>(d, nwg, waves, lds, st);
+    }
     return hipGetLastError();
 }
 

@@ -211,7 +211,7 @@ struct EmbedArgs {
     // the attention kernels need no pos-dependent load: rope_cur[b] = { cos[pos[b]][0..half), sin[pos[b]][0..half) }
     const float *rope_cos; const float *rope_sin; const uint32_t *pos; float *rope_cur; uint32_t half, _pad;
     // paged KV cache: kvrow[b] = pt_rows[b * pt_bstride + pos[b] / 64] + pos[b] % 64 (the pool row the step writes), or nullptr
-    const uint32_t *pt_rows; uint32_t *kvrow; uint32_t pt_bstride, _pad2;
+    const uint32_t *pt_rows; uint32_t *kvrow; uint32_t pt_bstride, pt_entries;   // pt_entries: table entries per slot (a position beyond them stages nothing)
 };
 hipError_t launch_embed(const EmbedArgs &a, uint32_t nb, hipStream_t st);
 

@@ -15,7 +15,10 @@ namespace nano {
 __device__ __forceinline__ void embed_row(const EmbedArgs &a, uint32_t b, uint32_t tok, uint32_t p, bool stage_pos) {
     float *x = a.x + (size_t)b * a.x_bstride;
     const uint32_t E = a.E;
-    if (stage_pos && a.kvrow && threadIdx.x == 0)            // paged KV cache: the pool row of this step's position
+    // paged KV cache: the pool row of this step's position.  (p >> 6) < pt_entries: the greedy loop's arg-max kernel embeds the token of
+    // the position AFTER the last step too -- with max_seq_len a multiple of 64 that position's block lies one entry past the slot's row
+    // of the table (round-3 advice: a device read out of bounds; the value was never used)
+    if (stage_pos && a.kvrow && threadIdx.x == 0 && (p >> 6) < a.pt_entries)
         a.kvrow[b] = a.pt_rows[(size_t)b * a.pt_bstride + (p >> 6)] + (p & 63u);
     if (stage_pos && a.rope_cur) {
         for (uint32_t i = threadIdx.x; i < a.half; i += blockDim.x) {

@@ -29,5 +29,13 @@ full)  # the whole GPU suite + the bench line as the driver runs it
   timeout 600 python bench.py --steps 20 --warmup 5 2> $O/bench_driver.err | tee $O/bench_driver.json | cut -c1-600
   tail -5 $O/bench_driver.err
   ;;
+g5t)   # G5's table fold (fast path, 17..64 tokens): parity subset, A/B against the chain
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py tests/test_gpu_e2e.py -m gpu -x -q -k "gemm or chained or large_batch or prefill" 2>&1 | tail -4
+  for b in 32 64; do
+    bench 4b_b${b}_table --model qwen3-4b --batch $b --steps 32 --warmup 4
+    NANO_G5_TABLE=0 bench 4b_b${b}_chain --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-kernel-table
+  done
+  for b in 64; do bench q06_b${b}_table --batch $b --steps 64 --warmup 4; NANO_G5_TABLE=0 bench q06_b${b}_chain --batch $b --steps 64 --warmup 4 --no-kernel-table; done
+  ;;
 *) echo "unknown mode $1";;
 esac
