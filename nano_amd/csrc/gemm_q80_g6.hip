@@ -47,7 +47,7 @@ static uint32_t g6_rows(const GemvArgs &a) {
 struct G6Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nw, nu, rounds; bool ms; size_t lds_common; };
 
 // tile height fitted to the chip: minimise the rows the busiest workgroup streams (+ a per-tile overhead worth ~2 rows)
-static bool g6_plan(const GemvArgs &a, G6Plan &p) {
+static bool g6_plan(const GemvArgs &a, G6Plan &p, uint32_t tt = 1) {
     const bool sw = a.epi == GEMV_EPI_SWIGLU;
     const uint32_t cus = a.cus ? a.cus : 256u, nseg = sw ? 1u : a.nseg, ng = a.n / 64u;
     p.nu = (ng + 7u) / 8u;
@@ -72,7 +72,7 @@ static bool g6_plan(const GemvArgs &a, G6Plan &p) {
     while (p.nw > items) p.nw >>= 1;                                   // a power of two (the kernel finds a tile's finisher with a mask)
     p.rounds = (items + p.nw - 1u) / p.nw;                             // the most items a wave owns
     p.ms = !sw && a.nseg > 1;
-    p.lds_common = (size_t)p.nw * G6_LDS_WAVE + (size_t)p.tpw * p.nu * 1024u + (size_t)((p.tpw + 3u) & ~3u) * 4u;
+    p.lds_common = (size_t)p.nw * G6_LDS_WAVE + (size_t)p.tpw * p.nu * tt * 1024u + (size_t)((p.tpw + 3u) & ~3u) * 4u;
     const uint32_t magic = (65536u + p.nu - 1u) / p.nu;
     for (uint32_t it = 0; it < items + 8u * G6_NW; it++) if (((it * magic) >> 16) != it / p.nu) return false;
     return true;
@@ -99,11 +99,17 @@ static G6Dev g6_dev(const GemvArgs &a, const G6Plan &p) {
 
 }  // namespace
 
-// MODE F: activations already quantized, MFMA B-fragment order (a.xq_in / a.xs_in), up to 16 tokens; up to 4 items per wave
+// MODE F: activations already quantized, MFMA B-fragment order (a.xq_in / a.xs_in), up to 64 tokens (1 | 2 | 4 token tiles: the unit-sum
+// table of all of a workgroup's tiles must fit LDS next to the waves' buffers); up to 4 items per wave
+static uint32_t g6_tt(const GemvArgs &a) { const uint32_t t = (a.nb + 15u) / 16u; return t <= 1u ? 1u : t == 2u ? 2u : 4u; }
 bool gemm_q80_g6_supports(const GemvArgs &a) {
-    if (!g6_common_ok(a) || a.nb > 16 || a.attn_part) return false;
+    static const uint32_t max_nb = [] { const char *e = getenv("NANO_G6_MAX_NB"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v ? v : 64u; }();   // A/B knob
+    if (!g6_common_ok(a) || a.nb > 64 || a.nb > max_nb || a.attn_part) return false;
     G6Plan p;
-    return g6_plan(a, p) && p.rounds <= 4u && p.lds_common + 64 <= 160u * 1024u;
+    const uint32_t tt = g6_tt(a);
+    // (4 token tiles x 4 rounds is not instantiated: its registers spill; the launches that would need it -- Qwen3-4B's W1|W3 beyond 32
+    //  tokens -- do not fit LDS either and stay with G5)
+    return g6_plan(a, p, tt) && p.rounds <= (tt == 4u ? 3u : 4u) && p.lds_common + 64 <= 160u * 1024u;
 }
 // MODE S where the activation fits LDS next to everything else (one 1 KB block per group + scales), else MODE F
 static size_t g6s_lds(const G6Plan &p) { const size_t ngp = (size_t)p.nu * 8u; return p.lds_common + ngp * 1024u + 64u + ngp * 64u + 64u; }
@@ -114,10 +120,11 @@ static bool g6s_ok(const GemvArgs &a, const G6Plan &p) {
 hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
     if (!a.xq_in || !a.xs_in || !gemm_q80_g6_supports(a)) return hipErrorInvalidValue;
     G6Plan p;
-    if (!g6_plan(a, p)) return hipErrorInvalidValue;
+    const uint32_t tt = g6_tt(a);
+    if (!g6_plan(a, p, tt)) return hipErrorInvalidValue;
     G6Dev d = g6_dev(a, p);
     d.xf = a.xq_in; d.xsf = a.xs_in;
-    if (g6s_ok(a, p)) {             // NV = 16-byte units per thread: 5 (rows up to 2560 values) or 8 (up to 4096)
+    if (tt == 1u && g6s_ok(a, p)) {         // NV = 16-byte units per thread: 5 (rows up to 2560 values) or 8 (up to 4096)
         const size_t lds = g6s_lds(p);
 #define G6S_GO(NV_, R_) do { return p.ms ? g6_launch_t<G6_S, false, 1, NV_, R_, true>(d, lds, st) : g6_launch_t<G6_S, false, 1, NV_, R_, false>(d, lds, st); } while (0)
 #define G6S_R(NV_) do { if (p.rounds <= 1) G6S_GO(NV_, 1); if (p.rounds == 2) G6S_GO(NV_, 2); G6S_GO(NV_, 4); } while (0)
@@ -127,11 +134,14 @@ hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
 #undef G6S_GO
     }
     const size_t lds = p.lds_common + 64;
-#define G6F_GO(R_) do { return p.ms ? g6_launch_t<G6_F, false, 1, 1, R_, true>(d, lds, st) : g6_launch_t<G6_F, false, 1, 1, R_, false>(d, lds, st); } while (0)
-    if (p.rounds <= 1) G6F_GO(1);
-    if (p.rounds == 2) G6F_GO(2);
-    if (p.rounds == 3) G6F_GO(3);
-    G6F_GO(4);
+#define G6F_GO(R_, T_) do { return p.ms ? g6_launch_t<G6_F, false, 1, 1, R_, true, T_>(d, lds, st) : g6_launch_t<G6_F, false, 1, 1, R_, false, T_>(d, lds, st); } while (0)
+#define G6F_R(T_) do { if (p.rounds <= 1) G6F_GO(1, T_); if (p.rounds == 2) G6F_GO(2, T_); if (p.rounds == 3) G6F_GO(3, T_); G6F_GO(4, T_); } while (0)
+    if (tt == 1u) G6F_R(1);
+    if (tt == 2u) G6F_R(2);
+    if (p.rounds <= 1) G6F_GO(1, 4);
+    if (p.rounds == 2) G6F_GO(2, 4);
+    G6F_GO(3, 4);
+#undef G6F_R
 #undef G6F_GO
 }
 

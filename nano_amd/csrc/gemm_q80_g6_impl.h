@@ -43,8 +43,11 @@ template <int R0, int R1, class F> __device__ __forceinline__ void g6_static_for
 
 // R  = rounds: the most items a wave of the launch owns (compile time: R issues and R consumes in straight-line code, nothing dead)
 // MS = several weight segments share the launch (q | k | v): a tile looks its segment up; single-segment launches skip that
-template <int MODE, bool COMB, int NBC, int NV, int R, bool MS>
+// TT = token tiles of 16 (MODE F: 1 | 2 | 4 -- up to 64 tokens; an item's weights are transposed once and multiplied with every token
+//      tile's fragments, tile t + 1's being fetched from L2 while tile t is multiplied; the other modes: 1)
+template <int MODE, bool COMB, int NBC, int NV, int R, bool MS, int TT = 1>
 __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
+    static_assert(TT == 1 || MODE == G6_F, "token tiles beyond the first come from L2 (MODE F)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int D = MODE == G6_F ? 2 : 4;                             // items in flight per wave (F: a slot also holds the item's 8 KB of B fragments)
     const GemvDev &a = d.g;
@@ -64,8 +67,8 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     int8_t *wbuf = reinterpret_cast<int8_t *>(smem) + (size_t)wid * G6_LDS_WAVE;
     float *wsl = reinterpret_cast<float *>(wbuf + G6_WBUF);            // [8 groups][16 rows]
     float *xslw = wsl + 128;                                           // MODE F: [8 groups][16 tokens]
-    float *T = reinterpret_cast<float *>(smem + (size_t)NW * G6_LDS_WAVE);          // [tpw][nu][256] unit sums
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(T + (size_t)d.tpw * nu * 256u);   // [tpw] units arrived
+    float *T = reinterpret_cast<float *>(smem + (size_t)NW * G6_LDS_WAVE);          // [tpw][nu][TT][256] unit sums
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(T + (size_t)d.tpw * nu * TT * 256u);   // [tpw] units arrived
     unsigned char *pbase = reinterpret_cast<unsigned char *>(cnt + ((d.tpw + 3u) & ~3u));
     // MODE P: the quantized activation [ngp][4 k-quarters][NBC][16 B] (groups >= ng zero), a 64-byte zero block (what the lanes of
     // token slots >= NBC read), the activation scales [ngp][16] (slots >= NBC unused, groups >= ng zero)
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
         if constexpr (MODE == G6_F) {               // the item's activation fragments FIRST (loads return in issue order)
             const uint32_t g0 = u * 8u;
             const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf + (size_t)g0 * 1024u, live ? (ng - g0) * 1024u : 0u);     // groups >= ng: out of range -> 0
-            const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf + (size_t)g0 * 16u, live ? (ng - g0) * 64u : 0u);
+            const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf + (size_t)g0 * 16u, live ? (ng - g0) * 64u : 0u);        // (token tile 0; the others: consume)
 #pragma unroll
             for (uint32_t j = 0; j < 8; j++) ring[sl].b[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)(lane * 16u + j * 1024u), 0, 0);
             ring[sl].xs = bload_f4(rxs, lane < 32u ? lane * 16u : OOB);             // lanes 0..31: group g0 + l/4, tokens 4 (l%4) .. +3
@@ -319,28 +322,64 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
         }
         if constexpr (MODE == G6_F) { if (lane < 32u) *reinterpret_cast<float4 *>(xslw + lane * 4u) = ring[sl].xs; }
         if constexpr (first) NANO_STAMP(a.stamps, 3, (float)ring[sl].w[7].x + ring[sl].s1.x);     // this wave's first weights (and scales) arrived
-        // 2. eight groups: A fragment from LDS, one MFMA, products, the unit sum in ascending group order (groups >= ng of a row's last
-        //    unit: zero activation bytes and scales -> products +0.0f)
-        float S[4] = {0.f, 0.f, 0.f, 0.f};
+        // 2. per token tile: eight groups -- A fragment from LDS, one MFMA, products, the unit sum in ascending group order (groups >= ng
+        //    of a row's last unit: zero activation bytes and scales -> products +0.0f); the sum goes to the tile's table
+        i32x4 nb_[MODE == G6_F && TT > 1 ? 8 : 1]; float4 nxs = make_float4(0.f, 0.f, 0.f, 0.f);       // the NEXT token tile's fragments and scales
+        const uint32_t ntt = (nb + 15u) >> 4;
 #pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const i32x4 fa = *reinterpret_cast<const i32x4 *>(wb_r + j * 64u);
-            i32x4 fb; float xsc;
-            if constexpr (MODE == G6_F) { fb = ring[sl].b[j]; xsc = xslw[j * 16u + m]; }
-            else {
-                fb = *reinterpret_cast<const i32x4 *>(xqc + pb_off + (g0 + j) * pb_str);
-                xsc = xs_l[px_off + (g0 + j) * px_str];
+        for (uint32_t t = 0; t < (uint32_t)TT; t++) {
+            if constexpr (MODE == G6_F && TT > 1) {
+                if (t > 0u) { if (lane < 32u) *reinterpret_cast<float4 *>(xslw + lane * 4u) = nxs; }
+                if (t + 1u < (uint32_t)TT) {        // token tile t + 1 of this unit: asked for now (unconditional loads; a tile beyond the batch reads through a zero-sized descriptor)
+                    const bool lv = t + 1u < ntt;
+                    const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf + ((size_t)(t + 1u) * ng + g0) * 1024u, lv ? (ng - g0) * 1024u : 0u);
+                    const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf + ((size_t)(t + 1u) * ng + g0) * 16u, lv ? (ng - g0) * 64u : 0u);
+                    i32x4 tmp[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) tmp[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)(lane * 16u + j * 1024u), 0, 0);
+                    const float4 txs = bload_f4(rxs, lane < 32u ? lane * 16u : OOB);
+                    // (the loads above are in flight while the MFMAs below read the CURRENT tile's registers)
+                    float S[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) {
+                        const i32x4 fa = *reinterpret_cast<const i32x4 *>(wb_r + j * 64u);
+                        const i32x4 fb = t == 0u ? ring[sl].b[j] : nb_[j];
+                        const float xsc = xslw[j * 16u + m];
+                        const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
+                        const float4 wv = *reinterpret_cast<const float4 *>(wsl_r + j * 16u);
+                        const float p0 = ((float)cv[0] * wv.x) * xsc, p1 = ((float)cv[1] * wv.y) * xsc;      // infer.c:672
+                        const float p2 = ((float)cv[2] * wv.z) * xsc, p3 = ((float)cv[3] * wv.w) * xsc;
+                        if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
+                        else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
+                    }
+                    *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * TT + t) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) nb_[j] = tmp[j];
+                    nxs = txs;
+                    continue;
+                }
             }
-            const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
-            const float4 wv = *reinterpret_cast<const float4 *>(wsl_r + j * 16u);
-            const float p0 = ((float)cv[0] * wv.x) * xsc, p1 = ((float)cv[1] * wv.y) * xsc;      // infer.c:672
-            const float p2 = ((float)cv[2] * wv.z) * xsc, p3 = ((float)cv[3] * wv.w) * xsc;
-            if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
-            else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
+            float S[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const i32x4 fa = *reinterpret_cast<const i32x4 *>(wb_r + j * 64u);
+                i32x4 fb; float xsc;
+                if constexpr (MODE == G6_F) { fb = (TT == 1 || t == 0u) ? ring[sl].b[j] : nb_[j]; xsc = xslw[j * 16u + m]; }
+                else {
+                    fb = *reinterpret_cast<const i32x4 *>(xqc + pb_off + (g0 + j) * pb_str);
+                    xsc = xs_l[px_off + (g0 + j) * px_str];
+                }
+                const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
+                const float4 wv = *reinterpret_cast<const float4 *>(wsl_r + j * 16u);
+                const float p0 = ((float)cv[0] * wv.x) * xsc, p1 = ((float)cv[1] * wv.y) * xsc;      // infer.c:672
+                const float p2 = ((float)cv[2] * wv.z) * xsc, p3 = ((float)cv[3] * wv.w) * xsc;
+                if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
+                else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
+            }
+            if constexpr (first) { if (t == 0u) NANO_STAMP(a.stamps, 4, S[3]); }             // ... multiplied
+            *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * TT + t) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
         }
-        if constexpr (first) NANO_STAMP(a.stamps, 4, S[3]);             // ... multiplied
         // 3. arrive
-        *reinterpret_cast<float4 *>(T + ((size_t)tl * nu + u) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
         if (lane == 0u) __hip_atomic_fetch_add(cnt + tl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // R rounds in straight-line code; the item of round r + D is requested as soon as round r's slot is free
@@ -356,38 +395,43 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
         if (((tl * nu + nu - 1u) & (NW - 1u)) != wid) continue;
         const TI t = decode(tl);
         const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;        // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
-        float oldv[4] = {oldv0[0], oldv0[1], oldv0[2], oldv0[3]};
-        uint32_t opos = opos0;
-        if (tl != ftl && m < nb) {                                     // (a wave that finishes several tiles: only the first one's were fetched up front)
-            if (t.ops) opos = a.pos[m];
-            if (epi == GEMV_EPI_RESID) {
-                const float *o = t.out + (size_t)m * t.obs + orow0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) oldv[i] = o[i];
-            }
-        }
         // (bounded: a miscounted tile must not hang the device -- 2^24 naps are ~0.5 s, the results are then wrong and the tests say so)
         for (uint32_t spin = 0; g6_lds_load_acq(cnt + tl) != nu && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
-        const float *tp = T + (size_t)tl * nu * 256u + lane * 4u;
-        float4 acc = *reinterpret_cast<const float4 *>(tp);
-        for (uint32_t u0 = 1; u0 < nu; u0 += 4) {                      // units ascending; the reads of four units go out together
-            float4 q[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) q[k] = (u0 + k < nu) ? *reinterpret_cast<const float4 *>(tp + (size_t)(u0 + k) * 256u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t tt = 0; tt < (uint32_t)TT; tt++) {
+            const uint32_t tok = tt * 16u + m;
+            if (tt * 16u >= nb) break;                                 // (wave-uniform)
+            float oldv[4] = {oldv0[0], oldv0[1], oldv0[2], oldv0[3]};
+            uint32_t opos = opos0;
+            if ((tl != ftl || tt != 0u) && tok < nb) {                 // (only the first finished tile's first token tile was fetched up front)
+                if (t.ops) opos = a.pos[tok];
+                if (epi == GEMV_EPI_RESID) {
+                    const float *o = t.out + (size_t)tok * t.obs + orow0;
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) if (u0 + k < nu) { acc.x += q[k].x; acc.y += q[k].y; acc.z += q[k].z; acc.w += q[k].w; }
-        }
-        const float tot[4] = {acc.x, acc.y, acc.z, acc.w};
-        float v3[4] = {0.f, 0.f, 0.f, 0.f};
-        if (sw) {                                                      // W3's values live 32 lanes up (rows 8..15 of the tile)
+                    for (int i = 0; i < 4; i++) if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) oldv[i] = o[i];
+                }
+            }
+            const float *tp = T + ((size_t)tl * nu * TT + tt) * 256u + lane * 4u;
+            float4 acc = *reinterpret_cast<const float4 *>(tp);
+            for (uint32_t u0 = 1; u0 < nu; u0 += 4) {                  // units ascending; the reads of four units go out together
+                float4 q[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) v3[i] = __shfl_xor(tot[i], 32, 64);
-        }
-        if (m < nb && (!sw || kq < 2u)) {
-            float *o = t.out + (size_t)m * t.obs + (size_t)opos * t.ops + orow0;
+                for (uint32_t k = 0; k < 4; k++) q[k] = (u0 + k < nu) ? *reinterpret_cast<const float4 *>(tp + (size_t)(u0 + k) * TT * 256u) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) o[i] = finish_epi(epi, tot[i], v3[i], oldv[i]);
+                for (uint32_t k = 0; k < 4; k++) if (u0 + k < nu) { acc.x += q[k].x; acc.y += q[k].y; acc.z += q[k].z; acc.w += q[k].w; }
+            }
+            const float tot[4] = {acc.x, acc.y, acc.z, acc.w};
+            float v3[4] = {0.f, 0.f, 0.f, 0.f};
+            if (sw) {                                                  // W3's values live 32 lanes up (rows 8..15 of the tile)
+#pragma unroll
+                for (int i = 0; i < 4; i++) v3[i] = __shfl_xor(tot[i], 32, 64);
+            }
+            if (tok < nb && (!sw || kq < 2u)) {
+                float *o = t.out + (size_t)tok * t.obs + (size_t)opos * t.ops + orow0;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) o[i] = finish_epi(epi, tot[i], v3[i], oldv[i]);
+            }
         }
     }
     NANO_STAMP_END(a.stamps, 6);                                    // the workgroup's last wave ends
@@ -395,9 +439,9 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
 
 
 // ---- launch plumbing shared by the translation units ---------------------------------------------------------------------------------
-template <int MODE, bool COMB, int NBC, int NV, int R, bool MS>
+template <int MODE, bool COMB, int NBC, int NV, int R, bool MS, int TT = 1>
 static hipError_t g6_launch_t(const G6Dev &d, size_t lds, hipStream_t st) {
-    auto kern = &gemm_q80_g6_kernel<MODE, COMB, NBC, NV, R, MS>;
+    auto kern = &gemm_q80_g6_kernel<MODE, COMB, NBC, NV, R, MS, TT>;
     static std::atomic<bool> armed[64];
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !armed[dev].load(std::memory_order_acquire)) {

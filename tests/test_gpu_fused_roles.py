@@ -190,7 +190,8 @@ def test_batched_g6_prologue_roles_q80(oracle, nb_, kind):
     check_q80(oracle, kind, n, segs, x, nw, old, nb_, routes=("g6p",) if nb_ <= 2 else ("frag_g6",))
 
 
-GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (9, 1, 3072, (1024,)), (40, 1, 2048, (1024,)), (64, 0, 1024, (2048, 1024, 1024)),
+GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (17, 0, 2560, (4096, 1024, 1024)), (32, 1, 9728, (2560,)), (64, 1, 9728, (2560,)), (48, 0, 2560, (4096, 1024, 1024)),
+              (30, 0, 2560, (9728, 9728)), (9, 1, 3072, (1024,)), (40, 1, 2048, (1024,)), (64, 0, 1024, (2048, 1024, 1024)),
               (8, 1, 9728, (2560,)), (16, 0, 2560, (4096, 1024, 1024)), (33, 1, 4096, (2560,)),
               (3, 1, 9728, (2560,)), (1, 0, 2560, (4096, 1024, 1024)),
               # tall matrices (>= 16384 rows): the classifier's kernel GC (gemm_q80_cls.hip) -- every token tile staged in LDS /
@@ -211,8 +212,7 @@ def gemm_route_case(oracle, nb_, kind, n, rows):
             ref = ref_q80(oracle, oracle.rmsnorm(x[b], nw), segs, n, 64)
             assert np.array_equal(bits(out[b]), bits(ref)), (b, float(np.abs(out[b] - ref).max()))
         return "frag_old"
-    return check_q80(oracle, kind, n, segs, x, nw, old, nb_, use_gemm=True,
-                     routes=("frag_g6",) if (nb_ <= 16 and n % 256 == 0) else ("frag_old",))
+    return check_q80(oracle, kind, n, segs, x, nw, old, nb_, use_gemm=True, routes=("frag_g6",) if n % 256 == 0 else ("frag_old",))
 
 
 def test_g6_ragged_segments(oracle):

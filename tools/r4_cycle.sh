@@ -37,5 +37,13 @@ g5t)   # G5's table fold (fast path, 17..64 tokens): parity subset, A/B against 
   done
   for b in 64; do bench q06_b${b}_table --batch $b --steps 64 --warmup 4; NANO_G5_TABLE=0 bench q06_b${b}_chain --batch $b --steps 64 --warmup 4 --no-kernel-table; done
   ;;
+g6t)   # G6 MODE F with 2 / 4 token tiles (17..64 tokens): parity subset, A/B against G5 (NANO_G6_MAX_NB=16)
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py tests/test_gpu_e2e.py -m gpu -x -q -k "gemm or chained or large_batch or prefill" 2>&1 | tail -4
+  for b in 32 64; do
+    bench 4b_b${b}_g6tt --model qwen3-4b --batch $b --steps 32 --warmup 4
+    NANO_G6_MAX_NB=16 bench 4b_b${b}_g5 --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-kernel-table
+  done
+  for b in 32 64; do bench q06_b${b}_g6tt --batch $b --steps 64 --warmup 4; NANO_G6_MAX_NB=16 bench q06_b${b}_g5 --batch $b --steps 64 --warmup 4 --no-kernel-table; done
+  ;;
 *) echo "unknown mode $1";;
 esac

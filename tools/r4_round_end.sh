@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 evidence on the GPU box: tests, smoke, bench lines, rocprofv3 summaries, phase stamps.  usage: r3_round_end.sh a|b|c|d
+# Round-4 evidence on the GPU box: tests, smoke, bench lines, rocprofv3 summaries, phase stamps.  usage: r4_round_end.sh a|b|c|d
 exec < /dev/null
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r3end
-T=r03
+O=$R/gpurun_out/r4end
+T=r04
 mkdir -p $O
 cd $R
 summ() {   # kernel_stats.csv -> short text
@@ -29,7 +29,7 @@ PY
 }
 prof() {   # prof TAG bench-args... : eager kernel-trace stats of a short bench run
   tag=$1; shift
-  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$tag && NANO_HIP_NO_GRAPH=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o k -- python $R/bench.py "$@" --no-cpu-baseline --no-kernel-table > /tmp/prof_$tag.log 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp NANO_BENCH_NO_TRAFFIC=1 && rm -rf /tmp/prof_$tag && NANO_HIP_NO_GRAPH=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o k -- python $R/bench.py "$@" --no-cpu-baseline --no-kernel-table > /tmp/prof_$tag.log 2>&1 )
   f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && summ $f > $O/${T}_${tag}_kernel_stats.txt && head -8 $O/${T}_${tag}_kernel_stats.txt
   f=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1)
@@ -64,17 +64,18 @@ PY
 one() { python3 -c "import json;d=json.loads(open('$1').read().strip().splitlines()[-1]);print('$2', d['value'], 'tok/s', d['ms_per_step'], 'ms', d['roofline']['frac'])" 2>/dev/null || echo "$2 FAILED"; }
 if [ "$1" = "a" ]; then
   timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee $O/${T}_pytest_gpu.txt
-  ( timeout 900 python -m pytest tests -m gpu -q -s -k "fullsize or strict or sampler_ids" 2>&1 | grep -E "strict|fast path|passed|failed" ) > $O/${T}_parity.txt; tail -3 $O/${T}_parity.txt
+  ( timeout 1500 python -m pytest tests -m gpu -q -s -k "fullsize or strict or sampler_ids or config4" 2>&1 | grep -E "strict|fast path|passed|failed" ) > $O/${T}_parity.txt; tail -3 $O/${T}_parity.txt
   timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/${T}_smoke.txt
   timeout 400 python bench.py 2> $O/${T}_bench_stderr.txt | tee $O/${T}_bench_line.json | cut -c1-300
   timeout 400 python bench.py --steps 20 --warmup 5 2>/dev/null > $O/${T}_bench_driver_flags.json; one $O/${T}_bench_driver_flags.json "driver flags"
 elif [ "$1" = "b" ]; then
   prof q06_q80_b1 --steps 100 --warmup 4
-  pmc q06_q80_b1 FETCH_SIZE python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-table
+  pmc q06_q80_b1 FETCH_SIZE python $R/bench.py --pmc-child --steps 24
   prof q06_q4k_b1 --quant q4k --steps 60 --warmup 4
   S=$R/nano_amd/lib/libnano_mi355x_stamps.so; S2=$R/nano_amd/lib/libnano_mi355x_stamps2.so
-  { for a in "qwen3-0.6b q80 1 30" "qwen3-0.6b q80 1 300" "qwen3-0.6b q4k 1 30" "wide-qwen3 q80 1 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done; } > $O/${T}_phase_stamps.txt; head -12 $O/${T}_phase_stamps.txt
-  { for a in "qwen3-0.6b q80 1 30" "qwen3-0.6b q80 1 300" "qwen3-0.6b q4k 1 30"; do NANO_STAMPS_LIGHT=1 NANO_STAMPS_GRAPH=1 NANO_LIB=$S2 timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -11; done; } > $O/${T}_timeline_light_stamps.txt
+  { for a in "qwen3-0.6b q80 1 30" "wide-qwen3 q80 1 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done; } > $O/${T}_phase_stamps.txt; head -12 $O/${T}_phase_stamps.txt
+  { for b in 2 8 16; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py wide-qwen3 q80 $b 30 2>&1 | tail -14; done
+    NANO_G6P_B1=1 NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py wide-qwen3 q80 1 30 2>&1 | tail -14; } > $O/${T}_g6_stamps.txt; head -8 $O/${T}_g6_stamps.txt
   timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -6 | tee $O/${T}_prefill_probe.txt
   timeout 300 python tools/long_ctx_probe.py 2>&1 | tail -10 > $O/${T}_long_ctx_probe.txt; head -5 $O/${T}_long_ctx_probe.txt
   pmc long_ctx_4095_fetch FETCH_SIZE python $R/tools/long_ctx_one.py 4095
@@ -86,13 +87,16 @@ elif [ "$1" = "c" ]; then
 import json
 for ln in open('$O/${T}_bench_all_configs.jsonl'):
     d=json.loads(ln); print(d.get('baseline_config'), d.get('value'), d.get('ms_per_step'))"
-  for b in 16 64; do timeout 300 python bench.py --batch $b --steps 64 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_q06_b$b.json; one $O/${T}_bench_q06_b$b.json "0.6B B=$b"; done
+  for b in 16 64; do NANO_BENCH_NO_TRAFFIC=1 timeout 300 python bench.py --batch $b --steps 64 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_q06_b$b.json; one $O/${T}_bench_q06_b$b.json "0.6B B=$b"; done
   timeout 300 python bench.py --replicas 2 --total-seqs 8 --steps 64 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_replicas2.json; cut -c1-160 $O/${T}_bench_replicas2.json; echo
 else
-  for b in 1 2 4 8 16 32 64; do timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_b$b.json; one $O/${T}_bench_4b_b$b.json "4B B=$b"; done
+  for b in 1 2 4 8 16 32 64; do NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_b$b.json; one $O/${T}_bench_4b_b$b.json "4B B=$b"; done
+  for b in 2 8 16; do NANO_GEMM_G6=0 NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_b${b}_round3_routes.json; one $O/${T}_bench_4b_b${b}_round3_routes.json "4B B=$b round-3 routes (NANO_GEMM_G6=0)"; done
+  NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --total-seqs 64 --steps 64 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_total64.json; one $O/${T}_bench_4b_total64.json "4B total-seqs 64"
   timeout 900 python bench.py --model qwen3-4b --quant q4k --steps 64 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_q4k_b1.json; one $O/${T}_bench_4b_q4k_b1.json "4B q4k"
+  export NANO_BENCH_NO_TRAFFIC=1
   prof 4b_b8 --model qwen3-4b --batch 8 --steps 8 --warmup 2
-  prof 4b_b64 --model qwen3-4b --batch 64 --steps 8 --warmup 2
-  pmc 4b_b16_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8" python $R/bench.py --model qwen3-4b --batch 16 --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-table
-  pmc 4b_b8_fetch FETCH_SIZE python $R/bench.py --model qwen3-4b --batch 8 --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-table
+  prof 4b_b1 --model qwen3-4b --batch 1 --steps 8 --warmup 2
+  pmc 4b_b16_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8" python $R/bench.py --pmc-child --model qwen3-4b --batch 16 --steps 6
+  pmc 4b_b8_fetch FETCH_SIZE python $R/bench.py --pmc-child --model qwen3-4b --batch 8 --steps 6
 fi
