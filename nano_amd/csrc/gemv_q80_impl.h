@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void gemv_q80_stream_kernel(const GemvDev a) {
         if (++cchunk == nchunk) { cchunk = 0; ctile++; }
     };
     // single register buffer: four waves per SIMD (128 VGPRs) keep the other tiles' loads in flight while one wave
-    // consumes -- measured 4-5 % faster than a two-buffer software pipeline at two waves per SIMD (tools/kbench)
+    // consumes -- measured 4-5 % faster than a two-buffer software pipeline at two waves per SIMD (round-1 kernel laboratory)
     for (uint32_t u = 0; u < nunits; u++) {
         if (u) issue(wA, sA);
         consume(wA, sA);
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void gemv_q80_stream_kernel(const GemvDev a) {
 // host side
 // ------------------------------------------------------------------------------------------------------------
 
-// rows per workgroup / waves per workgroup of a slab launch (tuned on Qwen3-0.6B with tools/kbench: the chain
+// rows per workgroup / waves per workgroup of a slab launch (tuned on Qwen3-0.6B with the round-1 kernel laboratory: the chain
 // time is flat within 3 % around these choices -- the kernels are latency bound)
 struct SlabPlan { uint32_t rw, nw, upw, nv; };
 static SlabPlan plan_slab(const GemvArgs &a, int B) {
