@@ -44,7 +44,7 @@ static uint32_t g6_rows(const GemvArgs &a) {
     return r;
 }
 
-struct G6Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nw, nu, rounds; bool ms; size_t lds_common; };
+struct G6Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nw, nu, rounds, tts; bool ms; size_t lds_common; };
 
 // tile height fitted to the chip: minimise the rows the busiest workgroup streams (+ a per-tile overhead worth ~2 rows)
 static bool g6_plan(const GemvArgs &a, G6Plan &p, uint32_t tt = 1) {
@@ -67,14 +67,22 @@ static bool g6_plan(const GemvArgs &a, G6Plan &p, uint32_t tt = 1) {
     for (uint32_t s = 0; s < nseg; s++) { tiles += (a.seg[s].rows + trw - 1) / trw; if (s < 2) tc[s] = tiles; }
     p.ntiles = tiles; p.tc0 = nseg > 1 ? tc[0] : 0xffffffffu; p.tc1 = nseg > 2 ? tc[1] : 0xffffffffu;
     p.grid = tiles < cus ? tiles : cus; p.tpw = (tiles + p.grid - 1) / p.grid;
-    const uint32_t items = p.tpw * p.nu;
+    // token tiles (tt = 1 | 2 | 4): SERIAL inside an item (an item's weights are transposed once and meet every tile), or -- small launches
+    // whose (tile, unit) items leave waves idle: Qwen3-0.6B's matrices at 17..64 tokens -- SPREAD over the waves: an item is (tile, unit,
+    // token tile), the weights of a (tile, unit) are fetched by up to four waves of the same workgroup (L1 / L2 hits on matrices of a few MB)
+    // MEASURED (round 4, Qwen3-0.6B, one box): 32 sequences 1.347 ms spread vs 1.386 serial; 64 sequences 2.039 vs 1.888, prompt ingestion
+    // of 64-token chunks 32.4 k vs 36.1 k tok/s -- four waves re-fetching and re-transposing an item's weights cost more than the idle waves
+    // they fill.  So: spread two tiles, keep four serial (NANO_G6_SPREAD=0 | 2 | 4: the most tiles spread).
+    static const uint32_t spread_max = [] { const char *e = getenv("NANO_G6_SPREAD"); return e ? (uint32_t)atoi(e) : 2u; }();
+    p.tts = (tt > 1u && tt <= spread_max && p.tpw * p.nu < G6_NW && p.tpw * p.nu * tt <= 4u * G6_NW) ? tt : 1u;
+    const uint32_t items = p.tpw * p.nu * p.tts;
     p.nw = G6_NW;
     while (p.nw > items) p.nw >>= 1;                                   // a power of two (the kernel finds a tile's finisher with a mask)
     p.rounds = (items + p.nw - 1u) / p.nw;                             // the most items a wave owns
     p.ms = !sw && a.nseg > 1;
     p.lds_common = (size_t)p.nw * G6_LDS_WAVE + (size_t)p.tpw * p.nu * tt * 1024u + (size_t)((p.tpw + 3u) & ~3u) * 4u;
-    const uint32_t magic = (65536u + p.nu - 1u) / p.nu;
-    for (uint32_t it = 0; it < items + 8u * G6_NW; it++) if (((it * magic) >> 16) != it / p.nu) return false;
+    const uint32_t ipt = p.nu * p.tts, magic = (65536u + ipt - 1u) / ipt;
+    for (uint32_t it = 0; it < items + 8u * G6_NW; it++) if (((it * magic) >> 16) != it / ipt) return false;
     return true;
 }
 
@@ -91,7 +99,8 @@ static G6Dev g6_dev(const GemvArgs &a, const G6Plan &p) {
     G6Dev d{};
     d.g = to_dev(a);
     d.g.nthr = p.nw * 64u;
-    d.hh = p.hh; d.nu = p.nu; d.magic_nu = (65536u + p.nu - 1u) / p.nu;
+    d.hh = p.hh; d.nu = p.nu; d.magic_nu = (65536u + p.nu * p.tts - 1u) / (p.nu * p.tts);
+    d.tts = p.tts; d.tts_log2 = p.tts == 4u ? 2u : p.tts == 2u ? 1u : 0u;
     d.ntiles = p.ntiles; d.tc0 = p.tc0; d.tc1 = p.tc1; d.grid = p.grid; d.tpw = p.tpw; d.nw = p.nw;
     d.full = p.ntiles - (p.tpw - 1u) * p.grid;
     return d;
@@ -109,7 +118,7 @@ bool gemm_q80_g6_supports(const GemvArgs &a) {
     const uint32_t tt = g6_tt(a);
     // (4 token tiles x 4 rounds is not instantiated: its registers spill; the launches that would need it -- Qwen3-4B's W1|W3 beyond 32
     //  tokens -- do not fit LDS either and stay with G5)
-    return g6_plan(a, p, tt) && p.rounds <= (tt == 4u ? 3u : 4u) && p.lds_common + 64 <= 160u * 1024u;
+    return g6_plan(a, p, tt) && p.rounds <= ((tt == 4u && p.tts == 1u) ? 3u : 4u) && p.lds_common + 64 <= 160u * 1024u;
 }
 // MODE S where the activation fits LDS next to everything else (one 1 KB block per group + scales), else MODE F
 static size_t g6s_lds(const G6Plan &p) { const size_t ngp = (size_t)p.nu * 8u; return p.lds_common + ngp * 1024u + 64u + ngp * 64u + 64u; }
@@ -136,7 +145,7 @@ hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
     const size_t lds = p.lds_common + 64;
 #define G6F_GO(R_, T_) do { return p.ms ? g6_launch_t<G6_F, false, 1, 1, R_, true, T_>(d, lds, st) : g6_launch_t<G6_F, false, 1, 1, R_, false, T_>(d, lds, st); } while (0)
 #define G6F_R(T_) do { if (p.rounds <= 1) G6F_GO(1, T_); if (p.rounds == 2) G6F_GO(2, T_); if (p.rounds == 3) G6F_GO(3, T_); G6F_GO(4, T_); } while (0)
-    if (tt == 1u) G6F_R(1);
+    if (tt == 1u || p.tts > 1u) G6F_R(1);       // (spread token tiles: one tile per item)
     if (tt == 2u) G6F_R(2);
     if (p.rounds <= 1) G6F_GO(1, 4);
     if (p.rounds == 2) G6F_GO(2, 4);

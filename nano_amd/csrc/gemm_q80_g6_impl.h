@@ -20,7 +20,8 @@ struct G6Dev {
     GemvDev g;                          // segments, n, ng, epi, flags, nb, the fp32 activation / norm weight / attention partials (MODE P)
     const int8_t *xf; const float *xsf; // MODE F: activations in MFMA B-fragment order [group][lane][16 B], scales [group][16 tokens]
     uint32_t hh;                        // live rows per half tile (1..8)
-    uint32_t nu, magic_nu;              // units per row; (it * magic_nu) >> 16 == it / nu for every item index of a workgroup
+    uint32_t nu, magic_nu;              // units per row; (it * magic_nu) >> 16 == it / (nu * tts) for every item index of a workgroup
+    uint32_t tts, tts_log2;             // MODE F, small launches: token tiles SPREAD over the waves (1 | 2 | 4): an item is (tile, unit, token tile)
     uint32_t ntiles, tc0, tc1;          // tiles; tiles up to the end of segment 0 / 1
     uint32_t grid, tpw;                 // workgroups; tiles per workgroup (max)
     uint32_t nw, full;                  // waves per workgroup (a power of two); workgroups that own tpw tiles (the others: tpw - 1)
@@ -58,6 +59,8 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     karg_touch(a.out_bstride[0]); karg_touch(a.out_pstride[2]); karg_touch(d.tc0); karg_touch(d.magic_nu);
     NANO_STAMP(a.stamps, 0, tid);
     const uint32_t n = a.n, ng = a.ng, nu = d.nu, hh = d.hh, NW = d.nw, nb = a.nb;
+    const uint32_t tts = MODE == G6_F ? d.tts : 1u, tsh = MODE == G6_F ? d.tts_log2 : 0u, ipt = nu << tsh;   // items per tile
+    const uint32_t NT = (uint32_t)TT << tsh;                              // token tiles of the unit-sum table
     const uint32_t epi = a.epi;
     const bool sw = epi == GEMV_EPI_SWIGLU;
     const uint32_t halfoff = sw ? 0u : hh;                              // rows between the two halves of a tile
@@ -67,8 +70,8 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     int8_t *wbuf = reinterpret_cast<int8_t *>(smem) + (size_t)wid * G6_LDS_WAVE;
     float *wsl = reinterpret_cast<float *>(wbuf + G6_WBUF);            // [8 groups][16 rows]
     float *xslw = wsl + 128;                                           // MODE F: [8 groups][16 tokens]
-    float *T = reinterpret_cast<float *>(smem + (size_t)NW * G6_LDS_WAVE);          // [tpw][nu][TT][256] unit sums
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(T + (size_t)d.tpw * nu * TT * 256u);   // [tpw] units arrived
+    float *T = reinterpret_cast<float *>(smem + (size_t)NW * G6_LDS_WAVE);          // [tpw][nu][NT token tiles][256] unit sums
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(T + (size_t)d.tpw * nu * NT * 256u);   // [tpw] items arrived
     unsigned char *pbase = reinterpret_cast<unsigned char *>(cnt + ((d.tpw + 3u) & ~3u));
     // MODE P: the quantized activation [ngp][4 k-quarters][NBC][16 B] (groups >= ng zero), a 64-byte zero block (what the lanes of
     // token slots >= NBC read), the activation scales [ngp][16] (slots >= NBC unused, groups >= ng zero)
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     // ---- the workgroup's items -----------------------------------------------------------------------------------------------
     const uint32_t bid = blockIdx.x;
     const uint32_t ntl = bid < d.full ? d.tpw : d.tpw - 1u;              // tiles of this workgroup
-    const uint32_t nitems = ntl * nu;
+    const uint32_t nitems = ntl * ipt;
 
     struct TI { uint32_t lrow0, rows0, obs, ops; const int8_t *wA, *wB; const float *sA, *sB; float *out; };
     auto decode = [&](uint32_t tl) -> TI {
@@ -125,12 +128,13 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     auto issue = [&](auto J, uint32_t it) {
         constexpr int sl = decltype(J)::value;
         const bool live = it < nitems;
-        const uint32_t tl = (it * d.magic_nu) >> 16, u = it - tl * nu;
+        const uint32_t tl = (it * d.magic_nu) >> 16, rem = it - tl * ipt, u = rem >> tsh, tk = rem & (tts - 1u);
         const TI t = decode(tl);
         if constexpr (MODE == G6_F) {               // the item's activation fragments FIRST (loads return in issue order)
             const uint32_t g0 = u * 8u;
-            const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf + (size_t)g0 * 1024u, live ? (ng - g0) * 1024u : 0u);     // groups >= ng: out of range -> 0
-            const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf + (size_t)g0 * 16u, live ? (ng - g0) * 64u : 0u);        // (token tile 0; the others: consume)
+            const bool lvb = live && tk * 16u < nb;  // (spread token tiles: tile tk of this item; serial ones: tile 0 here, the others in consume)
+            const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf + ((size_t)tk * ng + g0) * 1024u, lvb ? (ng - g0) * 1024u : 0u);     // groups >= ng: out of range -> 0
+            const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf + ((size_t)tk * ng + g0) * 16u, lvb ? (ng - g0) * 64u : 0u);
 #pragma unroll
             for (uint32_t j = 0; j < 8; j++) ring[sl].b[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)(lane * 16u + j * 1024u), 0, 0);
             ring[sl].xs = bload_f4(rxs, lane < 32u ? lane * 16u : OOB);             // lanes 0..31: group g0 + l/4, tokens 4 (l%4) .. +3
@@ -196,9 +200,9 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     }
     // ---- what the first tile this wave FINISHES needs for its epilogue (the old residual values, the position of a position-indexed
     //      output): asked for first, tiny, and only by launches that need them -- nothing at the end waits for a cold load of its own ---
-    // tile tl is finished by the wave that owns its last unit, item tl * nu + nu - 1
+    // tile tl is finished by the wave that owns its last item, tl * ipt + ipt - 1
     uint32_t ftl = 0xffffffffu;
-    for (uint32_t tl = 0; tl < ntl; tl++) if (((tl * nu + nu - 1u) & (NW - 1u)) == wid) { ftl = tl; break; }
+    for (uint32_t tl = 0; tl < ntl; tl++) if (((tl * ipt + ipt - 1u) & (NW - 1u)) == wid) { ftl = tl; break; }
     const uint32_t half = kq >> 1, rr0 = (kq & 1u) * 4u;              // this lane's four output rows: rows rr0 .. rr0 + 3 of half `half`
     float oldv0[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t opos0 = 0;
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     auto consume = [&](auto J, auto FIRST, uint32_t it) {
         constexpr int sl = decltype(J)::value;
         constexpr bool first = decltype(FIRST)::value;
-        const uint32_t tl = (it * d.magic_nu) >> 16, u = it - tl * nu;
+        const uint32_t tl = (it * d.magic_nu) >> 16, rem = it - tl * ipt, u = rem >> tsh, tk = rem & (tts - 1u);
         const uint32_t g0 = u * 8u;
         // 1. weight pieces -> transposition buffer; weight scales (and, F, activation scales) -> LDS
 #pragma unroll
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
                         if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
                         else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
                     }
-                    *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * TT + t) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
+                    *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * NT + t) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
 #pragma unroll
                     for (uint32_t j = 0; j < 8; j++) nb_[j] = tmp[j];
                     nxs = txs;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
                 else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
             }
             if constexpr (first) { if (t == 0u) NANO_STAMP(a.stamps, 4, S[3]); }             // ... multiplied
-            *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * TT + t) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
+            *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * NT + (TT == 1 ? tk : t)) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
         }
         // 3. arrive
         if (lane == 0u) __hip_atomic_fetch_add(cnt + tl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -392,13 +396,12 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     NANO_STAMP(a.stamps, 5, oldv0[0]);                                // this wave's items done
     // ---- the tiles this wave finishes: wait for the tile's units, add them in ascending order, epilogue ---------------------------
     for (uint32_t tl = ftl; tl < ntl; tl++) {
-        if (((tl * nu + nu - 1u) & (NW - 1u)) != wid) continue;
+        if (((tl * ipt + ipt - 1u) & (NW - 1u)) != wid) continue;
         const TI t = decode(tl);
         const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;        // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
         // (bounded: a miscounted tile must not hang the device -- 2^24 naps are ~0.5 s, the results are then wrong and the tests say so)
-        for (uint32_t spin = 0; g6_lds_load_acq(cnt + tl) != nu && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (uint32_t tt = 0; tt < (uint32_t)TT; tt++) {
+        for (uint32_t spin = 0; g6_lds_load_acq(cnt + tl) != ipt && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
+        for (uint32_t tt = 0; tt < NT; tt++) {
             const uint32_t tok = tt * 16u + m;
             if (tt * 16u >= nb) break;                                 // (wave-uniform)
             float oldv[4] = {oldv0[0], oldv0[1], oldv0[2], oldv0[3]};
@@ -411,12 +414,12 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
                     for (int i = 0; i < 4; i++) if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) oldv[i] = o[i];
                 }
             }
-            const float *tp = T + ((size_t)tl * nu * TT + tt) * 256u + lane * 4u;
+            const float *tp = T + ((size_t)tl * nu * NT + tt) * 256u + lane * 4u;
             float4 acc = *reinterpret_cast<const float4 *>(tp);
             for (uint32_t u0 = 1; u0 < nu; u0 += 4) {                  // units ascending; the reads of four units go out together
                 float4 q[4];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) q[k] = (u0 + k < nu) ? *reinterpret_cast<const float4 *>(tp + (size_t)(u0 + k) * TT * 256u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (uint32_t k = 0; k < 4; k++) q[k] = (u0 + k < nu) ? *reinterpret_cast<const float4 *>(tp + (size_t)(u0 + k) * NT * 256u) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) if (u0 + k < nu) { acc.x += q[k].x; acc.y += q[k].y; acc.z += q[k].z; acc.w += q[k].w; }
             }

@@ -45,5 +45,10 @@ g6t)   # G6 MODE F with 2 / 4 token tiles (17..64 tokens): parity subset, A/B ag
   done
   for b in 32 64; do bench q06_b${b}_g6tt --batch $b --steps 64 --warmup 4; NANO_G6_MAX_NB=16 bench q06_b${b}_g5 --batch $b --steps 64 --warmup 4 --no-kernel-table; done
   ;;
+g6s)   # spread token tiles on small matrices: parity subset, Qwen3-0.6B at 32 / 64 sequences and prompt ingestion, A/B
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py tests/test_gpu_e2e.py tests/test_gpu_fullsize.py -m gpu -x -q -k "gemm or chained or large_batch or prefill or batch_equals" 2>&1 | tail -4
+  for b in 32 64; do bench q06_b${b}_spread --batch $b --steps 64 --warmup 4; NANO_G6_SPREAD=0 bench q06_b${b}_serial --batch $b --steps 64 --warmup 4 --no-kernel-table; done
+  timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -4; NANO_G6_SPREAD=0 timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -4
+  ;;
 *) echo "unknown mode $1";;
 esac
