@@ -200,22 +200,26 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     }
     // ---- what the first tile this wave FINISHES needs for its epilogue (the old residual values, the position of a position-indexed
     //      output): asked for first, tiny, and only by launches that need them -- nothing at the end waits for a cold load of its own ---
-    // tile tl is finished by the wave that owns its last item, tl * ipt + ipt - 1
-    uint32_t ftl = 0xffffffffu;
-    for (uint32_t tl = 0; tl < ntl; tl++) if (((tl * ipt + ipt - 1u) & (NW - 1u)) == wid) { ftl = tl; break; }
+    // FINISHING is dealt out too: pair q = (tile q / NT, token tile q % NT) is folded by wave NW - 1 - q % NW (the high waves own one item
+    // less when the items do not divide evenly) once the tile's counter says every item has arrived -- round 4 first let the owner of a
+    // tile's last unit fold all its token tiles: 2.8 ... 4.4 us of a 64-token launch with seven waves idle (profiles/r04_stamps_64.txt)
+    constexpr uint32_t NTL2 = (TT == 4 ? 2u : TT == 2 ? 1u : 0u);
+    const uint32_t ntsh = NTL2 + tsh, npairs = ntl << ntsh, q0 = NW - 1u - wid;
+    const uint32_t ftl = q0 < npairs ? (q0 >> ntsh) : 0xffffffffu, ftt = q0 & (NT - 1u);
     const uint32_t half = kq >> 1, rr0 = (kq & 1u) * 4u;              // this lane's four output rows: rows rr0 .. rr0 + 3 of half `half`
     float oldv0[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t opos0 = 0;
     if (epi == GEMV_EPI_RESID || (a.out_pstride[0] | a.out_pstride[1] | a.out_pstride[2]) != 0u) {
         const TI t = decode(ftl == 0xffffffffu ? 0u : ftl);
         const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;
-        const bool lv = ftl != 0xffffffffu && m < nb;
+        const uint32_t tok0 = ftt * 16u + m;
+        const bool lv = ftl != 0xffffffffu && tok0 < nb;
         const __amdgpu_buffer_rsrc_t ro = mkrsrc(t.out, (ftl != 0xffffffffu && epi == GEMV_EPI_RESID) ? ((nb - 1u) * t.obs + t.rows0) * 4u : 0u);
         const __amdgpu_buffer_rsrc_t rp = mkrsrc(a.pos, (ftl != 0xffffffffu && t.ops) ? nb * 4u : 0u);
-        opos0 = __builtin_amdgcn_raw_buffer_load_b32(rp, (int)(lv ? m * 4u : OOB), 0, 0);
+        opos0 = __builtin_amdgcn_raw_buffer_load_b32(rp, (int)(lv ? tok0 * 4u : OOB), 0, 0);
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++)                               // (the residual stream is never position indexed)
-            oldv0[i] = bload_f(ro, (lv && rr0 + i < hh && orow0 + i < t.rows0) ? (m * t.obs + orow0 + i) * 4u : OOB);
+            oldv0[i] = bload_f(ro, (lv && rr0 + i < hh && orow0 + i < t.rows0) ? (tok0 * t.obs + orow0 + i) * 4u : OOB);
     }
     // ---- the first items go out.  MODE F: every round that has a slot, right away (its one barrier -- arming the counters -- is behind
     //      it: nothing waits on a wave that the memory pipeline holds up while it issues).  MODE P: ROUND 0 ONLY -- the prologue below has
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
                         if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
                         else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
                     }
+                    if constexpr (first) { if (t == 0u) NANO_STAMP(a.stamps, 4, S[3]); }     // ... multiplied (token tile 0)
                     *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * NT + t) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
 #pragma unroll
                     for (uint32_t j = 0; j < 8; j++) nb_[j] = tmp[j];
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
                 if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
                 else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
             }
-            if constexpr (first) { if (t == 0u) NANO_STAMP(a.stamps, 4, S[3]); }             // ... multiplied
+            if constexpr (first && TT == 1) { if (t == 0u) NANO_STAMP(a.stamps, 4, S[3]); }   // ... multiplied
             *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * NT + (TT == 1 ? tk : t)) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
         }
         // 3. arrive
@@ -394,47 +399,45 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
         if constexpr (r + D < R) issue(std::integral_constant<int, r % D>{}, it + (uint32_t)D * NW);
     });
     NANO_STAMP(a.stamps, 5, oldv0[0]);                                // this wave's items done
-    // ---- the tiles this wave finishes: wait for the tile's units, add them in ascending order, epilogue ---------------------------
-    for (uint32_t tl = ftl; tl < ntl; tl++) {
-        if (((tl * ipt + ipt - 1u) & (NW - 1u)) != wid) continue;
+    // ---- the (tile, token tile) pairs this wave finishes: wait for the tile's items, add the units in ascending order, epilogue ---------
+    for (uint32_t q = q0; q < npairs; q += NW) {
+        const uint32_t tl = q >> ntsh, tt = q & (NT - 1u);
+        if (tt * 16u >= nb) continue;                                  // (wave-uniform: a token tile beyond the batch)
         const TI t = decode(tl);
         const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;        // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
+        const uint32_t tok = tt * 16u + m;
+        float oldv[4] = {oldv0[0], oldv0[1], oldv0[2], oldv0[3]};
+        uint32_t opos = opos0;
+        if (q != q0 && tok < nb) {                                     // (only this wave's first pair was fetched up front)
+            if (t.ops) opos = a.pos[tok];
+            if (epi == GEMV_EPI_RESID) {
+                const float *o = t.out + (size_t)tok * t.obs + orow0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) oldv[i] = o[i];
+            }
+        }
         // (bounded: a miscounted tile must not hang the device -- 2^24 naps are ~0.5 s, the results are then wrong and the tests say so)
         for (uint32_t spin = 0; g6_lds_load_acq(cnt + tl) != ipt && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
-        for (uint32_t tt = 0; tt < NT; tt++) {
-            const uint32_t tok = tt * 16u + m;
-            if (tt * 16u >= nb) break;                                 // (wave-uniform)
-            float oldv[4] = {oldv0[0], oldv0[1], oldv0[2], oldv0[3]};
-            uint32_t opos = opos0;
-            if ((tl != ftl || tt != 0u) && tok < nb) {                 // (only the first finished tile's first token tile was fetched up front)
-                if (t.ops) opos = a.pos[tok];
-                if (epi == GEMV_EPI_RESID) {
-                    const float *o = t.out + (size_t)tok * t.obs + orow0;
+        const float *tp = T + ((size_t)tl * nu * NT + tt) * 256u + lane * 4u;
+        float4 acc = *reinterpret_cast<const float4 *>(tp);
+        for (uint32_t u0 = 1; u0 < nu; u0 += 4) {                      // units ascending; the reads of four units go out together
+            float4 qv[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) oldv[i] = o[i];
-                }
-            }
-            const float *tp = T + ((size_t)tl * nu * NT + tt) * 256u + lane * 4u;
-            float4 acc = *reinterpret_cast<const float4 *>(tp);
-            for (uint32_t u0 = 1; u0 < nu; u0 += 4) {                  // units ascending; the reads of four units go out together
-                float4 q[4];
+            for (uint32_t k = 0; k < 4; k++) qv[k] = (u0 + k < nu) ? *reinterpret_cast<const float4 *>(tp + (size_t)(u0 + k) * NT * 256u) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) q[k] = (u0 + k < nu) ? *reinterpret_cast<const float4 *>(tp + (size_t)(u0 + k) * NT * 256u) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t k = 0; k < 4; k++) if (u0 + k < nu) { acc.x += qv[k].x; acc.y += qv[k].y; acc.z += qv[k].z; acc.w += qv[k].w; }
+        }
+        const float tot[4] = {acc.x, acc.y, acc.z, acc.w};
+        float v3[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sw) {                                                      // W3's values live 32 lanes up (rows 8..15 of the tile)
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) if (u0 + k < nu) { acc.x += q[k].x; acc.y += q[k].y; acc.z += q[k].z; acc.w += q[k].w; }
-            }
-            const float tot[4] = {acc.x, acc.y, acc.z, acc.w};
-            float v3[4] = {0.f, 0.f, 0.f, 0.f};
-            if (sw) {                                                  // W3's values live 32 lanes up (rows 8..15 of the tile)
+            for (int i = 0; i < 4; i++) v3[i] = __shfl_xor(tot[i], 32, 64);
+        }
+        if (tok < nb && (!sw || kq < 2u)) {
+            float *o = t.out + (size_t)tok * t.obs + (size_t)opos * t.ops + orow0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) v3[i] = __shfl_xor(tot[i], 32, 64);
-            }
-            if (tok < nb && (!sw || kq < 2u)) {
-                float *o = t.out + (size_t)tok * t.obs + (size_t)opos * t.ops + orow0;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) o[i] = finish_epi(epi, tot[i], v3[i], oldv[i]);
-            }
+            for (int i = 0; i < 4; i++)
+                if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) o[i] = finish_epi(epi, tot[i], v3[i], oldv[i]);
         }
     }
     NANO_STAMP_END(a.stamps, 6);                                    // the workgroup's last wave ends

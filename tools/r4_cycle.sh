@@ -50,5 +50,15 @@ g6s)   # spread token tiles on small matrices: parity subset, Qwen3-0.6B at 32 /
   for b in 32 64; do bench q06_b${b}_spread --batch $b --steps 64 --warmup 4; NANO_G6_SPREAD=0 bench q06_b${b}_serial --batch $b --steps 64 --warmup 4 --no-kernel-table; done
   timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -4; NANO_G6_SPREAD=0 timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -4
   ;;
+st64)  # phase stamps of the 64-sequence step (G6 MODE F, four token tiles; G5 for Qwen3-4B's W1|W3)
+  for a in "qwen3-0.6b q80 64 30" "wide-qwen3 q80 64 30" "qwen3-0.6b q80 16 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$R/nano_amd/lib/libnano_mi355x_stamps.so timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done | tee $O/stamps_64.txt
+  ;;
+fin)   # finishing dealt over the waves: parity subset, A/B against the previous library (nano_amd/lib/libnano_mi355x_prev.so)
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py tests/test_gpu_e2e.py tests/test_gpu_fullsize.py -m gpu -x -q -k "q80 or g6 or gemm or chained or large_batch or prefill or batch_equals" 2>&1 | tail -4
+  for cfg in "qwen3-0.6b 64" "qwen3-0.6b 16" "qwen3-4b 8" "qwen3-4b 16" "qwen3-4b 64" "qwen3-4b 2"; do set -- $cfg; for lib in new prev new prev; do
+    L=$R/nano_amd/lib/libnano_mi355x.so; [ $lib = prev ] && L=$R/nano_amd/lib/libnano_mi355x_prev.so
+    NANO_BENCH_NO_TRAFFIC=1 NANO_LIB=$L bench ${1}_b${2}_$lib --model $1 --batch $2 --steps 32 --warmup 4 --no-kernel-table
+  done; done
+  ;;
 *) echo "unknown mode $1";;
 esac

@@ -33,7 +33,7 @@ for p in range(0, pos):                                     # some KV history (v
     m.forward([1] * B, [p] * B, want_logits=False)
 names = {1: "qkv", 2: "attention", 3: "wo", 4: "w1w3", 5: "w2"}
 phases = {1: ["issue", "x arrives(+norm sum)", "quantize", "w arrive+dots", "barrier", "fold+store"], 2: ["issue", "q/k norm+rope", "KV+softmax", "partials", "combine+store"]}
-G6 = quant == "q80" and model in ("qwen3-4b", "wide-qwen3") and os.environ.get("NANO_GEMM_G6") != "0"     # gemm_q80_g6.hip's stamps
+G6 = quant == "q80" and (B >= 9 or (B >= 2 and model in ("qwen3-4b", "wide-qwen3")) or os.environ.get("NANO_G6P_B1") == "1") and os.environ.get("NANO_GEMM_G6") != "0"     # gemm_q80_g6.hip's stamps
 g6_phases = ["issue", "x arrives, norm, quantize (P)", "first weights land", "first item multiplied", "this wave's other items", "finish tiles + last wave"]
 G5 = B > 1 and quant == "q80" and not G6          # batched Q80 steps of large matrices run the G5 GEMM: its first wave stamps entry, weights of its first half chunk
                                         # landed, scales + fragments landed and products done, its first chain link folded; the last phase = the rest of the chain
