@@ -60,5 +60,10 @@ fin)   # finishing dealt over the waves: parity subset, A/B against the previous
     NANO_BENCH_NO_TRAFFIC=1 NANO_LIB=$L bench ${1}_b${2}_$lib --model $1 --batch $2 --steps 32 --warmup 4 --no-kernel-table
   done; done
   ;;
+rng)   # attention range hint rounded to 16 / 32 instead of 64 at large batches (NANO_RANGE_STEP): A/B
+  for cfg in "qwen3-0.6b 64" "qwen3-0.6b 16" "qwen3-4b 64" "qwen3-4b 16"; do set -- $cfg; for st in 64 16 32 64 16; do
+    NANO_RANGE_STEP=$st NANO_BENCH_NO_TRAFFIC=1 bench ${1}_b${2}_step$st --model $1 --batch $2 --steps 32 --warmup 4 --no-kernel-table
+  done; done
+  ;;
 *) echo "unknown mode $1";;
 esac
