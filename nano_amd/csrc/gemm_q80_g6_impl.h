@@ -50,7 +50,8 @@ template <int MODE, bool COMB, int NBC, int NV, int R, bool MS, int TT = 1>
 __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     static_assert(TT == 1 || MODE == G6_F, "token tiles beyond the first come from L2 (MODE F)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int D = MODE == G6_F ? 2 : 4;                             // items in flight per wave (F: a slot also holds the item's 8 KB of B fragments)
+    constexpr int D = MODE == G6_F ? 2 : 4;                             // register slots per wave (F: a slot also holds the item's 8 KB of B fragments)
+    constexpr int LA = MODE == G6_F ? D : 2;                            // rounds requested ahead of the one being multiplied
     const GemvDev &a = d.g;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     }
     if constexpr (MODE != G6_F) {
         __syncthreads();                                               // counters armed, the quantized activation is in LDS
-        g6_static_for<1, (R < D ? R : D)>([&](auto K) { issue(K, wid + (uint32_t)decltype(K)::value * NW); });     // the other rounds that have a slot
+        g6_static_for<1, (R < LA ? R : LA)>([&](auto K) { issue(K, wid + (uint32_t)decltype(K)::value * NW); });   // round 1 (see LA)
     }
     NANO_STAMP(a.stamps, 2, cnt[0]);                                // (P) the activation arrived, normalised + quantized
 
@@ -391,12 +392,16 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
         // 3. arrive
         if (lane == 0u) __hip_atomic_fetch_add(cnt + tl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    // R rounds in straight-line code; the item of round r + D is requested as soon as round r's slot is free
+    // R rounds in straight-line code.  MODE F (a slot holds the item's fragments: two slots): the item of round r + 2 is requested when
+    // round r's slot is free.  MODES P / S (four slots): LOOK-AHEAD of two rounds -- round r + 2 is requested right before round r is
+    // multiplied.  (Round 4 first issued every round that had a slot at once: a wave then sits ~3 us in a full memory pipeline issuing
+    // 30 loads while its first item has long landed -- W1|W3's first multiply 6.2 us after entry, profiles/r04_g6_stamps.txt.)
     g6_static_for<0, R>([&](auto K) {
         constexpr int r = decltype(K)::value;
         const uint32_t it = wid + (uint32_t)r * NW;
+        if constexpr (MODE != G6_F && r + LA < R) issue(std::integral_constant<int, (r + LA) % D>{}, it + (uint32_t)LA * NW);
         if (it < nitems) consume(std::integral_constant<int, r % D>{}, std::integral_constant<bool, r == 0>{}, it);
-        if constexpr (r + D < R) issue(std::integral_constant<int, r % D>{}, it + (uint32_t)D * NW);
+        if constexpr (MODE == G6_F && r + D < R) issue(std::integral_constant<int, r % D>{}, it + (uint32_t)D * NW);
     });
     NANO_STAMP(a.stamps, 5, oldv0[0]);                                // this wave's items done
     // ---- the (tile, token tile) pairs this wave finishes: wait for the tile's items, add the units in ascending order, epilogue ---------

@@ -65,5 +65,12 @@ rng)   # attention range hint rounded to 16 / 32 instead of 64 at large batches 
     NANO_RANGE_STEP=$st NANO_BENCH_NO_TRAFFIC=1 bench ${1}_b${2}_step$st --model $1 --batch $2 --steps 32 --warmup 4 --no-kernel-table
   done; done
   ;;
+la)    # look-ahead of two rounds in MODES P / S: parity subset, A/B against the previous library
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py -m gpu -x -q -k "q80 or g6 or gemm" 2>&1 | tail -3
+  for cfg in "qwen3-4b 2" "qwen3-4b 8" "qwen3-4b 16" "qwen3-0.6b 16"; do set -- $cfg; for lib in new prev new prev; do
+    L=$R/nano_amd/lib/libnano_mi355x.so; [ $lib = prev ] && L=$R/nano_amd/lib/libnano_mi355x_prev.so
+    NANO_BENCH_NO_TRAFFIC=1 NANO_LIB=$L bench ${1}_b${2}_$lib --model $1 --batch $2 --steps 32 --warmup 4 --no-kernel-table
+  done; done
+  ;;
 *) echo "unknown mode $1";;
 esac
