@@ -265,7 +265,7 @@ def ref_q4k(oracle, act, WTs, n):
     return np.concatenate([oracle.matmul_q4k(XT, WT, 0, rows) for WT, rows in WTs])
 
 
-@pytest.mark.parametrize("n,rows", [(1024, (2048, 1024, 1024)), (2560, (1024, 256, 256))])
+@pytest.mark.parametrize("n,rows", [(1024, (2048, 1024, 1024)), (2560, (1024, 256, 256)), (2560, (4096, 1024, 1024)), (1024, (1000, 40, 36))])
 def test_k1_norm_qkv_q4k_bit_exact(oracle, n, rows):
     rng = np.random.default_rng(n + 7)
     x = order_free(rng, n)
@@ -276,7 +276,7 @@ def test_k1_norm_qkv_q4k_bit_exact(oracle, n, rows):
     assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
 
 
-@pytest.mark.parametrize("n,rows", [(2048, 1024), (3072, 1024)])
+@pytest.mark.parametrize("n,rows", [(2048, 1024), (3072, 1024), (9728, 2560), (4096, 2560), (768, 333)])
 def test_k3_k5_residual_q4k_bit_exact(oracle, n, rows):
     rng = np.random.default_rng(n + 9)
     x = (rng.standard_normal(n) * 2).astype(np.float32)
@@ -287,8 +287,8 @@ def test_k3_k5_residual_q4k_bit_exact(oracle, n, rows):
     assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
 
 
-def test_k4_norm_swiglu_q4k(oracle):
-    n, rows = 1024, 3072
+@pytest.mark.parametrize("n,rows", [(1024, 3072), (2560, 9728), (512, 1001)])
+def test_k4_norm_swiglu_q4k(oracle, n, rows):
     rng = np.random.default_rng(11)
     x = order_free(rng, n)
     nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
@@ -299,6 +299,18 @@ def test_k4_norm_swiglu_q4k(oracle):
     assert np.allclose(out, silu_mul(h1, h3), rtol=3e-6, atol=1e-9)
     both = nb.op_fused_gemv(Q4K, 0, n, [(W1[44:], None, rows), (W3[44:], None, rows)], x[None], nw)[0]
     assert np.array_equal(bits(both), bits(np.concatenate([h1, h3])))
+
+
+def test_classifier_q4k_persistent_workgroups_bit_exact(oracle):
+    # rows >= 65536, one STORE segment: gemv_q4k_chunk.hip's looping workgroups (ring of 8 loads per wave), last workgroup ragged
+    n, rows = 1024, 65536 + 37
+    rng = np.random.default_rng(17)
+    x = order_free(rng, n)
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    WT = q4k_weights(oracle, rng, rows, n)
+    ref = ref_q4k(oracle, oracle.rmsnorm(x, nw), [(WT, rows)], n)
+    out = nb.op_fused_gemv(Q4K, 0, n, [(WT[44:], None, rows)], x[None], nw)[0]
+    assert np.array_equal(bits(out), bits(ref)), float(np.abs(out - ref).max())
 
 
 def test_split_attention_combine_q4k_bit_exact(oracle):

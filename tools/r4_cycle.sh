@@ -72,5 +72,13 @@ la)    # look-ahead of two rounds in MODES P / S: parity subset, A/B against the
     NANO_BENCH_NO_TRAFFIC=1 NANO_LIB=$L bench ${1}_b${2}_$lib --model $1 --batch $2 --steps 32 --warmup 4 --no-kernel-table
   done; done
   ;;
+q4c)   # Q4K 16-byte-chunk kernel (gemv_q4k_chunk.hip): parity, A/B against round 3's kernel (NANO_Q4K_CHUNK=0), phase stamps
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py tests/test_gpu_ops.py tests/test_gpu_e2e.py tests/test_gpu_strict.py -m gpu -x -q -k "q4k" 2>&1 | tail -4
+  for cfg in "qwen3-0.6b" "qwen3-4b"; do for m in 1 0 1 0; do
+    NANO_Q4K_CHUNK=$m NANO_BENCH_NO_TRAFFIC=1 bench ${cfg}_q4k_chunk$m --model $cfg --quant q4k --steps 48 --warmup 4 --no-kernel-table
+  done; done
+  NANO_BENCH_NO_TRAFFIC=1 bench q06_q4k_table --quant q4k --steps 48 --warmup 4
+  for a in "wide-qwen3 q4k 1 30" "qwen3-0.6b q4k 1 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$R/nano_amd/lib/libnano_mi355x_stamps.so timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done | tee $O/stamps_q4k_chunk.txt
+  ;;
 *) echo "unknown mode $1";;
 esac
