@@ -114,6 +114,45 @@ template <int LPR> __device__ __forceinline__ float xsub_max(float v) {
     return v;
 }
 
+// ---- combining the splits of a head (flash-decoding's second half) ---------------------------------------------------------
+// The weights of the splits' partial outputs: w_s = e_s / L, e_s = exp(m_s - M) for the splits that saw a timestep, L = the 8-slot
+// pairwise-tree sum of l_s e_s per block of 8 splits, the blocks added in order -- gemv_common.h combine_weights() (the Wo GEMV's
+// prologue, <= 8 splits) has the same arithmetic, so whoever combines produces the same bits.  One wave does it (lane s <-> split
+// s, <= 64 splits): the tree of a block is three DPP steps (quad_perm xor 1, xor 2, row_half_mirror: lane 8k ends with
+// ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)), fp addition commutes), the blocks are read lane by lane.  (Round 3's version kept all
+// slots in every thread's registers: 32 expf + 32 divisions per thread, 5 us per launch at 32 splits.)  Called by EVERY thread of
+// the workgroup (>= 64 threads); ends with a barrier; wsh[0..63] then holds the weights (0 beyond nsplit).
+__device__ __forceinline__ void combine_weights_lds(const float *mlh, uint32_t nsplit, float *wsh) {
+    if (threadIdx.x < 64u) {
+        const uint32_t s = threadIdx.x;
+        const bool in = s < nsplit;
+        const float mm = in ? mlh[2 * s] : -INFINITY;
+        float v = in ? mlh[2 * s + 1] : 0.0f;
+        float M = v > 0.0f ? mm : -INFINITY;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+        const float e = v > 0.0f ? expf(mm - M) : 0.0f;
+        v = v * e;
+        v += DPP_F(v, 0xB1); v += DPP_F(v, 0x4E); v += DPP_F(v, 0x141);
+        float L = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+        if (nsplit > 8u) {
+            L += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 8));
+            L += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+            L += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 24));
+        }
+        if (nsplit > 32u) {
+            L += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+            L += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 40));
+            L += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+            L += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 56));
+        }
+        wsh[s] = e / L;
+    }
+    __syncthreads();
+}
+// slots the register version of this arithmetic carried (8 / 32 / 64): a launch with fewer splits added `0 * w` for the rest
+__device__ __forceinline__ uint32_t combine_slots(uint32_t nsplit) { return nsplit <= 8u ? 8u : nsplit <= 32u ? 32u : 64u; }
+
 constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight per round
 
 // A KV row (head_dim floats) is shared by LPR lanes, QV float4 each (lane j owns float4 j, j+LPR, ...: every load
@@ -597,12 +636,20 @@ static hipError_t launch_lpr(const AttnArgs &a, uint32_t nb, hipStream_t st) {
 // timesteps one workgroup covers per round for this head size
 static uint32_t steps_per_wg(uint32_t hd) { return NP * (256 / (hd > 128 ? 16 : 8)); }
 
-// number of splits for an upper bound `range_hint` of the attended range: <= 8 up to ATTN_WIDE_FROM positions (what the Wo
-// GEMV's prologue combines); beyond, up to ATTN_MAX_NSPLIT so that a long range still spreads over the chip (8 KV groups
+// number of splits for an upper bound `range_hint` of the attended range: <= 8 up to attention_wide_from() positions (what the Wo
+// GEMV's prologue combines); beyond, up to attention_split_cap() so that a long range still spreads over the chip (8 KV groups
 // x 32 splits), combined by attn_combine_tokens_kernel -- a launch of its own, which pays from about four rounds per
-// workgroup on (Qwen3-0.6B, tools/long_ctx_probe.py: position 4095 1042 -> 958 us per step; 1023 would lose 90 us)
+// workgroup on (Qwen3-0.6B, tools/long_ctx_probe.py).  NANO_ATTN_WIDE_FROM / NANO_ATTN_MAX_SPLITS: measurement knobs.
+uint32_t attention_wide_from() {
+    static const uint32_t v = [] { const char *e = getenv("NANO_ATTN_WIDE_FROM"); const uint32_t x = e ? (uint32_t)atoi(e) : 0u; return x >= 64u ? x : 2048u; }();
+    return v;
+}
+uint32_t attention_split_cap() {
+    static const uint32_t v = [] { const char *e = getenv("NANO_ATTN_MAX_SPLITS"); const uint32_t x = e ? (uint32_t)atoi(e) : 0u; return (x >= 9u && x <= ATTN_MAX_NSPLIT) ? x : 32u; }();
+    return v;
+}
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd) {
-    const uint32_t per = steps_per_wg(hd), cap = range_hint > ATTN_WIDE_FROM ? ATTN_MAX_NSPLIT : 8u;
+    const uint32_t per = steps_per_wg(hd), cap = range_hint > attention_wide_from() ? attention_split_cap() : 8u;
     uint32_t n = (range_hint + per - 1) / per;
     if (n < 1) n = 1;
     if (n > cap) n = cap;
@@ -641,44 +688,39 @@ hipError_t launch_attn_combine(const float *part, const float *ml, float *out, u
 }
 
 // The combine of the Wo GEMV's prologue (gemv_common.h combine_weights / combine4) as a kernel of its own, for steps
-// whose Wo cannot fold it in (batched prefill through the MFMA GEMM): same weights (8 slots, pairwise-tree sum of
-// l_s * exp(m_s - M), e / L), same ascending accumulation — the bits of x are those of the decode path.
-// NS: slots (8: the Wo prologue's arithmetic exactly; 32: long ranges, the 8-slot tree per block of 8, blocks added in order)
+// whose Wo cannot fold it in (batched prefill through the MFMA GEMM, ranges split more than 8 ways): same weights (8 slots,
+// pairwise-tree sum of l_s * exp(m_s - M), e / L), same ascending accumulation -- the bits of x are those of the decode path; more
+// than 8 splits: the 8-slot tree per block of 8, blocks added in order (combine_weights_lds above).  A thread owns ONE output
+// element and asks for all its partials before the weights exist: one memory round trip.
 template <int NS>
 __global__ __launch_bounds__(128) void attn_combine_tokens_kernel(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit,
                                                                   int8_t *xf_out, float *xsf_out) {
-    const uint32_t h = blockIdx.x, b = blockIdx.y, q_dim = n_head * hd;
-    const float *mlh = ml + (((size_t)b * n_head + h) * nsplit) * 2;
-    float mm[NS], e[NS], v[NS], w[NS];
-    float M = -INFINITY;
+    __shared__ float wsh[64];
+    const uint32_t b = blockIdx.y, q_dim = n_head * hd;
+    for (uint32_t i0 = 0; i0 < hd; i0 += 128u) {                 // (head_dim 256: two passes)
+        const uint32_t hh = blockIdx.x, i = i0 + threadIdx.x;
+        const bool live = i < hd;
+        const float *pb = part + (size_t)b * nsplit * q_dim + (size_t)hh * hd + i;
+        float o[NS];
 #pragma unroll
-    for (uint32_t s = 0; s < (uint32_t)NS; s++) {
-        const bool in = s < nsplit;
-        mm[s] = in ? mlh[2 * s] : -INFINITY; v[s] = in ? mlh[2 * s + 1] : 0.0f;
-        if (v[s] > 0.0f) M = fmaxf(M, mm[s]);
-    }
-#pragma unroll
-    for (uint32_t s = 0; s < (uint32_t)NS; s++) { e[s] = v[s] > 0.0f ? expf(mm[s] - M) : 0.0f; v[s] = v[s] * e[s]; }
-    float L = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-#pragma unroll
-    for (int k = 8; k < NS; k += 8) L += ((v[k] + v[k + 1]) + (v[k + 2] + v[k + 3])) + ((v[k + 4] + v[k + 5]) + (v[k + 6] + v[k + 7]));
-#pragma unroll
-    for (uint32_t s = 0; s < (uint32_t)NS; s++) w[s] = e[s] / L;
-    const float *pb = part + (size_t)b * nsplit * q_dim + (size_t)h * hd;
-    for (uint32_t i = threadIdx.x; i < hd; i += blockDim.x) {
+        for (int s = 0; s < NS; s++) o[s] = (live && (uint32_t)s < nsplit) ? pb[(size_t)s * q_dim] : 0.0f;
+        if (i0 == 0) combine_weights_lds(ml + (((size_t)b * n_head + hh) * nsplit) * 2, nsplit, wsh);
         float acc = 0.0f;
 #pragma unroll
-        for (uint32_t s = 0; s < (uint32_t)NS; s++) { const float o = s < nsplit ? pb[(size_t)s * q_dim + i] : 0.0f; acc += o * w[s]; }
-        out[(size_t)b * q_dim + (size_t)h * hd + i] = acc;
-        if (xf_out) {       // also as a Q80 group of 64 (= this wave's 64 lanes; head_dim % 64 == 0) in fragment order, see attention_kernel
-            float mx = fabsf(acc);
+        for (int s = 0; s < NS; s++) if ((uint32_t)s < nsplit) acc += o[s] * wsh[s];
+        if (nsplit < (uint32_t)NS) acc += 0.0f;                  // (the empty slots' +0 of the register version: -0 becomes +0 as it always did)
+        if (live) {
+            out[(size_t)b * q_dim + (size_t)hh * hd + i] = acc;
+            if (xf_out) {       // also as a Q80 group of 64 (= this wave's 64 lanes; head_dim % 64 == 0) in fragment order, see attention_kernel
+                float mx = fabsf(acc);
 #pragma unroll
-            for (int o2 = 1; o2 < 64; o2 <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
-            const float scale = div_const<127>(mx);
-            const uint32_t el = h * hd + i, g = el >> 6, jj = el & 63u, ng = q_dim >> 6;
-            const size_t gb = (size_t)(b >> 4) * ng + g;
-            xf_out[gb * 1024u + (size_t)((jj >> 4) * 16u + (b & 15u)) * 16u + (jj & 15u)] = (int8_t)q80_quant1(acc, scale);
-            if (jj == 0) xsf_out[gb * 16u + (b & 15u)] = scale;
+                for (int o2 = 1; o2 < 64; o2 <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+                const float scale = div_const<127>(mx);
+                const uint32_t el = hh * hd + i, g = el >> 6, jj = el & 63u, ng = q_dim >> 6;
+                const size_t gb = (size_t)(b >> 4) * ng + g;
+                xf_out[gb * 1024u + (size_t)((jj >> 4) * 16u + (b & 15u)) * 16u + (jj & 15u)] = (int8_t)q80_quant1(acc, scale);
+                if (jj == 0) xsf_out[gb * 16u + (b & 15u)] = scale;
+            }
         }
     }
 }
@@ -687,7 +729,8 @@ hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float 
     if (xf_out && (hd % 64u || !xsf_out)) return hipErrorInvalidValue;
     if (nsplit == 0 || nsplit > ATTN_MAX_NSPLIT) return hipErrorInvalidValue;
     if (nsplit <= 8) hipLaunchKernelGGL(attn_combine_tokens_kernel<8>, dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit, xf_out, xsf_out);
-    else hipLaunchKernelGGL((attn_combine_tokens_kernel<(int)ATTN_MAX_NSPLIT>), dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit, xf_out, xsf_out);
+    else if (nsplit <= 32) hipLaunchKernelGGL(attn_combine_tokens_kernel<32>, dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit, xf_out, xsf_out);
+    else hipLaunchKernelGGL(attn_combine_tokens_kernel<64>, dim3(n_head, nb), dim3(128), 0, st, part, ml, out, n_head, hd, nsplit, xf_out, xsf_out);
     return hipGetLastError();
 }
 

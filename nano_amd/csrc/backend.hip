@@ -386,7 +386,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
         kvn = L * (size_t)m->kv_pages * 64 * KD;
     }
     m->trace_cap = max_seq_len * max_batch;
-    m->nsplit_cap = max_seq_len > ATTN_WIDE_FROM ? ATTN_MAX_NSPLIT : 8;     // partial buffers are sized for the maximum
+    m->nsplit_cap = max_seq_len > attention_wide_from() ? attention_split_cap() : 8;     // partial buffers are sized for the maximum
     bool ok = hipMalloc(&m->x, Bs * E * 4) == hipSuccess && hipMalloc(&m->q, Bs * QD * 4) == hipSuccess &&
               hipMalloc(&m->kraw, Bs * KD * 4) == hipSuccess && hipMalloc(&m->xba, Bs * QD * 4) == hipSuccess &&
               hipMalloc(&m->hb, Bs * H * 4) == hipSuccess && hipMalloc(&m->logits, B * V * 4) == hipSuccess &&

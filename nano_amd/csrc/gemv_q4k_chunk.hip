@@ -36,11 +36,12 @@ __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
     const uint32_t epi = role_epi<ROLE>(a);
     const bool swiglu = epi == GEMV_EPI_SWIGLU;
     const uint32_t nmat = swiglu ? 2u : 1u;
-    // LDS: xg[GT] | red[16 (+ combine weights)] | scr[NW][64] | am[2 NW] | Dt[nmat][RW][BP]
+    // LDS: xg[GT] | red[16 (+ combine weights)] | scr[NW][SL][64] (SL = D lines per wave; looping launches: 1) | am[2 NW] | Dt[nmat][RW][BP]
     XGroup *xg = reinterpret_cast<XGroup *>(smem);
     float *red = reinterpret_cast<float *>(smem + (size_t)GT * sizeof(XGroup));
     float *scr = red + 16 + (has_flag<ROLE>(a, F_COMBINE) ? a.attn_n_head * 8u : 0u);
-    float *am = scr + NW * 64u;
+    constexpr uint32_t SL = LOOP ? 1u : (uint32_t)D;
+    float *am = scr + NW * SL * 64u;
     float *Dt = am + 2u * NW;
 
     // late-read arguments are fetched with the first ones (karg_touch, gemv_common.h)
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
     NANO_STAMP(a.stamps, 1, tid);                                   // every load of the first ring issued
 
     // ---- a wave-load in two halves: what needs only the weights (pre), what needs the staged activation (post) ----------------------
-    float *scw = scr + wid * 64u;                                   // this wave's line: group values of the six blocks in hand
+    float *scw = scr + wid * SL * 64u;                              // this wave's lines: group values of the six blocks of a wave-load
     const int ha0 = (int)(cl * 40u), ha1 = ha0 + 4;                 // byte addresses (ds_bpermute) of this lane's two header lanes
     const uint32_t g = (c - 2u) & 7u;                               // group of the block (lanes with c >= 2; the header lanes compute along, unused)
     struct Pre { float sp, bp, su; };
@@ -115,7 +116,10 @@ __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
         for (int m = 0; m < 4; m++) sump = __builtin_amdgcn_udot8(wn[m], 0x11111111u, sump, false);
         return Pre{(float)s6 * s_scale, (float)b6 * s_bias, (float)(int)sump};
     };
-    auto post = [&](const uint4 v, const Pre q, const uint32_t t) __attribute__((always_inline)) {
+    // post, step A: the group values of wave-load t into line `ln` of this wave's scratch; step B: the block's first lane adds the
+    // eight in order and files the block sum.  Straight-line launches run A for all their wave-loads, then B for all (the LDS round
+    // trips of D independent wave-loads overlap instead of queueing up behind one another).
+    auto post_a = [&](const uint4 v, const Pre q, const uint32_t t, float *ln) __attribute__((always_inline)) {
         const bool m1 = swiglu && t >= T;
         const uint32_t tl = t - (m1 ? T : 0u);
         const uint32_t b = tl * 6u + cl;                                // block of the workgroup's run
@@ -129,16 +133,21 @@ __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
             for (int m = 0; m < 4; m++) spq = __builtin_amdgcn_udot8(wn[m], xq.pk[m], spq, false);
             const float sp = q.sp, bp = q.bp, sq = xq.sq, bq = xq.bq;
             // reference tensor.c:425-428, same association (whole blocks: every group has 32 values)
-            scw[cl * 8u + g] = sp * sq * (float)(int)spq - sp * bq * q.su - sq * bp * (float)xq.sumq + 32 * bp * bq;
+            ln[cl * 8u + g] = sp * sq * (float)(int)spq - sp * bq * q.su - sq * bp * (float)xq.sumq + 32 * bp * bq;
         }
-        __builtin_amdgcn_wave_barrier();                                // (the LDS queue of a wave is in order: the reads below see the writes above)
+    };
+    auto post_b = [&](const uint32_t t, const float *ln) __attribute__((always_inline)) {
+        const bool m1 = swiglu && t >= T;
+        const uint32_t tl = t - (m1 ? T : 0u);
+        const uint32_t b = tl * 6u + cl;
+        const bool bv = t < TT && live && b < nblk;
+        const uint32_t rl = bpl == 1u ? b : __umulhi(b, a.magic_nchunk), blk = b - rl * bpl;
         if (bv && c == 0u) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(scw + cl * 8u), v1 = *reinterpret_cast<const float4 *>(scw + cl * 8u + 4u);
+            const float4 v0 = *reinterpret_cast<const float4 *>(ln + cl * 8u), v1 = *reinterpret_cast<const float4 *>(ln + cl * 8u + 4u);
             float d = 0.0f;                                             // the 8 groups of a block in order (tensor.c:359-434)
             d += v0.x; d += v0.y; d += v0.z; d += v0.w; d += v1.x; d += v1.y; d += v1.z; d += v1.w;
             Dt[((m1 ? RW : 0u) + rl) * BP + blk] = d;
         }
-        __builtin_amdgcn_wave_barrier();
     };
 
     // The activation: normalised from registers, block-quantized wave-locally into LDS.  A wave that is done with its blocks (or has
@@ -159,14 +168,20 @@ __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
 
     if constexpr (!LOOP) {
 #pragma unroll
-        for (int k = 0; k < D; k++) post(ring[k], pq[k], wid + (uint32_t)k * NW);
+        for (int k = 0; k < D; k++) post_a(ring[k], pq[k], wid + (uint32_t)k * NW, scw + k * 64);
+        __builtin_amdgcn_wave_barrier();                                // (the LDS queue of a wave is in order: the reads below see the writes above)
+#pragma unroll
+        for (int k = 0; k < D; k++) post_b(wid + (uint32_t)k * NW, scw + k * 64);
     } else {
         // persistent: `a.units` rounds of D wave-loads; a consumed slot is asked for again at once (loads past the end: out of range, no traffic)
         for (uint32_t r = 0; r < a.units; r++) {
 #pragma unroll
             for (int k = 0; k < D; k++) {
                 const uint32_t t = wid + (r * (uint32_t)D + (uint32_t)k) * NW;
-                post(ring[k], pre(ring[k]), t);
+                post_a(ring[k], pre(ring[k]), t, scw);
+                __builtin_amdgcn_wave_barrier();
+                post_b(t, scw);
+                __builtin_amdgcn_wave_barrier();
                 ring[k] = issue(t + (uint32_t)D * NW);
             }
         }
@@ -183,9 +198,12 @@ __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
             const float *f = Dt + ((size_t)mat * RW + tid) * BP;
             float line = 0.0f;
             uint32_t blk = 0;
-            for (; blk + 4 <= bpl; blk += 4) {
-                const float d0 = f[blk], d1 = f[blk + 1], d2 = f[blk + 2], d3 = f[blk + 3];
-                line += d0; line += d1; line += d2; line += d3;
+            for (; blk + 8 <= bpl; blk += 8) {                          // eight reads go out together; the sum itself is serial (the reference's order)
+                float dd[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) dd[k] = f[blk + k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) line += dd[k];
             }
             for (; blk < bpl; blk++) line += f[blk];
             res[mat] = line;
@@ -223,9 +241,9 @@ __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 struct ChunkPlan { uint32_t rw, nthr, d, loop, rounds, nv, wg[3], grid; size_t lds; };
 
-size_t chunk_lds_bytes(uint32_t n, bool combine, uint32_t attn_n_head, uint32_t nmat, uint32_t rw, uint32_t nw) {
+size_t chunk_lds_bytes(uint32_t n, bool combine, uint32_t attn_n_head, uint32_t nmat, uint32_t rw, uint32_t nw, uint32_t sl) {
     const size_t bpl = n >> 8, GT = bpl * 8;
-    return GT * sizeof(XGroup) + (16 + (combine ? (size_t)attn_n_head * 8 : 0) + (size_t)nw * 64 + 2 * (size_t)nw + (size_t)nmat * rw * (bpl | 1)) * 4 + 16;
+    return GT * sizeof(XGroup) + (16 + (combine ? (size_t)attn_n_head * 8 : 0) + (size_t)nw * sl * 64 + 2 * (size_t)nw + (size_t)nmat * rw * (bpl | 1)) * 4 + 16;
 }
 
 bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
@@ -251,7 +269,7 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
     uint32_t best = 0, best_cost = ~0u;
     for (uint32_t c = 1; c <= 1024; c++) {
         if ((uint64_t)c * bpl >= 65536u) break;                          // the kernel's ceil(nblk / 6) and b / bpl by multiplication
-        if (chunk_lds_bytes(a.n, a.attn_part != nullptr, a.attn_n_head, nmat, c, 16) * k > 150u * 1024u) break;
+        if (chunk_lds_bytes(a.n, a.attn_part != nullptr, a.attn_n_head, nmat, c, 16, 8) * k > 150u * 1024u) break;
         uint32_t wgs = 0;
         for (uint32_t s = 0; s < nseg; s++) wgs += (a.seg[s].rows + c - 1) / c;
         // rows of the busiest CU slot; several rounds of workgroups pay the prologue (activation, norm, block quantizer) once per round
@@ -276,7 +294,7 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
     if (p.nv > 4) return false;
     p.grid = 0;
     for (uint32_t s = 0; s < 3; s++) { p.wg[s] = s < nseg ? (a.seg[s].rows + best - 1) / best : 0; p.grid += p.wg[s]; }
-    p.lds = chunk_lds_bytes(a.n, a.attn_part != nullptr, a.attn_n_head, nmat, best, nw);
+    p.lds = chunk_lds_bytes(a.n, a.attn_part != nullptr, a.attn_n_head, nmat, best, nw, p.loop ? 1u : p.d);
     return p.lds <= 160u * 1024u;
 }
 

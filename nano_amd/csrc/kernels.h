@@ -123,7 +123,11 @@ uint32_t route_norm_order(const Q80Route &r, const GemvArgs &a);
 bool route_is_wide(const GemvArgs &a);
 
 // ---- attention ------------------------------------------------------------------------------------
-constexpr uint32_t ATTN_MAX_NSPLIT = 32, ATTN_WIDE_FROM = 2048;   // up to 32 splits of a range beyond 2048 positions (<= 8 below: attention_nsplit())
+// up to attention_split_cap() (default 32, capacity 64) splits of a range beyond attention_wide_from() positions (default 2048; <= 8
+// below, which the Wo GEMV's prologue combines: attention_nsplit())
+constexpr uint32_t ATTN_MAX_NSPLIT = 64;
+uint32_t attention_wide_from();
+uint32_t attention_split_cap();
 struct AttnArgs {
     const float *q;         // [nb][q_dim] raw q from the QKV GEMV (normed + roped in LDS, head-local)
     float *q_out;           // optional [nb][q_dim]: finished q written back (debug / traces), or nullptr

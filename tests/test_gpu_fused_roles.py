@@ -301,6 +301,36 @@ def test_k4_norm_swiglu_q4k(oracle, n, rows):
     assert np.array_equal(bits(both), bits(np.concatenate([h1, h3])))
 
 
+@pytest.mark.parametrize("nb_", [1, 2])
+def test_q4k_block_quantizer_ties_bit_exact(oracle, nb_):
+    """The register block quantizer rounds x / scale through a reciprocal where that is provably the reference's integer and divides
+    exactly next to a tie (gemv_q4k_impl.h quot_fast): activations whose quotients ARE ties (k + 1/2), one float off a tie, and whose
+    6-bit group scales are ties -- the launch's output moves if one nibble or one 6-bit scale differs from the reference's."""
+    n, rows = 1024, 512
+    rng = np.random.default_rng(23)
+    xs = []
+    for b in range(nb_):
+        x = (rng.standard_normal(n) * 2).astype(np.float32)
+        g = np.zeros(32, np.float32); g[0] = 0.0; g[1] = 15.0                       # scale 1, bias 0: quotients = values
+        g[2:17] = np.arange(15, dtype=np.float32) + 0.5                              # exact ties 0.5 .. 14.5
+        g[17:24] = np.nextafter(np.arange(7, dtype=np.float32) + 0.5, np.float32(100))
+        g[24:32] = np.nextafter(np.arange(8, dtype=np.float32) + 1.5, np.float32(-100))
+        x[0:32] = g
+        h = g - np.float32(3.0)                                                      # scale 1, bias 3: the same ties through v + bias
+        x[32:64] = h
+        x[64:96] = rng.uniform(0, 945, 32).astype(np.float32); x[64] = 0.0; x[65] = 945.0      # group scale 63 -> the block's s_scale = 1
+        x[96:128] = rng.uniform(0, 157.5, 32).astype(np.float32); x[96] = 0.0; x[97] = 157.5   # group scale 10.5: a 6-bit tie
+        x[128:160] = rng.uniform(0, 7.5, 32).astype(np.float32) - np.float32(22.5); x[128] = -22.5; x[129] = -15.0   # bias 22.5 against bmax
+        x[256:288] = g * np.float32(3.0)                                             # another block: scale 3, ties again
+        xs.append(x)
+    X = np.stack(xs)
+    old = rng.standard_normal((nb_, rows)).astype(np.float32)
+    WT = q4k_weights(oracle, rng, rows, n)
+    ref = np.stack([(old[b] + ref_q4k(oracle, X[b], [(WT, rows)], n)).astype(np.float32) for b in range(nb_)])
+    out = nb.op_fused_gemv(Q4K, 1, n, [(WT[44:], None, rows)], X, None, nb=nb_, resid=old)
+    assert np.array_equal(bits(out), bits(ref)), [(b, int((bits(out[b]) != bits(ref[b])).sum()), float(np.abs(out[b] - ref[b]).max())) for b in range(nb_)]
+
+
 def test_classifier_q4k_persistent_workgroups_bit_exact(oracle):
     # rows >= 65536, one STORE segment: gemv_q4k_chunk.hip's looping workgroups (ring of 8 loads per wave), last workgroup ragged
     n, rows = 1024, 65536 + 37

@@ -80,5 +80,11 @@ q4c)   # Q4K 16-byte-chunk kernel (gemv_q4k_chunk.hip): parity, A/B against roun
   NANO_BENCH_NO_TRAFFIC=1 bench q06_q4k_table --quant q4k --steps 48 --warmup 4
   for a in "wide-qwen3 q4k 1 30" "qwen3-0.6b q4k 1 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$R/nano_amd/lib/libnano_mi355x_stamps.so timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done | tee $O/stamps_q4k_chunk.txt
   ;;
+lc)    # long-context attention: parity subset, step time vs position for the split policies, phase stamps at 4095 / 2047
+  timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_e2e.py -m gpu -x -q -k "attention or long_context or prefill" 2>&1 | tail -4
+  timeout 300 python tools/long_ctx_probe.py 2>&1 | tail -10 | tee $O/long_ctx.txt
+  for cfg in "2048 64" "1024 32" "1024 64" "512 32"; do set -- $cfg; echo "NANO_ATTN_WIDE_FROM=$1 NANO_ATTN_MAX_SPLITS=$2"; NANO_ATTN_WIDE_FROM=$1 NANO_ATTN_MAX_SPLITS=$2 timeout 300 python tools/long_ctx_probe.py 2>&1 | grep "FP32" | grep -v "pos 255\|pos 511"; done | tee $O/long_ctx_policies.txt
+  for p in 4095 2047; do NANO_STAMPS_GRAPH=1 NANO_LIB=$R/nano_amd/lib/libnano_mi355x_stamps.so timeout 300 python tools/stamp_probe.py qwen3-0.6b q80 1 $p 2>&1 | tail -17 | head -8; done | tee $O/stamps_long_ctx.txt
+  ;;
 *) echo "unknown mode $1";;
 esac

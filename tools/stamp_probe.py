@@ -24,11 +24,12 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 pos = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 GHZ = float(os.environ.get("NANO_STAMP_GHZ", "2.1"))
 gs = 64 if quant == "q80" else 0
-spec = mf.preset(model, quant, group_size=gs, block_size=1024)
-path = f"/tmp/nano_bench_{model}_{quant}_gs{gs}.bin"
+bs = 1024 if pos < 1024 else ((pos + 1 + 1023) // 1024) * 1024     # rows of the RoPE tables
+spec = mf.preset(model, quant, group_size=gs, block_size=bs)
+path = f"/tmp/nano_bench_{model}_{quant}_gs{gs}.bin" if bs == 1024 else f"/tmp/nano_bench_{model}_{quant}_gs{gs}_bs{bs}.bin"
 if not (os.path.exists(path) and os.path.getsize(path) == mf.param_layout(spec).total_bytes):
     mf.write_model(path, spec, seed=39)
-m = nb.load_model_file(path, max_seq_len=512, max_batch=B)
+m = nb.load_model_file(path, max_seq_len=max(512, pos + 1), max_batch=B)
 for p in range(0, pos):                                     # some KV history (values irrelevant)
     m.forward([1] * B, [p] * B, want_logits=False)
 names = {1: "qkv", 2: "attention", 3: "wo", 4: "w1w3", 5: "w2"}
