@@ -162,8 +162,15 @@ constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight 
 // instruction of the one wave per SIMD is on the critical path): 0 generic (run-time flags), 1 Qwen3 decode (q/k-norm,
 // half-split RoPE, staged RoPE row, fresh k, causal), 2 Nano/Qwen2 decode (adjacent-pair RoPE, staged row, fresh k, causal).
 // PG: the paged KV cache (kernels.h AttnArgs::pt_rows) -- a template parameter so that the contiguous cache's code stays as it was
-template <int LPR, int QV, int KVM, int MODE, bool KVH, bool PG>
+// NPT: timestep blocks a workgroup keeps in flight per round (NPT = 2; 4 for the launches that would otherwise walk several rounds:
+// twice the rows requested at kernel entry, half the dependent round trips)
+// W16 (FP16 rows, QV a multiple of 4, head_dim % 8 == 0): a lane's loads stay 16 bytes wide -- EIGHT halfs, i.e. the float4 slots
+// 2c and 2c + 1 of chunk c = j + LPR * (q / 2) -- so a row costs half the load instructions and every instruction still asks for
+// whole 128-byte lines (round 3's 8-byte loads: as many requests as FP32 rows for half the bytes, and not a microsecond saved).
+// The RoPE partner of slot q stays slot q + QV / 2 of the same lane (f + 2 LPR = half a head further for QV = 4).
+template <int LPR, int QV, int KVM, int MODE, bool KVH, bool PG, int NPT, bool W16>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+    static_assert(!W16 || (KVH && QV % 4 == 0), "16-byte FP16 loads: two float4 slots per load");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = 256 / LPR;                 // timesteps per block
     const int tid = threadIdx.x, lane = tid & 63;
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const __amdgpu_buffer_rsrc_t rk = mkrsrc(kc, cache_bytes - g * hd * ESZ);
     const __amdgpu_buffer_rsrc_t rv = mkrsrc(vc, cache_bytes - g * hd * ESZ);
     const uint32_t sub = (uint32_t)tid / LPR, j = (uint32_t)tid % LPR;
+    auto fidx = [&](int q) -> uint32_t { return W16 ? 2u * (j + (uint32_t)LPR * (uint32_t)(q >> 1)) + (uint32_t)(q & 1) : j + (uint32_t)LPR * (uint32_t)q; };   // float4 slot q of this lane
     const uint32_t range_hint = fixed_range ? fixed_range : a.range_hint;
 
     // ---- q heads and the raw k row ------------------------------------------------------------------------------------
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         const __amdgpu_buffer_rsrc_t rr = mkrsrc(a.rope_cur + (size_t)b * 2 * half, 2 * half * 4u);
 #pragma unroll
         for (int q = 0; q < QV; q++) {
-            const uint32_t f = j + (uint32_t)LPR * q;
+            const uint32_t f = fidx(q);
             const uint32_t fo = (f * 4u < hd) ? f * 16u : OOB;
 #pragma unroll
             for (int m = 0; m < KVM; m++) qv[m][q] = bload_f4(rq, fo == OOB ? OOB : (h0 + m) * hd * 4u + fo);
@@ -301,11 +309,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         }
     }
     }
-    KVRaw<KVH> kreg[NP][QV], vreg[NP][QV];
+    KVRaw<KVH> kreg[NPT][QV], vreg[NPT][QV];
     auto issue_kv = [&](uint32_t round) {
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const uint32_t tb = ((round * NP + p) * nsplit + split) * R, t = tb + sub;
+        for (int p = 0; p < NPT; p++) {
+            const uint32_t tb = ((round * NPT + p) * nsplit + split) * R, t = tb + sub;
             uint32_t row = t;                                              // row of timestep t inside this sequence's / the pool's layer plane
             if constexpr (PG) {                                            // (a block of R <= 64 timesteps lies in one page)
                 const uint32_t blk = tb >> 6;
@@ -319,10 +327,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             }
 #pragma unroll
             for (int q = 0; q < QV; q++) {
-                const uint32_t f = j + (uint32_t)LPR * q;                  // float4 index inside the head
+                const uint32_t f = fidx(q);                                // float4 index inside the head
                 const uint32_t off = (f * 4u < hd && t < range_hint && row < 0x7fffffu) ? (row * a.kv_dim + f * 4u) * ESZ : OOB;
-                kreg[p][q] = kv_load4<KVH>(rk, off);
-                vreg[p][q] = kv_load4<KVH>(rv, off);
+                if constexpr (W16) {
+                    if ((q & 1) == 0) {                                        // slots q, q + 1: one 16-byte load
+                        const i32x4 kk = __builtin_amdgcn_raw_buffer_load_b128(rk, (int)off, 0, 0), vv = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)off, 0, 0);
+                        kreg[p][q].v = make_uint2((uint32_t)kk.x, (uint32_t)kk.y); kreg[p][q + 1].v = make_uint2((uint32_t)kk.z, (uint32_t)kk.w);
+                        vreg[p][q].v = make_uint2((uint32_t)vv.x, (uint32_t)vv.y); vreg[p][q + 1].v = make_uint2((uint32_t)vv.z, (uint32_t)vv.w);
+                    }
+                } else {
+                    kreg[p][q] = kv_load4<KVH>(rk, off);
+                    vreg[p][q] = kv_load4<KVH>(rv, off);
+                }
             }
         }
     };
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
             float *vrow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)prow * a.kv_dim * ESZ);
 #pragma unroll
             for (int q = 0; q < QV; q++) {
-                const uint32_t f = j + (uint32_t)LPR * q;
+                const uint32_t f = fidx(q);
                 if (f * 4u < hd) { kv_store4<KVH>(krow, 4u * f, kfresh[q]); if (KVH && fresh_v) kv_store4<KVH>(vrow, 4u * f, vfresh[q]); }
             }
         }
@@ -450,7 +466,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     if constexpr (KVH) {                                          // generic path: the fresh v row straight from scratch, rounded, stored by split 0
 #pragma unroll
         for (int q = 0; q < QV; q++) {
-            const uint32_t f = j + (uint32_t)LPR * q;
+            const uint32_t f = fidx(q);
             const bool ok = f * 4u < hd;
             vfresh[q] = kv_round<KVH>(bload_f4(rvr, ok ? g * hd * 4u + f * 16u : OOB));
             if (fresh_v && ok && split == 0 && sub == 0 && first_of_group)
@@ -463,7 +479,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     // ---- 3. scores, running softmax over rounds ------------------------------------------------------------------
 #pragma unroll
     for (int q = 0; q < QV; q++) {
-        const uint32_t f = j + (uint32_t)LPR * q;
+        const uint32_t f = fidx(q);
         const bool ok = f * 4u < hd;
 #pragma unroll
         for (int m = 0; m < KVM; m++) qv[m][q] = ok ? *reinterpret_cast<const float4 *>(qh + m * hd4 + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -480,15 +496,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
         for (int q = 0; q < QV; q++) acc[m][q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const uint32_t per_round = NP * nsplit * R;
+    const uint32_t per_round = NPT * nsplit * R;
     const uint32_t limit = range < range_hint ? range : range_hint;
     const uint32_t nround = (limit + per_round - 1) / per_round;
     for (uint32_t round = 0; round < nround; round++) {
         if (round) issue_kv(round);
-        float sc[KVM][NP];
+        float sc[KVM][NPT];
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const uint32_t t = ((round * NP + p) * nsplit + split) * R + sub;
+        for (int p = 0; p < NPT; p++) {
+            const uint32_t t = ((round * NPT + p) * nsplit + split) * R + sub;
             const bool fresh = fresh_k && t == pos;
 #pragma unroll
             for (int m = 0; m < KVM; m++) {
@@ -506,16 +522,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         for (int m = 0; m < KVM; m++) {
             float mx = mrun[m];
 #pragma unroll
-            for (int p = 0; p < NP; p++) mx = fmaxf(mx, sc[m][p]);
+            for (int p = 0; p < NPT; p++) mx = fmaxf(mx, sc[m][p]);
             const float scale = (mrun[m] == -INFINITY) ? 0.0f : expf(mrun[m] - mx);
             float l = lrun[m] * scale;
 #pragma unroll
             for (int q = 0; q < QV; q++) { acc[m][q].x *= scale; acc[m][q].y *= scale; acc[m][q].z *= scale; acc[m][q].w *= scale; }
 #pragma unroll
-            for (int p = 0; p < NP; p++) {
+            for (int p = 0; p < NPT; p++) {
                 const float e = (sc[m][p] == -INFINITY) ? 0.0f : expf(sc[m][p] - mx);
                 l += e;
-                const uint32_t tv = ((round * NP + p) * nsplit + split) * R + sub;
+                const uint32_t tv = ((round * NPT + p) * nsplit + split) * R + sub;
                 const bool vf = KVH && fresh_v && tv == pos;       // FP16 cache: the fresh v row is not in the cache yet
 #pragma unroll
                 for (int q = 0; q < QV; q++) {
@@ -542,7 +558,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
         for (int q = 0; q < QV; q++) {
             const float4 t = make_float4(xsub_sum<LPR>(acc[m][q].x * w), xsub_sum<LPR>(acc[m][q].y * w), xsub_sum<LPR>(acc[m][q].z * w), xsub_sum<LPR>(acc[m][q].w * w));
-            const uint32_t f = j + (uint32_t)LPR * q;
+            const uint32_t f = fidx(q);
             if (lane < LPR && f * 4u < hd) *reinterpret_cast<float4 *>(part + ((size_t)wid * KVM + m) * hd4 + 4 * f) = t;
         }
         if (lane == 0) { redm[m * 4 + wid] = Mw; redl[m * 4 + wid] = lw; }
@@ -590,9 +606,8 @@ template <int LPR, int QV, int MODE, bool KVH>
 static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t st) {
     const uint32_t kv_mul = a_in.n_head / a_in.n_kv_head;
     const uint32_t hd4 = (a_in.hd + 3) & ~3u;
-    constexpr uint32_t R = 256 / LPR;
+    constexpr uint32_t R = 256 / LPR;                          // timesteps per block
     auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + 4 * kvm + (size_t)4 * kvm * hd4) * sizeof(float); };
-    (void)R;
     // q heads per workgroup (KVM; h0 = KVM grp, KV head h0 / kv_mul): fewer heads = more workgroups with less dependent work each,
     // the K/V rows' repeated reads come from L2 (and the KV head's fresh k row is written by each of its workgroups: same
     // bits).  Same per-head arithmetic whatever the choice.  One head per workgroup while that leaves at most one workgroup
@@ -610,10 +625,26 @@ static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t 
     const uint64_t head_wgs = (uint64_t)a.n_head * nb * a.nsplit;
     uint32_t kvm = (head_wgs <= 256u || kv_mul % 2 != 0) ? 1u : (head_wgs <= 1024u || kv_mul % 4 != 0) ? 2u : 4u;
     if (forced == 1u || (forced == 2u && kv_mul % 2 == 0) || (forced == 4u && kv_mul % 4 == 0)) kvm = forced;
-#define ATTN_GO(KVM_) do { if (a.pt_rows) hipLaunchKernelGGL((attention_kernel<LPR, QV, KVM_, MODE, KVH, true>), dim3(a.n_head / KVM_, nb, a.nsplit), dim3(256), lds_for(KVM_), st, a); \
-                         else hipLaunchKernelGGL((attention_kernel<LPR, QV, KVM_, MODE, KVH, false>), dim3(a.n_head / KVM_, nb, a.nsplit), dim3(256), lds_for(KVM_), st, a); } while (0)
-    if (kvm == 4) ATTN_GO(4); else if (kvm == 2) ATTN_GO(2); else ATTN_GO(1);
+    // A workgroup that would walk exactly two rounds of NP blocks (513 .. 1024 positions at 8 splits) keeps four blocks in flight
+    // instead: every row of the launch requested at kernel entry (Qwen3-0.6B at position 1023: 639 -> 632 us per step).  Measured
+    // and NOT taken beyond: four rounds -> two at 2047 positions 754 -> 759 us, two -> one at 4095 with 32 splits 819 -> 836 (the
+    // issue phase grows from 3.1 to 5.9 us: `profiles/r04_long_ctx_np4.txt`).  Decided by the range and the split count alone --
+    // never by the batch: a token's attention is the same expression in a decode step and in a prefill chunk (the four-head
+    // workgroups of large batches give way to two heads).
+    static const bool np4_on = !(getenv("NANO_ATTN_NP4") && *getenv("NANO_ATTN_NP4") == '0');                // measurement knob
+    const bool np4 = np4_on && !a.prep_only && a.nsplit <= 8u && a.range_hint > a.nsplit * (uint32_t)NP * R && a.range_hint <= 2u * a.nsplit * (uint32_t)NP * R;
+    if (np4 && kvm == 4) kvm = 2;
+    constexpr bool CAN16 = KVH && QV % 4 == 0;
+    static const bool w16_on = !(getenv("NANO_ATTN_W16") && *getenv("NANO_ATTN_W16") == '0');                // measurement knob
+    const bool w16 = CAN16 && w16_on && a.hd % 8u == 0u;
+#define ATTN_GO3(KVM_, NP_, PG_) do { if constexpr (CAN16) { if (w16) { hipLaunchKernelGGL((attention_kernel<LPR, QV, KVM_, MODE, KVH, PG_, NP_, CAN16>), dim3(a.n_head / KVM_, nb, a.nsplit), dim3(256), lds_for(KVM_), st, a); break; } } \
+                         hipLaunchKernelGGL((attention_kernel<LPR, QV, KVM_, MODE, KVH, PG_, NP_, false>), dim3(a.n_head / KVM_, nb, a.nsplit), dim3(256), lds_for(KVM_), st, a); } while (0)
+#define ATTN_GO2(KVM_, NP_) do { if (a.pt_rows) ATTN_GO3(KVM_, NP_, true); else ATTN_GO3(KVM_, NP_, false); } while (0)
+#define ATTN_GO(KVM_) do { if (np4) ATTN_GO2(KVM_, 4); else ATTN_GO2(KVM_, NP); } while (0)
+    if (kvm == 4) ATTN_GO2(4, NP); else if (kvm == 2) ATTN_GO(2); else ATTN_GO(1);
 #undef ATTN_GO
+#undef ATTN_GO2
+#undef ATTN_GO3
     return hipGetLastError();
 }
 template <int LPR, int QV, int MODE>

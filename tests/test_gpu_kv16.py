@@ -101,6 +101,11 @@ def test_kv16_fullsize_long_context(model_dir):
         a, _ = m32.forward([int(ids[pos])], [pos])
         b, _ = m16.forward([int(ids[pos])], [pos])
         worst = max(worst, rel_err(b[0], a[0]))
+    # head_dim 128: the FP16 rows travel as 16-byte loads (eight halfs per lane, attn.hip W16) -- the stored rows are still the FP32
+    # path's rows rounded to FP16 (layer 0, position 0 depends on no cache row)
+    for name in ("k", "v"):
+        r32 = m32.read_state(name, spec.kv_dim, layer=0, pos=0); r16 = m16.read_state(name, spec.kv_dim, layer=0, pos=0)
+        assert np.array_equal(r16, r32.astype(np.float16).astype(np.float32)), name
     t32 = min(m32.time_step(1, 500, 30) for _ in range(2)) * 1e3
     t16 = min(m16.time_step(1, 500, 30) for _ in range(2)) * 1e3
     m32.close(); m16.close()
