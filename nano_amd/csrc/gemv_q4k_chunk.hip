@@ -198,12 +198,9 @@ __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
             const float *f = Dt + ((size_t)mat * RW + tid) * BP;
             float line = 0.0f;
             uint32_t blk = 0;
-            for (; blk + 8 <= bpl; blk += 8) {                          // eight reads go out together; the sum itself is serial (the reference's order)
-                float dd[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) dd[k] = f[blk + k];
-#pragma unroll
-                for (int k = 0; k < 8; k++) line += dd[k];
+            for (; blk + 4 <= bpl; blk += 4) {                          // four reads go out together; the sum itself is serial (the reference's order)
+                const float d0 = f[blk], d1 = f[blk + 1], d2 = f[blk + 2], d3 = f[blk + 3];
+                line += d0; line += d1; line += d2; line += d3;
             }
             for (; blk < bpl; blk++) line += f[blk];
             res[mat] = line;
@@ -256,7 +253,8 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
     uint32_t rows = 0;
     for (uint32_t s = 0; s < nseg; s++) rows += a.seg[s].rows;
     if (rows == 0) return false;
-    uint32_t want = ((a.n / 4 + 63) / 64) * 64;                        // the block quantizer: four elements per thread and pass
+    static const uint32_t want_div = [] { const char *e = getenv("NANO_Q4K_CHUNK_WANT"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v == 8u || v == 16u ? v : 4u; }();   // measurement knob
+    uint32_t want = ((a.n / want_div + 63) / 64) * 64;                 // the block quantizer: four elements per thread and pass
     if (want < 256) want = 256;
     if (want > 1024) want = 1024;
     const bool cls = nseg == 1 && a.epi == GEMV_EPI_STORE && rows >= 65536u;
@@ -282,7 +280,9 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
     p.rw = best;
     const uint32_t TT = nmat * ((best * bpl + 5) / 6);
     uint32_t nw = want / 64;
-    if (!cls) { const uint32_t m = TT < 16 ? TT : 16; if (nw < m) nw = m; }
+    // one wave-load per wave where the workgroup's waves allow it (<= 16): every load at kernel entry, no serial second item
+    static const uint32_t per_want = [] { const char *e = getenv("NANO_Q4K_CHUNK_PER"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v >= 1u && v <= 8u ? v : 2u; }();   // measurement knob
+    if (!cls) { uint32_t m = (TT + per_want - 1) / per_want; if (m > 16) m = 16; if (nw < m) nw = m; }
     if (nw * 64 < best) nw = (best + 63) / 64;                           // one fold thread per row
     if (nw > 16) return false;
     uint32_t per = (TT + nw - 1) / nw;

@@ -174,23 +174,6 @@ __device__ __forceinline__ void stage_xn(const GemvDev &a, Staged<B, NV> &r, flo
     }
 }
 
-// round-to-nearest-integer of a quotient without the IEEE division expansion (~12 instructions, v_div_scale .. v_div_fixup) where that is
-// provably the same integer.  The quantizers only use nearest_int_magic(num / den), and for |q| < 2^22 that is the round-half-even
-// integer of the correctly rounded quotient q = RN(num / den).  q~ = num * rcp(den): v_rcp_f32 is accurate to 1 ulp (relative
-// 2^-23; 2^-22 assumed here), the product rounds once more (2^-24), so for |num / den| < 64: |q~ - num / den| < 64 * 1.25 * 2^-22
-// < 2^-15.6, and |q - num / den| <= 2^-19.  If q~ is farther than 2^-13 (> 2 * 2^-15.6 + 2^-19) from every tie k + 1/2, the exact
-// quotient, its correct rounding and q~ all lie strictly between the same two ties: the same integer.  Otherwise -- and for
-// NaN, infinities (den denormal: the reciprocal overflows), |q~| >= 64 -- `safe` turns false and the caller divides exactly (a
-// wave-uniform branch: one lane in ~2^-12 per quotient).  Round 3 measured the same idea as neutral on Qwen3-0.6B (one block
-// per wave: latency, not instruction count, bounds that prologue); on Qwen3-4B's rows a SIMD runs 4 waves x 3 blocks of the
-// quantizer back to back (3.6 us of W2's 8.4) and the instruction count is the bound.
-__device__ __forceinline__ float quot_fast(float num, float rden, bool &safe) {
-    const float q = num * rden;
-    const float fr = __builtin_amdgcn_fractf(q);
-    safe = safe && (fabsf(fr - 0.5f) > 0x1p-13f) && (fabsf(q) < 64.0f);
-    return q;
-}
-
 // The block quantizer on values that are still in registers (whole blocks only: n % 256 == 0).  Thread t of a launch
 // holds elements 4 (t + j nthr) .. +3, so a 32-element group is 8 consecutive lanes and a 256-element block is exactly one
 // wave: group min / max / nibble sum by three DPP steps, the block's maximum scale and bias by three cross-lane steps more
@@ -220,20 +203,9 @@ __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged
                 const float gsc = (lo <= 0.0f) ? div_const<15>(hi - lo) : div_const<15>(hi);
                 const float gbi = (lo <= 0.0f) ? (-lo) : 0.0f;
                 uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-                {
-                    // round(x / gsc) through one reciprocal (quot_fast above); a wave with any quotient too close to a tie divides exactly
-                    const float rg = __builtin_amdgcn_rcpf(gsc);
-                    bool safe = true;
-                    const float q0 = quot_fast(v.x + gbi, rg, safe), q1 = quot_fast(v.y + gbi, rg, safe);
-                    const float q2 = quot_fast(v.z + gbi, rg, safe), q3 = quot_fast(v.w + gbi, rg, safe);
-                    if (__builtin_amdgcn_ballot_w64(!safe && gsc != 0.0f) == 0ull) {
-                        n0 = (uint32_t)(nearest_int_magic(q0) & 0x0f); n1 = (uint32_t)(nearest_int_magic(q1) & 0x0f);
-                        n2 = (uint32_t)(nearest_int_magic(q2) & 0x0f); n3 = (uint32_t)(nearest_int_magic(q3) & 0x0f);
-                    } else {
-                        n0 = (uint32_t)(nearest_int_magic((v.x + gbi) / gsc) & 0x0f); n1 = (uint32_t)(nearest_int_magic((v.y + gbi) / gsc) & 0x0f);
-                        n2 = (uint32_t)(nearest_int_magic((v.z + gbi) / gsc) & 0x0f); n3 = (uint32_t)(nearest_int_magic((v.w + gbi) / gsc) & 0x0f);
-                    }
-                    if (gsc == 0.0f) { n0 = 0; n1 = 0; n2 = 0; n3 = 0; }
+                if (gsc != 0.0f) {
+                    n0 = (uint32_t)(nearest_int_magic((v.x + gbi) / gsc) & 0x0f); n1 = (uint32_t)(nearest_int_magic((v.y + gbi) / gsc) & 0x0f);
+                    n2 = (uint32_t)(nearest_int_magic((v.z + gbi) / gsc) & 0x0f); n3 = (uint32_t)(nearest_int_magic((v.w + gbi) / gsc) & 0x0f);
                 }
                 const int sum = dpp_group_sum<8>((int)(n0 + n1 + n2 + n3));
                 // the block's 8 groups are the 8 lane-octets of this wave
@@ -257,20 +229,8 @@ __device__ __forceinline__ void quantize_q4k_regs(const GemvDev &a, const Staged
                     smax = (s1 > s0) ? s1 : s0; bmax = (b1 > b0) ? b1 : b0;
                 }
                 const float s_scale = div_const<63>(smax), s_bias = div_const<63>(bmax);
-                uint32_t s6, b6;
-                {
-                    bool safe = true;
-                    const float qs = quot_fast(gsc, __builtin_amdgcn_rcpf(s_scale), safe);
-                    bool safe_b = true;
-                    const float qb = quot_fast(gbi, __builtin_amdgcn_rcpf(s_bias), safe_b);
-                    if (__builtin_amdgcn_ballot_w64((!safe && s_scale != 0.0f) || (!safe_b && s_bias != 0.0f)) == 0ull) {
-                        s6 = (uint32_t)(nearest_int_magic(qs) & 0x3f); b6 = (uint32_t)(nearest_int_magic(qb) & 0x3f);
-                    } else {
-                        s6 = (uint32_t)(nearest_int_magic(gsc / s_scale) & 0x3f); b6 = (uint32_t)(nearest_int_magic(gbi / s_bias) & 0x3f);
-                    }
-                    if (s_scale == 0.0f) s6 = 0u;
-                    if (s_bias == 0.0f) b6 = 0u;
-                }
+                const uint32_t s6 = (s_scale == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(gsc / s_scale) & 0x3f);
+                const uint32_t b6 = (s_bias == 0.0f) ? 0u : (uint32_t)(nearest_int_magic(gbi / s_bias) & 0x3f);
                 if (valid) {
                     const uint32_t tg = tid & 7u;
                     XGroup *o = xg + (size_t)b * GT + (i >> 5);

@@ -303,9 +303,10 @@ def test_k4_norm_swiglu_q4k(oracle, n, rows):
 
 @pytest.mark.parametrize("nb_", [1, 2])
 def test_q4k_block_quantizer_ties_bit_exact(oracle, nb_):
-    """The register block quantizer rounds x / scale through a reciprocal where that is provably the reference's integer and divides
-    exactly next to a tie (gemv_q4k_impl.h quot_fast): activations whose quotients ARE ties (k + 1/2), one float off a tie, and whose
-    6-bit group scales are ties -- the launch's output moves if one nibble or one 6-bit scale differs from the reference's."""
+    """The register block quantizer on activations whose quotients x / scale ARE ties (k + 1/2), one float off a tie, and whose 6-bit
+    group scales are ties -- the launch's output moves if one nibble or one 6-bit scale differs from the reference's.  (Written for
+    round 4's reciprocal-with-exact-fallback quotients, which these inputs passed and a same-box A/B then removed: -2.7 % on
+    Qwen3-0.6B)"""
     n, rows = 1024, 512
     rng = np.random.default_rng(23)
     xs = []

@@ -35,6 +35,28 @@ def test_q4k_batch1_roles_issue_their_loads_without_waterfalls_or_full_waits():
                 check(k)
 
 
+def test_q4k_chunk_kernels_issue_their_loads_without_waterfalls_or_full_waits():
+    """gemv_q4k_chunk.hip (round 4, one sequence): the role kernels of a decode step, every ring depth; the looping classifier kernel
+    must wait for ONE slot of its ring of eight (vmcnt(7)), not for all of them, inside the loop."""
+    import isa_scan, re
+    asm = isa_scan.compile_to_asm(os.path.join(ROOT, "nano_amd", "csrc", "gemv_q4k_chunk.hip"))
+    recs = isa_scan.scan(asm, "gemv_q4k_chunk_kernel")
+    for role in (1, 2, 4):
+        for nv in (1, 2, 4):
+            for d, loop in ((1, 0), (2, 0), (4, 0), (8, 0), (8, 1)):
+                for k in hot(recs, [f"gemv_q4k_chunk_kernelILi{role}ELi{nv}ELi{d}ELb{loop}E"]):
+                    check(k)
+    lines = asm.split("\n")
+    start = next(i for i, ln in enumerate(lines) if ln.startswith("_Z") and "gemv_q4k_chunk_kernelILi1ELi1ELi8ELb1E" in ln and ln.rstrip().split(";")[0].rstrip().endswith(":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    body = "\n".join(lines[start:end])
+    bl = body.split("\n")
+    nt = [i for i, ln in enumerate(bl) if "buffer_load_dwordx4" in ln and " nt" in ln]
+    assert len(nt) == 16, len(nt)                          # eight at kernel entry, eight re-issues inside the loop
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(bl[nt[8]:nt[15]]))
+    assert len(waits) >= 7 and all(int(w) == 7 for w in waits), waits
+
+
 def test_q80_batch1_roles_fetch_their_arguments_up_front():
     import isa_scan
     recs = isa_scan.scan(isa_scan.compile_to_asm(os.path.join(ROOT, "nano_amd", "csrc", "gemv_q80_gs64.hip")), "gemv_q80_slab_kernel")

@@ -63,7 +63,8 @@ PY
 }
 one() { python3 -c "import json;d=json.loads(open('$1').read().strip().splitlines()[-1]);print('$2', d['value'], 'tok/s', d['ms_per_step'], 'ms', d['roofline']['frac'])" 2>/dev/null || echo "$2 FAILED"; }
 if [ "$1" = "a" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee $O/${T}_pytest_gpu.txt
+  timeout 1700 python -m pytest tests -m gpu -q > /tmp/pytest_gpu_full.txt 2>&1; echo "pytest exit code $?" >> /tmp/pytest_gpu_full.txt
+  grep -E "passed|failed|error|exit code" /tmp/pytest_gpu_full.txt | tail -6 | tee $O/${T}_pytest_gpu.txt
   ( timeout 1500 python -m pytest tests -m gpu -q -s -k "fullsize or strict or sampler_ids or config4" 2>&1 | grep -E "strict|fast path|passed|failed" ) > $O/${T}_parity.txt; tail -3 $O/${T}_parity.txt
   timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/${T}_smoke.txt
   timeout 400 python bench.py 2> $O/${T}_bench_stderr.txt | tee $O/${T}_bench_line.json | cut -c1-300
@@ -74,6 +75,8 @@ elif [ "$1" = "b" ]; then
   prof q06_q4k_b1 --quant q4k --steps 60 --warmup 4
   S=$R/nano_amd/lib/libnano_mi355x_stamps.so; S2=$R/nano_amd/lib/libnano_mi355x_stamps2.so
   { for a in "qwen3-0.6b q80 1 30" "wide-qwen3 q80 1 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done; } > $O/${T}_phase_stamps.txt; head -12 $O/${T}_phase_stamps.txt
+  { for a in "wide-qwen3 q4k 1 30" "qwen3-0.6b q4k 1 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done; } > $O/${T}_stamps_q4k_chunk.txt; head -6 $O/${T}_stamps_q4k_chunk.txt
+  { for p in 4095 2047; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 300 python tools/stamp_probe.py qwen3-0.6b q80 1 $p 2>&1 | tail -17 | head -8; done; } > $O/${T}_stamps_long_ctx.txt
   { for b in 2 8 16; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py wide-qwen3 q80 $b 30 2>&1 | tail -14; done
     NANO_G6P_B1=1 NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py wide-qwen3 q80 1 30 2>&1 | tail -14; } > $O/${T}_g6_stamps.txt; head -8 $O/${T}_g6_stamps.txt
   timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -6 | tee $O/${T}_prefill_probe.txt
@@ -93,7 +96,13 @@ else
   for b in 1 2 4 8 16 32 64; do NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_b$b.json; one $O/${T}_bench_4b_b$b.json "4B B=$b"; done
   for b in 2 8 16; do NANO_GEMM_G6=0 NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_b${b}_round3_routes.json; one $O/${T}_bench_4b_b${b}_round3_routes.json "4B B=$b round-3 routes (NANO_GEMM_G6=0)"; done
   NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --total-seqs 64 --steps 64 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_total64.json; one $O/${T}_bench_4b_total64.json "4B total-seqs 64"
-  timeout 900 python bench.py --model qwen3-4b --quant q4k --steps 64 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_q4k_b1.json; one $O/${T}_bench_4b_q4k_b1.json "4B q4k"
+  NANO_BENCH_NO_TRAFFIC=1 timeout 900 python bench.py --model qwen3-4b --quant q4k --steps 64 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_q4k_b1.json; one $O/${T}_bench_4b_q4k_b1.json "4B q4k"
+  NANO_Q4K_CHUNK=0 NANO_BENCH_NO_TRAFFIC=1 timeout 900 python bench.py --model qwen3-4b --quant q4k --steps 64 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_q4k_b1_round3_kernel.json; one $O/${T}_bench_4b_q4k_b1_round3_kernel.json "4B q4k, round 3's kernel (NANO_Q4K_CHUNK=0)"
+  rm -f $O/${T}_bench_q06_q80_vs_q4k.jsonl; for q in q80 q4k q80 q4k; do NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --quant $q --steps 64 --warmup 8 --no-cpu-baseline --no-kernel-table 2>/dev/null >> $O/${T}_bench_q06_q80_vs_q4k.jsonl; done
+  python3 -c "
+import json
+for ln in open('$O/${T}_bench_q06_q80_vs_q4k.jsonl'):
+    d=json.loads(ln); print(d['config']['workload'][:40], d['value'], d['ms_per_step'])"
   export NANO_BENCH_NO_TRAFFIC=1
   prof 4b_b8 --model qwen3-4b --batch 8 --steps 8 --warmup 2
   prof 4b_b1 --model qwen3-4b --batch 1 --steps 8 --warmup 2
