@@ -262,6 +262,8 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
     // workgroups per CU: the per-layer matrices get one (every workgroup quantizes the activation: once per CU); the classifier's
     // activation is short next to its rows, its workgroups are persistent and small (4 x 256 threads at n = 1024)
     if (cls && want > 512) want = 1024;
+    // (Measured and not taken, Qwen3-0.6B on one box: half the workgroups with twice the rows for Wo / W2, whose workgroups each bring
+    // n / 4 quantizer threads: 1686 vs 1720 tok/s; the quantizer on n / 8 threads, two blocks per wave: 1661; three wave-loads per wave: 1640.)
     const uint32_t k = cls ? 1024u / want : 1u, target = cus * k;
     static const uint32_t rw_env = getenv("NANO_Q4K_CHUNK_RW") ? (uint32_t)atoi(getenv("NANO_Q4K_CHUNK_RW")) : 0u;    // measurement knob
     uint32_t best = 0, best_cost = ~0u;
