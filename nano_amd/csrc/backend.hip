@@ -720,7 +720,11 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     uint32_t ntiles = 0;
     // probe: Q80 STREAM classifier (batch <= 8) -> the kernel's own start / stop timestamps (hipExtLaunchKernelGGL);
     // other classifiers -> events recorded around the launch (ev1..ev2 = an empty pair, the event overhead)
-    const bool probe_ext = m->probe_cls && d.quant_type == NANO_QUANT_Q80 && nb <= 8 && d.vocab_size >= 16384 && !route_takes_fragments(kind_of(m, classifier_args(m, nb)));
+    bool probe_ext = m->probe_cls && d.quant_type == NANO_QUANT_Q80 && nb <= 8 && d.vocab_size >= 16384 && !route_takes_fragments(kind_of(m, classifier_args(m, nb)));
+    if (m->probe_cls && d.quant_type == NANO_QUANT_Q4K && nb == 1 && d.vocab_size >= 65536) {      // gemv_q4k_chunk.hip's looping launch
+        GemvArgs ca = classifier_args(m, nb);
+        probe_ext = gemv_q4k_chunk_loops(ca);
+    }
     if (probe_ext) { g_q80_probe_start = m->ev0; g_q80_probe_stop = m->ev1; }
     else if (m->probe_cls && (e = hipEventRecord(m->ev0, m->st)) != hipSuccess) return e;
     if (!(skip & 32) && (e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;

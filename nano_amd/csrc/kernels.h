@@ -69,6 +69,7 @@ uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // tiles launch_gemv()
 hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t st);
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
 bool gemv_q4k_chunk_supports(const GemvArgs &a);            // gemv_q4k_chunk.hip: one sequence, whole 256-value blocks
+bool gemv_q4k_chunk_loops(const GemvArgs &a);               // ... and the launch is the looping (classifier) variant
 uint32_t gemv_q4k_chunk_partials(const GemvArgs &a);
 hipError_t launch_gemv_q4k_chunk(GemvArgs &a, hipStream_t st);
 uint32_t gemv_q4k_fit_batch(const GemvArgs &a);            // sequences per Q4K launch that fit in LDS (8 | 4 | 2 | 1)
