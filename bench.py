@@ -11,6 +11,9 @@ both sides; the MAX over ranks is the job's time.
 
   --gpus N        N > 1 without a torchrun environment: bench.py starts its own N ranks (python -m torch.distributed.run,
                   rendezvous on 127.0.0.1) and the JSON line reports the RCCL world size the ranks saw.
+                  NANO_BENCH_BACKEND=gloo (default nccl = RCCL): the two collectives go over gloo on the host and rank r uses
+                  device r mod #devices -- N ranks can then share ONE GPU (RCCL refuses two ranks on a device), which is how the
+                  N > 1 path is exercised on a 1-GPU box (tests/test_gpu_e2e.py); never a performance configuration.
   --batch B       B sequences per GPU, weak scaling (default 1): value = N*B*K / time.
   --total-seqs T  strong scaling, BASELINE configs[4] (`--model qwen3-4b --total-seqs 64`): T independent prompts,
                   sequence i on rank i mod N (T/N per GPU, no data-path collective; weights broadcast over RCCL at load,
@@ -50,6 +53,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+BACKEND = os.environ.get("NANO_BENCH_BACKEND", "nccl")      # "nccl" (= RCCL over xGMI) | "gloo" (host collectives; ranks may share a GPU)
 HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 PROMPT_LEN = 16
 SEQ_LEN = 512
@@ -102,12 +106,12 @@ def cpu_baseline(path, spec, budget_s=20.0, timeout_s=150):
     return out
 
 
-def cpu_baseline_run(path, spec, cores, budget_s, timeout_s):
+def cpu_baseline_run(path, spec, cores, budget_s, timeout_s, prompt_len=PROMPT_LEN, exact_steps=0):
     """Run the CPU baseline in a child process (own OpenMP runtime, hard time limit)."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(cores))
     code = ("import json, sys; sys.path.insert(0, %r); import bench; from nano_amd import modelfile as mf; "
-            "print(json.dumps(bench.cpu_baseline_worker(%r, mf.read_header(%r), %r, %d)))" % (ROOT, path, path, budget_s, cores))
+            "print(json.dumps(bench.cpu_baseline_worker(%r, mf.read_header(%r), %r, %d, %d, %d)))" % (ROOT, path, path, budget_s, cores, prompt_len, exact_steps))
     try:
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout_s)
         if r.returncode == 0 and r.stdout.strip():
@@ -118,8 +122,9 @@ def cpu_baseline_run(path, spec, cores, budget_s, timeout_s):
     return {"value": None, "unit": "tokens/s", "cores": cores, "kind": "reference", "sample": "CPU baseline failed: " + why}
 
 
-def cpu_baseline_worker(path, spec, budget_s, cores):
-    """Reference CPU engine on the same file / prompt / greedy settings, bounded sample."""
+def cpu_baseline_worker(path, spec, budget_s, cores, prompt_len=PROMPT_LEN, exact_steps=0):
+    """Reference CPU engine on the same file / prompt / greedy settings, bounded sample (exact_steps > 0: exactly that many decode steps)."""
+    PROMPT_LEN = prompt_len
     from nano_amd import modelfile as mf
     from oracle import binding as ob
     lib = ob.load_ref(fast=True)
@@ -139,6 +144,8 @@ def cpu_baseline_worker(path, spec, budget_s, cores):
         lib.next_token(ctx.h, ids, pos, 1)
     per = (time.time() - t0) / n_cal
     n_decode = int(max(4, min(128, budget_s / max(per, 1e-4) - PROMPT_LEN)))
+    if exact_steps > 0:
+        n_decode = int(exact_steps)
     ctx.close()
     ctx = ob.OracleCtx(lib, path, max_seq_len=SEQ_LEN)
     _, _, secs = ctx.generate(prompt, n_decode)
@@ -156,7 +163,7 @@ def self_launch(args):
     import subprocess
     from nano_amd import binding as nb
     have = nb.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (BACKEND == "gloo" and have >= 1):
         log(f"[bench] --gpus {args.gpus} but only {have} device(s) visible")
         sys.exit(2)
     s = socket.socket()
@@ -297,6 +304,23 @@ def measure_traffic(args, timeout_s=240):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def cpu_only(args):
+    """BASELINE.json configs[0]: Nano-56M FP32 on the reference's CPU engine, OMP_NUM_THREADS=1, a 12-token prompt + 128 greedy decode steps
+    (infer/main_cli.c:217-295 is what it stands for) -- plumbing, no GPU.  Any --model / --quant / --cpu-cores work the same way."""
+    gs = args.gs if args.quant == "q80" else 0
+    path, spec = ensure_model(args.model, args.quant, gs)
+    steps = args.steps if args.steps is not None else 128
+    r = cpu_baseline_run(path, spec, args.cpu_cores, 0.0, 1800, prompt_len=12, exact_steps=steps)
+    out = {"metric": "decode_tokens_per_sec", "value": r.get("value"), "unit": "tokens/s", "n_gpus": 0, "steps": steps, "warmup": 0,
+           "ms_per_step": round(1e3 / r["value"], 4) if r.get("value") else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": {"q80": "i8", "q4k": "u4", "f32": "f32"}[args.quant], "data": "synthetic",
+           "config": {"workload": f"{args.model} {args.quant.upper()}, the reference CPU engine (oracle/_ref: its own sources, its Makefile flags), OMP_NUM_THREADS={args.cpu_cores}, "
+                                  f"12-token prompt + {steps} greedy decode steps, seq_len {SEQ_LEN}", "sequences": 1},
+           "roofline": None, "cpu_baseline": r,
+           "algorithmic_bytes_per_token": int(spec.algorithmic_bytes_per_token())}
+    print(json.dumps(out), flush=True)
+
+
 def all_configs(args):
     """One JSON line per BASELINE.json config that runs here, each from a child run of this file; the default line last."""
     import subprocess
@@ -405,6 +429,8 @@ def main():
     ap.add_argument("--all-configs", action="store_true", help="one JSON line per BASELINE config, the default line last")
     ap.add_argument("--replicas", type=int, default=0, help="N weight replicas in ONE process through the C engine (no torch)")
     ap.add_argument("--min-window-s", type=float, default=0.25, help="repeat the K-step window until this much time is covered; report the median window")
+    ap.add_argument("--cpu-only", action="store_true", help="no GPU: the reference CPU engine on --model / --quant (BASELINE configs[0]: --model nano-56m --quant f32)")
+    ap.add_argument("--cpu-cores", type=int, default=1, help="OMP_NUM_THREADS of --cpu-only")
     ap.add_argument("--pmc-child", action="store_true", help="(internal) nothing but --steps eager decode steps: what measure_traffic() profiles")
     args = ap.parse_args()
     if args.pmc_child:
@@ -416,6 +442,8 @@ def main():
         m_.sync(); m_.close()
         return
 
+    if args.cpu_only:
+        return cpu_only(args)
     if args.all_configs:
         return all_configs(args)
     if args.replicas:
@@ -443,11 +471,15 @@ def main():
     if use_dist:
         import torch                                     # first: the HIP runtime torch bundles gets loaded once
         from nano_amd import dist as nd
-        dist = nd.init_process_group("nccl")
+        dist = nd.init_process_group(BACKEND)
         world_seen = dist.get_world_size()
+        if BACKEND != "nccl":
+            local = local % max(1, torch.cuda.device_count())      # ranks share the box's GPUs round-robin
+    cdev = f"cuda:{local}" if BACKEND == "nccl" else "cpu"    # where the collectives' tensors live
     from nano_amd import binding as nb
     from nano_amd import modelfile as mf
     from nano_amd.dist import shard_indices
+    import zlib
 
     # ---- sequences: global sequence i lives on rank i % N (round-robin) and uses seed 39 + i -------
     n_seq = args.total_seqs if strong else n_gpus * args.batch
@@ -465,11 +497,15 @@ def main():
     t0 = time.time()
     if use_dist:
         import torch
-        buf = nd.broadcast_file_bytes(path, src=0, device=f"cuda:{local}")
+        buf = nd.broadcast_file_bytes(path, src=0, device=cdev if BACKEND == "nccl" else None)
         head = bytes(buf[:260].cpu().numpy())
         spec, off = nd.split_model_bytes(head)
-        m = nb.DeviceModel(nb.desc_from_spec(spec), int(buf.data_ptr()) + off, buf.numel() - off, on_device=True,
-                           device=local, max_seq_len=SEQ_LEN, max_batch=B)
+        if BACKEND == "nccl":           # the blob is already in this GPU's memory: handed over as a device pointer
+            m = nb.DeviceModel(nb.desc_from_spec(spec), int(buf.data_ptr()) + off, buf.numel() - off, on_device=True,
+                               device=local, max_seq_len=SEQ_LEN, max_batch=B)
+        else:                           # gloo: the bytes arrived in host memory, one upload per rank
+            hostb = buf.numpy()[off:]
+            m = nb.DeviceModel(nb.desc_from_spec(spec), hostb, hostb.size, device=local, max_seq_len=SEQ_LEN, max_batch=B)
         m.spec = spec
         del buf
         torch.cuda.empty_cache()
@@ -491,7 +527,8 @@ def main():
         if dist is not None:
             dist.barrier()
             import torch
-            torch.cuda.synchronize()
+            if BACKEND == "nccl":
+                torch.cuda.synchronize()
         m.sync()
 
     # ---- the timed region: exactly K decode steps between barrier + device synchronisation on both sides.  Short windows
@@ -511,7 +548,7 @@ def main():
         n_win = int(min(max(3, args.min_window_s / max(first, 1e-6)), 400)) | 1      # odd: the median is a measured window
     if dist is not None:                                    # every rank must run the same number of windows
         import torch
-        t = torch.tensor([n_win], dtype=torch.int64, device=f"cuda:{local}")
+        t = torch.tensor([n_win], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         n_win = int(t.item())
     for _ in range(n_win - 1):
@@ -520,7 +557,7 @@ def main():
         assert (ids == timed_ids).all(), "a repeated window produced other ids"
     if dist is not None:                                    # per window: the slowest rank
         import torch
-        t = torch.tensor(wins, dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor(wins, dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wins = [float(v) for v in t.cpu().numpy()]
     elapsed = float(np.median(wins))
@@ -536,7 +573,7 @@ def main():
         e_full = time.perf_counter() - t0
         if dist is not None:
             import torch
-            t = torch.tensor([e_full], dtype=torch.float64, device=f"cuda:{local}")
+            t = torch.tensor([e_full], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e_full = float(t.item())
         full_win = {"value": round(n_seq * K_full / e_full, 2), "unit": "tokens/s", "steps": K_full, "ms_per_step": round(e_full / K_full * 1e3, 4),
@@ -566,9 +603,11 @@ def main():
     step_bytes = m.weight_bytes_per_step
     m.close()
 
+    all_ids = np.asarray(timed_ids.T, np.int64)            # [sequences of this rank, K]
     if dist is not None:                                   # the end-of-job all-gather of the TIMED ids
-        all_ids = nd.gather_ids(np.asarray(timed_ids.T, np.int64), owned, n_seq)
+        all_ids = nd.gather_ids(all_ids, owned, n_seq)
         assert all_ids.shape == (n_seq, K) and (all_ids >= 0).all()
+    ids_crc = zlib.crc32(np.ascontiguousarray(all_ids, np.int64).tobytes()) & 0xffffffff      # the same number whatever the sharding
 
     if rank != 0:
         return
@@ -619,6 +658,8 @@ def main():
         "config": {"workload": f"{args.model} {args.quant.upper()}" + (f" gs={spec.group_size}" if args.quant == "q80" else "") +
                                f", greedy decode, seq_len {SEQ_LEN}, positions {pos0}..{pos0 + K - 1} after a {PROMPT_LEN}-token prompt",
                    "sequences": n_seq, "sequences_per_gpu": B, "world_size_seen": world_seen,
+                   "collectives": (BACKEND if dist is not None else None), "windows_all_reduced": bool(dist is not None),
+                   "timed_ids_crc32": ids_crc,
                    "parallelism": f"dp{n_gpus} (independent sequences, sequence i on rank i mod {n_gpus}, weight replica per GPU)"},
         "roofline": roofline,
     }

@@ -272,13 +272,16 @@ int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *d);
 /* One device-resident copy of a model's parameter bytes per GPU from ONE host upload (replicate.hip; SURVEY 8e "broadcast(weights) at
  * load"): the bytes go to `root_device` over PCIe once and from there to the other devices over xGMI -- an RCCL broadcast (librccl.so
  * is dlopen()ed on first use) or, when RCCL is unavailable / NANO_REPLICATE_VIA=peer, hipMemcpyPeer; NANO_REPLICATE_VIA=host uploads
- * per device; NANO_REPLICATE_VIA=rccl insists on RCCL (also with one device: a 1-rank communicator).  devices[i]'s copy is
- * nano_hip_blob_ptr(share, i), to be handed to nano_hip_model_create[_ex] with params_on_device = 1; release frees the copies.
+ * per device; NANO_REPLICATE_VIA=rccl insists on RCCL, =peer on hipMemcpyPeer (also with one device: a 1-rank communicator / a copy whose
+ * source device is its destination).  devices[i]'s copy is nano_hip_blob_ptr(share, i), to be handed to
+ * nano_hip_model_create[_ex] with params_on_device = 1; nano_hip_blob_done(share, i) says replica i is built (the copy is freed once no
+ * later entry of `devices` shares it: the transient footprint is ONE extra copy of the parameters per device); release frees what is left.
  * Errors name the device. */
 typedef struct NanoBlobShare NanoBlobShare;
 int nano_hip_blob_share(NanoBlobShare **out, const void *host_params, size_t bytes, int root_device, const int *devices, int n_devices);
 const void *nano_hip_blob_ptr(const NanoBlobShare *s, int i);
 void nano_hip_blob_stats(const NanoBlobShare *s, double *upload_s, double *share_s, char *how, size_t how_cap);
+void nano_hip_blob_done(NanoBlobShare *s, int i);
 void nano_hip_blob_release(NanoBlobShare *s);
 int nano_hip_model_device(const NanoHipModel *m);
 

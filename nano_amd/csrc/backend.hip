@@ -576,6 +576,10 @@ static GemvArgs wo_args(const NanoHipModel *m, uint32_t nb, uint32_t nsplit) {
 // does the Wo launch combine the `nsplit` partials itself?  (else: a combine kernel of its own in front of it)
 static bool wo_takes_parts(const NanoHipModel *m, uint32_t nb, uint32_t nsplit) {
     if (nsplit <= 1 || nsplit > 8 || m->pf) return false;
+    // the plain-activation route first: a Wo launch the batched GEMM would take (Qwen3-4B at 2..8 sequences) keeps it -- the splits are
+    // then combined by a kernel of its own.  (Asking only about the launch WITH the partials attached always answered "GEMV": the
+    // batched routes refuse partials, and 4 sequences beyond 64 positions ran the 8-sequence SLAB GEMV: 2.6 ms against 2.0.)
+    if (route_takes_fragments(kind_of(m, wo_args(m, nb, 1)))) return false;
     return route_takes_attn_parts(kind_of(m, wo_args(m, nb, nsplit)));
 }
 // splits nano_hip_read_state still has to combine xba from after a decode step (1: the step left it final)
@@ -886,7 +890,9 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
     // 1.090 / 1.102 vs 1.057 / 1.044 at 16; Qwen3-4B 64 sequences 3.864 / 3.870 vs 3.811 / 3.836.  Same split count (ceil(hint / 64)),
     // same bits; four times as many graphs per context.
     static const uint32_t hint_env = [] { const char *e = getenv("NANO_RANGE_STEP"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return (v == 16u || v == 32u || v == 64u) ? v : 0u; }();
-    const uint32_t hint_step = hint_env ? hint_env : (nb >= 9u ? 16u : 64u);
+    // (batched prefill keeps the 64-position hint: a chunk's tokens must split exactly as each token's own decode step does, and with
+    //  head_dim > 128 -- 32 positions per workgroup and split -- ceil(round16(p + 1) / 32) is not ceil(round64(p + 1) / 32))
+    const uint32_t hint_step = hint_env ? hint_env : ((nb >= 9u && !(m->pf && m->hd > 128u)) ? 16u : 64u);
     uint32_t range_hint = is_causal ? ((max_pos + hint_step) / hint_step) * hint_step : m->S;
     if (range_hint > m->S) range_hint = m->S;
     if (m->kv_paged && (m->strict || m->lora_on)) FAIL(NANO_HIP_EINVAL, "the paged KV cache is served by the fused path only: not with strict mode or the LoRA side branches");

@@ -396,15 +396,25 @@ int nano_context_replicate(Nano_Context *ctx, const int *devices, int n_devices)
     int rc0 = nano_hip_blob_share(&sh, me->params, bytes, nano_hip_model_device(me->dev), devices, n_devices);
     if (rc0 != NANO_HIP_OK) return rc0;
     nano_hip_blob_stats(sh, &me->rep_upload_s, &me->rep_share_s, me->rep_how, sizeof me->rep_how);
+    /* Memory: while a replica is being built its device holds the parameter bytes twice (the shared copy + the model's own arena, whose
+     * tensors are re-based to aligned addresses); the copy is freed as soon as the device's last replica exists, so the transient is ONE
+     * extra copy per device (Qwen3-4B Q80: 4.3 GB), the root included.  A failure part-way leaves nothing behind: the replicas made by
+     * this call are destroyed again. */
+    const int first_new = me->n_replica;
     for (int i = 0; i < n_devices; i++) {
         NanoHipModel *r = NULL;
         int rc = nano_hip_model_create(&r, &me->desc, nano_hip_blob_ptr(sh, i), bytes, 1, devices[i], me->max_seq_len, me->max_batch);
-        if (rc != NANO_HIP_OK) { nano_hip_blob_release(sh); return rc; }
-        if (me->lora_params) {                                      /* a module loaded before the replicas were made */
+        if (rc == NANO_HIP_OK && me->lora_params) {                 /* a module loaded before the replicas were made */
             rc = nano_hip_lora_attach(r, me->lora_rank, me->lora_alpha, me->lora_params, me->lora_floats);
-            if (rc != NANO_HIP_OK) { nano_hip_model_destroy(r); nano_hip_blob_release(sh); return rc; }
+            if (rc != NANO_HIP_OK) { nano_hip_model_destroy(r); r = NULL; }
+        }
+        if (rc != NANO_HIP_OK) {
+            while (me->n_replica > first_new) { nano_hip_model_destroy(me->replica[--me->n_replica]); me->replica[me->n_replica] = NULL; }
+            nano_hip_blob_release(sh);
+            return rc;
         }
         me->replica[me->n_replica++] = r;
+        nano_hip_blob_done(sh, i);
     }
     nano_hip_blob_release(sh);
     return NANO_HIP_OK;

@@ -80,8 +80,18 @@ extern "C" void nano_hip_blob_release(NanoBlobShare *s) {
     delete s;
 }
 
+// the copy requested device i was built from is no longer needed by it: freed once no later target shares it (a device listed twice --
+// two replicas on one GPU -- keeps its copy until the second one is built).  Keeps the transient footprint at ONE extra copy per device.
+extern "C" void nano_hip_blob_done(NanoBlobShare *s, int i) {
+    if (!s || i < 0 || (size_t)i >= s->target.size()) return;
+    const int k = s->target[(size_t)i];
+    s->target[(size_t)i] = -1;
+    for (int t : s->target) if (t == k) return;
+    if (s->uptr[(size_t)k]) { (void)hipSetDevice(s->udev[(size_t)k]); (void)hipFree(s->uptr[(size_t)k]); s->uptr[(size_t)k] = nullptr; }
+}
+
 extern "C" const void *nano_hip_blob_ptr(const NanoBlobShare *s, int i) {
-    if (!s || i < 0 || (size_t)i >= s->target.size()) return nullptr;
+    if (!s || i < 0 || (size_t)i >= s->target.size() || s->target[(size_t)i] < 0) return nullptr;
     return s->uptr[(size_t)s->target[(size_t)i]];
 }
 
@@ -113,7 +123,8 @@ extern "C" int nano_hip_blob_share(NanoBlobShare **out, const void *host, size_t
     const std::string via = via_env ? via_env : "";
     // every distinct device gets its buffer; NANO_REPLICATE_VIA=rccl also gives the ROOT a second buffer and broadcasts into it, so that
     // the RCCL path runs (a 1-rank communicator) on a single-GPU box too -- what the tests can exercise without a multi-GPU node
-    const bool force_rccl = via == "rccl";
+    // (NANO_REPLICATE_VIA=peer on one device likewise: host -> a staging buffer, hipMemcpyPeer with source device == destination device)
+    const bool force_rccl = via == "rccl", force_peer = via == "peer";
     for (size_t k = 0; k < s->udev.size(); k++) {
         if (hipSetDevice(s->udev[k]) != hipSuccess || hipMalloc(&s->uptr[k], bytes) != hipSuccess) {
             const int d = s->udev[k];
@@ -125,7 +136,7 @@ extern "C" int nano_hip_blob_share(NanoBlobShare **out, const void *host, size_t
     double t0 = now_s();
     void *stage = nullptr;              // (forced RCCL on one device: host -> stage, RCCL stage -> the root's copy)
     (void)hipSetDevice(root_device);
-    if (force_rccl && s->udev.size() == 1) {
+    if ((force_rccl || force_peer) && s->udev.size() == 1) {
         if (hipMalloc(&stage, bytes) != hipSuccess) { nano_hip_blob_release(s); return fail(NANO_HIP_ENOMEM, "device %d: hipMalloc of the staging copy failed%s", root_device, ""); }
     }
     hipError_t e = hipMemcpy(stage ? stage : s->uptr[0], host, bytes, hipMemcpyHostToDevice);
@@ -180,9 +191,13 @@ extern "C" int nano_hip_blob_share(NanoBlobShare **out, const void *host, size_t
         nano_hip_blob_release(s);
         return fail(NANO_HIP_ERUNTIME, "device %d: NANO_REPLICATE_VIA=rccl but librccl.so could not be loaded%s", root_device, "");
     }
-    if (stage) { (void)hipSetDevice(root_device); (void)hipFree(stage); stage = nullptr; }
     if (!done && via != "host") {       // xGMI peer copies, one per device
         bool ok = true; int bad = -1; const char *why = "";
+        if (stage) {                    // one device, forced: the staging copy -> the device's own copy through the peer-copy call
+            (void)hipSetDevice(root_device);
+            const hipError_t pe = hipMemcpyPeer(s->uptr[0], root_device, stage, root_device, bytes);
+            if (pe != hipSuccess) { ok = false; bad = root_device; why = hipGetErrorString(pe); }
+        }
         for (size_t k = 1; k < nu && ok; k++) {
             (void)hipSetDevice(s->udev[k]);
             int can = 0;
@@ -193,8 +208,9 @@ extern "C" int nano_hip_blob_share(NanoBlobShare **out, const void *host, size_t
             if (pe != hipSuccess) { ok = false; bad = s->udev[k]; why = hipGetErrorString(pe); }
         }
         if (ok) { done = true; s->how = "hipMemcpyPeer per device"; }
-        else if (via == "peer") { nano_hip_blob_release(s); return fail(NANO_HIP_ERUNTIME, "device %d: peer copy of the parameters failed: %s", bad, why); }
+        else if (via == "peer") { if (stage) (void)hipFree(stage); nano_hip_blob_release(s); return fail(NANO_HIP_ERUNTIME, "device %d: peer copy of the parameters failed: %s", bad, why); }
     }
+    if (stage) { (void)hipSetDevice(root_device); (void)hipFree(stage); stage = nullptr; }
     if (!done) {                        // host upload per device (round 3's way)
         for (size_t k = 1; k < nu; k++) {
             (void)hipSetDevice(s->udev[k]);

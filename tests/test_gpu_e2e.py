@@ -631,7 +631,7 @@ def test_engine_per_phase_observation(model_dir):
     assert np.array_equal(ids, g["ids"][:len(prompt) + 3])
 
 
-@pytest.mark.parametrize("via,want_how", [("", "single device"), ("rccl", "rccl broadcast over 1 device"), ("peer", "single device"), ("host", "single device")])
+@pytest.mark.parametrize("via,want_how", [("", "single device"), ("rccl", "rccl broadcast over 1 device"), ("peer", "hipMemcpyPeer per device"), ("host", "single device")])
 def test_engine_replicas_serve_a_batch_concurrently(model_dir, via, want_how):
     """nano_context_replicate: replicas of the model (here a second one on the same GPU -- a 1-GPU box) share a prompt
     batch, sequence i on replica i mod G, steps begun on all replicas before any is waited for; every sequence's logits
@@ -658,7 +658,8 @@ def test_engine_replicas_serve_a_batch_concurrently(model_dir, via, want_how):
     assert e.L.nano_replicate_stats(e.ctx, C.byref(up), C.byref(sh), how, 64) == 0
     # the replica's weights came from ONE host upload + a device-side hand-over (replicate.hip): with the one GPU of this box the
     # default finds nothing to send ("single device": the replica is built from the root's copy); NANO_REPLICATE_VIA=rccl pushes the
-    # bytes through a 1-rank RCCL communicator (ncclCommInitAll + ncclBroadcast from librccl.so, opened with dlopen)
+    # bytes through a 1-rank RCCL communicator (ncclCommInitAll + ncclBroadcast from librccl.so, opened with dlopen), =peer through
+    # hipMemcpyPeer with source device == destination device (a staging copy -> the device's own copy)
     assert how.value.decode().startswith(want_how), how.value
     assert up.value > 0.0
     got = []

@@ -246,3 +246,37 @@ def test_config4_64_prompts_vs_reference_golden(model_dir):
           f"(positions {n_prompt - 1}..{S - 1}); fast path: worst max|dlogit|/max|logit| over {len(keep)} kept steps x 4 slots = {worst:.3e}, "
           f"arg-max agrees on {agree}/{4 * n_decode} steps")
     assert worst < floor
+
+
+@pytest.mark.parametrize("quant,gs", [("f32", 0), ("q4k", 0), ("q80", 128)])
+def test_nano56m_strict_equals_the_oracle_bit_for_bit(model_dir, oracle, quant, gs):
+    """BASELINE.json configs[0]'s model (Nano-56M: hidden size 1408 = 5.5 Q4K blocks, the ONE BASELINE shape that takes the reference's
+    partial-block source offset `j*d` end to end, infer/tensor.c:307,339) at its own size on the GPU in strict mode against the plain-C
+    oracle (bit-identical to the compiled reference: tests/test_oracle_golden.py) -- a 12-token prompt and 10 greedy steps, every
+    logit of every step; the FP32 file is the one `bench.py --model nano-56m --quant f32 --cpu-only` times on the CPU
+    (profiles/r05_cfg0_cpu.json).  Fast path recorded next to it."""
+    from oracle import binding as ob
+    path, spec = synth_model(model_dir, "nano-56m", quant, gs)
+    prompt = mf.prompt_ids(39, 12, spec.vocab_size)
+    n_decode = 10
+    ctx = ob.OracleCtx(oracle, path, max_seq_len=64)
+    ids, ref, _ = ctx.generate(prompt, n_decode, want_logits=True)
+    ctx.close()
+    m = nb.load_model_file(path, max_seq_len=64, max_batch=1)
+    worst_fast = 0.0
+    for strict in (True, False):
+        m.set_strict(strict)
+        for pos in range(len(ids) - 1):
+            want = pos >= len(prompt) - 1
+            logits, amax = m.forward([int(ids[pos])], [pos], want_logits=want, want_argmax=want)
+            if not want:
+                continue
+            r = ref[pos - (len(prompt) - 1)]
+            if strict:
+                assert np.array_equal(logits[0].view(np.uint32), r.view(np.uint32)), (quant, pos, float(np.abs(logits[0] - r).max()))
+                assert int(amax[0]) == int(ids[pos + 1])
+            else:
+                worst_fast = max(worst_fast, float(np.abs(logits[0] - r).max() / np.abs(r).max()))
+    m.close()
+    print(f"nano-56m/{quant}: strict == oracle bit for bit over {n_decode} steps; fast path worst {worst_fast:.3e}")
+    assert worst_fast <= {"f32": 1e-4, "q80": 5e-2, "q4k": 0.5}[quant]
