@@ -104,6 +104,7 @@ struct NanoHipModel {
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
     bool attn_quant = true;                               // batched steps: the attention kernel also writes the Wo GEMM's quantized input (NANO_ATTN_QUANT=0: quantizer launch)
     bool use_g5 = true;                                   // batched Q80 launches of group size 64 take gemm_q80_g5.hip's chained K-split kernel (NANO_GEMM_G5=0: G2 everywhere)
+    bool use_g7 = true;                                   // fast path, 17..64 tokens: gemm_q80_g7.hip (loader / consumer engine); NANO_GEMM_G7=0: G6 MODE F / G5 (same-box A/B)
     bool use_g6 = true;                                   // fast path, group size 64: gemm_q80_g6.hip's split-K kernel (<= 16 tokens; MODE P for 1..8 sequences on wide matrices); NANO_GEMM_G6=0: round 3's routes
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
@@ -429,6 +430,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
     if (const char *g5 = getenv("NANO_GEMM_G5")) m->use_g5 = *g5 && *g5 != '0';
     if (const char *g6 = getenv("NANO_GEMM_G6")) m->use_g6 = *g6 && *g6 != '0';
+    if (const char *g7 = getenv("NANO_GEMM_G7")) m->use_g7 = *g7 && *g7 != '0';
     if (const char *aq = getenv("NANO_ATTN_QUANT")) m->attn_quant = *aq && *aq != '0';
     if (const char *wq = getenv("NANO_W2_QUANT")) m->w2_quant = *wq && *wq != '0';
     HIP_TRY(hipDeviceSynchronize());
@@ -523,7 +525,7 @@ static Q80Route route_of(const NanoHipModel *m) {
     static const bool use_cls = !(getenv("NANO_GEMM_CLS") && *getenv("NANO_GEMM_CLS") == '0');
     Q80Route r{};
     r.quant = m->d.quant_type; r.cus = m->cus; r.mfma_min_nb = m->mfma_min_nb;
-    r.use_g5 = m->use_g5; r.use_g6 = m->use_g6; r.use_cls = use_cls;
+    r.use_g5 = m->use_g5; r.use_g6 = m->use_g6; r.use_cls = use_cls; r.use_g7 = m->use_g7;
     r.gq = m->gq; r.gxs = m->gxs; r.gq2 = m->gq2; r.gxs2 = m->gxs2;
     return r;
 }

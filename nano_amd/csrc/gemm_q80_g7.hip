@@ -1,0 +1,392 @@
+// gemm_q80_g7.hip -- G7: the Q80 (W8A8) projection kernel of the FAST path for 17..64 tokens per weight read (decode steps of 17..64
+// sequences, batched-prefill chunks) -- a loader / consumer engine: LDS-DMA loader waves stream BOTH operands through an LDS ring,
+// eight consumer waves multiply out of LDS and keep the canonical fold in registers.
+//
+// Why (round 5).  G6 MODE F / G5 at 2..4 token tiles spent 2.3 us per (8 KB of weights, token tile): a wave fetched the 8 KB of
+// activation fragments of every (item, token tile) from L2 into registers with one tile of look-ahead (4 x 8 KB of fragments per 8 KB
+// of weights, latency bound), and Qwen3-4B's W1|W3 did not fit G6 at all (100 KB of unit sums).  Here
+//   * one workgroup per CU owns `tpw` row tiles (<= 16 rows each, fitted to the chip like G6's) and walks the row length in STEPS of
+//     256 bytes (4 quantization groups); per step a loader wave DMAs the tiles' weights (global_load_lds_dwordx4, non-temporal; 16-byte
+//     chunks XOR-swizzled at the SOURCE so that the A-fragment ds_read_b128 is conflict free on row-major rows) and their scales, two
+//     more loader waves DMA the step's activation fragments of every token tile (already in MFMA B order: lane l reads slot l) and
+//     their scales -- ONCE per workgroup, whatever the number of row tiles that meet them.  No VGPR holds a byte in flight: the ring
+//     (`ns` stages, as many as fit 160 KB) is the prefetch queue, vmcnt is counted by hand (the loaders issue nothing else);
+//   * a consumer wave owns (row tile, token tile) PAIRS for the whole row length: one v_mfma_i32_16x16x64_i8 per group gives the exact
+//     int32 group sums of (16 rows x 16 tokens), products ((float)ival * ws) * xs (infer.c:672, two roundings), the unit sum S_u of 8
+//     groups in ascending order, the running row value += S_u in registers: the CANONICAL fold (kernels.h q80_canonical(),
+//     tests/canon.py) without a table, a counter or a finishing pass -- a batch stays bit for bit its sequences alone;
+//   * one s_barrier per step hands a landed stage to the consumers and the stage consumed before it back to the loaders.
+// Reference: matmul_quant infer/infer.c:654-679 (the arithmetic), the prompt loop :1258-1260 (what batched prefill replaces).
+// MFMA operand layout as in gemm_q80.hip (verified on gfx950): lane l holds A[m = l%16][k = 16 (l/16) .. +15], B[k][n = l%16],
+// c[i] = C[m = 4 (l/16) + i][n = l%16].
+#include <atomic>
+#include <type_traits>
+#include "gemv_common.h"
+
+namespace nano {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t G7_NCW = 8;                      // consumer waves
+constexpr uint32_t G7_NLB = 2;                      // activation loader waves (wave G7_NCW is the weight loader)
+constexpr uint32_t G7_NW = G7_NCW + 1u + G7_NLB;    // 11 waves
+constexpr uint32_t G7_MAXNS = 8;
+constexpr uint32_t G7_LDS = 160u * 1024u;
+
+struct G7Dev {
+    GemvDev g;                          // segments, n, ng, epi, nb, pos
+    const int8_t *xf; const float *xsf; // activations in MFMA B-fragment order [token tile][group][lane][16 B], scales [token tile][group][16 tokens]
+    uint32_t hh;                        // live rows per half tile (1..8)
+    uint32_t ntiles, tc0, tc1;          // tiles; tiles up to the end of segment 0 / 1
+    uint32_t grid, tpw, full;           // workgroups; tiles per workgroup (max); workgroups that own tpw tiles (the others: tpw - 1)
+    uint32_t nk, ttl, ns;               // steps (256 B of a row each); live token tiles; ring stages
+    uint32_t off_b, off_ws, off_xs, stage_bytes;   // byte offsets inside a stage: weights at 0
+};
+
+template <int AUX> __device__ __forceinline__ void g7_dma16(const void *gsrc, unsigned char *lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, AUX);
+}
+// the loaders' only wait: at most `n` of THIS wave's DMA instructions still in flight (n wave-uniform; loads land in issue order)
+#define G7_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+__device__ __forceinline__ void g7_wait_vm(uint32_t n) {
+    switch (n < 63u ? n : 63u) {
+        G7_W(0) G7_W(1) G7_W(2) G7_W(3) G7_W(4) G7_W(5) G7_W(6) G7_W(7) G7_W(8) G7_W(9) G7_W(10) G7_W(11) G7_W(12) G7_W(13) G7_W(14) G7_W(15)
+        G7_W(16) G7_W(17) G7_W(18) G7_W(19) G7_W(20) G7_W(21) G7_W(22) G7_W(23) G7_W(24) G7_W(25) G7_W(26) G7_W(27) G7_W(28) G7_W(29) G7_W(30) G7_W(31)
+        G7_W(32) G7_W(33) G7_W(34) G7_W(35) G7_W(36) G7_W(37) G7_W(38) G7_W(39) G7_W(40) G7_W(41) G7_W(42) G7_W(43) G7_W(44) G7_W(45) G7_W(46) G7_W(47)
+        G7_W(48) G7_W(49) G7_W(50) G7_W(51) G7_W(52) G7_W(53) G7_W(54) G7_W(55) G7_W(56) G7_W(57) G7_W(58) G7_W(59) G7_W(60) G7_W(61) G7_W(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+}
+#undef G7_W
+// (a loader must not drain its DMA queue at the barrier: no __syncthreads(), whose fence is a vmcnt(0))
+__device__ __forceinline__ void g7_loader_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int R0, int R1, class F> __device__ __forceinline__ void g7_static_for(F &&f) {
+    if constexpr (R0 < R1) { f(std::integral_constant<int, R0>{}); g7_static_for<R0 + 1, R1>(f); }
+}
+
+// TP   = row tiles per workgroup (capacity of the loader's address registers): 1 | 2 | 3 | 5 | 8
+// MAXP = (tile, token tile) pairs per consumer wave (capacity): ceil(tpw * token tiles / 8)
+// MS   = several weight segments share the launch (q | k | v)
+template <int TP, int MAXP, bool MS>
+__global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const GemvDev &a = d.g;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    NANO_STAMP(a.stamps, 0, tid);
+    const uint32_t n = a.n, ng = a.ng, hh = d.hh, nb = a.nb, nk = d.nk, ns = d.ns, ttl = d.ttl;
+    const uint32_t epi = a.epi;
+    const bool sw = epi == GEMV_EPI_SWIGLU;
+    const uint32_t halfoff = sw ? 0u : hh;                             // rows between the two halves of a tile
+    const uint32_t bid = blockIdx.x;
+    const uint32_t ntl = bid < d.full ? d.tpw : d.tpw - 1u;             // tiles of this workgroup
+
+    struct TI { uint32_t lrow0, rows0, obs, ops; const int8_t *wA, *wB; const float *sA, *sB; float *out; };
+    auto decode = [&](uint32_t tl) -> TI {
+        TI t;
+        const uint32_t tile = bid + tl * d.grid;
+        const int sel = !MS ? 0 : (int)(tile >= d.tc0) + (int)(tile >= d.tc1);
+        t.wA = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
+        t.sA = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
+        t.wB = sw ? a.w[1] : t.wA; t.sB = sw ? a.ws[1] : t.sA;
+        t.out = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
+        t.rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
+        t.obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
+        t.ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
+        t.lrow0 = (tile - (sel == 0 ? 0u : sel == 1 ? d.tc0 : d.tc1)) * (sw ? hh : 2u * hh);
+        return t;
+    };
+
+    if (wid == G7_NCW) {
+        // ================================================ weight loader ================================================================
+        // A stage holds, per tile, 16 rows x 256 B row-major; the 16-byte chunk c of tile row r sits at position c ^ r (an A-fragment
+        // ds_read_b128 -- lane (m, kq), group j: chunk 4 j + kq of row m -- then hits 16 distinct 16-byte bank slots per 16-lane group).
+        // DMA instruction i of a tile covers tile rows 4 i .. 4 i + 3: lane p writes LDS slot p = row 4 i + p / 16, position p % 16, so it
+        // FETCHES chunk (p % 16) ^ row of that row: the 16 lanes of a row still cover its 256 contiguous bytes (two whole 128-B lines).
+        // Tile rows 0..7 are half 0 (live: the first hh), 8..15 half 1 (SwiGLU: the same rows of W3); dead rows are not fetched (their
+        // LDS rows keep whatever they held: their results are never stored).
+        const uint32_t lr = lane >> 4, cp = lane & 15u;
+        const int8_t *src[TP][4];                                         // per lane: the address of step 0's chunk
+        uint32_t lvm = 0, ilm = 0, ips = 0;                                // bit 4 t + i: this lane fetches / the instruction is issued at all
+#pragma unroll
+        for (int t = 0; t < TP; t++) {
+            const bool tlive = (uint32_t)t < ntl;
+            const TI ti = decode(tlive ? (uint32_t)t : 0u);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t r = 4u * (uint32_t)i + lr, half = r >> 3, rr = r & 7u;
+                const uint32_t grow = ti.lrow0 + half * halfoff + rr;
+                const bool live = tlive && rr < hh && grow < ti.rows0;
+                src[t][i] = (half ? ti.wB : ti.wA) + ((size_t)grow * n + ((cp ^ (r & 15u)) << 4));
+                const uint32_t rr_first = (4u * (uint32_t)i) & 7u, grow_first = ti.lrow0 + ((uint32_t)i >> 1) * halfoff + rr_first;
+                const bool any = tlive && rr_first < hh && grow_first < ti.rows0;      // (wave-uniform: the instruction has a live lane)
+                lvm |= live ? 1u << (4 * t + i) : 0u;
+                ilm |= any ? 1u << (4 * t + i) : 0u;
+                ips += any ? 1u : 0u;
+            }
+        }
+        // weight scales of the step (16 rows x 4 groups per tile): one instruction per four tiles; lane p serves tile 4 s + p / 16, row p % 16
+        // -> that row's 16 bytes, LDS [tile][row][4 groups]
+        constexpr int NSI = (TP + 3) / 4;
+        const float *ssrc[NSI]; bool sl[NSI], sil[NSI];
+#pragma unroll
+        for (int s = 0; s < NSI; s++) {
+            const uint32_t t = 4u * (uint32_t)s + lr, r = cp;
+            const bool tlive = t < ntl;
+            const TI ti = decode(tlive ? t : 0u);
+            const uint32_t half = r >> 3, rr = r & 7u, grow = ti.lrow0 + half * halfoff + rr;
+            sl[s] = tlive && rr < hh && grow < ti.rows0;
+            ssrc[s] = (half ? ti.sB : ti.sA) + (size_t)grow * ng;
+            sil[s] = 4u * (uint32_t)s < ntl;
+            ips += sil[s] ? 1u : 0u;
+        }
+        auto issue = [&](uint32_t k, unsigned char *st) {
+            const uint32_t kb = k * 256u;
+#pragma unroll
+            for (int t = 0; t < TP; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (ilm & (1u << (4 * t + i))) { if (lvm & (1u << (4 * t + i))) g7_dma16<2>(src[t][i] + kb, st + (uint32_t)t * 4096u + (uint32_t)i * 1024u); }
+#pragma unroll
+            for (int s = 0; s < NSI; s++)
+                if (sil[s]) { if (sl[s]) g7_dma16<0>(ssrc[s] + k * 4u, st + d.off_ws + (uint32_t)s * 1024u); }
+        };
+        uint32_t issued = 0, sti = 0;                                      // steps issued; the stage the next issue goes to
+        const uint32_t pre = ns - 1u < nk ? ns - 1u : nk;
+        for (; issued < pre; issued++) { issue(issued, smem + sti * d.stage_bytes); sti = sti + 1u == ns ? 0u : sti + 1u; }
+        for (uint32_t k = 0; k < nk; k++) {
+            g7_wait_vm((issued - 1u - k) * ips);                           // step k has landed (the steps issued behind it may still fly)
+            g7_loader_barrier();
+            if (issued < nk) { issue(issued, smem + sti * d.stage_bytes); issued++; sti = sti + 1u == ns ? 0u : sti + 1u; }
+        }
+        return;
+    }
+    if (wid > G7_NCW) {
+        // ================================================ activation loaders ===========================================================
+        // the step's 4 groups of every live token tile: 4 KB contiguous per tile in the fragment buffer, 1 KB per instruction, lane l ->
+        // slot l (the B fragment of lane l).  Instruction q = 4 tt + j goes to loader q % G7_NLB; loader 0 also brings the scales.
+        const uint32_t b = wid - G7_NCW - 1u;
+        const int8_t *xl = d.xf + lane * 16u;
+        const uint32_t nq = 4u * ttl;
+        const uint32_t xs_tt = lane >> 4;
+        const bool xs_live = b == 0u && xs_tt < ttl;
+        const float *xsl = d.xsf + ((size_t)xs_tt * ng) * 16u + (lane & 15u) * 4u;
+        const uint32_t ips = (nq > b ? (nq - b + G7_NLB - 1u) / G7_NLB : 0u) + (b == 0u ? 1u : 0u);
+        auto issue = [&](uint32_t k, unsigned char *st) {
+            for (uint32_t q = b; q < nq; q += G7_NLB) {
+                const uint32_t tt = q >> 2, j = q & 3u;
+                g7_dma16<0>(xl + ((size_t)tt * ng + 4u * k + j) * 1024u, st + d.off_b + tt * 4096u + j * 1024u);
+            }
+            if (b == 0u) { if (xs_live) g7_dma16<0>(xsl + (size_t)k * 64u, st + d.off_xs); }
+        };
+        uint32_t issued = 0, sti = 0;
+        const uint32_t pre = ns - 1u < nk ? ns - 1u : nk;
+        for (; issued < pre; issued++) { issue(issued, smem + sti * d.stage_bytes); sti = sti + 1u == ns ? 0u : sti + 1u; }
+        for (uint32_t k = 0; k < nk; k++) {
+            g7_wait_vm((issued - 1u - k) * ips);
+            g7_loader_barrier();
+            if (issued < nk) { issue(issued, smem + sti * d.stage_bytes); issued++; sti = sti + 1u == ns ? 0u : sti + 1u; }
+        }
+        return;
+    }
+    // ==================================================== consumers ======================================================================
+    const uint32_t m = lane & 15u, kq = lane >> 4;
+    uint32_t a_off[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) a_off[j] = m * 256u + (((4u * j + kq) ^ m) << 4);
+    const uint32_t half = kq >> 1, rr0 = (kq & 1u) * 4u;              // this lane's four output rows: rows rr0 .. rr0 + 3 of half `half`
+    const uint32_t npairs = ntl * ttl;
+    uint32_t ptile[MAXP], ptt[MAXP]; bool plive[MAXP];
+    float acc[MAXP][4], S[MAXP][4], oldv[MAXP][4];
+    uint32_t opos[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; i++) {
+        const uint32_t q = wid + (uint32_t)i * G7_NCW;
+        plive[i] = q < npairs;
+        ptile[i] = plive[i] ? q / ttl : 0u;
+        ptt[i] = plive[i] ? q - ptile[i] * ttl : 0u;
+        opos[i] = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { acc[i][r] = 0.0f; S[i][r] = 0.0f; oldv[i][r] = 0.0f; }
+        // what the epilogue needs from memory (the old residual values, the position of a position-indexed output): asked for now
+        if (plive[i] && (epi == GEMV_EPI_RESID || (a.out_pstride[0] | a.out_pstride[1] | a.out_pstride[2]) != 0u)) {
+            const TI t = decode(ptile[i]);
+            const uint32_t orow0 = t.lrow0 + half * halfoff + rr0, tok = ptt[i] * 16u + m;
+            if (tok < nb) {
+                if (t.ops) opos[i] = a.pos[tok];
+                if (epi == GEMV_EPI_RESID) {
+                    const float *o = t.out + (size_t)tok * t.obs + orow0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < t.rows0) oldv[i][r] = o[r];
+                }
+            }
+        }
+    }
+    // one step of every pair of this wave: FIRST = the step opens a unit (its group 0 starts the unit sum)
+    auto step = [&](auto FIRST, const unsigned char *st) {
+        constexpr bool first = decltype(FIRST)::value;
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) {
+            if (!plive[i]) continue;                                   // (wave-uniform)
+            const unsigned char *A = st + ptile[i] * 4096u, *B = st + d.off_b + ptt[i] * 4096u + lane * 16u;
+            const float *WS = reinterpret_cast<const float *>(st + d.off_ws + ptile[i] * 256u) + kq * 16u;      // rows 4 kq .. + 3: [row][4 groups]
+            const float *XS = reinterpret_cast<const float *>(st + d.off_xs + ptt[i] * 256u) + m;               // [group][16 tokens]
+            const float4 w0 = *reinterpret_cast<const float4 *>(WS), w1 = *reinterpret_cast<const float4 *>(WS + 4);
+            const float4 w2 = *reinterpret_cast<const float4 *>(WS + 8), w3 = *reinterpret_cast<const float4 *>(WS + 12);
+            const float wr[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}, {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const i32x4 fa = *reinterpret_cast<const i32x4 *>(A + a_off[j]);
+                const i32x4 fb = *reinterpret_cast<const i32x4 *>(B + j * 1024);
+                const float xsc = XS[j * 16];
+                const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float p = ((float)cv[r] * wr[r][j]) * xsc;                    // infer.c:672
+                    if (first && j == 0) S[i][r] = p; else S[i][r] += p;
+                }
+            }
+        }
+    };
+    const uint32_t nu = (nk + 1u) >> 1;
+    uint32_t sti = 0;
+    for (uint32_t u = 0; u < nu; u++) {
+        __syncthreads();                                               // step 2 u has landed; everyone is done with step 2 u - 1
+        step(std::true_type{}, smem + sti * d.stage_bytes);
+        sti = sti + 1u == ns ? 0u : sti + 1u;
+        if (2u * u + 1u < nk) {
+            __syncthreads();
+            step(std::false_type{}, smem + sti * d.stage_bytes);
+            sti = sti + 1u == ns ? 0u : sti + 1u;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXP; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[i][r] = u == 0u ? S[i][r] : acc[i][r] + S[i][r];          // units ascending
+    }
+    // ---- epilogue: store | residual add | SwiGLU -----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < MAXP; i++) {
+        if (!plive[i]) continue;
+        const TI t = decode(ptile[i]);
+        const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;        // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
+        const uint32_t tok = ptt[i] * 16u + m;
+        float v3[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sw) {                                                      // W3's values live 32 lanes up (rows 8..15 of the tile)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v3[r] = __shfl_xor(acc[i][r], 32, 64);
+        }
+        if (tok < nb && (!sw || kq < 2u)) {
+            float *o = t.out + (size_t)tok * t.obs + (size_t)opos[i] * t.ops + orow0;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < t.rows0) o[r] = finish_epi(epi, acc[i][r], v3[r], oldv[i][r]);
+        }
+    }
+    NANO_STAMP_END(a.stamps, 6);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------------
+struct G7Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nk, ttl, ns, off_b, off_ws, off_xs, stage_bytes, tp, maxp; bool ms; size_t lds; };
+
+static uint32_t g7_rows(const GemvArgs &a) {
+    if (a.epi == GEMV_EPI_SWIGLU) return a.seg[0].rows;
+    uint32_t r = 0;
+    for (uint32_t s = 0; s < a.nseg; s++) r += a.seg[s].rows;
+    return r;
+}
+
+// tile height fitted to the chip (G6's rule): minimise the rows the busiest workgroup streams (+ a per-tile overhead worth ~2 rows)
+static bool g7_plan(const GemvArgs &a, G7Plan &p) {
+    const bool sw = a.epi == GEMV_EPI_SWIGLU;
+    const uint32_t cus = a.cus ? a.cus : 256u, nseg = sw ? 1u : a.nseg;
+    uint32_t best = 0, best_cost = ~0u;
+    for (uint32_t hh = 1; hh <= 8; hh++) {
+        const uint32_t trw = sw ? hh : 2u * hh;
+        uint32_t tiles = 0;
+        for (uint32_t s = 0; s < nseg; s++) tiles += (a.seg[s].rows + trw - 1) / trw;
+        const uint32_t grid = tiles < cus ? tiles : cus, tpw = (tiles + grid - 1) / grid;
+        const uint32_t cost = tpw * (trw * (sw ? 2u : 1u) + 2u);
+        if (cost <= best_cost) { best_cost = cost; best = hh; }       // ties: the taller tile
+    }
+    p.hh = best;
+    const uint32_t trw = sw ? best : 2u * best;
+    uint32_t tiles = 0, tc[2] = {0xffffffffu, 0xffffffffu};
+    for (uint32_t s = 0; s < nseg; s++) { tiles += (a.seg[s].rows + trw - 1) / trw; if (s < 2) tc[s] = tiles; }
+    p.ntiles = tiles; p.tc0 = nseg > 1 ? tc[0] : 0xffffffffu; p.tc1 = nseg > 2 ? tc[1] : 0xffffffffu;
+    p.grid = tiles < cus ? tiles : cus; p.tpw = (tiles + p.grid - 1) / p.grid;
+    p.ms = !sw && a.nseg > 1;
+    p.nk = a.n / 256u; p.ttl = (a.nb + 15u) / 16u;
+    p.tp = p.tpw <= 1 ? 1u : p.tpw == 2 ? 2u : p.tpw == 3 ? 3u : p.tpw <= 5 ? 5u : p.tpw <= 8 ? 8u : 0u;
+    if (!p.tp) return false;
+    p.maxp = (p.tpw * p.ttl + G7_NCW - 1u) / G7_NCW;
+    if (p.maxp > 4u) return false;
+    // a stage: weights | fragments | weight scales (one 1-KB DMA instruction per four tiles) | activation scales (one instruction)
+    p.off_b = p.tpw * 4096u; p.off_ws = p.off_b + p.ttl * 4096u; p.off_xs = p.off_ws + ((p.tpw + 3u) / 4u) * 1024u; p.stage_bytes = p.off_xs + 1024u;
+    uint32_t ns = G7_LDS / p.stage_bytes;
+    // vmcnt is a 6-bit counter: (ns - 2) steps of the busier loader stay in flight behind the one waited for
+    const uint32_t ips_a = 4u * p.tpw + (p.tpw + 3u) / 4u, ips_b = (4u * p.ttl + G7_NLB - 1u) / G7_NLB + 1u, ips = ips_a > ips_b ? ips_a : ips_b;
+    if (ns > 2u + 63u / ips) ns = 2u + 63u / ips;
+    if (ns > G7_MAXNS) ns = G7_MAXNS;
+    if (ns > p.nk + 1u) ns = p.nk + 1u;
+    if (ns < 2u) return false;
+    p.ns = ns;
+    p.lds = (size_t)ns * p.stage_bytes;
+    return true;
+}
+
+template <int TP, int MAXP, bool MS>
+static hipError_t g7_launch_t(const G7Dev &d, size_t lds, hipStream_t st) {
+    auto kern = &gemm_q80_g7_kernel<TP, MAXP, MS>;
+    static std::atomic<bool> armed[64];
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !armed[dev].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7_LDS);
+        if (dev >= 0 && dev < 64) armed[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(d.grid), dim3(G7_NW * 64u), lds, st, d);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm_q80_g7_supports(const GemvArgs &a) {
+    if (a.gs != 64 || a.nb < 17u || a.nb > 64u || a.n % 256u || a.nseg == 0 || a.nseg > 3) return false;
+    if (a.ordered || a.resid_add || a.tile_max || a.attn_part || a.frag_out) return false;
+    if (a.epi == GEMV_EPI_SWIGLU && (a.nseg != 2 || a.seg[0].rows != a.seg[1].rows)) return false;
+    const uint32_t nseg = a.epi == GEMV_EPI_SWIGLU ? 1u : a.nseg;
+    for (uint32_t s = 0; s < nseg; s++) if ((uint64_t)a.seg[s].rows * a.n >= (1ull << 32) - (1u << 20)) return false;   // 32-bit row offsets per segment
+    if (g7_rows(a) >= 65536u) return false;                            // (the classifier has kernels of its own: STREAM / GC)
+    G7Plan p;
+    return g7_plan(a, p);
+}
+
+hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st) {
+    if (!a.xq_in || !a.xs_in || !gemm_q80_g7_supports(a)) return hipErrorInvalidValue;
+    G7Plan p;
+    if (!g7_plan(a, p)) return hipErrorInvalidValue;
+    G7Dev d{};
+    d.g = to_dev(a);
+    d.g.nthr = G7_NW * 64u;
+    d.xf = a.xq_in; d.xsf = a.xs_in;
+    d.hh = p.hh; d.ntiles = p.ntiles; d.tc0 = p.tc0; d.tc1 = p.tc1; d.grid = p.grid; d.tpw = p.tpw;
+    d.full = p.ntiles - (p.tpw - 1u) * p.grid;
+    d.nk = p.nk; d.ttl = p.ttl; d.ns = p.ns;
+    d.off_b = p.off_b; d.off_ws = p.off_ws; d.off_xs = p.off_xs; d.stage_bytes = p.stage_bytes;
+#define G7_GO(TP_, MP_) do { return p.ms ? g7_launch_t<TP_, MP_, true>(d, p.lds, st) : g7_launch_t<TP_, MP_, false>(d, p.lds, st); } while (0)
+    // (tile capacity, pair capacity): the pairs of a workgroup are tpw x token tiles (2..4) dealt to eight waves
+    if (p.tp == 1u) G7_GO(1, 1);
+    if (p.tp == 2u) G7_GO(2, 1);
+    if (p.tp == 3u) G7_GO(3, 2);
+    if (p.tp == 5u) { if (p.maxp <= 2u) G7_GO(5, 2); G7_GO(5, 3); }
+    if (p.maxp <= 2u) G7_GO(8, 2);
+    if (p.maxp == 3u) G7_GO(8, 3);
+    G7_GO(8, 4);
+#undef G7_GO
+}
+
+}  // namespace nano

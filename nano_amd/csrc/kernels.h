@@ -89,6 +89,10 @@ bool gemm_q80_g6_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st);
 bool gemm_q80_g6p_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_g6p(const GemvArgs &a, hipStream_t st);
+// G7 (gemm_q80_g7.hip): the fast path's kernel for 17..64 tokens -- LDS-DMA loader waves stream weights AND activation fragments through an
+// LDS ring, consumer waves own (row tile, token tile) pairs for the whole row length (canonical fold in registers); same inputs as MODE F
+bool gemm_q80_g7_supports(const GemvArgs &a);
+hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st);
 // GC, tall matrices with short rows (the classifier): persistent waves, activation fragments staged in LDS (gemm_q80_cls.hip)
 bool gemm_q80_cls_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_cls(const GemvArgs &a, hipStream_t st);
@@ -109,13 +113,14 @@ enum RouteKind : uint32_t {
     ROUTE_G6P,             // G6 MODE P: fp32 activation (or split-attention partials), quantized in the kernel's prologue
     ROUTE_FRAG_G6,         // fragment-order activations (quantizer launch unless frag_ready) + G6 MODE F
     ROUTE_FRAG_OLD,        // fragment-order activations + GC | G5 | G2
+    ROUTE_FRAG_G7,         // fragment-order activations + G7 (17..64 tokens, the fast path)
 };
-inline bool route_takes_fragments(RouteKind k) { return k == ROUTE_FRAG_G6 || k == ROUTE_FRAG_OLD; }
+inline bool route_takes_fragments(RouteKind k) { return k == ROUTE_FRAG_G6 || k == ROUTE_FRAG_OLD || k == ROUTE_FRAG_G7; }
 inline bool route_takes_attn_parts(RouteKind k) { return k == ROUTE_GEMV || k == ROUTE_G6P || k == ROUTE_Q4K; }
 struct Q80Route {
     uint32_t quant; int cus;
     uint32_t mfma_min_nb;  // sequences from which the small Q80 matrices take the batched route (9; measurement: NANO_MFMA_MIN_NB)
-    bool use_g5, use_g6, use_cls;
+    bool use_g5, use_g6, use_cls, use_g7;
     int8_t *gq; float *gxs; int8_t *gq2; float *gxs2;   // fragment-order activation scratch (nullptr: no batched route)
 };
 RouteKind route_kind(const Q80Route &r, const GemvArgs &a);

@@ -230,6 +230,7 @@ extern "C" int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *dp) {
     r.quant = d.quant; r.cus = (int)a.cus; r.mfma_min_nb = d.use_gemm ? 1u : 9u;
     r.use_g5 = !(getenv("NANO_GEMM_G5") && *getenv("NANO_GEMM_G5") == '0');
     r.use_g6 = !(getenv("NANO_GEMM_G6") && *getenv("NANO_GEMM_G6") == '0');
+    r.use_g7 = !(getenv("NANO_GEMM_G7") && *getenv("NANO_GEMM_G7") == '0');
     r.use_cls = !(getenv("NANO_GEMM_CLS") && *getenv("NANO_GEMM_CLS") == '0');
     if (d.quant == NANO_QUANT_Q80) {
         const size_t n16 = (d.n + 15) & ~(size_t)15, tt = (d.nb + 15) / 16;

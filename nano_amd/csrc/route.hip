@@ -6,7 +6,8 @@
 //   Q80, fast path          SLAB GEMV (1..8 sequences on the small per-layer matrices)           gemv_q80_impl.h
 //                           G6 MODE P (1..8 sequences on matrices of >= 8 M weights: Qwen3-4B)    gemm_q80_g6.hip
 //                           G6 MODE F (fragment-order activations, <= 16 tokens)                 gemm_q80_g6.hip
-//                           G5 (17..64 tokens), G2 (group sizes other than 64)                   gemm_q80_g5.hip, gemm_q80.hip
+//                           G7 (17..64 tokens: loader / consumer engine, both operands through LDS) gemm_q80_g7.hip
+//                           G5 / G2 (what G7 / G6 do not take: group sizes other than 64)          gemm_q80_g5.hip, gemm_q80.hip
 //                           STREAM GEMV / GC for the classifier                                   gemv_q80_impl.h, gemm_q80_cls.hip
 //   Q80, strict mode        the kernels that keep the reference's ascending group order: SLAB, G5, GC, G2 (a.ordered = 1)
 #include <stdlib.h>
@@ -54,6 +55,7 @@ RouteKind route_kind(const Q80Route &r, const GemvArgs &a) {
         static const bool p_b1 = getenv("NANO_G6P_B1") && *getenv("NANO_G6P_B1") == '1';
         if (wide && !a.xq_in && a.nb <= 8 && (a.nb >= 2 || p_b1) && r.mfma_min_nb == 9 && p_worthwhile(a) && gemm_q80_g6p_supports(a)) return ROUTE_G6P;
         const bool batched = a.nb >= r.mfma_min_nb || (r.mfma_min_nb == 9 && ((a.nb == 8 && gemv_is_heavy(a)) || (wide && a.nb >= 2)));
+        if (batched && scratch && r.use_g7 && gemm_q80_g7_supports(a)) return ROUTE_FRAG_G7;      // 17..64 tokens
         if (batched && scratch && !a.attn_part && !a.resid_add && gemm_q80_g6_supports(a)) return ROUTE_FRAG_G6;
     }
     // the older batched route: 9..64 sequences always; 8 sequences when the matrix is large; per-layer matrices of >= 8 M weights from 2
@@ -104,6 +106,7 @@ hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st) {
     case ROUTE_G6P:
         return launch_gemm_q80_g6p(a, st);
     case ROUTE_FRAG_G6:
+    case ROUTE_FRAG_G7:
     case ROUTE_FRAG_OLD: {
         // quantize every sequence's activation once, straight into MFMA fragment order (unless the producing kernel already did), then
         // the GEMM
@@ -113,6 +116,7 @@ hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st) {
         }
         a.xq_in = a.frag_ready == 2u ? r.gq2 : r.gq; a.xs_in = a.frag_ready == 2u ? r.gxs2 : r.gxs;
         if (k == ROUTE_FRAG_G6) return launch_gemm_q80_g6(a, st);
+        if (k == ROUTE_FRAG_G7) return launch_gemm_q80_g7(a, st);
         // the classifier of a batched step: GC (persistent waves, the activation fragments staged in LDS once per workgroup)
         if (r.use_cls && !a.frag_out && gemm_q80_cls_supports(a)) return launch_gemm_q80_cls(a, st);
         if (r.use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, a.frag_out, a.frag_scale_out, st);

@@ -60,6 +60,7 @@ def ref_q80(oracle, act, segs, n, gs, canon=False):
 
 
 ROUTES_FREE = os.environ.get("NANO_GEMM_G6") == "0"        # round 3's routes (A/B knob): the expected-route assertions do not apply
+G7_OFF = os.environ.get("NANO_GEMM_G7") == "0"             # 17..64 tokens through G6 MODE F / G5 instead of G7 (A/B knob)
 # one sequence on Qwen3-4B's matrices: the SLAB GEMV (leaner, measured faster); NANO_G6P_B1=1 sends it through G6 MODE P
 W1 = "g6p" if os.environ.get("NANO_G6P_B1") == "1" else "gemv"
 
@@ -193,6 +194,10 @@ def test_batched_g6_prologue_roles_q80(oracle, nb_, kind):
 GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (17, 0, 2560, (4096, 1024, 1024)), (32, 1, 9728, (2560,)), (64, 1, 9728, (2560,)), (48, 0, 2560, (4096, 1024, 1024)),
               (30, 0, 2560, (9728, 9728)), (9, 1, 3072, (1024,)), (40, 1, 2048, (1024,)), (64, 0, 1024, (2048, 1024, 1024)),
               (8, 1, 9728, (2560,)), (16, 0, 2560, (4096, 1024, 1024)), (33, 1, 4096, (2560,)),
+              # G7's shapes (round 5): Qwen3-4B's W1|W3 at 64 tokens (5 tiles per workgroup, 3 pairs per wave), Qwen3-0.6B's W1|W3 / Wo / W2,
+              # an odd step count (768 = 3 steps: the last unit is half a unit), three token tiles, segment ends inside a tile
+              (64, 0, 2560, (9728, 9728)), (64, 0, 1024, (3072, 3072)), (64, 1, 2048, (1024,)), (57, 1, 3072, (1024,)), (19, 1, 768, (512,)),
+              (47, 0, 1024, (2064, 1040, 1008)), (64, 1, 4096, (2560,)),
               (3, 1, 9728, (2560,)), (1, 0, 2560, (4096, 1024, 1024)),
               # tall matrices (>= 16384 rows): the classifier's kernel GC (gemm_q80_cls.hip) -- every token tile staged in LDS /
               # two staged + two from L2 (64 tokens at row length 2560), a ragged last row tile, group counts 16 / 40 / 12
@@ -212,7 +217,8 @@ def gemm_route_case(oracle, nb_, kind, n, rows):
             ref = ref_q80(oracle, oracle.rmsnorm(x[b], nw), segs, n, 64)
             assert np.array_equal(bits(out[b]), bits(ref)), (b, float(np.abs(out[b] - ref).max()))
         return "frag_old"
-    return check_q80(oracle, kind, n, segs, x, nw, old, nb_, use_gemm=True, routes=("frag_g6",) if n % 256 == 0 else ("frag_old",))
+    want = ("frag_old",) if n % 256 else ("frag_g7",) if (nb_ >= 17 and not G7_OFF) else ("frag_g6", "frag_old") if nb_ >= 17 else ("frag_g6",)
+    return check_q80(oracle, kind, n, segs, x, nw, old, nb_, use_gemm=True, routes=want)
 
 
 def test_g6_ragged_segments(oracle):
@@ -245,7 +251,7 @@ def test_one_sequence_through_g6_mode_p():
 def test_mfma_gemm_route_older_kernels():
     """NANO_GEMM_G6=0 (round 3's routes: G5 for every batched launch, its fold canonical in the fast path too) and NANO_GEMM_G5=0
     (the general kernel G2, the reference's order only: strict mode); the knobs are read per call / per process"""
-    for env in ({"NANO_GEMM_G6": "0"}, {"NANO_GEMM_G6": "0", "NANO_G5_BALANCED": "1"}):
+    for env in ({"NANO_GEMM_G7": "0"}, {"NANO_GEMM_G6": "0"}, {"NANO_GEMM_G6": "0", "NANO_G5_BALANCED": "1"}):
         code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);\n"
                 "import test_gpu_fused_roles as t; from oracle import binding as ob; o = ob.load_oracle()\n"
                 "import canon\n"

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round-5 GPU cycles (one script, modes by name): usage tools/r5_cycle.sh MODE
+exec < /dev/null
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r5; mkdir -p $O; cd $R
+export NANO_BENCH_NO_TRAFFIC=1
+one() { python3 -c "import json;d=json.loads(open('$1').read().strip().splitlines()[-1]);k=d.get('roofline',{}).get('kernels') or [];print('$2', d['value'], 'tok/s', d['ms_per_step'], 'ms |', '  '.join(f\"{x['kernel'].split('_')[0]} {x['us_per_launch']}\" for x in k))" 2>/dev/null || { echo "$2 FAILED"; tail -3 $1.err 2>/dev/null; }; }
+bench() { tag=$1; shift; timeout 400 python bench.py "$@" --no-cpu-baseline > $O/$tag.json 2> $O/$tag.json.err; one $O/$tag.json "$tag"; }
+summ() {
+python3 - "$1" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"].replace("void nano::(anonymous namespace)::", "").replace("nano::(anonymous namespace)::", "").replace("nano::", "")
+    print(f'{n[:78]:78s} {int(r["Calls"]):6d} calls  avg {float(r["AverageNs"])/1e3:8.2f} us  min {float(r["MinNs"])/1e3:8.2f}  {float(r["Percentage"]):5.1f}%')
+PY
+}
+bygrid() {
+python3 - "$1" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Kernel_Name"].replace("void nano::(anonymous namespace)::", "").replace("nano::(anonymous namespace)::", "").replace("nano::", "")[:60]
+    g = r.get("Grid_Size_X", r.get("Grid_Size", "?")); w = r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?"))
+    a = acc[(n, g, w)]; a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+print("kernel | grid threads | workgroup threads | launches | average us (rocprofv3 kernel trace, eager launches)")
+for (n, g, w), (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:24]:
+    print(f"{n:60s} | {g:>8s} | {w:>5s} | {c:6d} | {t / c:8.2f}")
+PY
+}
+prof() {   # prof TAG bench-args... : eager kernel-trace stats of a short bench run
+  tag=$1; shift
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$tag && NANO_HIP_NO_GRAPH=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o k -- python $R/bench.py "$@" --no-cpu-baseline --no-kernel-table > /tmp/prof_$tag.log 2>&1 )
+  f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && summ $f > $O/${tag}_kernel_stats.txt && head -10 $O/${tag}_kernel_stats.txt
+  f=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1)
+  [ -n "$f" ] && bygrid $f > $O/${tag}_kernels_by_grid.txt && head -12 $O/${tag}_kernels_by_grid.txt
+}
+case "$1" in
+g7a)   # first light of G7 (LDS-DMA loader / consumer GEMM for 17..64 tokens): the DMA assumptions, diagnosis tool, parity subset, A/B against G6 F / G5
+  timeout 60 tools/kbench/dma_probe 2>&1 | tee $O/dma_probe.txt
+  timeout 300 python tools/g7_check.py 2>&1 | tail -30 | tee $O/g7_check.txt
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py -m gpu -x -q -k "gemm_route or ragged" 2>&1 | tail -6
+  timeout 900 python -m pytest tests/test_gpu_dist.py tests/test_gpu_fullsize.py tests/test_gpu_e2e.py -m gpu -x -q -k "gloo or nano56m or replicas_serve" 2>&1 | tail -6
+  for b in 64 32; do
+    bench 4b_b${b}_g7 --model qwen3-4b --batch $b --steps 32 --warmup 4
+    NANO_GEMM_G7=0 bench 4b_b${b}_old --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-kernel-table
+  done
+  bench q06_b64_g7 --batch 64 --steps 64 --warmup 4
+  NANO_GEMM_G7=0 bench q06_b64_old --batch 64 --steps 64 --warmup 4 --no-kernel-table
+  timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -4 | tee $O/prefill_g7.txt
+  NANO_GEMM_G7=0 timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -4 | tee $O/prefill_old.txt
+  prof 4b_b64 --model qwen3-4b --batch 64 --steps 12 --warmup 2
+  timeout 300 python bench.py --model nano-56m --quant f32 --cpu-only > $O/cfg0_cpu.json 2>/dev/null; cut -c1-200 $O/cfg0_cpu.json
+  ;;
+*) echo "unknown mode $1";;
+esac
