@@ -1,21 +1,27 @@
 // gemm_q80_g7.hip -- G7: the Q80 (W8A8) projection kernel of the FAST path for 17..64 tokens per weight read (decode steps of 17..64
-// sequences, batched-prefill chunks) -- a loader / consumer engine: LDS-DMA loader waves stream BOTH operands through an LDS ring,
-// eight consumer waves multiply out of LDS and keep the canonical fold in registers.
+// sequences, batched-prefill chunks) -- a loader / consumer engine: the WEIGHTS stream through a deep LDS ring by LDS-DMA, the
+// activation fragments are staged in LDS once per workgroup by the consumer waves themselves, eight consumer waves multiply out of LDS
+// and keep the canonical fold in registers.
 //
 // Why (round 5).  G6 MODE F / G5 at 2..4 token tiles spent 2.3 us per (8 KB of weights, token tile): a wave fetched the 8 KB of
 // activation fragments of every (item, token tile) from L2 into registers with one tile of look-ahead (4 x 8 KB of fragments per 8 KB
 // of weights, latency bound), and Qwen3-4B's W1|W3 did not fit G6 at all (100 KB of unit sums).  Here
 //   * one workgroup per CU owns `tpw` row tiles (<= 16 rows each, fitted to the chip like G6's) and walks the row length in STEPS of
-//     256 bytes (4 quantization groups); per step a loader wave DMAs the tiles' weights (global_load_lds_dwordx4, non-temporal; 16-byte
-//     chunks XOR-swizzled at the SOURCE so that the A-fragment ds_read_b128 is conflict free on row-major rows) and their scales, two
-//     more loader waves DMA the step's activation fragments of every token tile (already in MFMA B order: lane l reads slot l) and
-//     their scales -- ONCE per workgroup, whatever the number of row tiles that meet them.  No VGPR holds a byte in flight: the ring
-//     (`ns` stages, as many as fit 160 KB) is the prefetch queue, vmcnt is counted by hand (the loaders issue nothing else);
+//     256 bytes (4 quantization groups);
+//   * two loader waves DMA the tiles' weights of alternate steps (global_load_lds_dwordx4, non-temporal; 16-byte chunks XOR-swizzled
+//     at the SOURCE so that the A-fragment ds_read_b128 is conflict free on row-major rows) and their scales into a ring of `nsa`
+//     stages -- no VGPR holds a weight byte in flight, the ring IS the prefetch queue (tens of KB per CU, what the HBM latency asks
+//     for), vmcnt is counted by hand (the loaders issue nothing else);
+//   * the step's activation fragments (already in MFMA B order: lane l reads slot l) come from L2: every consumer wave fetches a
+//     share of step k + 4's fragments into registers (vector loads: 64 B / clk / CU, where LDS-DMA measured ~30 GB/s per CU --
+//     round 5's first build, profiles/r05_g7_first_build.txt) and parks step k + 1's in one of two LDS stages -- ONCE per
+//     workgroup, whatever the number of row tiles that meet them;
 //   * a consumer wave owns (row tile, token tile) PAIRS for the whole row length: one v_mfma_i32_16x16x64_i8 per group gives the exact
 //     int32 group sums of (16 rows x 16 tokens), products ((float)ival * ws) * xs (infer.c:672, two roundings), the unit sum S_u of 8
 //     groups in ascending order, the running row value += S_u in registers: the CANONICAL fold (kernels.h q80_canonical(),
 //     tests/canon.py) without a table, a counter or a finishing pass -- a batch stays bit for bit its sequences alone;
-//   * one s_barrier per step hands a landed stage to the consumers and the stage consumed before it back to the loaders.
+//   * one s_barrier per step hands a landed weight stage and a parked fragment stage to the consumers and the stages consumed before
+//     them back to their writers.
 // Reference: matmul_quant infer/infer.c:654-679 (the arithmetic), the prompt loop :1258-1260 (what batched prefill replaces).
 // MFMA operand layout as in gemm_q80.hip (verified on gfx950): lane l holds A[m = l%16][k = 16 (l/16) .. +15], B[k][n = l%16],
 // c[i] = C[m = 4 (l/16) + i][n = l%16].
@@ -30,10 +36,11 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t G7_NCW = 8;                      // consumer waves
-constexpr uint32_t G7_NLB = 2;                      // activation loader waves (wave G7_NCW is the weight loader)
-constexpr uint32_t G7_NW = G7_NCW + 1u + G7_NLB;    // 11 waves
-constexpr uint32_t G7_MAXNS = 8;
+constexpr uint32_t G7_NLA = 2;                      // weight loader waves (steps k % 2)
+constexpr uint32_t G7_NW = G7_NCW + G7_NLA;         // 10 waves
+constexpr uint32_t G7_MAXNSA = 32;
 constexpr uint32_t G7_LDS = 160u * 1024u;
+constexpr int G7_BD = 4;                            // steps of activation fragments a consumer wave keeps in flight (registers)
 
 struct G7Dev {
     GemvDev g;                          // segments, n, ng, epi, nb, pos
@@ -41,8 +48,10 @@ struct G7Dev {
     uint32_t hh;                        // live rows per half tile (1..8)
     uint32_t ntiles, tc0, tc1;          // tiles; tiles up to the end of segment 0 / 1
     uint32_t grid, tpw, full;           // workgroups; tiles per workgroup (max); workgroups that own tpw tiles (the others: tpw - 1)
-    uint32_t nk, ttl, ns;               // steps (256 B of a row each); live token tiles; ring stages
-    uint32_t off_b, off_ws, off_xs, stage_bytes;   // byte offsets inside a stage: weights at 0
+    uint32_t nk, ttl, nsa;              // steps (256 B of a row each); live token tiles; weight-ring stages
+    uint32_t a_stage, a_ws;             // bytes of a weight stage (tiles' weights at 0, their scales at a_ws)
+    uint32_t b_base, b_stage, b_xs;     // the two fragment stages: LDS offset of the first, bytes of one, offset of the activation scales inside
+    uint32_t dbg;                       // DEVELOPMENT ONLY (NANO_G7_DBG): 1 consumers only synchronise, 2 no weight DMA, 4 no fragment loads
 };
 
 template <int AUX> __device__ __forceinline__ void g7_dma16(const void *gsrc, unsigned char *lds_dst) {
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     NANO_STAMP(a.stamps, 0, tid);
-    const uint32_t n = a.n, ng = a.ng, hh = d.hh, nb = a.nb, nk = d.nk, ns = d.ns, ttl = d.ttl;
+    const uint32_t n = a.n, ng = a.ng, hh = d.hh, nb = a.nb, nk = d.nk, nsa = d.nsa, ttl = d.ttl;
     const uint32_t epi = a.epi;
     const bool sw = epi == GEMV_EPI_SWIGLU;
     const uint32_t halfoff = sw ? 0u : hh;                             // rows between the two halves of a tile
@@ -101,8 +110,9 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
         return t;
     };
 
-    if (wid == G7_NCW) {
-        // ================================================ weight loader ================================================================
+    if (wid >= G7_NCW) {
+        // ================================================ weight loaders ===============================================================
+        // loader a = wid - 8 brings the steps k with k % 2 == a
         // A stage holds, per tile, 16 rows x 256 B row-major; the 16-byte chunk c of tile row r sits at position c ^ r (an A-fragment
         // ds_read_b128 -- lane (m, kq), group j: chunk 4 j + kq of row m -- then hits 16 distinct 16-byte bank slots per 16-lane group).
         // DMA instruction i of a tile covers tile rows 4 i .. 4 i + 3: lane p writes LDS slot p = row 4 i + p / 16, position p % 16, so it
@@ -145,6 +155,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
             ips += sil[s] ? 1u : 0u;
         }
         auto issue = [&](uint32_t k, unsigned char *st) {
+            if (d.dbg & 2u) return;
             const uint32_t kb = k * 256u;
 #pragma unroll
             for (int t = 0; t < TP; t++)
@@ -153,43 +164,19 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
                     if (ilm & (1u << (4 * t + i))) { if (lvm & (1u << (4 * t + i))) g7_dma16<2>(src[t][i] + kb, st + (uint32_t)t * 4096u + (uint32_t)i * 1024u); }
 #pragma unroll
             for (int s = 0; s < NSI; s++)
-                if (sil[s]) { if (sl[s]) g7_dma16<0>(ssrc[s] + k * 4u, st + d.off_ws + (uint32_t)s * 1024u); }
+                if (sil[s]) { if (sl[s]) g7_dma16<0>(ssrc[s] + k * 4u, st + d.a_ws + (uint32_t)s * 1024u); }
         };
-        uint32_t issued = 0, sti = 0;                                      // steps issued; the stage the next issue goes to
-        const uint32_t pre = ns - 1u < nk ? ns - 1u : nk;
-        for (; issued < pre; issued++) { issue(issued, smem + sti * d.stage_bytes); sti = sti + 1u == ns ? 0u : sti + 1u; }
+        // Step j lives in stage j % nsa.  Before barrier k the steps 0 .. k + nsa - 2 have been asked for (stage (k - 1) % nsa is still being
+        // read); after it step k + nsa - 1 may go out.  `mine` = steps THIS loader has issued; its step k is its (k / 2)-th.
+        const uint32_t la = wid - G7_NCW;
+        uint32_t mine = 0;
+        const uint32_t pre = nsa - 1u < nk ? nsa - 1u : nk;
+        for (uint32_t j = 0; j < pre; j++) if ((j & 1u) == la) { issue(j, smem + (j % nsa) * d.a_stage); mine++; }
+        uint32_t jn = pre, stn = pre % nsa;                                // the next step to go out and its stage
         for (uint32_t k = 0; k < nk; k++) {
-            g7_wait_vm((issued - 1u - k) * ips);                           // step k has landed (the steps issued behind it may still fly)
+            if ((k & 1u) == la) g7_wait_vm((mine - 1u - (k >> 1)) * ips);      // step k has landed (this loader's later steps may still fly)
             g7_loader_barrier();
-            if (issued < nk) { issue(issued, smem + sti * d.stage_bytes); issued++; sti = sti + 1u == ns ? 0u : sti + 1u; }
-        }
-        return;
-    }
-    if (wid > G7_NCW) {
-        // ================================================ activation loaders ===========================================================
-        // the step's 4 groups of every live token tile: 4 KB contiguous per tile in the fragment buffer, 1 KB per instruction, lane l ->
-        // slot l (the B fragment of lane l).  Instruction q = 4 tt + j goes to loader q % G7_NLB; loader 0 also brings the scales.
-        const uint32_t b = wid - G7_NCW - 1u;
-        const int8_t *xl = d.xf + lane * 16u;
-        const uint32_t nq = 4u * ttl;
-        const uint32_t xs_tt = lane >> 4;
-        const bool xs_live = b == 0u && xs_tt < ttl;
-        const float *xsl = d.xsf + ((size_t)xs_tt * ng) * 16u + (lane & 15u) * 4u;
-        const uint32_t ips = (nq > b ? (nq - b + G7_NLB - 1u) / G7_NLB : 0u) + (b == 0u ? 1u : 0u);
-        auto issue = [&](uint32_t k, unsigned char *st) {
-            for (uint32_t q = b; q < nq; q += G7_NLB) {
-                const uint32_t tt = q >> 2, j = q & 3u;
-                g7_dma16<0>(xl + ((size_t)tt * ng + 4u * k + j) * 1024u, st + d.off_b + tt * 4096u + j * 1024u);
-            }
-            if (b == 0u) { if (xs_live) g7_dma16<0>(xsl + (size_t)k * 64u, st + d.off_xs); }
-        };
-        uint32_t issued = 0, sti = 0;
-        const uint32_t pre = ns - 1u < nk ? ns - 1u : nk;
-        for (; issued < pre; issued++) { issue(issued, smem + sti * d.stage_bytes); sti = sti + 1u == ns ? 0u : sti + 1u; }
-        for (uint32_t k = 0; k < nk; k++) {
-            g7_wait_vm((issued - 1u - k) * ips);
-            g7_loader_barrier();
-            if (issued < nk) { issue(issued, smem + sti * d.stage_bytes); issued++; sti = sti + 1u == ns ? 0u : sti + 1u; }
+            if (jn < nk) { if ((jn & 1u) == la) { issue(jn, smem + stn * d.a_stage); mine++; } jn++; stn = stn + 1u == nsa ? 0u : stn + 1u; }
         }
         return;
     }
@@ -226,15 +213,49 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
             }
         }
     }
+    // ---- the activation fragments: 1-KB chunk c = 4 tt + j of a step (token tile tt, group j of the step) is fetched and parked by wave c % 8
+    //      (two chunks per wave at four token tiles); wave 0 also moves the step's activation scales (256 B per token tile).  A chunk sits
+    //      in registers for G7_BD steps: asked for at step k - 3, parked in LDS stage (k + 1) % 2 at step k, multiplied at step k + 1.
+    // The step loop below has NO branch around a load or an LDS store (a chunk that does not exist is read through an out-of-range offset
+    // -- zeros, no memory access -- and parked in a dummy kilobyte): every s_waitcnt the compiler places is then the exact count
+    // (vmcnt(6): the two younger steps stay in flight), where a merge point made it wait for everything (the first build: vmcnt(0)).
+    const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf, ttl * ng * 1024u);
+    const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf, ttl * ng * 64u);
+    const uint32_t dummy = d.b_base + 2u * d.b_stage + lane * 16u;     // 1 KB behind the fragment stages
+    uint32_t c_src[2], c_dst[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t c = wid + (uint32_t)i * G7_NCW, tt = c >> 2, j = c & 3u;
+        const bool live = c < 4u * ttl;
+        c_src[i] = (live && !(d.dbg & 4u)) ? (tt * ng + j) * 1024u + lane * 16u : OOB;             // + 4 k groups = 4096 k bytes
+        c_dst[i] = live ? tt * 4096u + j * 1024u + lane * 16u : 0xffffffffu;                       // (inside a fragment stage; dead: the dummy)
+    }
+    const bool xs_wave = wid == 0u;
+    const uint32_t xs_src = (xs_wave && (lane >> 4) < ttl && !(d.dbg & 4u)) ? (((lane >> 4) * ng) * 16u + (lane & 15u) * 4u) * 4u : OOB;   // + 4 k groups = 256 k bytes
+    i32x4 breg[G7_BD][2], xreg[G7_BD];
+    auto b_issue = [&](auto SL, uint32_t k) {                          // the loads of step k (beyond the last step: nothing) into register slot SL
+        constexpr int sl = decltype(SL)::value;
+        const bool in = k < nk;
+        breg[sl][0] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)((in && c_src[0] != OOB) ? c_src[0] + k * 4096u : OOB), 0, 0);
+        breg[sl][1] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)((in && c_src[1] != OOB) ? c_src[1] + k * 4096u : OOB), 0, 0);
+        xreg[sl] = __builtin_amdgcn_raw_buffer_load_b128(rxs, (int)((in && xs_src != OOB) ? xs_src + k * 256u : OOB), 0, 0);
+    };
+    auto b_park = [&](auto SL, uint32_t k) {                           // register slot SL (step k) -> fragment stage k % 2 (a step beyond the last: harmless,
+        constexpr int sl = decltype(SL)::value;                        //  that stage is not read again)
+        const uint32_t bs = d.b_base + (k & 1u) * d.b_stage;
+        *reinterpret_cast<i32x4 *>(smem + (c_dst[0] != 0xffffffffu ? bs + c_dst[0] : dummy)) = breg[sl][0];
+        *reinterpret_cast<i32x4 *>(smem + (c_dst[1] != 0xffffffffu ? bs + c_dst[1] : dummy)) = breg[sl][1];
+        *reinterpret_cast<i32x4 *>(smem + (xs_wave ? bs + d.b_xs + lane * 16u : dummy)) = xreg[sl];
+    };
     // one step of every pair of this wave: FIRST = the step opens a unit (its group 0 starts the unit sum)
-    auto step = [&](auto FIRST, const unsigned char *st) {
+    auto step = [&](auto FIRST, const unsigned char *st, const unsigned char *bs) {
         constexpr bool first = decltype(FIRST)::value;
 #pragma unroll
         for (int i = 0; i < MAXP; i++) {
             if (!plive[i]) continue;                                   // (wave-uniform)
-            const unsigned char *A = st + ptile[i] * 4096u, *B = st + d.off_b + ptt[i] * 4096u + lane * 16u;
-            const float *WS = reinterpret_cast<const float *>(st + d.off_ws + ptile[i] * 256u) + kq * 16u;      // rows 4 kq .. + 3: [row][4 groups]
-            const float *XS = reinterpret_cast<const float *>(st + d.off_xs + ptt[i] * 256u) + m;               // [group][16 tokens]
+            const unsigned char *A = st + ptile[i] * 4096u, *B = bs + ptt[i] * 4096u + lane * 16u;
+            const float *WS = reinterpret_cast<const float *>(st + d.a_ws + ptile[i] * 256u) + kq * 16u;        // rows 4 kq .. + 3: [row][4 groups]
+            const float *XS = reinterpret_cast<const float *>(bs + d.b_xs + ptt[i] * 256u) + m;                 // [group][16 tokens]
             const float4 w0 = *reinterpret_cast<const float4 *>(WS), w1 = *reinterpret_cast<const float4 *>(WS + 4);
             const float4 w2 = *reinterpret_cast<const float4 *>(WS + 8), w3 = *reinterpret_cast<const float4 *>(WS + 12);
             const float wr[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}, {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
@@ -252,22 +273,31 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
             }
         }
     };
-    const uint32_t nu = (nk + 1u) >> 1;
-    uint32_t sti = 0;
-    for (uint32_t u = 0; u < nu; u++) {
-        __syncthreads();                                               // step 2 u has landed; everyone is done with step 2 u - 1
-        step(std::true_type{}, smem + sti * d.stage_bytes);
-        sti = sti + 1u == ns ? 0u : sti + 1u;
-        if (2u * u + 1u < nk) {
-            __syncthreads();
-            step(std::false_type{}, smem + sti * d.stage_bytes);
-            sti = sti + 1u == ns ? 0u : sti + 1u;
-        }
+    auto fold = [&](uint32_t u) {
 #pragma unroll
         for (int i = 0; i < MAXP; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[i][r] = u == 0u ? S[i][r] : acc[i][r] + S[i][r];          // units ascending
-    }
+    };
+    // prologue: the first G7_BD steps' fragments are asked for, step 0's parked (behind the first barrier everyone may read them)
+    g7_static_for<0, G7_BD>([&](auto SL) { b_issue(SL, (uint32_t)decltype(SL)::value); });
+    b_park(std::integral_constant<int, 0>{}, 0u);
+    uint32_t sta = 0;                                                  // weight stage of the current step
+    auto one_step = [&](auto SI, uint32_t k) {                         // step k, k % G7_BD == SI
+        constexpr int si = decltype(SI)::value;
+        __syncthreads();                                               // weights of step k landed (the loaders), fragments of step k parked; everyone is done with step k - 1
+        b_park(std::integral_constant<int, (si + 1) % G7_BD>{}, k + 1u);       // stage (k + 1) % 2 was last read at step k - 1
+        b_issue(SI, k + (uint32_t)G7_BD);                              // slot si was parked at step k - 1
+        step(std::integral_constant<bool, si % 2 == 0>{}, smem + sta * d.a_stage, smem + d.b_base + (k & 1u) * d.b_stage);
+        sta = sta + 1u == nsa ? 0u : sta + 1u;
+    };
+    uint32_t k4 = 0;
+    for (; k4 + (uint32_t)G7_BD <= nk; k4 += (uint32_t)G7_BD)          // whole rounds of G7_BD steps: straight-line code
+        g7_static_for<0, G7_BD>([&](auto SI) { one_step(SI, k4 + (uint32_t)decltype(SI)::value); if (decltype(SI)::value % 2 == 1) fold((k4 + (uint32_t)decltype(SI)::value) >> 1); });
+    g7_static_for<0, G7_BD - 1>([&](auto SI) {                         // the last nk % G7_BD steps
+        const uint32_t k = k4 + (uint32_t)decltype(SI)::value;
+        if (k < nk) { one_step(SI, k); if (decltype(SI)::value % 2 == 1 || k + 1u == nk) fold(k >> 1); }
+    });
     // ---- epilogue: store | residual add | SwiGLU -----------------------------------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < MAXP; i++) {
@@ -291,7 +321,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
-struct G7Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nk, ttl, ns, off_b, off_ws, off_xs, stage_bytes, tp, maxp; bool ms; size_t lds; };
+struct G7Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nk, ttl, nsa, a_stage, a_ws, b_base, b_stage, b_xs, tp, maxp; bool ms; size_t lds; };
 
 static uint32_t g7_rows(const GemvArgs &a) {
     if (a.epi == GEMV_EPI_SWIGLU) return a.seg[0].rows;
@@ -325,17 +355,22 @@ static bool g7_plan(const GemvArgs &a, G7Plan &p) {
     if (!p.tp) return false;
     p.maxp = (p.tpw * p.ttl + G7_NCW - 1u) / G7_NCW;
     if (p.maxp > 4u) return false;
-    // a stage: weights | fragments | weight scales (one 1-KB DMA instruction per four tiles) | activation scales (one instruction)
-    p.off_b = p.tpw * 4096u; p.off_ws = p.off_b + p.ttl * 4096u; p.off_xs = p.off_ws + ((p.tpw + 3u) / 4u) * 1024u; p.stage_bytes = p.off_xs + 1024u;
-    uint32_t ns = G7_LDS / p.stage_bytes;
-    // vmcnt is a 6-bit counter: (ns - 2) steps of the busier loader stay in flight behind the one waited for
-    const uint32_t ips_a = 4u * p.tpw + (p.tpw + 3u) / 4u, ips_b = (4u * p.ttl + G7_NLB - 1u) / G7_NLB + 1u, ips = ips_a > ips_b ? ips_a : ips_b;
-    if (ns > 2u + 63u / ips) ns = 2u + 63u / ips;
-    if (ns > G7_MAXNS) ns = G7_MAXNS;
-    if (ns > p.nk + 1u) ns = p.nk + 1u;
-    if (ns < 2u) return false;
-    p.ns = ns;
-    p.lds = (size_t)ns * p.stage_bytes;
+    // LDS: the weight ring (a stage = the tiles' 16 rows x 256 B + their scales, one 1-KB DMA instruction per four tiles), then the two
+    // fragment stages (token tiles x 4 KB + 1 KB of activation scales)
+    p.a_ws = p.tpw * 4096u; p.a_stage = p.a_ws + ((p.tpw + 3u) / 4u) * 1024u;
+    p.b_xs = p.ttl * 4096u; p.b_stage = p.b_xs + 1024u;
+    if (2u * p.b_stage + 1024u + 2u * p.a_stage > G7_LDS) return false;
+    uint32_t nsa = (G7_LDS - 2u * p.b_stage - 1024u) / p.a_stage;
+    // vmcnt is a 6-bit counter per wave: a loader's steps in flight behind the one it waits for (every second step is its own)
+    const uint32_t ips = 4u * p.tpw + (p.tpw + 3u) / 4u;
+    if (nsa > 1u + 2u * (63u / ips)) nsa = 1u + 2u * (63u / ips);
+    if (nsa > G7_MAXNSA) nsa = G7_MAXNSA;
+    if (nsa > p.nk + 1u) nsa = p.nk + 1u;
+    if (const char *e = getenv("NANO_G7_NS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 2u && v < nsa) nsa = v; }     // DEVELOPMENT ONLY
+    if (nsa < 2u) return false;
+    p.nsa = nsa;
+    p.b_base = nsa * p.a_stage;
+    p.lds = (size_t)p.b_base + 2u * p.b_stage + 1024u;                  // + the dummy kilobyte dead chunks are parked in
     return true;
 }
 
@@ -375,8 +410,9 @@ hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st) {
     d.xf = a.xq_in; d.xsf = a.xs_in;
     d.hh = p.hh; d.ntiles = p.ntiles; d.tc0 = p.tc0; d.tc1 = p.tc1; d.grid = p.grid; d.tpw = p.tpw;
     d.full = p.ntiles - (p.tpw - 1u) * p.grid;
-    d.nk = p.nk; d.ttl = p.ttl; d.ns = p.ns;
-    d.off_b = p.off_b; d.off_ws = p.off_ws; d.off_xs = p.off_xs; d.stage_bytes = p.stage_bytes;
+    d.nk = p.nk; d.ttl = p.ttl; d.nsa = p.nsa;
+    d.a_stage = p.a_stage; d.a_ws = p.a_ws; d.b_base = p.b_base; d.b_stage = p.b_stage; d.b_xs = p.b_xs;
+    { const char *e = getenv("NANO_G7_DBG"); d.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #define G7_GO(TP_, MP_) do { return p.ms ? g7_launch_t<TP_, MP_, true>(d, p.lds, st) : g7_launch_t<TP_, MP_, false>(d, p.lds, st); } while (0)
     // (tile capacity, pair capacity): the pairs of a workgroup are tpw x token tiles (2..4) dealt to eight waves
     if (p.tp == 1u) G7_GO(1, 1);

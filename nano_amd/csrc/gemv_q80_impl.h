@@ -601,7 +601,8 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     // busy on a 2560-row matrix (rw 16) where rw = 10 gives every CU one workgroup.  On a tie the larger slab (fewer
     // workgroups re-staging the activation).  Round 2's rule (powers of two, 64-160 KB) is kept as NANO_SLAB_BALANCED=0.
     uint32_t large_nw = 0;
-    if (B == 1 && (uint64_t)rows * a.n * nmat >= (8u << 20)) {
+    // (round 5 experiment, NANO_WIDE_GEMV_NB: 2..4 sequences on these matrices through the same balanced slabs, the product table B times as large)
+    if (B <= 4 && (uint64_t)rows * a.n * nmat >= (8u << 20)) {
         static const bool balanced = [] { const char *e = getenv("NANO_SLAB_BALANCED"); return !(e && *e == '0'); }();
         const uint32_t cus = a.cus ? a.cus : 256u;
         uint32_t best = 0, best_cost = ~0u;
@@ -610,7 +611,7 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
             for (uint32_t c = 4; c <= 64; c++) {
                 const uint32_t tpw = (c + 3) / 4;
                 if (tpw * nchunk * nmat > 64) break;                           // <= 16 waves x 4 units
-                if ((size_t)nmat * tpw * 4 * pitch * 4 > 96 * 1024) break;     // product table
+                if ((size_t)B * nmat * tpw * 4 * pitch * 4 > 96 * 1024) break;     // product table
                 uint32_t wgs = 0;
                 if (nseg > 1) for (uint32_t s2 = 0; s2 < nseg; s2++) wgs += (a.seg[s2].rows + c - 1) / c; else wgs = (rows + c - 1) / c;
                 // rows of the busiest CU; more than one workgroup per CU pays its prologue several times over on shared issue

@@ -20,7 +20,8 @@ def run_bench(extra, env_extra, timeout=900):
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--total-seqs", "6", "--steps", "8", "--warmup", "2",
                         "--no-cpu-baseline", "--no-kernel-table"] + extra, env=env, capture_output=True, text=True, timeout=timeout)
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    # (torch.distributed.run --tee prefixes every line of a rank with "[default0]:")
+    lines = [ln[ln.index('{"metric"'):] for ln in r.stdout.strip().splitlines() if '{"metric"' in ln]
     assert r.returncode == 0 and lines, (r.returncode, r.stderr[-3000:])
     return json.loads(lines[-1])
 

@@ -51,5 +51,30 @@ g7a)   # first light of G7 (LDS-DMA loader / consumer GEMM for 17..64 tokens): t
   prof 4b_b64 --model qwen3-4b --batch 64 --steps 12 --warmup 2
   timeout 300 python bench.py --model nano-56m --quant f32 --cpu-only > $O/cfg0_cpu.json 2>/dev/null; cut -c1-200 $O/cfg0_cpu.json
   ;;
+g7b)   # where G7's time goes: the kernel with parts switched off (NANO_G7_DBG: 1 consumers only synchronise, 2 no weight DMA, 4 no activation DMA), ring depth
+  timeout 600 python -m pytest tests/test_gpu_dist.py -m gpu -x -q 2>&1 | tail -40
+  for v in 0 1 6 2 4 5 3; do NANO_G7_DBG=$v bench 4b_b64_dbg$v --model qwen3-4b --batch 64 --steps 16 --warmup 2; done
+  for v in 2 3; do NANO_G7_NS=$v bench 4b_b64_ns$v --model qwen3-4b --batch 64 --steps 16 --warmup 2; done
+  NANO_G7_DBG=1 bench q06_b64_dbg1 --batch 64 --steps 32 --warmup 2
+  NANO_G7_DBG=6 bench q06_b64_dbg6 --batch 64 --steps 32 --warmup 2
+  for b in 2 4; do
+    bench 4b_b${b} --model qwen3-4b --batch $b --steps 32 --warmup 4
+    NANO_WIDE_GEMV_NB=4 bench 4b_b${b}_slab --model qwen3-4b --batch $b --steps 32 --warmup 4
+  done
+  ;;
+g7c)   # G7 second build (weights by LDS-DMA in a deep ring, fragments staged by the consumers): parity, A/B, parts switched off
+  timeout 300 python tools/g7_check.py 2>&1 | tail -14 | tee $O/g7_check.txt
+  timeout 900 python -m pytest tests/test_gpu_fused_roles.py -m gpu -x -q -k "gemm_route or ragged" 2>&1 | tail -4
+  timeout 600 python -m pytest tests/test_gpu_dist.py -m gpu -x -q 2>&1 | tail -30
+  for b in 64 32; do
+    bench 4b_b${b}_g7 --model qwen3-4b --batch $b --steps 32 --warmup 4
+    NANO_GEMM_G7=0 bench 4b_b${b}_old --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-kernel-table
+  done
+  for v in 2 4 6; do NANO_G7_DBG=$v bench 4b_b64_dbg$v --model qwen3-4b --batch 64 --steps 16 --warmup 2 --no-kernel-table; done
+  bench q06_b64_g7 --batch 64 --steps 64 --warmup 4
+  NANO_GEMM_G7=0 bench q06_b64_old --batch 64 --steps 64 --warmup 4 --no-kernel-table
+  timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -4 | tee $O/prefill_g7.txt
+  prof 4b_b64 --model qwen3-4b --batch 64 --steps 12 --warmup 2
+  ;;
 *) echo "unknown mode $1";;
 esac
