@@ -35,12 +35,12 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t G7_NCW = 8;                      // consumer waves
+constexpr uint32_t G7_NCW = 14;                     // consumer waves
 constexpr uint32_t G7_NLA = 2;                      // weight loader waves (steps k % 2)
-constexpr uint32_t G7_NW = G7_NCW + G7_NLA;         // 10 waves
+constexpr uint32_t G7_NW = G7_NCW + G7_NLA;         // 16 waves: four per SIMD (<= 128 registers each)
 constexpr uint32_t G7_MAXNSA = 32;
 constexpr uint32_t G7_LDS = 160u * 1024u;
-constexpr int G7_BD = 4;                            // steps of activation fragments a consumer wave keeps in flight (registers)
+constexpr int G7_BD = 3;                            // steps of activation fragments a consumer wave keeps in flight (registers)
 
 struct G7Dev {
     GemvDev g;                          // segments, n, ng, epi, nb, pos
@@ -77,10 +77,10 @@ template <int R0, int R1, class F> __device__ __forceinline__ void g7_static_for
     if constexpr (R0 < R1) { f(std::integral_constant<int, R0>{}); g7_static_for<R0 + 1, R1>(f); }
 }
 
-// TP   = row tiles per workgroup (capacity of the loader's address registers): 1 | 2 | 3 | 5 | 8
-// MAXP = (tile, token tile) pairs per consumer wave (capacity): ceil(tpw * token tiles / 8)
-// MS   = several weight segments share the launch (q | k | v)
-template <int TP, int MAXP, bool MS>
+// TP = row tiles per workgroup (capacity of the loaders' address registers): 1 | 2 | 3 | 5 | 8
+// PP = token tiles per consumer wave (1 | 2): the smallest with tpw x ceil(token tiles / PP) <= 14 waves
+// MS = several weight segments share the launch (q | k | v)
+template <int TP, int PP, bool MS>
 __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const GemvDev &a = d.g;
@@ -181,101 +181,103 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
         return;
     }
     // ==================================================== consumers ======================================================================
+    // Wave w < nact multiplies row tile w / gpt with the PP consecutive token tiles (w % gpt) PP .. + PP - 1: the tile's A fragments and
+    // weight scales are read from LDS once per step for all of them.  Straight-line code per step: the loads of all operands, the 4 PP
+    // matrix instructions, then the products and sums (no branch between them: the scheduler overlaps the pairs' chains).
     const uint32_t m = lane & 15u, kq = lane >> 4;
     uint32_t a_off[4];
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) a_off[j] = m * 256u + (((4u * j + kq) ^ m) << 4);
     const uint32_t half = kq >> 1, rr0 = (kq & 1u) * 4u;              // this lane's four output rows: rows rr0 .. rr0 + 3 of half `half`
-    const uint32_t npairs = ntl * ttl;
-    uint32_t ptile[MAXP], ptt[MAXP]; bool plive[MAXP];
-    float acc[MAXP][4], S[MAXP][4], oldv[MAXP][4];
-    uint32_t opos[MAXP];
+    const uint32_t gpt = (ttl + (uint32_t)PP - 1u) / (uint32_t)PP;    // waves per row tile
+    const bool active = wid < ntl * gpt;
+    const uint32_t wtile = active ? wid / gpt : 0u, tt0 = active ? (wid - wtile * gpt) * (uint32_t)PP : 0u;
+    float acc[PP][4], S[PP][4], oldv[PP][4];
+    uint32_t opos[PP];
+    const TI wt = decode(wtile);
+    const uint32_t orow0 = wt.lrow0 + half * halfoff + rr0;           // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
 #pragma unroll
-    for (int i = 0; i < MAXP; i++) {
-        const uint32_t q = wid + (uint32_t)i * G7_NCW;
-        plive[i] = q < npairs;
-        ptile[i] = plive[i] ? q / ttl : 0u;
-        ptt[i] = plive[i] ? q - ptile[i] * ttl : 0u;
+    for (int i = 0; i < PP; i++) {
         opos[i] = 0u;
 #pragma unroll
         for (int r = 0; r < 4; r++) { acc[i][r] = 0.0f; S[i][r] = 0.0f; oldv[i][r] = 0.0f; }
         // what the epilogue needs from memory (the old residual values, the position of a position-indexed output): asked for now
-        if (plive[i] && (epi == GEMV_EPI_RESID || (a.out_pstride[0] | a.out_pstride[1] | a.out_pstride[2]) != 0u)) {
-            const TI t = decode(ptile[i]);
-            const uint32_t orow0 = t.lrow0 + half * halfoff + rr0, tok = ptt[i] * 16u + m;
-            if (tok < nb) {
-                if (t.ops) opos[i] = a.pos[tok];
-                if (epi == GEMV_EPI_RESID) {
-                    const float *o = t.out + (size_t)tok * t.obs + orow0;
+        const uint32_t tok = (tt0 + (uint32_t)i) * 16u + m;
+        if (active && tok < nb && (epi == GEMV_EPI_RESID || wt.ops != 0u)) {
+            if (wt.ops) opos[i] = a.pos[tok];
+            if (epi == GEMV_EPI_RESID) {
+                const float *o = wt.out + (size_t)tok * wt.obs + orow0;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < t.rows0) oldv[i][r] = o[r];
-                }
+                for (int r = 0; r < 4; r++) if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < wt.rows0) oldv[i][r] = o[r];
             }
         }
     }
-    // ---- the activation fragments: 1-KB chunk c = 4 tt + j of a step (token tile tt, group j of the step) is fetched and parked by wave c % 8
-    //      (two chunks per wave at four token tiles); wave 0 also moves the step's activation scales (256 B per token tile).  A chunk sits
-    //      in registers for G7_BD steps: asked for at step k - 3, parked in LDS stage (k + 1) % 2 at step k, multiplied at step k + 1.
+    // ---- the activation fragments: the step's 1-KB chunks -- c = 4 tt + j: token tile tt, group j of the step; c = 4 ttl: the step's
+    //      activation scales (256 B per token tile) -- are fetched and parked by wave c % 14 (<= two chunks per wave).  A chunk sits in
+    //      registers for G7_BD steps: asked for at step k - 2, parked in LDS stage (k + 1) % 2 at step k, multiplied at step k + 1.
     // The step loop below has NO branch around a load or an LDS store (a chunk that does not exist is read through an out-of-range offset
-    // -- zeros, no memory access -- and parked in a dummy kilobyte): every s_waitcnt the compiler places is then the exact count
-    // (vmcnt(6): the two younger steps stay in flight), where a merge point made it wait for everything (the first build: vmcnt(0)).
-    const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf, ttl * ng * 1024u);
-    const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf, ttl * ng * 64u);
+    // -- zeros, no memory access -- and parked in a dummy kilobyte): every s_waitcnt the compiler places is then the exact count (the
+    // younger steps stay in flight), where a merge point made it wait for everything (the first build: vmcnt(0)).
     const uint32_t dummy = d.b_base + 2u * d.b_stage + lane * 16u;     // 1 KB behind the fragment stages
-    uint32_t c_src[2], c_dst[2];
+    uint32_t c_src[2], c_dst[2], c_step[2];
+    __amdgpu_buffer_rsrc_t c_rs[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const uint32_t c = wid + (uint32_t)i * G7_NCW, tt = c >> 2, j = c & 3u;
-        const bool live = c < 4u * ttl;
-        c_src[i] = (live && !(d.dbg & 4u)) ? (tt * ng + j) * 1024u + lane * 16u : OOB;             // + 4 k groups = 4096 k bytes
-        c_dst[i] = live ? tt * 4096u + j * 1024u + lane * 16u : 0xffffffffu;                       // (inside a fragment stage; dead: the dummy)
+        const bool frag = c < 4u * ttl, scal = c == 4u * ttl;
+        c_rs[i] = scal ? mkrsrc(d.xsf, ttl * ng * 64u) : mkrsrc(d.xf, ttl * ng * 1024u);
+        // fragments: + 4 groups = 4096 bytes per step; scales: lane l -> token tile l / 16, the 16 bytes l % 16 of its 4 groups x 16 tokens: + 256 bytes per step
+        c_src[i] = (d.dbg & 4u) ? OOB : frag ? (tt * ng + j) * 1024u + lane * 16u : (scal && (lane >> 4) < ttl) ? (((lane >> 4) * ng) * 16u + (lane & 15u) * 4u) * 4u : OOB;
+        c_step[i] = scal ? 256u : 4096u;
+        c_dst[i] = frag ? tt * 4096u + j * 1024u + lane * 16u : scal ? d.b_xs + lane * 16u : 0xffffffffu;     // (inside a fragment stage; no chunk: the dummy)
     }
-    const bool xs_wave = wid == 0u;
-    const uint32_t xs_src = (xs_wave && (lane >> 4) < ttl && !(d.dbg & 4u)) ? (((lane >> 4) * ng) * 16u + (lane & 15u) * 4u) * 4u : OOB;   // + 4 k groups = 256 k bytes
-    i32x4 breg[G7_BD][2], xreg[G7_BD];
+    i32x4 breg[G7_BD][2];
     auto b_issue = [&](auto SL, uint32_t k) {                          // the loads of step k (beyond the last step: nothing) into register slot SL
         constexpr int sl = decltype(SL)::value;
         const bool in = k < nk;
-        breg[sl][0] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)((in && c_src[0] != OOB) ? c_src[0] + k * 4096u : OOB), 0, 0);
-        breg[sl][1] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)((in && c_src[1] != OOB) ? c_src[1] + k * 4096u : OOB), 0, 0);
-        xreg[sl] = __builtin_amdgcn_raw_buffer_load_b128(rxs, (int)((in && xs_src != OOB) ? xs_src + k * 256u : OOB), 0, 0);
+        breg[sl][0] = __builtin_amdgcn_raw_buffer_load_b128(c_rs[0], (int)((in && c_src[0] != OOB) ? c_src[0] + k * c_step[0] : OOB), 0, 0);
+        breg[sl][1] = __builtin_amdgcn_raw_buffer_load_b128(c_rs[1], (int)((in && c_src[1] != OOB) ? c_src[1] + k * c_step[1] : OOB), 0, 0);
     };
     auto b_park = [&](auto SL, uint32_t k) {                           // register slot SL (step k) -> fragment stage k % 2 (a step beyond the last: harmless,
         constexpr int sl = decltype(SL)::value;                        //  that stage is not read again)
         const uint32_t bs = d.b_base + (k & 1u) * d.b_stage;
         *reinterpret_cast<i32x4 *>(smem + (c_dst[0] != 0xffffffffu ? bs + c_dst[0] : dummy)) = breg[sl][0];
         *reinterpret_cast<i32x4 *>(smem + (c_dst[1] != 0xffffffffu ? bs + c_dst[1] : dummy)) = breg[sl][1];
-        *reinterpret_cast<i32x4 *>(smem + (xs_wave ? bs + d.b_xs + lane * 16u : dummy)) = xreg[sl];
     };
-    // one step of every pair of this wave: FIRST = the step opens a unit (its group 0 starts the unit sum)
-    auto step = [&](auto FIRST, const unsigned char *st, const unsigned char *bs) {
-        constexpr bool first = decltype(FIRST)::value;
+    // one step of this wave's pairs: FIRST = the step opens a unit (its group 0 starts the unit sum)
+    auto step = [&](const bool first, const unsigned char *st, const unsigned char *bs) {
+        const unsigned char *A = st + wtile * 4096u;
+        const float *WS = reinterpret_cast<const float *>(st + d.a_ws + wtile * 256u) + kq * 16u;              // rows 4 kq .. + 3: [row][4 groups]
+        i32x4 fa[4];
 #pragma unroll
-        for (int i = 0; i < MAXP; i++) {
-            if (!plive[i]) continue;                                   // (wave-uniform)
-            const unsigned char *A = st + ptile[i] * 4096u, *B = bs + ptt[i] * 4096u + lane * 16u;
-            const float *WS = reinterpret_cast<const float *>(st + d.a_ws + ptile[i] * 256u) + kq * 16u;        // rows 4 kq .. + 3: [row][4 groups]
-            const float *XS = reinterpret_cast<const float *>(bs + d.b_xs + ptt[i] * 256u) + m;                 // [group][16 tokens]
-            const float4 w0 = *reinterpret_cast<const float4 *>(WS), w1 = *reinterpret_cast<const float4 *>(WS + 4);
-            const float4 w2 = *reinterpret_cast<const float4 *>(WS + 8), w3 = *reinterpret_cast<const float4 *>(WS + 12);
-            const float wr[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}, {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
+        for (int j = 0; j < 4; j++) fa[j] = *reinterpret_cast<const i32x4 *>(A + a_off[j]);
+        const float4 w0 = *reinterpret_cast<const float4 *>(WS), w1 = *reinterpret_cast<const float4 *>(WS + 4);
+        const float4 w2 = *reinterpret_cast<const float4 *>(WS + 8), w3 = *reinterpret_cast<const float4 *>(WS + 12);
+        const float wr[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}, {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
+#pragma unroll
+        for (int i = 0; i < PP; i++) {                                 // per token tile: 4 fragment reads, 4 matrix instructions back to back, then the VALU work
+            const unsigned char *B = bs + (tt0 + (uint32_t)i) * 4096u + lane * 16u;
+            const float *XS = reinterpret_cast<const float *>(bs + d.b_xs + (tt0 + (uint32_t)i) * 256u) + m;    // [group][16 tokens]
+            v4i cv[4];
+            float xsc[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const i32x4 fa = *reinterpret_cast<const i32x4 *>(A + a_off[j]);
                 const i32x4 fb = *reinterpret_cast<const i32x4 *>(B + j * 1024);
-                const float xsc = XS[j * 16];
-                const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
+                xsc[j] = XS[j * 16];
+                cv[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[j], fb, v4i{0, 0, 0, 0}, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float p = ((float)cv[r] * wr[r][j]) * xsc;                    // infer.c:672
-                    if (first && j == 0) S[i][r] = p; else S[i][r] += p;
+                    const float p = ((float)cv[j][r] * wr[r][j]) * xsc[j];              // infer.c:672
+                    if (j == 0) S[i][r] = first ? p : S[i][r] + p; else S[i][r] += p;
                 }
-            }
         }
     };
     auto fold = [&](uint32_t u) {
 #pragma unroll
-        for (int i = 0; i < MAXP; i++)
+        for (int i = 0; i < PP; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[i][r] = u == 0u ? S[i][r] : acc[i][r] + S[i][r];          // units ascending
     };
@@ -288,40 +290,38 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
         __syncthreads();                                               // weights of step k landed (the loaders), fragments of step k parked; everyone is done with step k - 1
         b_park(std::integral_constant<int, (si + 1) % G7_BD>{}, k + 1u);       // stage (k + 1) % 2 was last read at step k - 1
         b_issue(SI, k + (uint32_t)G7_BD);                              // slot si was parked at step k - 1
-        step(std::integral_constant<bool, si % 2 == 0>{}, smem + sta * d.a_stage, smem + d.b_base + (k & 1u) * d.b_stage);
+        if (active) step((k & 1u) == 0u, smem + sta * d.a_stage, smem + d.b_base + (k & 1u) * d.b_stage);
         sta = sta + 1u == nsa ? 0u : sta + 1u;
     };
     uint32_t k4 = 0;
     for (; k4 + (uint32_t)G7_BD <= nk; k4 += (uint32_t)G7_BD)          // whole rounds of G7_BD steps: straight-line code
-        g7_static_for<0, G7_BD>([&](auto SI) { one_step(SI, k4 + (uint32_t)decltype(SI)::value); if (decltype(SI)::value % 2 == 1) fold((k4 + (uint32_t)decltype(SI)::value) >> 1); });
+        g7_static_for<0, G7_BD>([&](auto SI) { const uint32_t k = k4 + (uint32_t)decltype(SI)::value; one_step(SI, k); if (k & 1u) fold(k >> 1); });
     g7_static_for<0, G7_BD - 1>([&](auto SI) {                         // the last nk % G7_BD steps
         const uint32_t k = k4 + (uint32_t)decltype(SI)::value;
-        if (k < nk) { one_step(SI, k); if (decltype(SI)::value % 2 == 1 || k + 1u == nk) fold(k >> 1); }
+        if (k < nk) { one_step(SI, k); if ((k & 1u) || k + 1u == nk) fold(k >> 1); }
     });
     // ---- epilogue: store | residual add | SwiGLU -----------------------------------------------------------------------------------------
+    if (!active) return;
 #pragma unroll
-    for (int i = 0; i < MAXP; i++) {
-        if (!plive[i]) continue;
-        const TI t = decode(ptile[i]);
-        const uint32_t orow0 = t.lrow0 + half * halfoff + rr0;        // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
-        const uint32_t tok = ptt[i] * 16u + m;
+    for (int i = 0; i < PP; i++) {
+        const uint32_t tok = (tt0 + (uint32_t)i) * 16u + m;
         float v3[4] = {0.f, 0.f, 0.f, 0.f};
         if (sw) {                                                      // W3's values live 32 lanes up (rows 8..15 of the tile)
 #pragma unroll
             for (int r = 0; r < 4; r++) v3[r] = __shfl_xor(acc[i][r], 32, 64);
         }
         if (tok < nb && (!sw || kq < 2u)) {
-            float *o = t.out + (size_t)tok * t.obs + (size_t)opos[i] * t.ops + orow0;
+            float *o = wt.out + (size_t)tok * wt.obs + (size_t)opos[i] * wt.ops + orow0;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < t.rows0) o[r] = finish_epi(epi, acc[i][r], v3[r], oldv[i][r]);
+                if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < wt.rows0) o[r] = finish_epi(epi, acc[i][r], v3[r], oldv[i][r]);
         }
     }
     NANO_STAMP_END(a.stamps, 6);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
-struct G7Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nk, ttl, nsa, a_stage, a_ws, b_base, b_stage, b_xs, tp, maxp; bool ms; size_t lds; };
+struct G7Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nk, ttl, nsa, a_stage, a_ws, b_base, b_stage, b_xs, tp, pp; bool ms; size_t lds; };
 
 static uint32_t g7_rows(const GemvArgs &a) {
     if (a.epi == GEMV_EPI_SWIGLU) return a.seg[0].rows;
@@ -353,12 +353,13 @@ static bool g7_plan(const GemvArgs &a, G7Plan &p) {
     p.nk = a.n / 256u; p.ttl = (a.nb + 15u) / 16u;
     p.tp = p.tpw <= 1 ? 1u : p.tpw == 2 ? 2u : p.tpw == 3 ? 3u : p.tpw <= 5 ? 5u : p.tpw <= 8 ? 8u : 0u;
     if (!p.tp) return false;
-    p.maxp = (p.tpw * p.ttl + G7_NCW - 1u) / G7_NCW;
-    if (p.maxp > 4u) return false;
+    p.pp = 0;
+    for (uint32_t pp = 1; pp <= 2u && !p.pp; pp *= 2u) if (p.tpw * ((p.ttl + pp - 1u) / pp) <= G7_NCW) p.pp = pp;
+    if (!p.pp) return false;
     // LDS: the weight ring (a stage = the tiles' 16 rows x 256 B + their scales, one 1-KB DMA instruction per four tiles), then the two
     // fragment stages (token tiles x 4 KB + 1 KB of activation scales)
     p.a_ws = p.tpw * 4096u; p.a_stage = p.a_ws + ((p.tpw + 3u) / 4u) * 1024u;
-    p.b_xs = p.ttl * 4096u; p.b_stage = p.b_xs + 1024u;
+    p.b_xs = ((p.ttl + p.pp - 1u) / p.pp) * p.pp * 4096u; p.b_stage = p.b_xs + 1024u;    // (token tiles rounded up to the waves' PP: a wave reads all of its PP)
     if (2u * p.b_stage + 1024u + 2u * p.a_stage > G7_LDS) return false;
     uint32_t nsa = (G7_LDS - 2u * p.b_stage - 1024u) / p.a_stage;
     // vmcnt is a 6-bit counter per wave: a loader's steps in flight behind the one it waits for (every second step is its own)
@@ -374,9 +375,9 @@ static bool g7_plan(const GemvArgs &a, G7Plan &p) {
     return true;
 }
 
-template <int TP, int MAXP, bool MS>
+template <int TP, int PP, bool MS>
 static hipError_t g7_launch_t(const G7Dev &d, size_t lds, hipStream_t st) {
-    auto kern = &gemm_q80_g7_kernel<TP, MAXP, MS>;
+    auto kern = &gemm_q80_g7_kernel<TP, PP, MS>;
     static std::atomic<bool> armed[64];
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !armed[dev].load(std::memory_order_acquire)) {
@@ -413,15 +414,11 @@ hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st) {
     d.nk = p.nk; d.ttl = p.ttl; d.nsa = p.nsa;
     d.a_stage = p.a_stage; d.a_ws = p.a_ws; d.b_base = p.b_base; d.b_stage = p.b_stage; d.b_xs = p.b_xs;
     { const char *e = getenv("NANO_G7_DBG"); d.dbg = e ? (uint32_t)atoi(e) : 0u; }
-#define G7_GO(TP_, MP_) do { return p.ms ? g7_launch_t<TP_, MP_, true>(d, p.lds, st) : g7_launch_t<TP_, MP_, false>(d, p.lds, st); } while (0)
-    // (tile capacity, pair capacity): the pairs of a workgroup are tpw x token tiles (2..4) dealt to eight waves
-    if (p.tp == 1u) G7_GO(1, 1);
-    if (p.tp == 2u) G7_GO(2, 1);
-    if (p.tp == 3u) G7_GO(3, 2);
-    if (p.tp == 5u) { if (p.maxp <= 2u) G7_GO(5, 2); G7_GO(5, 3); }
-    if (p.maxp <= 2u) G7_GO(8, 2);
-    if (p.maxp == 3u) G7_GO(8, 3);
-    G7_GO(8, 4);
+#define G7_GO(TP_, PP_) do { return p.ms ? g7_launch_t<TP_, PP_, true>(d, p.lds, st) : g7_launch_t<TP_, PP_, false>(d, p.lds, st); } while (0)
+#define G7_TP(PP_) do { if (p.tp == 1u) G7_GO(1, PP_); if (p.tp == 2u) G7_GO(2, PP_); if (p.tp == 3u) G7_GO(3, PP_); if (p.tp == 5u) G7_GO(5, PP_); G7_GO(8, PP_); } while (0)
+    if (p.pp == 1u) G7_TP(1);
+    G7_TP(2);
+#undef G7_TP
 #undef G7_GO
 }
 
