@@ -104,6 +104,8 @@ struct NanoHipModel {
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
     bool attn_quant = true;                               // batched steps: the attention kernel also writes the Wo GEMM's quantized input (NANO_ATTN_QUANT=0: quantizer launch)
     bool use_g5 = true;                                   // batched Q80 launches of group size 64 take gemm_q80_g5.hip's chained K-split kernel (NANO_GEMM_G5=0: G2 everywhere)
+    bool fuse_qkv_attn = true;                            // one sequence, Q80 gs 64, Qwen3 head_dim 128: q|k|v projection + attention in one launch; NANO_FUSE_QKV_ATTN=0: two launches (same bits)
+    unsigned long long *hand[2] = {nullptr, nullptr};     // its two granule buffers (q_dim + 2 kv_dim entries each)
     bool use_g7 = true;                                   // fast path, 17..64 tokens: gemm_q80_g7.hip (loader / consumer engine); NANO_GEMM_G7=0: G6 MODE F / G5 (same-box A/B)
     bool use_g6 = true;                                   // fast path, group size 64: gemm_q80_g6.hip's split-K kernel (<= 16 tokens; MODE P for 1..8 sequences on wide matrices); NANO_GEMM_G6=0: round 3's routes
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
@@ -198,7 +200,7 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att, m->vraw, m->gq2, m->gxs2, m->stamps, m->pt, m->kvrow };
+                    m->xn, m->hb2, m->att, m->vraw, m->gq2, m->gxs2, m->stamps, m->pt, m->kvrow, m->hand[0], m->hand[1] };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -431,6 +433,13 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (const char *g5 = getenv("NANO_GEMM_G5")) m->use_g5 = *g5 && *g5 != '0';
     if (const char *g6 = getenv("NANO_GEMM_G6")) m->use_g6 = *g6 && *g6 != '0';
     if (const char *g7 = getenv("NANO_GEMM_G7")) m->use_g7 = *g7 && *g7 != '0';
+    if (const char *fz = getenv("NANO_FUSE_QKV_ATTN")) m->fuse_qkv_attn = *fz && *fz != '0';
+    if (m->d.quant_type == NANO_QUANT_Q80 && m->d.group_size == 64) {
+        for (int i = 0; i < 2; i++) {
+            const size_t hb = (size_t)(m->QD + 2 * m->KD) * 8;
+            if (hipMalloc(reinterpret_cast<void **>(&m->hand[i]), hb) != hipSuccess || hipMemset(m->hand[i], 0, hb) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off granules failed"); }
+        }
+    }
     if (const char *aq = getenv("NANO_ATTN_QUANT")) m->attn_quant = *aq && *aq != '0';
     if (const char *wq = getenv("NANO_W2_QUANT")) m->w2_quant = *wq && *wq != '0';
     HIP_TRY(hipDeviceSynchronize());
@@ -621,20 +630,42 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
 
     for (uint32_t l = 0; l < L; l++) {
         const size_t layer_rows = (size_t)l * S;                    // cache row offset of this layer within a slot
-        {   // q | raw k | v (straight into the cache row)   reference infer.c:758-786
-            GemvArgs a{};
-            a.nseg = 3;
-            a.seg[0] = mkseg(m->W[WQ][l], m->q, QD, QD);
-            a.seg[1] = mkseg(m->W[WK][l], m->kraw, KD, KD);
-            // v goes straight to its cache row; prefill: every token of the step is a position of KV slot pf_slot
-            a.seg[2] = m->kv_half ? mkseg(m->W[WV][l], m->vraw, KD, KD)          // FP16 cache: the attention kernel rounds and stores the row
-                     : m->kv_paged ? mkseg(m->W[WV][l], m->vcache + (size_t)l * plane, KD, 0, KD)      // paged: row kvrow[b] of this layer's plane
-                     : m->pf ? mkseg(m->W[WV][l], m->vcache + ((size_t)m->pf_slot * L * S + layer_rows) * KD, KD, 0, KD)
-                             : mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
-            a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_STORE;
-            a.norm_w = m->rms_attn + (size_t)l * E; a.pos = (m->kv_paged && !m->kv_half) ? m->kvrow : m->pos;     // (the only position-indexed output)
-            a.stamps = next_stamps(m, 1);
-            if (!(skip & 1) && (e = gemv(m, a)) != hipSuccess) return e;
+        // q | raw k | v (straight into the cache row)   reference infer.c:758-786
+        GemvArgs qa{};
+        qa.nseg = 3;
+        qa.seg[0] = mkseg(m->W[WQ][l], m->q, QD, QD);
+        qa.seg[1] = mkseg(m->W[WK][l], m->kraw, KD, KD);
+        // v goes straight to its cache row; prefill: every token of the step is a position of KV slot pf_slot
+        qa.seg[2] = m->kv_half ? mkseg(m->W[WV][l], m->vraw, KD, KD)          // FP16 cache: the attention kernel rounds and stores the row
+                  : m->kv_paged ? mkseg(m->W[WV][l], m->vcache + (size_t)l * plane, KD, 0, KD)      // paged: row kvrow[b] of this layer's plane
+                  : m->pf ? mkseg(m->W[WV][l], m->vcache + ((size_t)m->pf_slot * L * S + layer_rows) * KD, KD, 0, KD)
+                          : mkseg(m->W[WV][l], m->vcache + layer_rows * KD, KD, (uint32_t)((size_t)L * S * KD), KD);
+        qa.n = E; qa.gs = d.group_size; qa.nb = nb; qa.xin = m->x; qa.xin_bstride = E; qa.epi = GEMV_EPI_STORE;
+        qa.norm_w = m->rms_attn + (size_t)l * E; qa.pos = (m->kv_paged && !m->kv_half) ? m->kvrow : m->pos;     // (the only position-indexed output)
+        // qk-norm, rope, k-cache write, attention   reference infer.c:810-879
+        AttnArgs a{};
+        a.q = m->q; a.q_out = nullptr; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
+        a.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
+        a.k_norm = m->k_norm ? m->k_norm + (size_t)l * m->hd : nullptr;
+        a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.rope_cur = m->rope_cos ? m->rope_cur : nullptr; a.out = m->attn_part; a.ml = m->attn_ml; a.xba_out = m->xba; a.nsplit = nsplit; a.range_hint = range_hint;
+        a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
+        a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
+        a.cache_bstride_rows = L * S; a.fixed_range = 0;
+        a.kv_half = m->kv_half ? 1u : 0u; a.vraw = m->kv_half ? m->vraw : nullptr;
+        if (wo_frag && nsplit == 1) { a.xf_out = m->gq; a.xsf_out = m->gxs; }
+        if (m->kv_paged) { a.pt_rows = pt_base; a.kvrow = m->kvrow; a.pt_stride = m->pt_stride; a.pt_bstride = pt_bstride; a.pool_rows = m->kv_pages * 64u; }
+        // ONE launch for both (one sequence, Q80 group size 64, Qwen3 attention at head_dim 128: gemv_q80_impl.h qkv_attn_fused_kernel): the
+        // attention workgroups start with the projection's, ask for their K / V rows and take q / k / v from it as write-through granules.
+        // Two granule buffers alternate by layer (each launch zeroes the one the next launch fills): an even layer count keeps the
+        // alternation across steps.
+        qa.ordered = 0; qa.cus = (uint32_t)m->cus;
+        const bool fused = m->fuse_qkv_attn && m->hand[0] && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && (L % 2u) == 0u && !(skip & 3u) &&
+                           d.quant_type == NANO_QUANT_Q80 && kind_of(m, qa) == ROUTE_GEMV && qkv_attn_fused_supports(qa, a);
+        if (fused) {
+            if ((e = launch_qkv_attn_fused(qa, a, m->hand[l & 1u], m->hand[(l + 1u) & 1u], m->st)) != hipSuccess) return e;
+        } else {
+            qa.stamps = next_stamps(m, 1);
+            if (!(skip & 1) && (e = gemv(m, qa)) != hipSuccess) return e;
             if (m->lora_on) {       // q / k / v += (alpha/rank) B (A xb)   reference infer.c:792-808
                 const size_t la = (size_t)l * m->lora_rank * E, lbq = (size_t)l * E * m->lora_rank, lbk = (size_t)l * KD * m->lora_rank;
                 LoraArgs la_{};
@@ -647,19 +678,6 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 la_.pos = m->pos; la_.E = E; la_.KD = KD; la_.rank = m->lora_rank; la_.alpha = m->lora_alpha;
                 if ((e = launch_lora_qkv(la_, nb, m->st)) != hipSuccess) return e;
             }
-        }
-        {   // qk-norm, rope, k-cache write, attention   reference infer.c:810-879
-            AttnArgs a{};
-            a.q = m->q; a.q_out = nullptr; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
-            a.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
-            a.k_norm = m->k_norm ? m->k_norm + (size_t)l * m->hd : nullptr;
-            a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin; a.rope_cur = m->rope_cos ? m->rope_cur : nullptr; a.out = m->attn_part; a.ml = m->attn_ml; a.xba_out = m->xba; a.nsplit = nsplit; a.range_hint = range_hint;
-            a.layer = l; a.n_layer = L; a.S = S; a.hd = m->hd; a.n_head = d.n_head; a.n_kv_head = d.n_kv_head;
-            a.q_dim = QD; a.kv_dim = KD; a.rope_qwen3 = (d.arch == NANO_ARCH_QWEN3); a.is_causal = is_causal;
-            a.cache_bstride_rows = L * S; a.fixed_range = 0;
-            a.kv_half = m->kv_half ? 1u : 0u; a.vraw = m->kv_half ? m->vraw : nullptr;
-            if (wo_frag && nsplit == 1) { a.xf_out = m->gq; a.xsf_out = m->gxs; }
-            if (m->kv_paged) { a.pt_rows = pt_base; a.kvrow = m->kvrow; a.pt_stride = m->pt_stride; a.pt_bstride = pt_bstride; a.pool_rows = m->kv_pages * 64u; }
             if (m->pf && m->kv_paged) {
                 a.prep_only = 1;                                                     // pass 1: every token's k row into its page
                 if ((e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
@@ -678,6 +696,8 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             }
             a.stamps = next_stamps(m, 2);
             if (!(skip & 2) && (e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
+        }
+        {
             if (pf_combine && (e = launch_attn_combine_tokens(m->attn_part, m->attn_ml, m->xba, d.n_head, m->hd, nsplit, nb, wo_frag ? m->gq : nullptr, wo_frag ? m->gxs : nullptr, m->st)) != hipSuccess) return e;
         }
         {   // x += Wo . xba   reference infer.c:885-908

@@ -51,7 +51,6 @@ struct G7Dev {
     uint32_t nk, ttl, nsa;              // steps (256 B of a row each); live token tiles; weight-ring stages
     uint32_t a_stage, a_ws;             // bytes of a weight stage (tiles' weights at 0, their scales at a_ws)
     uint32_t b_base, b_stage, b_xs;     // the two fragment stages: LDS offset of the first, bytes of one, offset of the activation scales inside
-    uint32_t dbg;                       // DEVELOPMENT ONLY (NANO_G7_DBG): 1 consumers only synchronise, 2 no weight DMA, 4 no fragment loads
 };
 
 template <int AUX> __device__ __forceinline__ void g7_dma16(const void *gsrc, unsigned char *lds_dst) {
@@ -155,7 +154,6 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
             ips += sil[s] ? 1u : 0u;
         }
         auto issue = [&](uint32_t k, unsigned char *st) {
-            if (d.dbg & 2u) return;
             const uint32_t kb = k * 256u;
 #pragma unroll
             for (int t = 0; t < TP; t++)
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
         const bool frag = c < 4u * ttl, scal = c == 4u * ttl;
         c_rs[i] = scal ? mkrsrc(d.xsf, ttl * ng * 64u) : mkrsrc(d.xf, ttl * ng * 1024u);
         // fragments: + 4 groups = 4096 bytes per step; scales: lane l -> token tile l / 16, the 16 bytes l % 16 of its 4 groups x 16 tokens: + 256 bytes per step
-        c_src[i] = (d.dbg & 4u) ? OOB : frag ? (tt * ng + j) * 1024u + lane * 16u : (scal && (lane >> 4) < ttl) ? (((lane >> 4) * ng) * 16u + (lane & 15u) * 4u) * 4u : OOB;
+        c_src[i] = frag ? (tt * ng + j) * 1024u + lane * 16u : (scal && (lane >> 4) < ttl) ? (((lane >> 4) * ng) * 16u + (lane & 15u) * 4u) * 4u : OOB;
         c_step[i] = scal ? 256u : 4096u;
         c_dst[i] = frag ? tt * 4096u + j * 1024u + lane * 16u : scal ? d.b_xs + lane * 16u : 0xffffffffu;     // (inside a fragment stage; no chunk: the dummy)
     }
@@ -284,22 +282,26 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
     // prologue: the first G7_BD steps' fragments are asked for, step 0's parked (behind the first barrier everyone may read them)
     g7_static_for<0, G7_BD>([&](auto SL) { b_issue(SL, (uint32_t)decltype(SL)::value); });
     b_park(std::integral_constant<int, 0>{}, 0u);
+    NANO_STAMP(a.stamps, 1, breg[0][0].x);                          // prologue done: step 0's fragments arrived and are parked
     uint32_t sta = 0;                                                  // weight stage of the current step
     auto one_step = [&](auto SI, uint32_t k) {                         // step k, k % G7_BD == SI
         constexpr int si = decltype(SI)::value;
         __syncthreads();                                               // weights of step k landed (the loaders), fragments of step k parked; everyone is done with step k - 1
+        if (k == 0u) NANO_STAMP(a.stamps, 2, sta);                     // the first weights have landed
         b_park(std::integral_constant<int, (si + 1) % G7_BD>{}, k + 1u);       // stage (k + 1) % 2 was last read at step k - 1
         b_issue(SI, k + (uint32_t)G7_BD);                              // slot si was parked at step k - 1
         if (active) step((k & 1u) == 0u, smem + sta * d.a_stage, smem + d.b_base + (k & 1u) * d.b_stage);
         sta = sta + 1u == nsa ? 0u : sta + 1u;
+        if (k == 0u) NANO_STAMP(a.stamps, 3, S[0][0]);                 // step 0 multiplied
     };
     uint32_t k4 = 0;
     for (; k4 + (uint32_t)G7_BD <= nk; k4 += (uint32_t)G7_BD)          // whole rounds of G7_BD steps: straight-line code
-        g7_static_for<0, G7_BD>([&](auto SI) { const uint32_t k = k4 + (uint32_t)decltype(SI)::value; one_step(SI, k); if (k & 1u) fold(k >> 1); });
+        g7_static_for<0, G7_BD>([&](auto SI) { const uint32_t k = k4 + (uint32_t)decltype(SI)::value; one_step(SI, k); if ((k & 1u) || k + 1u == nk) fold(k >> 1); });
     g7_static_for<0, G7_BD - 1>([&](auto SI) {                         // the last nk % G7_BD steps
         const uint32_t k = k4 + (uint32_t)decltype(SI)::value;
         if (k < nk) { one_step(SI, k); if ((k & 1u) || k + 1u == nk) fold(k >> 1); }
     });
+    NANO_STAMP(a.stamps, 4, acc[0][0]);                             // every step done
     // ---- epilogue: store | residual add | SwiGLU -----------------------------------------------------------------------------------------
     if (!active) return;
 #pragma unroll
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
                 if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < wt.rows0) o[r] = finish_epi(epi, acc[i][r], v3[r], oldv[i][r]);
         }
     }
+    NANO_STAMP(a.stamps, 5, acc[0][0]);                             // stores issued
     NANO_STAMP_END(a.stamps, 6);
 }
 
@@ -367,7 +370,6 @@ static bool g7_plan(const GemvArgs &a, G7Plan &p) {
     if (nsa > 1u + 2u * (63u / ips)) nsa = 1u + 2u * (63u / ips);
     if (nsa > G7_MAXNSA) nsa = G7_MAXNSA;
     if (nsa > p.nk + 1u) nsa = p.nk + 1u;
-    if (const char *e = getenv("NANO_G7_NS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 2u && v < nsa) nsa = v; }     // DEVELOPMENT ONLY
     if (nsa < 2u) return false;
     p.nsa = nsa;
     p.b_base = nsa * p.a_stage;
@@ -398,7 +400,12 @@ bool gemm_q80_g7_supports(const GemvArgs &a) {
     for (uint32_t s = 0; s < nseg; s++) if ((uint64_t)a.seg[s].rows * a.n >= (1ull << 32) - (1u << 20)) return false;   // 32-bit row offsets per segment
     if (g7_rows(a) >= 65536u) return false;                            // (the classifier has kernels of its own: STREAM / GC)
     G7Plan p;
-    return g7_plan(a, p);
+    if (!g7_plan(a, p)) return false;
+    // Where it pays (round 5, same-box A/B against G6 MODE F / G5, profiles/r05_g7_stamps.txt): launches with several row tiles per CU
+    // (q|k|v, W1|W3: one weight stage feeds 8..20 matrix-core pairs) and very short rows.  A launch of ONE row tile per CU and a long
+    // row (Wo, W2 of Qwen3-4B: 16 / 38 steps of ~0.6 us with four of the fourteen consumer waves at work) stays with G6, whose eight
+    // waves split the row length: 8.3 / 15.8 us there against 13.9 / 27.9 here.
+    return p.tpw * p.ttl >= 8u || p.nk <= 4u;
 }
 
 hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st) {
@@ -413,7 +420,6 @@ hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st) {
     d.full = p.ntiles - (p.tpw - 1u) * p.grid;
     d.nk = p.nk; d.ttl = p.ttl; d.nsa = p.nsa;
     d.a_stage = p.a_stage; d.a_ws = p.a_ws; d.b_base = p.b_base; d.b_stage = p.b_stage; d.b_xs = p.b_xs;
-    { const char *e = getenv("NANO_G7_DBG"); d.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #define G7_GO(TP_, PP_) do { return p.ms ? g7_launch_t<TP_, PP_, true>(d, p.lds, st) : g7_launch_t<TP_, PP_, false>(d, p.lds, st); } while (0)
 #define G7_TP(PP_) do { if (p.tp == 1u) G7_GO(1, PP_); if (p.tp == 2u) G7_GO(2, PP_); if (p.tp == 3u) G7_GO(3, PP_); if (p.tp == 5u) G7_GO(5, PP_); G7_GO(8, PP_); } while (0)
     if (p.pp == 1u) G7_TP(1);

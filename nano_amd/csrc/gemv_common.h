@@ -2,6 +2,7 @@
 // gemv_q4k.hip): DPP reductions, buffer-descriptor loads, the device-side argument block, kernel roles, and the
 // workgroup-cooperative activation loads (plain vector or split-attention combine).
 #pragma once
+#define NANO_GEMV_COMMON_H 1
 #include <stdlib.h>
 #include "device_common.h"
 #include "kernels.h"

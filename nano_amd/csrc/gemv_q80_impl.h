@@ -239,9 +239,13 @@ __device__ __forceinline__ float fold_row_canon_ng(const float *p, uint32_t ng) 
 // ------------------------------------------------------------------------------------------------------------
 // SLAB kernel
 // ------------------------------------------------------------------------------------------------------------
-template <int ROLE, int GS, int B, int NV, int UPW>
-__global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Hand-off of a launch's results to consumers INSIDE the same launch (the fused q | k | v + attention kernel below): every result is
+// also stored as an 8-byte {value, tag 1} granule (ONE write-through store: the data is the flag), and each workgroup zeroes its share
+// of the OTHER granule buffer -- the one the next launch of this kind will fill.
+struct SlabHand { unsigned long long *cur, *nxt; uint32_t base[3], total, zper; };
+
+template <int ROLE, int GS, int B, int NV, int UPW, bool HAND>
+__device__ __forceinline__ void gemv_q80_slab_body(const GemvDev &a, const uint32_t bid, unsigned char *smem, const SlabHand &hand) {
     constexpr int TR = 4;
     constexpr int LPG = GS / 16, GC = 1024 / GS;
     constexpr int NS = (TR + LPG - 1) / LPG;               // rows a lane owns after the group reduction
@@ -275,7 +279,6 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     if (!(NANO_STAMPS && (a.dbg & 2u))) stage_issue<ROLE, B, NV>(a, sx);
 
     // ---- 2. all weight / scale loads of this wave; the workgroup's rows lie inside ONE segment ------------
-    const uint32_t bid = blockIdx.x;
     // (the residual and SwiGLU launches of a decode step have ONE weight segment: their roles skip the selection chains)
     constexpr bool ONESEG = ROLE == R_RESID || ROLE == R_RESID_COMBINE || ROLE == R_NORM_SWIGLU;
     const int sel = (ONESEG || swiglu) ? 0 : (int)(bid >= a.wg_c0) + (int)(bid >= a.wg_c1);
@@ -428,10 +431,47 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
             // the next kernel's start waits for (round 3, measured: 1807 -> 1836 tok/s at positions 20..39, 1681 -> 1718 over 31..510;
             // measurement builds: NANO_DBG bit 4 restores the plain store for A/B runs)
             if (NANO_STAMPS && (a.dbg & 4u)) *dst = val; else __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (HAND)
+                __hip_atomic_store(hand.cur + (sel == 0 ? hand.base[0] : sel == 1 ? hand.base[1] : hand.base[2]) + lrow0 + (uint32_t)frl,
+                                   (1ull << 32) | (unsigned long long)__float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if constexpr (HAND) {                                           // the other buffer: zero for the launch after this one
+        const uint32_t zi = bid * hand.zper + (uint32_t)tid;
+        if ((uint32_t)tid < hand.zper && zi < hand.total) __hip_atomic_store(hand.nxt + zi, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     NANO_STAMP_END(a.stamps, 6);                                    // folded and stored: the workgroup's last wave ends
 }
+
+template <int ROLE, int GS, int B, int NV, int UPW>
+__global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemv_q80_slab_body<ROLE, GS, B, NV, UPW, false>(a, blockIdx.x, smem, SlabHand{});
+}
+
+#if NANO_Q80_GS == 64
+}  // namespace
+}  // namespace nano
+#include "attn_impl.h"
+namespace nano {
+namespace {
+// ---- q | k | v projection + attention in ONE launch (Qwen3 decode, one sequence, head_dim 128; round 5) --------------------------------------
+// The first `n_attn` workgroups are the attention's (head x split): they ask for their K / V rows at entry, exactly as the attention kernel
+// does, and then wait for q, the raw k row and the fresh v row of their KV group as granules; the other workgroups are the projection's SLAB
+// GEMV (role: rmsnorm + quantize + store), whose fold threads also store every result as a granule.  What the boundary between the two
+// kernels cost -- the gap, the attention's entry ramp and its K / V round trip -- now overlaps the projection.  Bits: the same two bodies.
+// Reference: infer/infer.c:758-879.
+template <int NV, int UPW>
+__global__ __launch_bounds__(256) void qkv_attn_fused_kernel(const GemvDev g, const AttnArgs a, const SlabHand hand, const uint32_t n_attn, const uint32_t head_wgs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x < n_attn) {
+        const uint32_t split = blockIdx.x / head_wgs, grp = blockIdx.x - split * head_wgs;
+        attention_body<8, 4, 1, 1, false, false, 2, false, true>(a, smem, grp, 0u, split, hand.cur, hand.base[1], hand.base[2]);
+    } else {
+        gemv_q80_slab_body<R_NORM_STORE, 64, 1, NV, UPW, true>(g, blockIdx.x - n_attn, smem, hand);
+    }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // STREAM kernel (classifier)
@@ -742,6 +782,63 @@ static hipError_t launch_stream_b(GemvDev &d, hipStream_t st) {
     if (d.flags == F_NORM) return launch_stream_r<R_NORM_STORE, GS, B>(d, st);      // the classifier
     return launch_stream_r<R_GENERIC, GS, B>(d, st);
 }
+
+#if NANO_Q80_GS == 64
+// ---- the fused q | k | v + attention launch: host side -----------------------------------------------------------------------------------
+static bool fused_shape(const GemvArgs &ga, const AttnArgs &aa, SlabPlan &p) {
+    if (ga.gs != 64 || ga.nb != 1 || ga.nseg != 3 || ga.epi != GEMV_EPI_STORE || !ga.norm_w || ga.xq_in || ga.attn_part || ga.tile_max || ga.resid_add) return false;
+    if (ga.n % 64u || ga.n > 4096u || use_stream(ga)) return false;
+    if (ga.seg[0].out_pstride || ga.seg[1].out_pstride) return false;            // (only v is position indexed: its cache row)
+    p = plan_slab(ga, 1);
+    if (p.nw != 4u || p.upw > 4u || !(p.nv == 1u || p.nv == 2u || p.nv == 4u)) return false;        // 256 threads, like the attention workgroups
+    // Qwen3 decode attention on an FP32 contiguous cache, head_dim 128, one head per workgroup, two timestep blocks in flight
+    if (aa.hd != 128u || !aa.q_norm || !aa.k_norm || !aa.rope_qwen3 || !aa.rope_cos || !aa.rope_cur || !aa.kraw || aa.fixed_range || !aa.is_causal || aa.q_out) return false;
+    if (aa.kv_half || aa.pt_rows || aa.prep_only || aa.xf_out || aa.nsplit == 0 || aa.nsplit > 8u) return false;
+    const uint32_t kv_mul = aa.n_kv_head ? aa.n_head / aa.n_kv_head : 0u;
+    if (!aa.n_kv_head || (aa.n_kv_head & (aa.n_kv_head - 1u)) || !kv_mul || (kv_mul & (kv_mul - 1u))) return false;
+    if ((uint64_t)aa.n_head * aa.nsplit > 256u) return false;                   // (beyond: the attention launcher puts several heads in a workgroup)
+    if (aa.range_hint > aa.nsplit * 2u * 32u) return false;                     // (more than one round: the launcher may pick four blocks in flight)
+    if (aa.q_dim != ga.seg[0].rows || aa.kv_dim != ga.seg[1].rows || aa.kv_dim != ga.seg[2].rows || aa.q_dim != aa.n_head * aa.hd) return false;
+    return true;
+}
+bool qkv_attn_fused_supports(const GemvArgs &ga, const AttnArgs &aa) { SlabPlan p; return fused_shape(ga, aa, p); }
+
+hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st) {
+    SlabPlan p;
+    if (!hand_cur || !hand_nxt || !fused_shape(ga, aa, p)) return hipErrorInvalidValue;
+    GemvDev d = to_dev(ga);
+    d.tile_max = nullptr;
+    d.rw = p.rw; d.tpw = (p.rw + 3) / 4; d.magic_rw = 65536u / p.rw + 1u; d.log2_tiles = 0;
+    d.units = d.tpw * d.nchunk;
+    uint32_t wg[3];
+    for (uint32_t s2 = 0; s2 < 3; s2++) wg[s2] = (ga.seg[s2].rows + p.rw - 1) / p.rw;
+    d.wg_c0 = wg[0]; d.wg_c1 = wg[0] + wg[1];
+    const uint32_t ngemv = wg[0] + wg[1] + wg[2];
+    d.nthr = 256;
+    AttnArgs a = aa;
+    { uint32_t l2 = 0; while ((1u << l2) < a.n_kv_head) l2++; a.kv_log2 = l2; }
+    { const uint32_t kv_mul = a.n_head / a.n_kv_head; uint32_t l2 = 0; while ((1u << l2) < kv_mul) l2++; a.kvmul_log2 = l2; }
+    SlabHand h{};
+    h.cur = hand_cur; h.nxt = hand_nxt;
+    h.base[0] = 0; h.base[1] = a.q_dim; h.base[2] = a.q_dim + a.kv_dim; h.total = a.q_dim + 2u * a.kv_dim;
+    h.zper = (h.total + ngemv - 1) / ngemv;
+    if (h.zper > 256u) return hipErrorInvalidValue;
+    const uint32_t n_attn = a.n_head * a.nsplit;
+    const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u, pitch = ((d.ng + 47) / 64) * 64 + 16;
+    const size_t lds_g = n16 + ng4 * 4 + 64 + (size_t)(d.tpw * 4) * pitch * 4;
+    const size_t hd4 = a.hd, lds_a = (hd4 + hd4 + 4 + 4 + 4 * hd4 + hd4) * sizeof(float);            // q | k | maxima | sums | 4 waves' partials | the fresh v row
+    const size_t lds = lds_g > lds_a ? lds_g : lds_a;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
+#define FUSED_GO(NV_, UPW_) do { hipLaunchKernelGGL((qkv_attn_fused_kernel<NV_, UPW_>), dim3(n_attn + ngemv), dim3(256), lds, st, d, a, h, n_attn, a.n_head); return hipGetLastError(); } while (0)
+#define FUSED_NV(NV_) do { if (upw == 1) FUSED_GO(NV_, 1); if (upw == 2) FUSED_GO(NV_, 2); FUSED_GO(NV_, 4); } while (0)
+    if (p.nv == 1u) FUSED_NV(1);
+    if (p.nv == 2u) FUSED_NV(2);
+    FUSED_NV(4);
+#undef FUSED_NV
+#undef FUSED_GO
+}
+#endif
 
 template <int GS, int B>
 static hipError_t launch_b(const GemvArgs &a, hipStream_t st) {

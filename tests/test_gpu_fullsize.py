@@ -280,3 +280,33 @@ def test_nano56m_strict_equals_the_oracle_bit_for_bit(model_dir, oracle, quant, 
     m.close()
     print(f"nano-56m/{quant}: strict == oracle bit for bit over {n_decode} steps; fast path worst {worst_fast:.3e}")
     assert worst_fast <= {"f32": 1e-4, "q80": 5e-2, "q4k": 0.5}[quant]
+
+
+def test_fused_qkv_attention_launch_equals_the_two_launches(model_dir):
+    """One sequence on Qwen3-0.6B Q80: the q|k|v projection and the attention run as ONE launch (qkv_attn_fused_kernel: the attention
+    workgroups take q / k / v from the projection's workgroups as write-through granules inside the launch).  Same two kernel bodies, so
+    every logit of every step -- one split and several (positions beyond 64), eager first use and graph replays, the greedy loop -- must be
+    BIT-IDENTICAL to the two-launch form (NANO_FUSE_QKV_ATTN=0, read at model creation: a child process)."""
+    import os
+    import subprocess
+    import sys
+    import zlib
+    from conftest import ROOT
+    path, spec = synth_model(model_dir, "qwen3-0.6b", "q80", 64)
+    code = ("import sys, zlib, numpy as np; sys.path.insert(0, %r)\n"
+            "from nano_amd import binding as nb, modelfile as mf\n"
+            "m = nb.load_model_file(%r, max_seq_len=256, max_batch=1)\n"
+            "ids = mf.prompt_ids(7, 150, %d)\n"
+            "crc = 0\n"
+            "for pos in range(150):\n"
+            "    lg, am = m.forward([int(ids[pos])], [pos], want_logits=True, want_argmax=True)\n"
+            "    crc = zlib.crc32(lg.tobytes(), crc)\n"
+            "out = m.decode_greedy([int(ids[-1])], [150], 40)\n"
+            "print('CRC', crc & 0xffffffff, zlib.crc32(out.tobytes()) & 0xffffffff)\n" % (ROOT, path, spec.vocab_size))
+    res = []
+    for fuse in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NANO_FUSE_QKV_ATTN=fuse), capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("CRC")]
+        assert r.returncode == 0 and lines, r.stderr[-2000:]
+        res.append(lines[-1])
+    assert res[0] == res[1], res

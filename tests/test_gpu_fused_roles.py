@@ -198,10 +198,27 @@ GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (17, 0, 2560, (4096, 1024, 1024
               # an odd step count (768 = 3 steps: the last unit is half a unit), three token tiles, segment ends inside a tile
               (64, 0, 2560, (9728, 9728)), (64, 0, 1024, (3072, 3072)), (64, 1, 2048, (1024,)), (57, 1, 3072, (1024,)), (19, 1, 768, (512,)),
               (47, 0, 1024, (2064, 1040, 1008)), (64, 1, 4096, (2560,)),
+              # ... its residual epilogue and a two-token-tile launch on shapes with several row tiles per CU
+              (64, 1, 3072, (8192,)), (32, 1, 2048, (16000,)), (25, 0, 2560, (4096, 1024, 1024)),
               (3, 1, 9728, (2560,)), (1, 0, 2560, (4096, 1024, 1024)),
               # tall matrices (>= 16384 rows): the classifier's kernel GC (gemm_q80_cls.hip) -- every token tile staged in LDS /
               # two staged + two from L2 (64 tokens at row length 2560), a ragged last row tile, group counts 16 / 40 / 12
               (16, 0, 1024, (16400,)), (64, 0, 1024, (16391,)), (8, 0, 2560, (16512,)), (64, 0, 2560, (16390,)), (33, 0, 768, (16384,))]
+
+
+def g7_pays(n, rows, nb_, kind, cus=256):
+    """gemm_q80_g7.hip's rule, restated: row tiles per workgroup x token tiles >= 8, or at most four 256-byte steps"""
+    best, best_cost = 0, None
+    for hh in range(1, 9):
+        trw = 2 * hh
+        tiles = sum((r + trw - 1) // trw for r in rows)
+        tpw = (tiles + min(tiles, cus) - 1) // min(tiles, cus)
+        cost = tpw * (trw + 2)
+        if best_cost is None or cost <= best_cost:
+            best, best_cost = hh, cost
+    tiles = sum((r + 2 * best - 1) // (2 * best) for r in rows)
+    tpw = (tiles + min(tiles, cus) - 1) // min(tiles, cus)
+    return tpw * ((nb_ + 15) // 16) >= 8 or n // 256 <= 4
 
 
 def gemm_route_case(oracle, nb_, kind, n, rows):
@@ -217,8 +234,26 @@ def gemm_route_case(oracle, nb_, kind, n, rows):
             ref = ref_q80(oracle, oracle.rmsnorm(x[b], nw), segs, n, 64)
             assert np.array_equal(bits(out[b]), bits(ref)), (b, float(np.abs(out[b] - ref).max()))
         return "frag_old"
-    want = ("frag_old",) if n % 256 else ("frag_g7",) if (nb_ >= 17 and not G7_OFF) else ("frag_g6", "frag_old") if nb_ >= 17 else ("frag_g6",)
+    # 17..64 tokens: G7 where it pays (several row tiles per CU, or very short rows: gemm_q80_g7_supports), else G6 MODE F / G5
+    g7 = nb_ >= 17 and not G7_OFF and n % 256 == 0 and g7_pays(n, rows, nb_, kind)
+    want = ("frag_old",) if n % 256 else ("frag_g7",) if g7 else ("frag_g6", "frag_old") if nb_ >= 17 else ("frag_g6",)
     return check_q80(oracle, kind, n, segs, x, nw, old, nb_, use_gemm=True, routes=want)
+
+
+@pytest.mark.parametrize("nb_,n,rows", [(40, 2560, 9728), (64, 1024, 3072)])
+def test_g7_swiglu_epilogue(oracle, nb_, n, rows):
+    """W1|W3 at 17..64 tokens through G7 (the loader / consumer kernel): the SwiGLU epilogue on its canonical projections (the store
+    form of the same pair is in GEMM_CASES, bit for bit)"""
+    rng = np.random.default_rng(nb_ + rows)
+    x = order_free(rng, (nb_, n))
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    segs = [(*q80_weights(rng, rows, n, 64), rows) for _ in range(2)]
+    out, r = nb.op_fused_gemv(Q80, 2, n, segs, x, nw, gs=64, nb=nb_, use_gemm=True, want_route=True)
+    assert G7_OFF or r == "frag_g7", r
+    for b in range(nb_):
+        xn = oracle.rmsnorm(x[b], nw)
+        want = silu_mul(ref_q80(oracle, xn, segs[:1], n, 64, canon=True), ref_q80(oracle, xn, segs[1:], n, 64, canon=True))
+        assert np.allclose(out[b], want, rtol=3e-6, atol=1e-9), b
 
 
 def test_g6_ragged_segments(oracle):

@@ -76,5 +76,31 @@ g7c)   # G7 second build (weights by LDS-DMA in a deep ring, fragments staged by
   timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -4 | tee $O/prefill_g7.txt
   prof 4b_b64 --model qwen3-4b --batch 64 --steps 12 --warmup 2
   ;;
+g7s)   # phase stamps of G7's launches (consumer wave 0: prologue | first weights land | step 0 multiplied | every step done | stores issued | last wave ends)
+  timeout 300 python tools/g7_check.py 2>&1 | tail -4
+  for b in 64 32; do NANO_STAMPS_GRAPH=1 NANO_LIB=$R/nano_amd/lib/libnano_mi355x_stamps.so timeout 200 python tools/stamp_probe.py wide-qwen3 q80 $b 30 2>&1 | tail -16; done | tee $O/g7_stamps.txt
+  NANO_GEMM_G7=0 NANO_STAMPS_GRAPH=1 NANO_LIB=$R/nano_amd/lib/libnano_mi355x_stamps.so timeout 200 python tools/stamp_probe.py wide-qwen3 q80 64 30 2>&1 | tail -16 | tee $O/g7off_stamps.txt
+  NANO_STAMPS_GRAPH=1 NANO_LIB=$R/nano_amd/lib/libnano_mi355x_stamps.so timeout 200 python tools/stamp_probe.py qwen3-0.6b q80 64 30 2>&1 | tail -16 | tee $O/g7_stamps_q06.txt
+  ;;
+fz)    # fused q|k|v + attention launch (one sequence, Qwen3-0.6B): parity against the two launches, A/B at the driver's flags and over the full window
+  timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "fused_qkv or batch_equals or prefill_equals" 2>&1 | tail -15
+  timeout 600 python -m pytest tests/test_gpu_fused_roles.py -m gpu -x -q -k "gemm_route or ragged or g7" 2>&1 | tail -4
+  for r in 1 2 3; do
+    bench q06_b1_fused_$r --steps 20 --warmup 5 --no-kernel-table
+    NANO_FUSE_QKV_ATTN=0 bench q06_b1_two_$r --steps 20 --warmup 5 --no-kernel-table
+  done
+  python3 - <<'PY'
+import json, glob
+for t in ("fused", "two"):
+    v = [json.loads(open(f).read().strip().splitlines()[-1]) for f in sorted(glob.glob("gpurun_out/r5/q06_b1_%s_*.json" % t))]
+    print(t, [d["value"] for d in v], "full window", [d["value_full_window"]["value"] for d in v if d.get("value_full_window")])
+PY
+  for b in 64 32; do
+    bench 4b_b${b}_g7 --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-kernel-table
+    NANO_GEMM_G7=0 bench 4b_b${b}_old --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-kernel-table
+  done
+  bench q06_b64_g7 --batch 64 --steps 64 --warmup 4 --no-kernel-table
+  NANO_GEMM_G7=0 bench q06_b64_old --batch 64 --steps 64 --warmup 4 --no-kernel-table
+  ;;
 *) echo "unknown mode $1";;
 esac
