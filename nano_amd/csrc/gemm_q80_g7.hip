@@ -333,17 +333,23 @@ static uint32_t g7_rows(const GemvArgs &a) {
     return r;
 }
 
-// tile height fitted to the chip (G6's rule): minimise the rows the busiest workgroup streams (+ a per-tile overhead worth ~2 rows)
+// Tile height.  At 17..64 tokens a launch is bound by the consumers' VALU work as much as by its bytes (measured, round 5: ~120 SIMD-cycles
+// per matrix-core result of 16 rows x 16 tokens x one group -- cvt, two multiplies and an add per output -- i.e. ~0.23 us per row tile and
+// step at four token tiles, where the tile's 16 x 256 B stream in ~0.18 us), and a tile costs that whatever its live rows: minimise
+// (tiles per CU) x max(VALU, bytes), ties to the taller tile (Qwen3-4B's q|k|v: 384 tiles of 16 rows, 2 on the busiest CU, instead of G6's
+// 768 tiles of 8 rows, 3 per CU).
 static bool g7_plan(const GemvArgs &a, G7Plan &p) {
     const bool sw = a.epi == GEMV_EPI_SWIGLU;
     const uint32_t cus = a.cus ? a.cus : 256u, nseg = sw ? 1u : a.nseg;
+    const uint32_t ttl0 = (a.nb + 15u) / 16u;
     uint32_t best = 0, best_cost = ~0u;
     for (uint32_t hh = 1; hh <= 8; hh++) {
         const uint32_t trw = sw ? hh : 2u * hh;
         uint32_t tiles = 0;
         for (uint32_t s = 0; s < nseg; s++) tiles += (a.seg[s].rows + trw - 1) / trw;
         const uint32_t grid = tiles < cus ? tiles : cus, tpw = (tiles + grid - 1) / grid;
-        const uint32_t cost = tpw * (trw * (sw ? 2u : 1u) + 2u);
+        const uint32_t valu = 6u * ttl0, bytes = trw * (sw ? 2u : 1u) + 2u;
+        const uint32_t cost = tpw * (valu > bytes ? valu : bytes);
         if (cost <= best_cost) { best_cost = cost; best = hh; }       // ties: the taller tile
     }
     p.hh = best;

@@ -641,8 +641,9 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     // busy on a 2560-row matrix (rw 16) where rw = 10 gives every CU one workgroup.  On a tie the larger slab (fewer
     // workgroups re-staging the activation).  Round 2's rule (powers of two, 64-160 KB) is kept as NANO_SLAB_BALANCED=0.
     uint32_t large_nw = 0;
-    // (round 5 experiment, NANO_WIDE_GEMV_NB: 2..4 sequences on these matrices through the same balanced slabs, the product table B times as large)
-    if (B <= 4 && (uint64_t)rows * a.n * nmat >= (8u << 20)) {
+    // (round 5: TWO sequences on these matrices take the same balanced slabs, the product table twice as large -- Qwen3-4B at 2 sequences
+    //  1.833 ms per step against 1.923 through G6 MODE P, same box; four sequences: 2.80 against 1.99 through G6, so two is where it ends)
+    if (B <= 2 && (uint64_t)rows * a.n * nmat >= (8u << 20)) {
         static const bool balanced = [] { const char *e = getenv("NANO_SLAB_BALANCED"); return !(e && *e == '0'); }();
         const uint32_t cus = a.cus ? a.cus : 256u;
         uint32_t best = 0, best_cost = ~0u;
@@ -801,6 +802,28 @@ static bool fused_shape(const GemvArgs &ga, const AttnArgs &aa, SlabPlan &p) {
     if (aa.q_dim != ga.seg[0].rows || aa.kv_dim != ga.seg[1].rows || aa.kv_dim != ga.seg[2].rows || aa.q_dim != aa.n_head * aa.hd) return false;
     return true;
 }
+#endif
+
+template <int GS, int B>
+static hipError_t launch_b(const GemvArgs &a, hipStream_t st) {
+    GemvDev d = to_dev(a);
+    if (use_stream(a)) return launch_stream_b<GS, B>(d, st);
+    d.tile_max = nullptr;
+    return launch_slab_b<GS, B>(d, a, st);
+}
+template <int GS>
+static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
+    if (a.nb <= 1) return launch_b<GS, 1>(a, st);
+    if (a.nb <= 2) return launch_b<GS, 2>(a, st);
+    if (a.nb <= 4) return launch_b<GS, 4>(a, st);
+    return launch_b<GS, 8>(a, st);
+}
+
+}  // namespace
+
+hipError_t NANO_Q80_ENTRY(const GemvArgs &a, hipStream_t st) { return launch_gs<NANO_Q80_GS>(a, st); }
+
+#if NANO_Q80_GS == 64
 bool qkv_attn_fused_supports(const GemvArgs &ga, const AttnArgs &aa) { SlabPlan p; return fused_shape(ga, aa, p); }
 
 hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st) {
@@ -839,24 +862,5 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
 #undef FUSED_GO
 }
 #endif
-
-template <int GS, int B>
-static hipError_t launch_b(const GemvArgs &a, hipStream_t st) {
-    GemvDev d = to_dev(a);
-    if (use_stream(a)) return launch_stream_b<GS, B>(d, st);
-    d.tile_max = nullptr;
-    return launch_slab_b<GS, B>(d, a, st);
-}
-template <int GS>
-static hipError_t launch_gs(const GemvArgs &a, hipStream_t st) {
-    if (a.nb <= 1) return launch_b<GS, 1>(a, st);
-    if (a.nb <= 2) return launch_b<GS, 2>(a, st);
-    if (a.nb <= 4) return launch_b<GS, 4>(a, st);
-    return launch_b<GS, 8>(a, st);
-}
-
-}  // namespace
-
-hipError_t NANO_Q80_ENTRY(const GemvArgs &a, hipStream_t st) { return launch_gs<NANO_Q80_GS>(a, st); }
 
 }  // namespace nano

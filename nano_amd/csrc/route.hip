@@ -49,9 +49,9 @@ RouteKind route_kind(const Q80Route &r, const GemvArgs &a) {
     const bool scratch = r.gq && r.gxs;
     const bool canon = q80_canonical(a);
     const bool wide = route_is_wide(a);
-    // round 5 experiment (A/B, then decided and removed): 2..NANO_WIDE_GEMV_NB sequences on wide matrices through the balanced SLAB GEMV
-    static const uint32_t wide_gemv_nb = [] { const char *e = getenv("NANO_WIDE_GEMV_NB"); return e ? (uint32_t)atoi(e) : 0u; }();
-    if (canon && wide && a.nb >= 2 && a.nb <= wide_gemv_nb && a.nb <= 4 && !a.xq_in) return ROUTE_GEMV;
+    // two sequences on wide matrices: the balanced SLAB GEMV (capacity 2) -- measured against G6 MODE P on one box, round 5: Qwen3-4B 1.833 vs
+    // 1.923 ms per step (profiles/r05_wide_two_sequences.txt); from three sequences on the batched route is the faster one (four: 1.99 vs 2.80)
+    if (canon && wide && a.nb == 2 && !a.xq_in) return ROUTE_GEMV;
     if (canon && r.use_g6) {
         // one sequence: the SLAB GEMV is the leaner kernel (measured, round 4, Qwen3-4B: 1.48 ms per step against MODE P's 1.77;
         // NANO_G6P_B1=1 routes it through MODE P for A/B runs)

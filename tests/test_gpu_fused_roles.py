@@ -171,24 +171,24 @@ def test_batched_gemv_roles_q80(oracle, nb_, kind):
 @pytest.mark.parametrize("nb_", [2, 3, 4, 8])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_batched_g6_prologue_roles_q80(oracle, nb_, kind):
-    """Qwen3-4B's shapes, 2..8 sequences: two sequences quantize in G6's prologue (MODE P, capacity 2), more take fragment-order
-    activations from a quantizer launch (MODE F)"""
+    """Qwen3-4B's shapes, 2..8 sequences: two sequences through the balanced SLAB GEMV (round 5: faster than G6's MODE P there), more take
+    fragment-order activations from a quantizer launch (G6 MODE F / S)"""
     n, rows = [(2560, (4096, 1024, 1024)), (4096, (2560,)), (2560, (9728, 9728))][kind]
     rng = np.random.default_rng(nb_ * 7 + kind)
     x = order_free(rng, (nb_, n))
     nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32) if kind != 1 else None
     segs = [(*q80_weights(rng, r, n, 64), r) for r in rows]
     if kind == 2:                                          # SwiGLU: the pair's store form pins the bits, the fused form the epilogue
-        check_q80(oracle, 0, n, segs, x, nw, None, nb_, routes=("g6p",) if nb_ <= 2 else ("frag_g6",))
+        check_q80(oracle, 0, n, segs, x, nw, None, nb_, routes=("gemv",) if nb_ <= 2 else ("frag_g6",))
         out, r = nb.op_fused_gemv(Q80, 2, n, segs, x, nw, gs=64, nb=nb_, want_route=True)
-        assert r == ("g6p" if nb_ <= 2 else "frag_g6")
+        assert r == ("gemv" if nb_ <= 2 else "frag_g6")
         for b in range(nb_):
             xn = oracle.rmsnorm(x[b], nw)
             want = silu_mul(ref_q80(oracle, xn, segs[:1], n, 64, canon=True), ref_q80(oracle, xn, segs[1:], n, 64, canon=True))
             assert np.allclose(out[b], want, rtol=3e-6, atol=1e-9), b
         return
     old = rng.standard_normal((nb_, sum(rows))).astype(np.float32)
-    check_q80(oracle, kind, n, segs, x, nw, old, nb_, routes=("g6p",) if nb_ <= 2 else ("frag_g6",))
+    check_q80(oracle, kind, n, segs, x, nw, old, nb_, routes=("gemv",) if nb_ <= 2 else ("frag_g6",))
 
 
 GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (17, 0, 2560, (4096, 1024, 1024)), (32, 1, 9728, (2560,)), (64, 1, 9728, (2560,)), (48, 0, 2560, (4096, 1024, 1024)),
@@ -213,7 +213,7 @@ def g7_pays(n, rows, nb_, kind, cus=256):
         trw = 2 * hh
         tiles = sum((r + trw - 1) // trw for r in rows)
         tpw = (tiles + min(tiles, cus) - 1) // min(tiles, cus)
-        cost = tpw * (trw + 2)
+        cost = tpw * max(6 * ((nb_ + 15) // 16), trw + 2)
         if best_cost is None or cost <= best_cost:
             best, best_cost = hh, cost
     tiles = sum((r + 2 * best - 1) // (2 * best) for r in rows)
@@ -265,7 +265,7 @@ def test_g6_ragged_segments(oracle):
     nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
     segs = [(*q80_weights(rng, r, n, 64), r) for r in rows]
     check_q80(oracle, 0, n, segs, x, nw, None, nb_, use_gemm=True, routes=("frag_g6",), strict_too=False)
-    check_q80(oracle, 0, n, segs, x[:2], nw, None, 2, routes=("g6p",))
+    check_q80(oracle, 0, n, segs, x[:2], nw, None, 2, routes=("gemv",))
 
 
 @pytest.mark.parametrize("nb_,kind,n,rows", GEMM_CASES)
