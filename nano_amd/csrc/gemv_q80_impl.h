@@ -244,209 +244,18 @@ __device__ __forceinline__ float fold_row_canon_ng(const float *p, uint32_t ng) 
 // of the OTHER granule buffer -- the one the next launch of this kind will fill.
 struct SlabHand { unsigned long long *cur, *nxt; uint32_t base[3], total, zper; };
 
-template <int ROLE, int GS, int B, int NV, int UPW, bool HAND>
-__device__ __forceinline__ void gemv_q80_slab_body(const GemvDev &a, const uint32_t bid, unsigned char *smem, const SlabHand &hand) {
-    constexpr int TR = 4;
-    constexpr int LPG = GS / 16, GC = 1024 / GS;
-    constexpr int NS = (TR + LPG - 1) / LPG;               // rows a lane owns after the group reduction
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = (int)(a.nthr >> 6);
-    const uint32_t n = a.n, ng = a.ng;
-    const uint32_t n16 = (n + 15) & ~15u, ng4 = (ng + 3) & ~3u;
-    const uint32_t PITCH = (GC == 16) ? (((ng + 47) / 64) * 64 + 16) : (ng4 + 4);
-    const uint32_t RW = a.rw, TPW = a.tpw, RWP = TPW * TR;         // rows of this workgroup, its four-row tiles, rows of the product table
-    const uint32_t epi = role_epi<ROLE>(a);
-    const bool swiglu = epi == GEMV_EPI_SWIGLU;
-    const uint32_t nmat = swiglu ? 2 : 1;
-    int8_t *xq = reinterpret_cast<int8_t *>(smem);                 // [B][n16]
-    float *xs = reinterpret_cast<float *>(smem + B * n16);         // [B][ng4]
-    float *red = xs + B * ng4;                                     // [B][16] (+ combine weights [B][n_head][8])
-    float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);   // [B][nmat][RWP][PITCH]
-
-    // every argument the chain below reads late (output slots, strides, positions, the residual addend) is fetched NOW, with
-    // the first ones (karg_touch, gemv_common.h)
-    karg_touch(a.out[0]); karg_touch(a.out_bstride[0]); karg_touch(a.out_pstride[0]); karg_touch(a.rows[0]); karg_touch(a.magic_rw); karg_touch(a.nb);
-    if (!(ROLE == R_RESID || ROLE == R_RESID_COMBINE || ROLE == R_NORM_SWIGLU)) {
-        karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.out_bstride[1]); karg_touch(a.out_bstride[2]);
-        karg_touch(a.out_pstride[1]); karg_touch(a.out_pstride[2]); karg_touch(a.rows[1]); karg_touch(a.rows[2]);
-    }
-    karg_touch(a.pos); karg_touch(a.canon);
-    if (ROLE == R_GENERIC || ROLE == R_RESID || ROLE == R_RESID_COMBINE) { karg_touch(a.resid_add); karg_touch(a.resid_add_bstride); }
-    NANO_STAMP(a.stamps, 0, tid);
-    // ---- 1. activation loads (critical path) ------------------------------------------------------------
-    Staged<B, NV> sx;
-    if (!(NANO_STAMPS && (a.dbg & 2u))) stage_issue<ROLE, B, NV>(a, sx);
-
-    // ---- 2. all weight / scale loads of this wave; the workgroup's rows lie inside ONE segment ------------
-    // (the residual and SwiGLU launches of a decode step have ONE weight segment: their roles skip the selection chains)
-    constexpr bool ONESEG = ROLE == R_RESID || ROLE == R_RESID_COMBINE || ROLE == R_NORM_SWIGLU;
-    const int sel = (ONESEG || swiglu) ? 0 : (int)(bid >= a.wg_c0) + (int)(bid >= a.wg_c1);
-    const int8_t *w0 = sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2];
-    const float *ws0 = sel == 0 ? a.ws[0] : sel == 1 ? a.ws[1] : a.ws[2];
-    float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
-    const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
-    const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
-    const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
-    const uint32_t lrow0 = (bid - (sel == 0 ? 0u : sel == 1 ? a.wg_c0 : a.wg_c1)) * RW;
-
-    int4 wv[UPW][TR];
-    float sv[UPW][NS];
-#pragma unroll
-    for (int k = 0; k < UPW; k++) {
-        const uint32_t u = (uint32_t)wid + (uint32_t)k * NW;
-        const uint32_t t = (u * a.magic_nchunk) >> 16;                 // u / nchunk
-        const uint32_t c = u - t * a.nchunk;
-        const uint32_t mat = t >= TPW ? 1u : 0u, tl = t - mat * TPW;
-        const bool live = u < a.units;
-        const __amdgpu_buffer_rsrc_t rw_ = mkrsrc(mat ? a.w[1] : w0, live ? rows0 * n : 0u);
-        const __amdgpu_buffer_rsrc_t rs_ = mkrsrc(mat ? a.ws[1] : ws0, live ? rows0 * ng * 4u : 0u);
-        const uint32_t lrow = lrow0 + tl * TR;
-        const uint32_t col = (c << 10) + (uint32_t)lane * 16u;
-        const uint32_t base = (col < n) ? lrow * n + col : OOB;
-        // rows of the tile beyond the workgroup's RW belong to the next workgroup (RW % 4 != 0): a wave-uniform select
-#pragma unroll
-        for (int r = 0; r < TR; r++) wv[k][r] = bload_w(rw_, base + ((tl * TR + (uint32_t)r < RW) ? (uint32_t)r * n : OOB));
-        const uint32_t g = c * GC + (uint32_t)lane / LPG;
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const uint32_t r = ((uint32_t)lane % LPG) + s * LPG;
-            sv[k][s] = bload_f(rs_, (r < TR && tl * TR + r < RW && g < ng) ? ((lrow + r) * ng + g) * 4u : OOB);
-        }
-    }
-    if (NANO_STAMPS && (a.dbg & 2u)) stage_issue<ROLE, B, NV>(a, sx);          // (experiment: the activation behind the weights)
-    // ---- 3. the fold thread's output slot (residual: old value) -----------------------------------------------
-    const int fb = (int)(((uint32_t)tid * a.magic_rw) >> 16);          // tid / RW: fold thread -> (sequence, local row)
-    const int frl = tid - fb * (int)RW;
-    const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
-    // the position of a pos-indexed output (v-cache row) is fetched now and used only by the final store: no wait
-    // here (a wait on it would also wait for every weight load issued above -- vmcnt counts in order)
-    uint32_t opos = 0;
-    if (ops && fold_live) opos = a.pos[fb];
-    float oldv = 0.0f;
-    if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];      // residual stream: never pos-indexed
-    float addv = 0.0f;                                              // LoRA o-branch: x += (W.act + addv), reference order
-    const bool has_add = epi == GEMV_EPI_RESID && a.resid_add != nullptr;
-    if (has_add && fold_live) addv = a.resid_add[(size_t)fb * a.resid_add_bstride + lrow0 + frl];
-
-    NANO_STAMP(a.stamps, 1, oldv);                                  // every load issued
-    // ---- 4. rmsnorm + quantization from registers (weights in flight) ----------------------------------------
-    stage_finish<ROLE, GS, B, NV>(a, sx, xq, xs, red, n16, ng4);
-    NANO_STAMP(a.stamps, 3, xs[0]);                                 // activation normalised + quantized in LDS (stamp 2: inside, the activation arrived)
-
-    // ---- 5. integer dots, group products into the LDS table ----------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < UPW; k++) {
-        const uint32_t u = (uint32_t)wid + (uint32_t)k * NW;
-        if (u < a.units) {
-            const uint32_t t = (u * a.magic_nchunk) >> 16;
-            const uint32_t c = u - t * a.nchunk;
-            const uint32_t mat = t >= TPW ? 1u : 0u, tl = t - mat * TPW;
-            const uint32_t col = (c << 10) + (uint32_t)lane * 16u;
-            const uint32_t g = c * GC + (uint32_t)lane / LPG;
-#pragma unroll
-            for (int b = 0; b < B; b++) {
-                if (b < (int)a.nb) {
-                    const int4 xv = (col < n) ? *reinterpret_cast<const int4 *>(xq + b * n16 + col) : make_int4(0, 0, 0, 0);
-                    int iv[TR];
-#pragma unroll
-                    for (int r = 0; r < TR; r++) {
-                        int d = __builtin_amdgcn_sdot4(wv[k][r].x, xv.x, 0, false);
-                        d = __builtin_amdgcn_sdot4(wv[k][r].y, xv.y, d, false);
-                        d = __builtin_amdgcn_sdot4(wv[k][r].z, xv.z, d, false);
-                        d = __builtin_amdgcn_sdot4(wv[k][r].w, xv.w, d, false);
-                        iv[r] = dpp_group_sum<LPG>(d);
-                    }
-                    const float xsc = (g < ng) ? xs[b * ng4 + g] : 0.0f;
-#pragma unroll
-                    for (int s = 0; s < NS; s++) {
-                        const uint32_t r = ((uint32_t)lane % LPG) + s * LPG;
-                        int v = iv[0];
-#pragma unroll
-                        for (int q = 1; q < TR; q++) v = (q == (int)r) ? iv[q] : v;
-                        if (r < TR && g < ng)                                                   // infer.c:672
-                            P[(((size_t)b * nmat + mat) * RWP + tl * TR + r) * PITCH + g] = ((float)v * sv[k][s]) * xsc;
-                    }
-                }
-            }
-        }
-    }
-    NANO_STAMP(a.stamps, 4, wv[UPW - 1][TR - 1].w);                 // this wave's weights arrived, its products are in the table
-    __syncthreads();
-    NANO_STAMP(a.stamps, 5, P[0]);                                  // every wave's products are in the table
-
-    // ---- 6. ordered fold (infer.c:668-674) + epilogue -------------------------------------------------------------
-    if (tid < (int)(RW * B)) {
-        // all LDS reads of a 16-group batch are issued before the dependent add chain; groups beyond ng add
-        // +0.0f (exact: the running value is never -0.0f)
-        float v0 = 0.0f, v1 = 0.0f;
-        const float *p0 = P + (((size_t)fb * nmat) * RWP + frl) * PITCH;
-        const float *p1 = p0 + (size_t)RWP * PITCH;
-        if (GS == 64 && a.canon) {                              // the fast path's canonical fold (strict mode: the reference's order below)
-            v0 = fold_row_canon_ng(p0, ng);
-            if (swiglu) v1 = fold_row_canon_ng(p1, ng);
-        } else
-        if (!swiglu && ng == 48u) v0 = fold_row<12>(p0);        // the row lengths of Qwen3-0.6B at group size 64 (3072 / 2048 / 1024): every
-        else if (!swiglu && ng == 32u) v0 = fold_row<8>(p0);    // LDS read of the row goes out before the dependent add chain starts (round 3:
-        else if (ng == 16u) {                                   // the batch-by-batch loop below exposes one LDS round trip per 16 groups)
-            if (swiglu) fold_row2<4>(p0, p1, v0, v1); else v0 = fold_row<4>(p0);
-        } else if ((ng & 15u) == 0) {       // whole 16-group batches (every BASELINE shape): no per-element selects
-            for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
-                float4 t[4], u[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) { t[q] = *reinterpret_cast<const float4 *>(p0 + g0 + 4 * q); if (swiglu) u[q] = *reinterpret_cast<const float4 *>(p1 + g0 + 4 * q); }
-#pragma unroll
-                for (int q = 0; q < 4; q++) { v0 += t[q].x; v0 += t[q].y; v0 += t[q].z; v0 += t[q].w; }
-                if (swiglu) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { v1 += u[q].x; v1 += u[q].y; v1 += u[q].z; v1 += u[q].w; }
-                }
-            }
-        } else {
-        for (uint32_t g0 = 0; g0 < ng; g0 += 16) {
-                float4 t[4], u[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    t[q] = (g0 + 4 * q < ng4) ? *reinterpret_cast<const float4 *>(p0 + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (swiglu) u[q] = (g0 + 4 * q < ng4) ? *reinterpret_cast<const float4 *>(p1 + g0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t g = g0 + 4 * q;
-                    v0 += (g < ng) ? t[q].x : 0.0f; v0 += (g + 1 < ng) ? t[q].y : 0.0f; v0 += (g + 2 < ng) ? t[q].z : 0.0f; v0 += (g + 3 < ng) ? t[q].w : 0.0f;
-                }
-                if (swiglu) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t g = g0 + 4 * q;
-                        v1 += (g < ng) ? u[q].x : 0.0f; v1 += (g + 1 < ng) ? u[q].y : 0.0f; v1 += (g + 2 < ng) ? u[q].z : 0.0f; v1 += (g + 3 < ng) ? u[q].w : 0.0f;
-                    }
-                }
-            }
-        }
-        if (fold_live) {
-            float *dst = out0 + (size_t)fb * obs + (size_t)opos * ops + lrow0 + frl;
-            const float val = finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv);
-            // WRITE-THROUGH (sc1) store: the result leaves the XCD's L2 now instead of in the write-back at the end of the kernel, which
-            // the next kernel's start waits for (round 3, measured: 1807 -> 1836 tok/s at positions 20..39, 1681 -> 1718 over 31..510;
-            // measurement builds: NANO_DBG bit 4 restores the plain store for A/B runs)
-            if (NANO_STAMPS && (a.dbg & 4u)) *dst = val; else __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if constexpr (HAND)
-                __hip_atomic_store(hand.cur + (sel == 0 ? hand.base[0] : sel == 1 ? hand.base[1] : hand.base[2]) + lrow0 + (uint32_t)frl,
-                                   (1ull << 32) | (unsigned long long)__float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if constexpr (HAND) {                                           // the other buffer: zero for the launch after this one
-        const uint32_t zi = bid * hand.zper + (uint32_t)tid;
-        if ((uint32_t)tid < hand.zper && zi < hand.total) __hip_atomic_store(hand.nxt + zi, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    NANO_STAMP_END(a.stamps, 6);                                    // folded and stored: the workgroup's last wave ends
-}
-
 template <int ROLE, int GS, int B, int NV, int UPW>
 __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gemv_q80_slab_body<ROLE, GS, B, NV, UPW, false>(a, blockIdx.x, smem, SlabHand{});
+#define SLAB_A a
+#define SLAB_BID blockIdx.x
+#define SLAB_HAND false
+#define SLAB_HANDV (SlabHand{})
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_A
+#undef SLAB_BID
+#undef SLAB_HAND
+#undef SLAB_HANDV
 }
 
 #if NANO_Q80_GS == 64
@@ -461,15 +270,25 @@ namespace {
 // GEMV (role: rmsnorm + quantize + store), whose fold threads also store every result as a granule.  What the boundary between the two
 // kernels cost -- the gap, the attention's entry ramp and its K / V round trip -- now overlaps the projection.  Bits: the same two bodies.
 // Reference: infer/infer.c:758-879.
+struct FusedArgs { GemvDev g; AttnArgs a; SlabHand hand; uint32_t n_attn, head_wgs; };
 template <int NV, int UPW>
-__global__ __launch_bounds__(256) void qkv_attn_fused_kernel(const GemvDev g, const AttnArgs a, const SlabHand hand, const uint32_t n_attn, const uint32_t head_wgs) {
+__global__ __launch_bounds__(256) void qkv_attn_fused_kernel(const FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (blockIdx.x < n_attn) {
-        const uint32_t split = blockIdx.x / head_wgs, grp = blockIdx.x - split * head_wgs;
-        attention_body<8, 4, 1, 1, false, false, 2, false, true>(a, smem, grp, 0u, split, hand.cur, hand.base[1], hand.base[2]);
-    } else {
-        gemv_q80_slab_body<R_NORM_STORE, 64, 1, NV, UPW, true>(g, blockIdx.x - n_attn, smem, hand);
+    if (blockIdx.x < fa.n_attn) {
+        const uint32_t split = blockIdx.x / fa.head_wgs, grp = blockIdx.x - split * fa.head_wgs;
+        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand.cur, fa.hand.base[1], fa.hand.base[2]);
+        return;
     }
+    constexpr int ROLE = R_NORM_STORE, GS = 64, B = 1;
+#define SLAB_A fa.g
+#define SLAB_BID (blockIdx.x - fa.n_attn)
+#define SLAB_HAND true
+#define SLAB_HANDV fa.hand
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_A
+#undef SLAB_BID
+#undef SLAB_HAND
+#undef SLAB_HANDV
 }
 #endif
 
@@ -853,7 +672,9 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
     const size_t lds = lds_g > lds_a ? lds_g : lds_a;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
-#define FUSED_GO(NV_, UPW_) do { hipLaunchKernelGGL((qkv_attn_fused_kernel<NV_, UPW_>), dim3(n_attn + ngemv), dim3(256), lds, st, d, a, h, n_attn, a.n_head); return hipGetLastError(); } while (0)
+    FusedArgs fa{};
+    fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = n_attn; fa.head_wgs = a.n_head;
+#define FUSED_GO(NV_, UPW_) do { hipLaunchKernelGGL((qkv_attn_fused_kernel<NV_, UPW_>), dim3(n_attn + ngemv), dim3(256), lds, st, fa); return hipGetLastError(); } while (0)
 #define FUSED_NV(NV_) do { if (upw == 1) FUSED_GO(NV_, 1); if (upw == 2) FUSED_GO(NV_, 2); FUSED_GO(NV_, 4); } while (0)
     if (p.nv == 1u) FUSED_NV(1);
     if (p.nv == 2u) FUSED_NV(2);
