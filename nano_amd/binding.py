@@ -37,7 +37,7 @@ class NanoFusedGemvDesc(C.Structure):
 
 
 # RouteKind of nano_amd/csrc/kernels.h (what NanoFusedGemvDesc.route_out reports)
-ROUTE_NAMES = ("gemv", "gemv_preq", "gemv_sliced", "q4k", "g6p", "frag_g6", "frag_old", "frag_g7")
+ROUTE_NAMES = ("gemv", "gemv_preq", "gemv_sliced", "q4k", "reserved", "frag_g6", "frag_old", "frag_g7")
 
 
 class NanoHipError(RuntimeError):

@@ -36,8 +36,7 @@ static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t 
     // per CU, two while at most two, else the whole KV group (measured: Qwen3-0.6B batch 1 6.15 -> 5.35 us per launch = +3.7 %
     // tokens/s; Qwen3-4B's kv_mul 4: 8.65 -> 6.03 us at batch 1, 10.05 -> 7.22 with two heads at 16 sequences, where one head
     // per workgroup costs 10.3; at 64 sequences the KV rows' bandwidth rules and four heads share them: 13.7 vs 16.4).
-    static const uint32_t forced = getenv("NANO_ATTN_KVM") ? (uint32_t)atoi(getenv("NANO_ATTN_KVM")) : 0u;   // measurement knob
-    static const bool xcd_order = !(getenv("NANO_ATTN_XCD") && *getenv("NANO_ATTN_XCD") == '0');             // measurement knob
+    constexpr bool xcd_order = true;
     AttnArgs a = a_in;
     a.kv_log2 = 0xffffffffu; a.kvmul_log2 = 0;
     const bool kv_pow2 = (a.n_kv_head & (a.n_kv_head - 1)) == 0, mul_pow2 = (kv_mul & (kv_mul - 1)) == 0;
@@ -46,19 +45,16 @@ static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t 
     if (MODE != 0 && !(kv_pow2 && mul_pow2)) return hipErrorInvalidValue;       // launch_lpr() sends such shapes to the generic mode
     const uint64_t head_wgs = (uint64_t)a.n_head * nb * a.nsplit;
     uint32_t kvm = (head_wgs <= 256u || kv_mul % 2 != 0) ? 1u : (head_wgs <= 1024u || kv_mul % 4 != 0) ? 2u : 4u;
-    if (forced == 1u || (forced == 2u && kv_mul % 2 == 0) || (forced == 4u && kv_mul % 4 == 0)) kvm = forced;
     // A workgroup that would walk exactly two rounds of NP blocks (513 .. 1024 positions at 8 splits) keeps four blocks in flight
     // instead: every row of the launch requested at kernel entry (Qwen3-0.6B at position 1023: 639 -> 632 us per step).  Measured
     // and NOT taken beyond: four rounds -> two at 2047 positions 754 -> 759 us, two -> one at 4095 with 32 splits 819 -> 836 (the
     // issue phase grows from 3.1 to 5.9 us: `profiles/r04_long_ctx_np4.txt`).  Decided by the range and the split count alone --
     // never by the batch: a token's attention is the same expression in a decode step and in a prefill chunk (the four-head
     // workgroups of large batches give way to two heads).
-    static const bool np4_on = !(getenv("NANO_ATTN_NP4") && *getenv("NANO_ATTN_NP4") == '0');                // measurement knob
-    const bool np4 = np4_on && !a.prep_only && a.nsplit <= 8u && a.range_hint > a.nsplit * (uint32_t)NP * R && a.range_hint <= 2u * a.nsplit * (uint32_t)NP * R;
+    const bool np4 = !a.prep_only && a.nsplit <= 8u && a.range_hint > a.nsplit * (uint32_t)NP * R && a.range_hint <= 2u * a.nsplit * (uint32_t)NP * R;
     if (np4 && kvm == 4) kvm = 2;
     constexpr bool CAN16 = KVH && QV % 4 == 0;
-    static const bool w16_on = !(getenv("NANO_ATTN_W16") && *getenv("NANO_ATTN_W16") == '0');                // measurement knob
-    const bool w16 = CAN16 && w16_on && a.hd % 8u == 0u;
+    const bool w16 = CAN16 && a.hd % 8u == 0u;
 #define ATTN_GO3(KVM_, NP_, PG_) do { if constexpr (CAN16) { if (w16) { hipLaunchKernelGGL((attention_kernel<LPR, QV, KVM_, MODE, KVH, PG_, NP_, CAN16>), dim3(a.n_head / KVM_, nb, a.nsplit), dim3(256), lds_for(KVM_), st, a); break; } } \
                          hipLaunchKernelGGL((attention_kernel<LPR, QV, KVM_, MODE, KVH, PG_, NP_, false>), dim3(a.n_head / KVM_, nb, a.nsplit), dim3(256), lds_for(KVM_), st, a); } while (0)
 #define ATTN_GO2(KVM_, NP_) do { if (a.pt_rows) ATTN_GO3(KVM_, NP_, true); else ATTN_GO3(KVM_, NP_, false); } while (0)
@@ -92,14 +88,12 @@ static uint32_t steps_per_wg(uint32_t hd) { return NP * (256 / (hd > 128 ? 16 : 
 // number of splits for an upper bound `range_hint` of the attended range: <= 8 up to attention_wide_from() positions (what the Wo
 // GEMV's prologue combines); beyond, up to attention_split_cap() so that a long range still spreads over the chip (8 KV groups
 // x 32 splits), combined by attn_combine_tokens_kernel -- a launch of its own, which pays from about four rounds per
-// workgroup on (Qwen3-0.6B, tools/long_ctx_probe.py).  NANO_ATTN_WIDE_FROM / NANO_ATTN_MAX_SPLITS: measurement knobs.
+// workgroup on (Qwen3-0.6B, tools/long_ctx_probe.py).
 uint32_t attention_wide_from() {
-    static const uint32_t v = [] { const char *e = getenv("NANO_ATTN_WIDE_FROM"); const uint32_t x = e ? (uint32_t)atoi(e) : 0u; return x >= 64u ? x : 2048u; }();
-    return v;
+    return 2048u;
 }
 uint32_t attention_split_cap() {
-    static const uint32_t v = [] { const char *e = getenv("NANO_ATTN_MAX_SPLITS"); const uint32_t x = e ? (uint32_t)atoi(e) : 0u; return (x >= 9u && x <= ATTN_MAX_NSPLIT) ? x : 32u; }();
-    return v;
+    return 32u;
 }
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd) {
     const uint32_t per = steps_per_wg(hd), cap = range_hint > attention_wide_from() ? attention_split_cap() : 8u;

@@ -345,12 +345,21 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
         const uint32_t t7 = (uint32_t)tid & 127u;
         const unsigned long long *g0p = (uint32_t)tid < 128u ? hand + (size_t)h0 * hd + t7 : hand + hand_k0 + (size_t)g * hd + t7;
         const unsigned long long *g1p = hand + hand_v0 + (size_t)g * hd + t7;
+        // TWO sweeps in flight (A, B): a sweep is a memory round trip (~1 us), the next one is on its way while this one is looked at
         unsigned long long g0 = 0, g1 = 0;
-        for (uint32_t spin = 0; spin < (1u << 14); spin++) {   // (bounded, ~10 ms: a projection that never arrives must not hang the device -- the tests see the garbage)
-            g0 = __hip_atomic_load(g0p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g1 = (uint32_t)tid < 128u ? __hip_atomic_load(g1p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 32);
-            const bool ok = (uint32_t)(g0 >> 32) == 1u && (uint32_t)(g1 >> 32) == 1u;
-            if (__all(ok)) break;
+        const bool two = (uint32_t)tid < 128u;
+        auto sweep = [&](unsigned long long &x0, unsigned long long &x1) {
+            x0 = __hip_atomic_load(g0p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x1 = two ? __hip_atomic_load(g1p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 32);
+        };
+        auto ready = [&](unsigned long long x0, unsigned long long x1) { return __all((uint32_t)(x0 >> 32) == 1u && (uint32_t)(x1 >> 32) == 1u) != 0; };
+        unsigned long long a0, a1, b0, b1;
+        sweep(a0, a1);
+        for (uint32_t spin = 0; spin < (1u << 13); spin++) {   // (bounded, ~10 ms: a projection that never arrives must not hang the device -- the tests see the garbage)
+            sweep(b0, b1);
+            if (ready(a0, a1)) { g0 = a0; g1 = a1; break; }
+            sweep(a0, a1);
+            if (ready(b0, b1)) { g0 = b0; g1 = b1; break; }
         }
         if ((uint32_t)tid < 128u) { qh[t7] = __uint_as_float((uint32_t)g0); vh[t7] = __uint_as_float((uint32_t)g1); }
         else kh[t7] = __uint_as_float((uint32_t)g0);

@@ -87,8 +87,6 @@ struct NanoHipModel {
     const float *lora_t[8] = {nullptr};                   // qa qb ka kb va vb oa ob, each [L][...]
     uint32_t lora_rank = 0, lora_alpha = 0; bool lora_on = false;
     int8_t *gq = nullptr; float *gxs = nullptr;           // MFMA GEMM path (batch > 8, Q80): quantized activations of all sequences
-    int8_t *gq2 = nullptr; float *gxs2 = nullptr;         // ... second scratch: W2's input, written by the W1|W3 GEMM's epilogue
-    bool w2_quant = true;                                 // (NANO_W2_QUANT=0: a quantizer launch of its own)
     float *rope_cur = nullptr;                            // RoPE rows of the current positions [B][2][hd/2], staged by the embed kernel
     float *kcache = nullptr, *vcache = nullptr;
     uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
@@ -102,14 +100,10 @@ struct NanoHipModel {
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
-    bool attn_quant = true;                               // batched steps: the attention kernel also writes the Wo GEMM's quantized input (NANO_ATTN_QUANT=0: quantizer launch)
-    bool use_g5 = true;                                   // batched Q80 launches of group size 64 take gemm_q80_g5.hip's chained K-split kernel (NANO_GEMM_G5=0: G2 everywhere)
     bool fuse_qkv_attn = true;                            // one sequence, Q80 gs 64, Qwen3 head_dim 128: q|k|v projection + attention in one launch; NANO_FUSE_QKV_ATTN=0: two launches (same bits)
     unsigned long long *hand[2] = {nullptr, nullptr};     // its two granule buffers (q_dim + 2 kv_dim entries each)
-    bool use_g7 = true;                                   // fast path, 17..64 tokens: gemm_q80_g7.hip (loader / consumer engine); NANO_GEMM_G7=0: G6 MODE F / G5 (same-box A/B)
-    bool use_g6 = true;                                   // fast path, group size 64: gemm_q80_g6.hip's split-K kernel (<= 16 tokens; MODE P for 1..8 sequences on wide matrices); NANO_GEMM_G6=0: round 3's routes
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
-    uint32_t skip_mask = 0;       // NANO_HIP_SKIP (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
+    uint32_t skip_mask = 0;       // nano_hip_time_step_masked (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
     uint32_t pending_batch = 0;   // sequences of the step queued by nano_hip_forward_begin
     bool kv_half = false;         // opt-in FP16 KV cache: rows hold __half, v passes through vraw like k through kraw
@@ -200,7 +194,7 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att, m->vraw, m->gq2, m->gxs2, m->stamps, m->pt, m->kvrow, m->hand[0], m->hand[1] };
+                    m->xn, m->hb2, m->att, m->vraw, m->stamps, m->pt, m->kvrow, m->hand[0], m->hand[1] };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -404,8 +398,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
               hipMalloc(&m->rope_cur, Bs * m->hd * 4 + 64) == hipSuccess;
     if (ok && Bs > 8 && d.quant_type == NANO_QUANT_Q80) {
         size_t nmax = E > QD ? E : QD; if (H > nmax) nmax = H;
-        ok = hipMalloc(&m->gq, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, Bs * (nmax / d.group_size) * 4) == hipSuccess &&
-             hipMalloc(&m->gq2, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs2, Bs * (nmax / d.group_size) * 4) == hipSuccess;
+        ok = hipMalloc(&m->gq, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, Bs * (nmax / d.group_size) * 4) == hipSuccess;
     }
     if (ok && m->kv_paged) {
         const size_t ptn = B * m->pt_stride;
@@ -429,10 +422,6 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
         hipEventCreate(&m->ev1) != hipSuccess || hipEventCreate(&m->ev2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "stream/event creation failed"); }
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
-    if (const char *sk = getenv("NANO_HIP_SKIP")) m->skip_mask = (uint32_t)strtoul(sk, nullptr, 0);
-    if (const char *g5 = getenv("NANO_GEMM_G5")) m->use_g5 = *g5 && *g5 != '0';
-    if (const char *g6 = getenv("NANO_GEMM_G6")) m->use_g6 = *g6 && *g6 != '0';
-    if (const char *g7 = getenv("NANO_GEMM_G7")) m->use_g7 = *g7 && *g7 != '0';
     if (const char *fz = getenv("NANO_FUSE_QKV_ATTN")) m->fuse_qkv_attn = *fz && *fz != '0';
     if (m->d.quant_type == NANO_QUANT_Q80 && m->d.group_size == 64) {
         for (int i = 0; i < 2; i++) {
@@ -440,8 +429,6 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
             if (hipMalloc(reinterpret_cast<void **>(&m->hand[i]), hb) != hipSuccess || hipMemset(m->hand[i], 0, hb) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off granules failed"); }
         }
     }
-    if (const char *aq = getenv("NANO_ATTN_QUANT")) m->attn_quant = *aq && *aq != '0';
-    if (const char *wq = getenv("NANO_W2_QUANT")) m->w2_quant = *wq && *wq != '0';
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
     if (const char *sm = getenv("NANO_STRICT")) if (*sm && *sm != '0') return nano_hip_set_strict(m, 1);
@@ -531,11 +518,9 @@ static GemvSeg mkseg(const TensorRef &t, float *out, uint32_t rows, uint32_t bst
 
 // the router's view of the model (route.hip): which kernel a projection launch goes to
 static Q80Route route_of(const NanoHipModel *m) {
-    static const bool use_cls = !(getenv("NANO_GEMM_CLS") && *getenv("NANO_GEMM_CLS") == '0');
     Q80Route r{};
     r.quant = m->d.quant_type; r.cus = m->cus; r.mfma_min_nb = m->mfma_min_nb;
-    r.use_g5 = m->use_g5; r.use_g6 = m->use_g6; r.use_cls = use_cls; r.use_g7 = m->use_g7;
-    r.gq = m->gq; r.gxs = m->gxs; r.gq2 = m->gq2; r.gxs2 = m->gxs2;
+    r.gq = m->gq; r.gxs = m->gxs;
     return r;
 }
 static RouteKind kind_of(const NanoHipModel *m, GemvArgs a) { a.ordered = m->strict ? 1u : 0u; a.cus = (uint32_t)m->cus; return route_kind(route_of(m), a); }
@@ -575,7 +560,7 @@ static uint32_t step_nsplit(const NanoHipModel *m, uint32_t nb, uint32_t range_h
 }
 
 // the Wo launch of a step of nb sequences: with the plain (combined, normalised) attention output as its input, and -- a split
-// attention -- with the splits' partials as its input (combined in its prologue: SLAB GEMV / G6 MODE P of one sequence)
+// attention -- with the splits' partials as its input (combined in its prologue: SLAB GEMV)
 static GemvArgs wo_args(const NanoHipModel *m, uint32_t nb, uint32_t nsplit) {
     GemvArgs wa{};
     wa.nseg = 1; wa.seg[0] = mkseg(m->W[WO][0], m->x, m->d.n_embd, m->d.n_embd); wa.n = m->QD; wa.gs = m->d.group_size; wa.nb = nb;
@@ -616,7 +601,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     m->nsplit = pf_combine ? 1 : nsplit;
     // Single-split attention (or the combine kernel) of a step whose Wo launch goes to the batched GEMM: that kernel writes
     // Wo's quantized input itself (Q80 groups of 64 inside a head, fragment order) -- one quantizer launch less per layer.
-    const bool wo_frag = m->attn_quant && wo_gemm && d.group_size == 64 && m->hd % 64 == 0;
+    const bool wo_frag = wo_gemm && d.group_size == 64 && m->hd % 64 == 0;
     EmbedArgs ea{ m->tok.w, m->tok.s, m->tokens, m->x, E, d.group_size, d.quant_type, E,
                   m->rope_cos, m->rope_sin, m->pos, m->rope_cos ? m->rope_cur : nullptr, m->hd / 2, 0, nullptr, nullptr, 0, 0 };
     // paged KV cache: the step's sequences are slots 0..nb-1 (batched prefill: every token is a position of slot pf_slot); the
@@ -716,19 +701,11 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             a.stamps = next_stamps(m, 3);
             if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
         }
-        bool w2_frag = false;
         {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
             GemvArgs a{};
             a.nseg = 2; a.seg[0] = mkseg(m->W[W1][l], m->hb, H, H); a.seg[1] = mkseg(m->W[W3][l], m->hb, H, H);
             a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_SWIGLU;
             a.norm_w = m->rms_ffn + (size_t)l * E; a.pos = m->pos;
-            // both FFN launches on the batched GEMM path and this one on G5: its epilogue quantizes hb for W2 (64-row groups)
-            // (the older batched route only: G6 quantizes nothing in its epilogue -- its tiles are fitted to the CUs, not to 64-row groups)
-            if (m->w2_quant && m->use_g5 && m->gq2 && !(skip & 8) && kind_of(m, a) == ROUTE_FRAG_OLD && gemm_q80_g5_can_quantize_outputs(a)) {
-                GemvArgs w2{};
-                w2.nseg = 1; w2.seg[0] = mkseg(m->W[W2][l], m->x, E, E); w2.n = H; w2.gs = d.group_size; w2.nb = nb; w2.xin = m->hb; w2.xin_bstride = H; w2.epi = GEMV_EPI_RESID;
-                if (kind_of(m, w2) == ROUTE_FRAG_OLD) { w2_frag = true; a.frag_out = m->gq2; a.frag_scale_out = m->gxs2; }
-            }
             a.stamps = next_stamps(m, 4);
             if (!(skip & 8) && (e = gemv(m, a)) != hipSuccess) return e;
         }
@@ -736,7 +713,6 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[W2][l], m->x, E, E);
             a.n = H; a.gs = d.group_size; a.nb = nb; a.xin = m->hb; a.xin_bstride = H; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
-            a.frag_ready = w2_frag ? 2u : 0u;
             a.stamps = next_stamps(m, 5);
             if (!(skip & 16) && (e = gemv(m, a)) != hipSuccess) return e;
         }
@@ -905,16 +881,15 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
     // range_hint and masks those beyond pos.  The hint is rounded up to the 64 positions of a split's range.  Round 3 measured
     // a hint rounded to 16 (the last block's rows beyond it are not fetched; four times as many graphs): 1845.9 vs 1846.0 tok/s
     // at positions 20..39, 1709.6 vs 1707.8 over 31..510 -- an out-of-range load still costs its issue slot, and that, not
-    // the bytes, is what the kernel's load phase pays for.  NANO_RANGE_STEP=16|32 keeps the finer hint for A/B runs.
+    // the bytes, is what the kernel's load phase pays for.
     // Round 4, batched steps (>= 9 sequences): the hint is rounded to 16.  At 64 sequences the K / V rows are the larger part of a
     // Qwen3-0.6B step's bytes (33.5 MB per layer at a 64-row hint against 15.7 MB of weights) and the rows between the position and the
     // hint are fetched for nothing: measured on one box 1.632 / 1.602 ms per step (hint step 64) vs 1.540 / 1.545 (16) at 64 sequences,
     // 1.090 / 1.102 vs 1.057 / 1.044 at 16; Qwen3-4B 64 sequences 3.864 / 3.870 vs 3.811 / 3.836.  Same split count (ceil(hint / 64)),
     // same bits; four times as many graphs per context.
-    static const uint32_t hint_env = [] { const char *e = getenv("NANO_RANGE_STEP"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return (v == 16u || v == 32u || v == 64u) ? v : 0u; }();
     // (batched prefill keeps the 64-position hint: a chunk's tokens must split exactly as each token's own decode step does, and with
     //  head_dim > 128 -- 32 positions per workgroup and split -- ceil(round16(p + 1) / 32) is not ceil(round64(p + 1) / 32))
-    const uint32_t hint_step = hint_env ? hint_env : ((nb >= 9u && !(m->pf && m->hd > 128u)) ? 16u : 64u);
+    const uint32_t hint_step = (nb >= 9u && !(m->pf && m->hd > 128u)) ? 16u : 64u;
     uint32_t range_hint = is_causal ? ((max_pos + hint_step) / hint_step) * hint_step : m->S;
     if (range_hint > m->S) range_hint = m->S;
     if (m->kv_paged && (m->strict || m->lora_on)) FAIL(NANO_HIP_EINVAL, "the paged KV cache is served by the fused path only: not with strict mode or the LoRA side branches");
@@ -926,7 +901,11 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
     }
     if (m->kv_half && m->lora_on) FAIL(NANO_HIP_EINVAL, "the LoRA side branches write FP32 v rows: not available with the FP16 KV cache");
     // (measurement builds: NANO_STAMPS_GRAPH=1 captures the stamped step too -- the stamp slots are baked into a graph of its own key)
+#if NANO_STAMPS
     static const bool stamps_graph = getenv("NANO_STAMPS_GRAPH") && *getenv("NANO_STAMPS_GRAPH") == '1';
+#else
+    constexpr bool stamps_graph = false;
+#endif
     if (!m->use_graph || (m->stamps_on && !stamps_graph)) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); m->nsplit = xba_nsplit(m, nb, range_hint); return 0; }
     const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)(m->stamps_on ? 1 : 0) << 50) | ((uint64_t)((m->skip_embed && mode == MODE_LOOP) ? 1 : 0) << 49) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) |
                          ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;

@@ -1,6 +1,6 @@
 // gemm_q80.hip -- Q80 (W8A8) skinny GEMM on the matrix cores for 9..64 tokens per weight read (large decode batches,
 // batched prefill): the general kernel (G2: any group size 32..256, any group count) and the
-// activation quantizers of the batched path.  gemm_q80_g5.hip holds the faster kernel for group size 64.
+// activation quantizers of the batched path.  gemm_q80_g6.hip / gemm_q80_g7.hip hold the faster kernels for group size 64.
 // out[t][r] = matmul_quant(W[r,:], x_t) for every token t, BIT-IDENTICAL to the per-token reference
 // (infer/infer.c:654-679): one v_mfma_i32_16x16x64_i8 forms the exact int32 group sums of a 16-row x 16-token tile for one
 // 64-wide run of a quantization group, the group product ((float)ival * ws[r][g]) * xs[t][g] is applied on the VALU and
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void quant_rows_frag_kernel(const float *x, ui
     float4 v = live ? *reinterpret_cast<const float4 *>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 w = (live && norm_w) ? *reinterpret_cast<const float4 *>(norm_w + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     float ss = 1.0f;
-    if (norm_w && order512) {           // rmsnorm scale in the tree order of gemm_q80_g6.hip's MODE P prologue (512 threads: thread T adds the float4
+    if (norm_w && order512) {           // rmsnorm scale in the 512-thread tree order of route_norm_order() (512 threads: thread T adds the float4
         // items T, T + 512, ...; eight wave sums added in order): this thread plays T = tid and T = tid + 256 -- the same additions,
         // so 1..8 sequences (quantized in that prologue) and 9..64 (quantized here) see the same bits
         float acc0 = 0.0f, acc1 = 0.0f;

@@ -4,16 +4,16 @@
 // in its own registers -- no chain between waves, no LDS product table, no barrier after the prologue.
 //
 //   * the activations (quant_rows_frag_kernel's MFMA B-fragment order, gemm_q80.hip) of the first LT token tiles are staged in
-//     LDS ONCE per workgroup and read from there by every wave for every row tile (G5 gives each wave its own row tile and lets
+//     LDS ONCE per workgroup and read from there by every wave for every row tile (round 3's GEMM gave each wave its own row tile and lets
 //     it fetch the fragments from L2 again: for a 151 936-row classifier that is as many L2 bytes as weight bytes per token
 //     tile -- 131 us at 8 tokens and 205..290 us at 64 where the weights alone stream in ~65 us); token tiles that do not fit
 //     LDS come from L2 as before;
 //   * a wave keeps the next half chunk's 16 x 512 B of weights in flight (registers) while it multiplies the current one out of
 //     its transposition buffer (wave-private LDS, pitch 528: conflict-free ds_read_b128 of the MFMA A fragments);
 //   * one v_mfma_i32_16x16x64_i8 per (group, token tile) -> exact int32 group sums -> ((float)ival * ws) * xs (infer.c:672) added
-//     to the running value of (row, token) in ascending group order: bit-identical to the GEMV path, to G5 and to the reference.
+//     to the running value of (row, token) in ascending group order: bit-identical to the GEMV path and to the reference.
 // Takes: group size 64, one STORE segment of >= 16384 rows, group count a multiple of 8 or 4.  (backend.hip routes the classifier
-// of batched steps here; NANO_GEMM_CLS=0 leaves it with G5.)
+// of batched steps here.)
 #include <atomic>
 #include "gemv_common.h"
 

@@ -24,9 +24,7 @@
 //     epilogue (store | residual add | SwiGLU).  One counter wait per tile, no chain.
 //   * the activation comes first in every wave's load queue (loads return in issue order; round 3 measured the activation of a
 //     52.9 MB launch "arriving" after the whole weight burst when it was issued behind it):
-//       MODE P  (1..8 sequences): rmsnorm | split-attention combine + Q80 quantization (tensor.c:21-46, bit-exact) run in the
-//               kernel's prologue from registers while the weights are in flight, into a compact fragment layout in LDS --
-//               no quantizer launch, 5 launches per layer at batch 1;
+//       MODE S  (fragment-order activations that fit LDS: rows <= 4096 values, <= 16 tokens): the workgroup's copy is staged once;
 //       MODE F  (fragment-order activations from quant_rows_frag_kernel / the attention kernel): each item's 8 KB of B fragments
 //               are requested right before its weights.
 // MFMA operand layout as in gemm_q80.hip (verified on gfx950, tools/kbench/mfma_probe.hip).
@@ -60,7 +58,6 @@ static bool g6_plan(const GemvArgs &a, G6Plan &p, uint32_t tt = 1) {
         const uint32_t cost = tpw * (trw * (sw ? 2u : 1u) + 2u);
         if (cost <= best_cost) { best_cost = cost; best = hh; }       // ties: the taller tile
     }
-    if (const char *e = getenv("NANO_G6_HH")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v <= 8) best = v; }   // measurement knob
     p.hh = best;
     const uint32_t trw = sw ? best : 2u * best;
     uint32_t tiles = 0, tc[2] = {0xffffffffu, 0xffffffffu};
@@ -72,8 +69,8 @@ static bool g6_plan(const GemvArgs &a, G6Plan &p, uint32_t tt = 1) {
     // token tile), the weights of a (tile, unit) are fetched by up to four waves of the same workgroup (L1 / L2 hits on matrices of a few MB)
     // MEASURED (round 4, Qwen3-0.6B, one box): 32 sequences 1.347 ms spread vs 1.386 serial; 64 sequences 2.039 vs 1.888, prompt ingestion
     // of 64-token chunks 32.4 k vs 36.1 k tok/s -- four waves re-fetching and re-transposing an item's weights cost more than the idle waves
-    // they fill.  So: spread two tiles, keep four serial (NANO_G6_SPREAD=0 | 2 | 4: the most tiles spread).
-    static const uint32_t spread_max = [] { const char *e = getenv("NANO_G6_SPREAD"); return e ? (uint32_t)atoi(e) : 2u; }();
+    // they fill.  So: spread two tiles, keep four serial.
+    constexpr uint32_t spread_max = 2u;
     p.tts = (tt > 1u && tt <= spread_max && p.tpw * p.nu < G6_NW && p.tpw * p.nu * tt <= 4u * G6_NW) ? tt : 1u;
     const uint32_t items = p.tpw * p.nu * p.tts;
     p.nw = G6_NW;
@@ -112,8 +109,7 @@ static G6Dev g6_dev(const GemvArgs &a, const G6Plan &p) {
 // table of all of a workgroup's tiles must fit LDS next to the waves' buffers); up to 4 items per wave
 static uint32_t g6_tt(const GemvArgs &a) { const uint32_t t = (a.nb + 15u) / 16u; return t <= 1u ? 1u : t == 2u ? 2u : 4u; }
 bool gemm_q80_g6_supports(const GemvArgs &a) {
-    static const uint32_t max_nb = [] { const char *e = getenv("NANO_G6_MAX_NB"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v ? v : 64u; }();   // A/B knob
-    if (!g6_common_ok(a) || a.nb > 64 || a.nb > max_nb || a.attn_part) return false;
+    if (!g6_common_ok(a) || a.nb > 64 || a.attn_part) return false;
     G6Plan p;
     const uint32_t tt = g6_tt(a);
     // (4 token tiles x 4 rounds is not instantiated: its registers spill; the launches that would need it -- Qwen3-4B's W1|W3 beyond 32
@@ -123,8 +119,7 @@ bool gemm_q80_g6_supports(const GemvArgs &a) {
 // MODE S where the activation fits LDS next to everything else (one 1 KB block per group + scales), else MODE F
 static size_t g6s_lds(const G6Plan &p) { const size_t ngp = (size_t)p.nu * 8u; return p.lds_common + ngp * 1024u + 64u + ngp * 64u + 64u; }
 static bool g6s_ok(const GemvArgs &a, const G6Plan &p) {
-    static const bool on = !(getenv("NANO_G6_STAGE") && *getenv("NANO_G6_STAGE") == '0');       // A/B knob
-    return on && p.nw == G6_NW && a.n <= 4096u && g6s_lds(p) <= 160u * 1024u;
+    return p.nw == G6_NW && a.n <= 4096u && g6s_lds(p) <= 160u * 1024u;
 }
 hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
     if (!a.xq_in || !a.xs_in || !gemm_q80_g6_supports(a)) return hipErrorInvalidValue;
@@ -135,7 +130,7 @@ hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
     d.xf = a.xq_in; d.xsf = a.xs_in;
     if (tt == 1u && g6s_ok(a, p)) {         // NV = 16-byte units per thread: 5 (rows up to 2560 values) or 8 (up to 4096)
         const size_t lds = g6s_lds(p);
-#define G6S_GO(NV_, R_) do { return p.ms ? g6_launch_t<G6_S, false, 1, NV_, R_, true>(d, lds, st) : g6_launch_t<G6_S, false, 1, NV_, R_, false>(d, lds, st); } while (0)
+#define G6S_GO(NV_, R_) do { return p.ms ? g6_launch_t<G6_S, NV_, R_, true>(d, lds, st) : g6_launch_t<G6_S, NV_, R_, false>(d, lds, st); } while (0)
 #define G6S_R(NV_) do { if (p.rounds <= 1) G6S_GO(NV_, 1); if (p.rounds == 2) G6S_GO(NV_, 2); G6S_GO(NV_, 4); } while (0)
         if (a.n <= 2560u) G6S_R(5);
         G6S_R(8);
@@ -143,7 +138,7 @@ hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
 #undef G6S_GO
     }
     const size_t lds = p.lds_common + 64;
-#define G6F_GO(R_, T_) do { return p.ms ? g6_launch_t<G6_F, false, 1, 1, R_, true, T_>(d, lds, st) : g6_launch_t<G6_F, false, 1, 1, R_, false, T_>(d, lds, st); } while (0)
+#define G6F_GO(R_, T_) do { return p.ms ? g6_launch_t<G6_F, 1, R_, true, T_>(d, lds, st) : g6_launch_t<G6_F, 1, R_, false, T_>(d, lds, st); } while (0)
 #define G6F_R(T_) do { if (p.rounds <= 1) G6F_GO(1, T_); if (p.rounds == 2) G6F_GO(2, T_); if (p.rounds == 3) G6F_GO(3, T_); G6F_GO(4, T_); } while (0)
     if (tt == 1u || p.tts > 1u) G6F_R(1);       // (spread token tiles: one tile per item)
     if (tt == 2u) G6F_R(2);
@@ -152,46 +147,6 @@ hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st) {
     G6F_GO(3, 4);
 #undef G6F_R
 #undef G6F_GO
-}
-
-// MODE P: fp32 activations (a.xin | the split-attention partials), 1..8 sequences; rmsnorm / combine + quantization in the prologue
-static size_t g6p_lds(const GemvArgs &a, const G6Plan &p, uint32_t nbc) {       // the kernel's carve-up: xqc | zero block | xs_l | red | wgt
-    const size_t ngp = (size_t)p.nu * 8u;
-    return p.lds_common + ngp * 64u * nbc + 64u + ngp * 64u + (size_t)nbc * 32u + (a.attn_part ? (size_t)a.attn_n_head * 32u : 0u) + 64u;
-}
-static bool g6p_shape(const GemvArgs &a, uint32_t &nbc, uint32_t &nv) {
-    if (a.nb > 2) return false;
-    nbc = a.nb <= 1 ? 1u : 2u;
-    nv = a.n <= 4096u ? 2u : a.n <= 10240u ? 5u : 0u;
-    if (!nv || nbc * nv > 16u) return false;
-    if (a.attn_part && (a.nb != 1 || nv != 2u || a.norm_w || a.attn_nsplit > 8 || a.attn_hd % 4 || a.attn_n_head > 128)) return false;
-    return true;
-}
-// the instantiated round counts of a (NV, multi-segment, combine) family: the smallest one that covers `need`, or 0
-static uint32_t g6p_rounds(uint32_t nv, uint32_t nbc, uint32_t need, bool ms, bool comb) {
-    for (uint32_t r = need; r <= 4u; r++) if (g6p_has(nv, nbc, r, ms, comb)) return r;
-    return 0u;
-}
-bool gemm_q80_g6p_supports(const GemvArgs &a) {
-    if (!g6_common_ok(a) || a.nb > 2 || a.xq_in || (!a.xin && !a.attn_part)) return false;
-    uint32_t nbc, nv;
-    if (!g6p_shape(a, nbc, nv)) return false;
-    G6Plan p;
-    if (!g6_plan(a, p) || p.nw != G6_NW) return false;               // the prologue's tree is the 512-thread one
-    if (!g6p_rounds(nv, nbc, p.rounds, p.ms, a.attn_part != nullptr)) return false;
-    return g6p_lds(a, p, nbc) <= 160u * 1024u;
-}
-hipError_t launch_gemm_q80_g6p(const GemvArgs &a, hipStream_t st) {
-    if (!gemm_q80_g6p_supports(a)) return hipErrorInvalidValue;
-    uint32_t nbc, nv;
-    G6Plan p;
-    if (!g6p_shape(a, nbc, nv) || !g6_plan(a, p)) return hipErrorInvalidValue;
-    G6Dev d = g6_dev(a, p);
-    const size_t lds = g6p_lds(a, p, nbc);
-    const bool comb = a.attn_part != nullptr;
-    const uint32_t r = g6p_rounds(nv, nbc, p.rounds, p.ms, comb);
-    if (nv == 2u) return g6p_launch_nv2(&d, lds, nbc, r, p.ms, comb, st);
-    return g6p_launch_nv5(&d, lds, nbc, r, p.ms, st);
 }
 
 }  // namespace nano

@@ -1,5 +1,5 @@
 // gemm_q80_g6_impl.h -- the G6 kernel (see gemm_q80_g6.hip for the design); included by the translation units that instantiate it
-// (gemm_q80_g6.hip: MODE F and the host side; gemm_q80_g6_p*.hip: MODE P) so that the instantiations build in parallel.
+// (gemm_q80_g6.hip).
 #pragma once
 #include <atomic>
 #include <type_traits>
@@ -11,13 +11,13 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-enum : int { G6_F = 0, G6_P = 1, G6_S = 2 };
+enum : int { G6_F = 0, G6_S = 2 };
 constexpr uint32_t G6_PITCH = 528, G6_WBUF = 16 * G6_PITCH;
 constexpr uint32_t G6_LDS_WAVE = G6_WBUF + 512 + 512;          // + weight scales [8 groups][16 rows] + (F) activation scales [8][16 tokens]
 constexpr uint32_t G6_NW = 8;                                   // waves of a workgroup (launches with fewer items use fewer)
 
 struct G6Dev {
-    GemvDev g;                          // segments, n, ng, epi, flags, nb, the fp32 activation / norm weight / attention partials (MODE P)
+    GemvDev g;                          // segments, n, ng, epi, flags, nb
     const int8_t *xf; const float *xsf; // MODE F: activations in MFMA B-fragment order [group][lane][16 B], scales [group][16 tokens]
     uint32_t hh;                        // live rows per half tile (1..8)
     uint32_t nu, magic_nu;              // units per row; (it * magic_nu) >> 16 == it / (nu * tts) for every item index of a workgroup
@@ -29,15 +29,6 @@ struct G6Dev {
 
 __device__ __forceinline__ uint32_t g6_lds_load_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// the fp32 activation items of a thread (MODE P): float4 item q = tid + j * 512 of every sequence
-template <int NBC, int NV, bool COMB>
-struct G6X {
-    float4 x[NBC][NV];
-    float4 nw[NV];
-    float4 pv[COMB ? NV : 1][COMB ? 8 : 1];     // split-attention partials (one sequence): all splits of this thread's items
-    float ml_m, ml_l;
-};
-
 template <int R0, int R1, class F> __device__ __forceinline__ void g6_static_for(F &&f) {
     if constexpr (R0 < R1) { f(std::integral_constant<int, R0>{}); g6_static_for<R0 + 1, R1>(f); }
 }
@@ -46,7 +37,7 @@ template <int R0, int R1, class F> __device__ __forceinline__ void g6_static_for
 // MS = several weight segments share the launch (q | k | v): a tile looks its segment up; single-segment launches skip that
 // TT = token tiles of 16 (MODE F: 1 | 2 | 4 -- up to 64 tokens; an item's weights are transposed once and multiplied with every token
 //      tile's fragments, tile t + 1's being fetched from L2 while tile t is multiplied; the other modes: 1)
-template <int MODE, bool COMB, int NBC, int NV, int R, bool MS, int TT = 1>
+template <int MODE, int NV, int R, bool MS, int TT = 1>
 __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     static_assert(TT == 1 || MODE == G6_F, "token tiles beyond the first come from L2 (MODE F)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -74,15 +65,11 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     float *T = reinterpret_cast<float *>(smem + (size_t)NW * G6_LDS_WAVE);          // [tpw][nu][NT token tiles][256] unit sums
     uint32_t *cnt = reinterpret_cast<uint32_t *>(T + (size_t)d.tpw * nu * NT * 256u);   // [tpw] items arrived
     unsigned char *pbase = reinterpret_cast<unsigned char *>(cnt + ((d.tpw + 3u) & ~3u));
-    // MODE P: the quantized activation [ngp][4 k-quarters][NBC][16 B] (groups >= ng zero), a 64-byte zero block (what the lanes of
-    // token slots >= NBC read), the activation scales [ngp][16] (slots >= NBC unused, groups >= ng zero)
-    // MODE S: the fragment-order activation itself [ngp][64 lanes][16 B] (NBC = 16 token slots), scales [ngp][16]
-    constexpr uint32_t SLOTS = MODE == G6_S ? 16u : (uint32_t)NBC;     // token slots of a group's 64-byte k-quarter
+    // MODE S: the fragment-order activation itself [ngp][64 lanes][16 B] (16 token slots per group's 64-byte k-quarter), scales [ngp][16]
+    constexpr uint32_t SLOTS = 16u;
     int8_t *xqc = reinterpret_cast<int8_t *>(pbase);
     unsigned char *zblk = pbase + (size_t)ngp * 64u * SLOTS;
     float *xs_l = reinterpret_cast<float *>(zblk + 64);
-    float *red = xs_l + (size_t)ngp * 16u;                             // [NBC][8] wave partials of the sums of squares
-    float *wgt = red + NBC * 8;                                        // COMB: [n_head][8] combine weights
 
     // ---- lane parts of every address of the item loop (item-invariant) --------------------------------------------------------------
     // weight pieces of an item: 16 rows x 512 B, two rows per load instruction: load k (and k + 4, the other half) reads row
@@ -97,10 +84,10 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     const int8_t *wb_r = wbuf + (size_t)m * G6_PITCH + kq * 16u;       // + 64 j
     float *wsl_w = wsl + ((lane & 1u) * 4u) * 16u + (lane >> 1);       // lanes 0..15: [4 (l%2) + k][row l/2], half 1: + 8
     const float *wsl_r = wsl + kq * 4u;                                // + 16 j
-    // MODE P: token slot m of the compact layout, or the zero block
+    // MODE S: token slot m of a group's staged fragments
     const uint32_t pb_off = m < SLOTS ? kq * 16u * SLOTS + m * 16u : (uint32_t)(zblk - reinterpret_cast<unsigned char *>(xqc));
     const uint32_t pb_str = m < SLOTS ? 64u * SLOTS : 0u;
-    const uint32_t px_off = m < SLOTS ? m : 15u, px_str = 16u;       // (slot 15 of a group's scales is never written when NBC < 16: zero-filled)
+    const uint32_t px_off = m < SLOTS ? m : 15u, px_str = 16u;       // 
 
     // ---- the workgroup's items -----------------------------------------------------------------------------------------------
     const uint32_t bid = blockIdx.x;
@@ -156,38 +143,6 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
         ring[sl].s1 = bload_f4(qB, svoff);
     };
 
-    // ---- MODE P: the fp32 activation is asked for before any weight --------------------------------------------------------------
-    G6X<NBC, NV, COMB> sx;
-    const bool norm = (a.flags & F_NORM) != 0;
-    if constexpr (MODE == G6_P) {
-        const __amdgpu_buffer_rsrc_t rx = mkrsrc(a.xin, COMB ? 0u : ((nb - 1u) * a.xin_bstride + n) * 4u);
-        const __amdgpu_buffer_rsrc_t rn = mkrsrc(a.norm_w, norm ? n * 4u : 0u);
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
-            const uint32_t off = (i < n) ? i * 4u : OOB;
-            if constexpr (!COMB) {
-#pragma unroll
-                for (int b = 0; b < NBC; b++) sx.x[b][j] = bload_f4(rx, (b < (int)nb) ? off + (uint32_t)b * a.xin_bstride * 4u : OOB);
-            }
-            sx.nw[j] = bload_f4(rn, off);
-        }
-        if constexpr (COMB) {
-            const uint32_t ns = a.attn_nsplit, nh = a.attn_n_head;
-            const __amdgpu_buffer_rsrc_t rp = mkrsrc(a.attn_part, ns * n * 4u);
-            const __amdgpu_buffer_rsrc_t rm = mkrsrc(a.attn_ml, nh * ns * 8u);
-#pragma unroll
-            for (int j = 0; j < NV; j++) {
-                const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
-#pragma unroll
-                for (int sp = 0; sp < 8; sp++) sx.pv[j][sp] = bload_f4(rp, (i < n && (uint32_t)sp < ns) ? ((uint32_t)sp * n + i) * 4u : OOB);
-            }
-            const uint32_t sp = tid & 7u, h = tid >> 3;
-            const uint32_t mo = (h < nh && sp < ns) ? (h * ns + sp) * 8u : OOB;
-            sx.ml_m = bload_f(rm, mo);
-            sx.ml_l = bload_f(rm, mo == OOB ? OOB : mo + 4u);
-        }
-    }
     // ---- MODE S: the workgroup's copy of the fragment-order activation (quant_rows_frag_kernel / the attention kernel wrote it): thread
     //      t fetches the 16-byte units t, t + 512, ... (NV of them; a group is 64 units) and one float4 of the scales -- asked for before
     //      any weight, parked in LDS behind the first barrier, read by every item of every tile of the workgroup -------------------------
@@ -223,84 +178,13 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
             oldv0[i] = bload_f(ro, (lv && rr0 + i < hh && orow0 + i < t.rows0) ? (tok0 * t.obs + orow0 + i) * 4u : OOB);
     }
     // ---- the first items go out.  MODE F: every round that has a slot, right away (its one barrier -- arming the counters -- is behind
-    //      it: nothing waits on a wave that the memory pipeline holds up while it issues).  MODE P: ROUND 0 ONLY -- the prologue below has
-    //      barriers, and a wave stuck issuing 30 KB into a full memory pipeline keeps the whole workgroup from its first multiply
-    //      (measured, round 4: W1|W3 of Qwen3-4B multiplied its first item 8.3 us after entry, when the stream was nearly over) -----------
+    //      it: nothing waits on a wave that the memory pipeline holds up while it issues).  MODE S: ROUND 0 ONLY -- the staging below has a
+    //      barrier, and a wave stuck issuing 30 KB into a full memory pipeline keeps the whole workgroup from its first multiply ---------
     if (tid < d.tpw) cnt[tid] = 0u;
     if constexpr (MODE == G6_F) __syncthreads();
     g6_static_for<0, (MODE == G6_F ? (R < D ? R : D) : 1)>([&](auto K) { issue(K, wid + (uint32_t)decltype(K)::value * NW); });
     NANO_STAMP(a.stamps, 1, opos0);                                 // the loads of the first round(s) issued
 
-    // ---- MODE P prologue: combine | rmsnorm, Q80 quantization (tensor.c:21-46) into the compact fragment layout ---------------------
-    if constexpr (MODE == G6_P) {
-        // what no quantizer thread writes: the zero block, the padding groups of a row's last unit, the unused scale slots
-        if (tid < 16u) reinterpret_cast<uint32_t *>(zblk)[tid] = 0u;
-        for (uint32_t i = tid * 4u; i < ngp * 16u; i += 2048u) *reinterpret_cast<float4 *>(xs_l + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t i = ng * 64u * NBC + tid * 16u; i < ngp * 64u * NBC; i += 8192u) *reinterpret_cast<int4 *>(xqc + i) = make_int4(0, 0, 0, 0);
-        if constexpr (COMB) {
-            const bool pre_ml = a.attn_n_head * 8u <= 512u;           // every (head, split) pair has its own thread
-            if (pre_ml) combine_weights<1, true>(a, wgt, sx.ml_m, sx.ml_l); else combine_weights<1, false>(a, wgt, 0.0f, 0.0f);
-#pragma unroll
-            for (int j = 0; j < NV; j++) {
-                const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
-                const float *wg = wgt + (size_t)((i < n ? i : 0u) / a.attn_hd) * 8u;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int sp = 0; sp < 8; sp++) {                      // splits >= nsplit: partial read as 0, weight 0 (gemv_q80_impl.h)
-                    const float w = wg[sp];
-                    acc.x += sx.pv[j][sp].x * w; acc.y += sx.pv[j][sp].y * w; acc.z += sx.pv[j][sp].z * w; acc.w += sx.pv[j][sp].w * w;
-                }
-                sx.x[0][j] = acc;
-            }
-        } else __syncthreads();                                        // (the zero fills above precede the quantizer's scale stores)
-        float ss[NBC];
-#pragma unroll
-        for (int b = 0; b < NBC; b++) ss[b] = 1.0f;
-        if (norm) {                     // rmsnorm scale (infer.c:603-609): the 512-thread tree (quant_rows_frag_kernel repeats it for batches > 8)
-#pragma unroll
-            for (int b = 0; b < NBC; b++) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < NV; j++) {
-                    acc += sx.x[b][j].x * sx.x[b][j].x; acc += sx.x[b][j].y * sx.x[b][j].y;
-                    acc += sx.x[b][j].z * sx.x[b][j].z; acc += sx.x[b][j].w * sx.x[b][j].w;
-                }
-                acc = dpp_wave_sum(acc);
-                if (lane == 0) red[b * 8 + wid] = acc;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < NBC; b++) {
-                float t = 0.0f;
-#pragma unroll
-                for (int w = 0; w < 8; w++) t += red[b * 8 + w];
-                t /= (float)n; t += 1e-5f;
-                ss[b] = 1.0f / sqrtf(t);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const uint32_t i = (tid + (uint32_t)j * 512u) * 4u;
-            const uint32_t g = i >> 6, q4 = (i >> 4) & 3u, e = i & 15u;
-#pragma unroll
-            for (int b = 0; b < NBC; b++) {
-                float4 v = sx.x[b][j];
-                if (norm) {
-                    v.x = sx.nw[j].x * (ss[b] * v.x); v.y = sx.nw[j].y * (ss[b] * v.y);
-                    v.z = sx.nw[j].z * (ss[b] * v.z); v.w = sx.nw[j].w * (ss[b] * v.w);
-                }
-                float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-                mx = dpp_group_max<16>(mx);                           // a group of 64 = 16 consecutive threads
-                const float scale = div_const<127>(mx);
-                if (i < n) {
-                    const int q0 = q80_quant1(v.x, scale), q1 = q80_quant1(v.y, scale), q2 = q80_quant1(v.z, scale), q3 = q80_quant1(v.w, scale);
-                    *reinterpret_cast<uint32_t *>(xqc + (size_t)g * 64u * NBC + (size_t)q4 * 16u * NBC + (size_t)b * 16u + e) =
-                        (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-                    if ((tid & 15u) == 0u) xs_l[g * 16u + (uint32_t)b] = scale;
-                }
-            }
-        }
-    }
     if constexpr (MODE == G6_S) {                                      // (loads beyond the ng groups returned 0: the padding groups of a row's last unit)
 #pragma unroll
         for (int j = 0; j < NV; j++) { const uint32_t un = tid + (uint32_t)j * 512u; if (un < ngp * 64u) *reinterpret_cast<i32x4 *>(xqc + (size_t)un * 16u) = sb[j]; }
@@ -310,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
         __syncthreads();                                               // counters armed, the quantized activation is in LDS
         g6_static_for<1, (R < LA ? R : LA)>([&](auto K) { issue(K, wid + (uint32_t)decltype(K)::value * NW); });   // round 1 (see LA)
     }
-    NANO_STAMP(a.stamps, 2, cnt[0]);                                // (P) the activation arrived, normalised + quantized
+    NANO_STAMP(a.stamps, 2, cnt[0]);                                // (S) the activation is staged
 
     // ---- the items of this wave ---------------------------------------------------------------------------------------------------
     // consume: slot registers -> LDS, eight MFMAs, the unit sum into the table, the tile's counter.  No load, no store, no wait for
@@ -450,9 +334,9 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
 
 
 // ---- launch plumbing shared by the translation units ---------------------------------------------------------------------------------
-template <int MODE, bool COMB, int NBC, int NV, int R, bool MS, int TT = 1>
+template <int MODE, int NV, int R, bool MS, int TT = 1>
 static hipError_t g6_launch_t(const G6Dev &d, size_t lds, hipStream_t st) {
-    auto kern = &gemm_q80_g6_kernel<MODE, COMB, NBC, NV, R, MS, TT>;
+    auto kern = &gemm_q80_g6_kernel<MODE, NV, R, MS, TT>;
     static std::atomic<bool> armed[64];
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !armed[dev].load(std::memory_order_acquire)) {
@@ -464,10 +348,5 @@ static hipError_t g6_launch_t(const G6Dev &d, size_t lds, hipStream_t st) {
 }
 
 }  // namespace
-
-// MODE P launchers by (NV, rounds, multi-segment); defined in gemm_q80_g6_p*.hip.  nbc = sequence capacity 1 | 2 | 4 | 8
-hipError_t g6p_launch_nv2(const void *dv, size_t lds, uint32_t nbc, uint32_t rounds, bool ms, bool comb, hipStream_t st);
-hipError_t g6p_launch_nv5(const void *dv, size_t lds, uint32_t nbc, uint32_t rounds, bool ms, hipStream_t st);
-bool g6p_has(uint32_t nv, uint32_t nbc, uint32_t rounds, bool ms, bool comb);
 
 }  // namespace nano

@@ -400,7 +400,7 @@ static hipError_t g7_launch_t(const G7Dev &d, size_t lds, hipStream_t st) {
 
 bool gemm_q80_g7_supports(const GemvArgs &a) {
     if (a.gs != 64 || a.nb < 17u || a.nb > 64u || a.n % 256u || a.nseg == 0 || a.nseg > 3) return false;
-    if (a.ordered || a.resid_add || a.tile_max || a.attn_part || a.frag_out) return false;
+    if (a.ordered || a.resid_add || a.tile_max || a.attn_part) return false;
     if (a.epi == GEMV_EPI_SWIGLU && (a.nseg != 2 || a.seg[0].rows != a.seg[1].rows)) return false;
     const uint32_t nseg = a.epi == GEMV_EPI_SWIGLU ? 1u : a.nseg;
     for (uint32_t s = 0; s < nseg; s++) if ((uint64_t)a.seg[s].rows * a.n >= (1ull << 32) - (1u << 20)) return false;   // 32-bit row offsets per segment

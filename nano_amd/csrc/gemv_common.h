@@ -231,7 +231,9 @@ static GemvDev to_dev(const GemvArgs &a) {
     d.resid_add = a.resid_add; d.resid_add_bstride = a.resid_add_bstride;
     d.stamps = a.stamps;
     d.canon = q80_canonical(a) ? 1u : 0u;
-    { static const uint32_t dbg = getenv("NANO_DBG") ? (uint32_t)strtoul(getenv("NANO_DBG"), nullptr, 0) : 0u; d.dbg = dbg; }
+#if NANO_STAMPS
+    { static const uint32_t dbg = getenv("NANO_DBG") ? (uint32_t)strtoul(getenv("NANO_DBG"), nullptr, 0) : 0u; d.dbg = dbg; }      // measurement builds only
+#endif
     return d;
 }
 

@@ -252,16 +252,11 @@ static Q4kPlan plan_q4k(const GemvArgs &a, int B) {
     uint32_t rw = 4;
     // Every workgroup quantizes the whole activation before its first product, so large matrices (Qwen3-4B's layers, >= 8 M
     // weights) take up to 4096 items per workgroup: swept on the device with tools/q4k_wide.sh (QKV 17.0 -> 9.0 us, W1|W3
-    // 28.0 -> 19.9, Wo 10.4 -> 7.5); Qwen3-0.6B's are fastest at 512 (1024: -3 %).  NANO_Q4K_ITEMS overrides the former.
+    // 28.0 -> 19.9, Wo 10.4 -> 7.5); Qwen3-0.6B's are fastest at 512 (1024: -3 %).
     const bool large = (uint64_t)rows * a.n >= (8u << 20);
     uint32_t cap = large ? 4096u : rows >= 16384 ? 2048u : 512u;
-    static const char *cap_env = getenv("NANO_Q4K_ITEMS");           // measurement knobs: items per workgroup (large matrices),
-    if (cap_env && large) cap = (uint32_t)strtoul(cap_env, nullptr, 0);
-    static const uint32_t cap_small = getenv("NANO_Q4K_ITEMS_SMALL") ? (uint32_t)strtoul(getenv("NANO_Q4K_ITEMS_SMALL"), nullptr, 0) : 0u;   // ... (per-layer matrices of small models),
-    static const uint32_t nthr_max = getenv("NANO_Q4K_NTHR") ? (uint32_t)strtoul(getenv("NANO_Q4K_NTHR"), nullptr, 0) : 512u;                 // ... threads per workgroup
-    if (cap_small && !large && rows < 16384) cap = cap_small;
-    static const uint32_t cap_swiglu = getenv("NANO_Q4K_ITEMS_SWIGLU") ? (uint32_t)strtoul(getenv("NANO_Q4K_ITEMS_SWIGLU"), nullptr, 0) : 0u;   // ... of the two-matrix launch alone
-    if (!large && nmat == 2 && rows < 16384) cap = cap_swiglu ? cap_swiglu : 1024u;     // measured (Qwen3-0.6B W1|W3): 384 workgroups of 512 items 1542 tok/s, 192 of 1024: 1595
+    constexpr uint32_t nthr_max = 512u;
+    if (!large && nmat == 2 && rows < 16384) cap = 1024u;     // measured (Qwen3-0.6B W1|W3): 384 workgroups of 512 items 1542 tok/s, 192 of 1024: 1595
     while (rw < 64 && (align % (rw * 2)) == 0 && (rw * 2) * GT * nmat <= cap && rows / (rw * 2) >= 128) rw *= 2;
     for (;; rw /= 2) {
         const uint32_t items = rw * GT * nmat;

@@ -247,8 +247,6 @@ size_t chunk_lds_bytes(uint32_t n, bool combine, uint32_t attn_n_head, uint32_t 
 }
 
 bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
-    static const int mode = [] { const char *e = getenv("NANO_Q4K_CHUNK"); return e ? atoi(e) : 1; }();   // 0: never (round 3's kernel everywhere), 1: default
-    if (!mode) return false;
     if (a.nb != 1 || a.n == 0 || (a.n & 255u) || a.n > 16384u || a.nseg == 0 || a.nseg > 3) return false;
     if (a.attn_part && (a.norm_w || a.attn_nsplit > 8 || a.attn_hd % 4)) return false;
     const bool sw = a.epi == GEMV_EPI_SWIGLU;
@@ -256,7 +254,7 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
     uint32_t rows = 0;
     for (uint32_t s = 0; s < nseg; s++) rows += a.seg[s].rows;
     if (rows == 0) return false;
-    static const uint32_t want_div = [] { const char *e = getenv("NANO_Q4K_CHUNK_WANT"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v == 8u || v == 16u ? v : 4u; }();   // measurement knob
+    constexpr uint32_t want_div = 4u;
     uint32_t want = ((a.n / want_div + 63) / 64) * 64;                 // the block quantizer: four elements per thread and pass
     if (want < 256) want = 256;
     if (want > 1024) want = 1024;
@@ -268,7 +266,6 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
     // (Measured and not taken, Qwen3-0.6B on one box: half the workgroups with twice the rows for Wo / W2, whose workgroups each bring
     // n / 4 quantizer threads: 1686 vs 1720 tok/s; the quantizer on n / 8 threads, two blocks per wave: 1661; three wave-loads per wave: 1640.)
     const uint32_t k = cls ? 1024u / want : 1u, target = cus * k;
-    static const uint32_t rw_env = getenv("NANO_Q4K_CHUNK_RW") ? (uint32_t)atoi(getenv("NANO_Q4K_CHUNK_RW")) : 0u;    // measurement knob
     uint32_t best = 0, best_cost = ~0u;
     for (uint32_t c = 1; c <= 1024; c++) {
         if ((uint64_t)c * bpl >= 65536u) break;                          // the kernel's ceil(nblk / 6) and b / bpl by multiplication
@@ -280,13 +277,12 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
         if (wgs > target) cost += cost * 15u / 100u;
         if (cost <= best_cost) { best_cost = cost; best = c; }          // ties: the larger slab (fewer workgroups staging the activation)
     }
-    if (rw_env && !cls) best = rw_env;
     if (!best) return false;
     p.rw = best;
     const uint32_t TT = nmat * ((best * bpl + 5) / 6);
     uint32_t nw = want / 64;
     // one wave-load per wave where the workgroup's waves allow it (<= 16): every load at kernel entry, no serial second item
-    static const uint32_t per_want = [] { const char *e = getenv("NANO_Q4K_CHUNK_PER"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v >= 1u && v <= 8u ? v : 2u; }();   // measurement knob
+    constexpr uint32_t per_want = 2u;
     if (!cls) { uint32_t m = (TT + per_want - 1) / per_want; if (m > 16) m = 16; if (nw < m) nw = m; }
     if (nw * 64 < best) nw = (best + 63) / 64;                           // one fold thread per row
     if (nw > 16) return false;

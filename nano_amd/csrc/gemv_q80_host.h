@@ -7,12 +7,8 @@
 namespace nano {
 
 constexpr uint32_t STREAM_MIN_ROWS = 16384;     // taller matrices go to the stream kernel
-// workgroups of a STREAM launch: 1024 = two resident rounds of 512 (2 per CU at the kernel's register footprint);
-// NANO_STREAM_WGS overrides for experiments
-static inline uint32_t stream_wgs() {
-    static const uint32_t v = [] { const char *e = getenv("NANO_STREAM_WGS"); const uint32_t x = e ? (uint32_t)atoi(e) : 0u; return x ? x : 1024u; }();
-    return v;
-}
+// workgroups of a STREAM launch: 1024 = two resident rounds of 512 (2 per CU at the kernel's register footprint)
+static inline uint32_t stream_wgs() { return 1024u; }
 #define STREAM_WGS (::nano::stream_wgs())
 
 static inline uint32_t total_rows(const GemvArgs &a) {

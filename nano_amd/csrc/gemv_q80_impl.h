@@ -229,6 +229,20 @@ __device__ __forceinline__ float fold_row_canon_any(const float *p, uint32_t ng)
     }
     return v;
 }
+// two rows (W1's and W3's of a SwiGLU launch): every LDS read of both goes out before the first add
+template <int NQ> __device__ __forceinline__ void fold_row2_canon(const float *p0, const float *p1, float &v0, float &v1) {
+    static_assert(NQ % 2 == 0, "whole units");
+    float4 t[NQ], u[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { t[q] = *reinterpret_cast<const float4 *>(p0 + 4 * q); u[q] = *reinterpret_cast<const float4 *>(p1 + 4 * q); }
+    v0 = unit_sum(t[0], t[1]); v1 = unit_sum(u[0], u[1]);
+#pragma unroll
+    for (int q = 2; q < NQ; q += 2) { v0 += unit_sum(t[q], t[q + 1]); v1 += unit_sum(u[q], u[q + 1]); }
+}
+__device__ __forceinline__ void fold_row2_canon_ng(const float *p0, const float *p1, uint32_t ng, float &v0, float &v1) {
+    if (ng == 16u) { fold_row2_canon<4>(p0, p1, v0, v1); return; }
+    v0 = fold_row_canon_any(p0, ng); v1 = fold_row_canon_any(p1, ng);
+}
 __device__ __forceinline__ float fold_row_canon_ng(const float *p, uint32_t ng) {
     if (ng == 16u) return fold_row_canon<4>(p);
     if (ng == 32u) return fold_row_canon<8>(p);
@@ -458,12 +472,12 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     // it runs: the launch ends when the CU with the most rows ends.  BALANCED slabs (round 3): rw = ANY row count, chosen to
     // minimise (rounds of `cus` workgroups) x rw = the rows the busiest CU streams; a power-of-two slab left 160 of 256 CUs
     // busy on a 2560-row matrix (rw 16) where rw = 10 gives every CU one workgroup.  On a tie the larger slab (fewer
-    // workgroups re-staging the activation).  Round 2's rule (powers of two, 64-160 KB) is kept as NANO_SLAB_BALANCED=0.
+    // workgroups re-staging the activation).
     uint32_t large_nw = 0;
     // (round 5: TWO sequences on these matrices take the same balanced slabs, the product table twice as large -- Qwen3-4B at 2 sequences
     //  1.833 ms per step against 1.923 through G6 MODE P, same box; four sequences: 2.80 against 1.99 through G6, so two is where it ends)
     if (B <= 2 && (uint64_t)rows * a.n * nmat >= (8u << 20)) {
-        static const bool balanced = [] { const char *e = getenv("NANO_SLAB_BALANCED"); return !(e && *e == '0'); }();
+        constexpr bool balanced = true;                            // (round 2's power-of-two rule below is kept for the record of what was measured)
         const uint32_t cus = a.cus ? a.cus : 256u;
         uint32_t best = 0, best_cost = ~0u;
         if (balanced) {
@@ -495,19 +509,10 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
             large_nw = u / 2 < 8 ? 8 : (u / 2 > 16 ? 16 : u / 2);
         }
     }
-    // measurement only: NANO_SLAB_PLAN="ROWSxN:rw:nw,..." pins the slab shape of the matrices with that many rows / columns
-    uint32_t force_nw = 0;
-    {
-        static const char *env = getenv("NANO_SLAB_PLAN");
-        for (const char *q = env; q && *q;) {
-            unsigned r_ = 0, n_ = 0, rw_ = 0, nw_ = 0;
-            if (sscanf(q, "%ux%u:%u:%u", &r_, &n_, &rw_, &nw_) == 4 && r_ == rows && n_ == a.n && rw_ >= 4) { rw = rw_; force_nw = nw_; }
-            q = strchr(q, ','); if (q) q++;
-        }
-    }
+    const uint32_t force_nw = 0;
     const uint32_t units = ((rw + 3) / 4) * nchunk * nmat;
     uint32_t nw = units < 4 ? units : 4;
-    static const uint32_t want_div = [] { const char *e = getenv("NANO_SLAB_WANT"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v >= 64 ? v : 512u; }();   // measurement knob
+    constexpr uint32_t want_div = 512u;
     uint32_t want = (a.n * (uint32_t)(B > 2 ? B / 2 : 1) + want_div - 1) / want_div;     // idle waves still help the activation prologue
     if (want > 16) want = 16;
     if (nw < want) nw = want;
@@ -569,7 +574,9 @@ static hipError_t launch_slab_b(GemvDev &d, const GemvArgs &a, hipStream_t st) {
     d.wg_c0 = nseg > 1 ? wg[0] : 0xffffffffu;
     d.wg_c1 = nseg > 2 ? wg[0] + wg[1] : 0xffffffffu;
     const uint32_t rows = wg[0] + wg[1] + wg[2];                       // the grid
-    if constexpr (B == 1) {         // the per-layer launches of a batch-1 step: flags resolved at compile time
+    // the per-layer launches of a batch-1 step: flags resolved at compile time.  Group size 64: the role kernels carry the canonical fold
+    // only, so a launch that is not canonical (strict mode; a row length that is no multiple of 256) takes the generic kernel
+    if constexpr (B == 1) if (GS != 64 || d.canon) {
         const uint32_t f = d.flags;
         if (f == F_NORM && d.epi == GEMV_EPI_STORE) return launch_slab_r<R_NORM_STORE, GS, B>(d, p, rows, st);
         if (f == 0 && d.epi == GEMV_EPI_RESID) return launch_slab_r<R_RESID, GS, B>(d, p, rows, st);
@@ -607,7 +614,7 @@ static hipError_t launch_stream_b(GemvDev &d, hipStream_t st) {
 // ---- the fused q | k | v + attention launch: host side -----------------------------------------------------------------------------------
 static bool fused_shape(const GemvArgs &ga, const AttnArgs &aa, SlabPlan &p) {
     if (ga.gs != 64 || ga.nb != 1 || ga.nseg != 3 || ga.epi != GEMV_EPI_STORE || !ga.norm_w || ga.xq_in || ga.attn_part || ga.tile_max || ga.resid_add) return false;
-    if (ga.n % 64u || ga.n > 4096u || use_stream(ga)) return false;
+    if (ga.n % 64u || ga.n > 4096u || use_stream(ga) || !q80_canonical(ga)) return false;        // (the role kernels of group size 64 carry the canonical fold only)
     if (ga.seg[0].out_pstride || ga.seg[1].out_pstride) return false;            // (only v is position indexed: its cache row)
     p = plan_slab(ga, 1);
     if (p.nw != 4u || p.upw > 4u || !(p.nv == 1u || p.nv == 2u || p.nv == 4u)) return false;        // 256 threads, like the attention workgroups

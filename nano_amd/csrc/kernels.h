@@ -33,9 +33,7 @@ struct GemvArgs {
     const float *norm_w;    // rmsnorm weight or nullptr
     const uint32_t *pos;    // device positions [nb] (for out_pstride)
     uint32_t tiles;         // filled by the launcher
-    uint32_t frag_ready;    // batched GEMM path: the fragment-order activations already exist -- 1: in the step's first scratch (the attention
-                            // kernel wrote them), 2: in the second (the W1|W3 GEMM wrote them)
-    int8_t *frag_out; float *frag_scale_out;   // SwiGLU launch through G5: also write the outputs as the next GEMM's fragments, or nullptr
+    uint32_t frag_ready;    // batched GEMM path: 1 = the fragment-order activations already exist in the step's scratch (the attention kernel wrote them)
     // operator-test inputs: an already quantized activation (skips the quantizing prologue)
     const int8_t *xq_in;    // Q80 int8[n] (batched GEMM path with frag_ready: all tokens, MFMA B-fragment order)
     const float *xs_in;     // Q80 float[n/gs]
@@ -58,8 +56,13 @@ struct GemvArgs {
 
 // The fast path's reduction shape of a Q80 projection (group size 64, row length a multiple of 256; not the classifier-like tall
 // STORE launches, whose kernels hold whole rows per wave and keep the reference's order): row = ((S_0 + S_1) + ...), S_u = the 8
-// group products of unit u added in ascending order.  Every kernel a launch can be routed to (SLAB GEMV, G6, G5) implements this
-// one shape, so a batch stays bit for bit its sequences alone whatever route each size takes.  Strict mode: never.
+// group products of unit u added in ascending order.  Every kernel a launch can be routed to (SLAB GEMV, G6, G7) implements this
+// one shape: given the same quantized activations, a batch's projections are bit for bit its sequences' alone whatever route each
+// size takes.  What a batch shares beyond that: the rmsnorm sum-of-squares tree in front of the quantizer is 256 threads wide on
+// every route of the small matrices (Qwen3-0.6B: batches ARE their sequences alone end to end, tests/test_gpu_fullsize.py::test_batch_equals_sequences_alone_and_runs_repeat asserts it);
+// on the wide matrices (route_is_wide(), Qwen3-4B) the one- and two-sequence SLAB launches run the tree of their own thread count
+// and the >= 3-sequence launches the 512-thread one (route_norm_order()), so a scale may differ in its last ulp between batch
+// sizes there -- inside the fast path's stated tolerance, not a bit-for-bit promise.  Strict mode: never canonical.
 inline bool q80_canonical(const GemvArgs &a) {
     if (a.ordered || a.gs != 64 || a.n % 256u) return false;
     if (a.nseg == 1 && a.epi == GEMV_EPI_STORE && a.seg[0].rows >= 16384u && a.seg[0].out_pstride == 0) return false;
@@ -75,20 +78,15 @@ hipError_t launch_gemv_q4k_chunk(GemvArgs &a, hipStream_t st);
 uint32_t gemv_q4k_fit_batch(const GemvArgs &a);            // sequences per Q4K launch that fit in LDS (8 | 4 | 2 | 1)
 hipError_t launch_gemv_q80(const GemvArgs &a, hipStream_t st);      // gemv_q80.hip
 hipError_t launch_gemv_f32(const GemvArgs &a, hipStream_t st);      // gemv_f32.hip
-// 9..64 tokens per weight read on the int8 matrix cores.  G2 (gemm_q80.hip): the general kernel, activations in MFMA
-// B-fragment order (a.xq_in / a.xs_in = launch_quant_rows_frag's output)
+// 9..64 tokens per weight read on the int8 matrix cores.  G2 (gemm_q80.hip): the general kernel in the reference's ascending group order --
+// strict mode's batched route, and the launches the canonical-fold kernels do not take (group sizes other than 64, rows that are no multiple
+// of 256); activations in MFMA B-fragment order (a.xq_in / a.xs_in = launch_quant_rows_frag's output)
 bool gemm_q80_g2_supports(const GemvArgs &a);                       // host predicate: shapes / features the GEMM takes
 hipError_t launch_gemm_q80_g2(const GemvArgs &a, hipStream_t st);
-// G5, row length split over a chained team of waves, all token tiles per wave (gemm_q80_g5.hip): same inputs as G2
-bool gemm_q80_g5_supports(const GemvArgs &a);
-bool gemm_q80_g5_can_quantize_outputs(const GemvArgs &a);           // SwiGLU launches: the outputs also as Q80 fragments (xf2 / xsf2)
-hipError_t launch_gemm_q80_g5(const GemvArgs &a, int8_t *xf2, float *xsf2, hipStream_t st);
-// G6 (gemm_q80_g6.hip): the fast path's split-K kernel, canonical fold, group size 64.  MODE F: fragment-order activations, up to 16
-// tokens; MODE P: fp32 activations of 1..8 sequences, rmsnorm | split-attention combine + quantization in the kernel's prologue
+// G6 (gemm_q80_g6.hip): the fast path's split-K kernel, canonical fold, group size 64, fragment-order activations (MODE S: staged in LDS
+// once per workgroup, <= 16 tokens; MODE F: fetched per item, 1 / 2 / 4 token tiles)
 bool gemm_q80_g6_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_g6(const GemvArgs &a, hipStream_t st);
-bool gemm_q80_g6p_supports(const GemvArgs &a);
-hipError_t launch_gemm_q80_g6p(const GemvArgs &a, hipStream_t st);
 // G7 (gemm_q80_g7.hip): the fast path's kernel for 17..64 tokens -- LDS-DMA loader waves stream weights AND activation fragments through an
 // LDS ring, consumer waves own (row tile, token tile) pairs for the whole row length (canonical fold in registers); same inputs as MODE F
 bool gemm_q80_g7_supports(const GemvArgs &a);
@@ -96,7 +94,7 @@ hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st);
 // GC, tall matrices with short rows (the classifier): persistent waves, activation fragments staged in LDS (gemm_q80_cls.hip)
 bool gemm_q80_cls_supports(const GemvArgs &a);
 hipError_t launch_gemm_q80_cls(const GemvArgs &a, hipStream_t st);
-// order: threads of the rmsnorm sum-of-squares tree -- 256 (the SLAB GEMV prologue's of the small matrices) or 512 (G6 MODE P's)
+// order: threads of the rmsnorm sum-of-squares tree -- 256 (the SLAB GEMV prologue's of the small matrices) or 512 (the wide matrices' batched launches, route_norm_order())
 hipError_t launch_quant_rows_frag(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
                                   int8_t *xf, float *xsf, hipStream_t st, uint32_t order = 256);
 hipError_t launch_quant_rows(const float *x, uint32_t x_bstride, const float *norm_w, uint32_t n, uint32_t gs, uint32_t nb,
@@ -110,18 +108,17 @@ enum RouteKind : uint32_t {
     ROUTE_GEMV_PREQ,       // Q80: row-major quantizer launch + GEMV reading the quantized rows (2..8 sequences on large inputs)
     ROUTE_GEMV_SLICED,     // more than 8 sequences through the GEMV kernels in groups of 8
     ROUTE_Q4K,
-    ROUTE_G6P,             // G6 MODE P: fp32 activation (or split-attention partials), quantized in the kernel's prologue
+    ROUTE_RESERVED,        // (round 4's G6 MODE P; the value stays so that the route numbers the tests read do not move)
     ROUTE_FRAG_G6,         // fragment-order activations (quantizer launch unless frag_ready) + G6 MODE F
-    ROUTE_FRAG_OLD,        // fragment-order activations + GC | G5 | G2
+    ROUTE_FRAG_OLD,        // fragment-order activations + GC (the classifier) | G2 (the reference's group order)
     ROUTE_FRAG_G7,         // fragment-order activations + G7 (17..64 tokens, the fast path)
 };
 inline bool route_takes_fragments(RouteKind k) { return k == ROUTE_FRAG_G6 || k == ROUTE_FRAG_OLD || k == ROUTE_FRAG_G7; }
-inline bool route_takes_attn_parts(RouteKind k) { return k == ROUTE_GEMV || k == ROUTE_G6P || k == ROUTE_Q4K; }
+inline bool route_takes_attn_parts(RouteKind k) { return k == ROUTE_GEMV || k == ROUTE_Q4K; }
 struct Q80Route {
     uint32_t quant; int cus;
-    uint32_t mfma_min_nb;  // sequences from which the small Q80 matrices take the batched route (9; measurement: NANO_MFMA_MIN_NB)
-    bool use_g5, use_g6, use_cls, use_g7;
-    int8_t *gq; float *gxs; int8_t *gq2; float *gxs2;   // fragment-order activation scratch (nullptr: no batched route)
+    uint32_t mfma_min_nb;  // sequences from which the small Q80 matrices take the batched route (9; NANO_MFMA_MIN_NB)
+    int8_t *gq; float *gxs;  // fragment-order activation scratch (nullptr: no batched route)
 };
 RouteKind route_kind(const Q80Route &r, const GemvArgs &a);
 hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st);

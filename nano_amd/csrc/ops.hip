@@ -224,14 +224,10 @@ extern "C" int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *dp) {
     hipDeviceProp_t prop; OP_HIP(hipGetDeviceProperties(&prop, device));
     a.cus = (uint32_t)prop.multiProcessorCount;
     // the step's own router (route.hip): use_gemm = 1 forces the fragment-order route of batched steps (quantizer launch + G6 MODE F /
-    // G5 / GC / G2); ordered = 1 is strict mode (the reference's group order in every kernel)
+    // GC / G2); ordered = 1 is strict mode (the reference's group order in every kernel)
     a.ordered = d.ordered ? 1u : 0u;
     Q80Route r{};
     r.quant = d.quant; r.cus = (int)a.cus; r.mfma_min_nb = d.use_gemm ? 1u : 9u;
-    r.use_g5 = !(getenv("NANO_GEMM_G5") && *getenv("NANO_GEMM_G5") == '0');
-    r.use_g6 = !(getenv("NANO_GEMM_G6") && *getenv("NANO_GEMM_G6") == '0');
-    r.use_g7 = !(getenv("NANO_GEMM_G7") && *getenv("NANO_GEMM_G7") == '0');
-    r.use_cls = !(getenv("NANO_GEMM_CLS") && *getenv("NANO_GEMM_CLS") == '0');
     if (d.quant == NANO_QUANT_Q80) {
         const size_t n16 = (d.n + 15) & ~(size_t)15, tt = (d.nb + 15) / 16;
         r.gq = B.alloc<int8_t>(tt * 16 * n16); r.gxs = B.alloc<float>(tt * 16 * (d.n / d.gs));

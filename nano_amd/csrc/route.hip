@@ -3,13 +3,12 @@
 // exercise exactly the launches a step issues.
 //
 //   FP32 / Q4K              the GEMV kernels (gemv_f32.hip, gemv_q4k.hip), more than 8 sequences in groups
-//   Q80, fast path          SLAB GEMV (1..8 sequences on the small per-layer matrices)           gemv_q80_impl.h
-//                           G6 MODE P (1..8 sequences on matrices of >= 8 M weights: Qwen3-4B)    gemm_q80_g6.hip
-//                           G6 MODE F (fragment-order activations, <= 16 tokens)                 gemm_q80_g6.hip
+//   Q80, fast path          SLAB GEMV (1..8 sequences on the small per-layer matrices; 1..2 on those of >= 8 M weights)   gemv_q80_impl.h
+//                           G6 (fragment-order activations: MODE S staged in LDS, MODE F per item; 2..64 tokens) gemm_q80_g6.hip
 //                           G7 (17..64 tokens: loader / consumer engine, both operands through LDS) gemm_q80_g7.hip
-//                           G5 / G2 (what G7 / G6 do not take: group sizes other than 64)          gemm_q80_g5.hip, gemm_q80.hip
+//                           G2 (group sizes other than 64, rows no multiple of 256: the reference's order) gemm_q80.hip
 //                           STREAM GEMV / GC for the classifier                                   gemv_q80_impl.h, gemm_q80_cls.hip
-//   Q80, strict mode        the kernels that keep the reference's ascending group order: SLAB, G5, GC, G2 (a.ordered = 1)
+//   Q80, strict mode        the kernels that keep the reference's ascending group order: SLAB, GC, G2 (a.ordered = 1)
 #include <stdlib.h>
 #include "kernels.h"
 
@@ -27,20 +26,11 @@ static bool gemv_is_heavy(const GemvArgs &a) { return (uint64_t)(route_rows(a) /
 bool route_is_wide(const GemvArgs &a) { const uint32_t rows = route_rows(a); return rows < 65536u && (uint64_t)rows * a.n >= (8u << 20); }
 
 // the rmsnorm sum-of-squares tree the activation quantizer launch must repeat for this matrix (launch_quant_rows_frag order)
-// (not a function of the A/B knobs: with NANO_GEMM_G6=0 the batched launches of wide matrices keep MODE P's tree, so that switching
-// G6 off changes kernels, not bits)
+// (512 threads on the wide matrices -- the order the >= 3-sequence launches of Qwen3-4B have had since round 4; the one- and
+// two-sequence SLAB launches of those matrices run the tree of their own thread count, see kernels.h "what a batch shares")
 uint32_t route_norm_order(const Q80Route &r, const GemvArgs &a) {
     (void)r;
     return (q80_canonical(a) && route_is_wide(a) && a.n <= 10240u) ? 512u : 256u;
-}
-
-// MODE P quantizes nb x n values in EVERY workgroup: taken when the launch needs fp32 processing anyway (a norm or the split-attention
-// combine: the quantizer launch it replaces costs ~3.5 us) or when the activation is small
-// -- up to two sequences: measured (round 4, Qwen3-4B's QKV at 8 sequences) the prologue of 8 x 2560 values per workgroup lasts 9.7 us
-// where the quantizer launch it replaces costs 3.5
-static bool p_worthwhile(const GemvArgs &a) {
-    static const uint32_t pmax = [] { const char *e = getenv("NANO_G6P_MAX_NB"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v ? v : 2u; }();
-    return a.nb <= pmax && (a.norm_w || a.attn_part || (uint64_t)a.nb * a.n <= 12288u);
 }
 
 RouteKind route_kind(const Q80Route &r, const GemvArgs &a) {
@@ -52,23 +42,21 @@ RouteKind route_kind(const Q80Route &r, const GemvArgs &a) {
     // two sequences on wide matrices: the balanced SLAB GEMV (capacity 2) -- measured against G6 MODE P on one box, round 5: Qwen3-4B 1.833 vs
     // 1.923 ms per step (profiles/r05_wide_two_sequences.txt); from three sequences on the batched route is the faster one (four: 1.99 vs 2.80)
     if (canon && wide && a.nb == 2 && !a.xq_in) return ROUTE_GEMV;
-    if (canon && r.use_g6) {
-        // one sequence: the SLAB GEMV is the leaner kernel (measured, round 4, Qwen3-4B: 1.48 ms per step against MODE P's 1.77;
-        // NANO_G6P_B1=1 routes it through MODE P for A/B runs)
-        static const bool p_b1 = getenv("NANO_G6P_B1") && *getenv("NANO_G6P_B1") == '1';
-        if (wide && !a.xq_in && a.nb <= 8 && (a.nb >= 2 || p_b1) && r.mfma_min_nb == 9 && p_worthwhile(a) && gemm_q80_g6p_supports(a)) return ROUTE_G6P;
+    if (canon) {
         const bool batched = a.nb >= r.mfma_min_nb || (r.mfma_min_nb == 9 && ((a.nb == 8 && gemv_is_heavy(a)) || (wide && a.nb >= 2)));
-        if (batched && scratch && r.use_g7 && gemm_q80_g7_supports(a)) return ROUTE_FRAG_G7;      // 17..64 tokens
+        if (batched && scratch && gemm_q80_g7_supports(a)) return ROUTE_FRAG_G7;      // 17..64 tokens, where it pays
         if (batched && scratch && !a.attn_part && !a.resid_add && gemm_q80_g6_supports(a)) return ROUTE_FRAG_G6;
     }
-    // the older batched route: 9..64 sequences always; 8 sequences when the matrix is large; per-layer matrices of >= 8 M weights from 2
-    // sequences on (tools/wide_batch.sh, round 2); the classifier keeps its STREAM GEMV up to 7 sequences
+    // launches that are not canonical (strict mode, other group sizes, the classifier): 9..64 sequences always; 8 sequences when the matrix is
+    // large; per-layer matrices of >= 8 M weights from 2 sequences on; the classifier keeps its STREAM GEMV up to 7 sequences
     bool mfma = false;
     if (scratch) {
         if (a.nb >= r.mfma_min_nb) mfma = true;
         else if (r.mfma_min_nb == 9) mfma = (a.nb == 8 && gemv_is_heavy(a)) || (a.nb >= 2 && wide);
     }
-    if (mfma && !a.attn_part && !a.resid_add && gemm_q80_g2_supports(a)) return ROUTE_FRAG_OLD;
+    // (a CANONICAL launch neither G6 nor G7 takes does not go to G2, whose fold is the reference's: it would no longer be bit for bit its
+    //  sequences alone -- it runs through the GEMV kernels in groups of 8 below)
+    if (mfma && !canon && !a.attn_part && !a.resid_add && gemm_q80_g2_supports(a)) return ROUTE_FRAG_OLD;
     if (a.nb > 8) return ROUTE_GEMV_SLICED;
     if (a.nb > 1 && !a.attn_part && !a.xq_in && scratch && gemv_is_heavy(a)) return ROUTE_GEMV_PREQ;
     return ROUTE_GEMV;
@@ -106,8 +94,6 @@ hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st) {
         }
         return hipSuccess;
     }
-    case ROUTE_G6P:
-        return launch_gemm_q80_g6p(a, st);
     case ROUTE_FRAG_G6:
     case ROUTE_FRAG_G7:
     case ROUTE_FRAG_OLD: {
@@ -117,13 +103,11 @@ hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st) {
             const hipError_t e = launch_quant_rows_frag(a.xin, a.xin_bstride, a.norm_w, a.n, a.gs, a.nb, r.gq, r.gxs, st, route_norm_order(r, a));
             if (e != hipSuccess) return e;
         }
-        a.xq_in = a.frag_ready == 2u ? r.gq2 : r.gq; a.xs_in = a.frag_ready == 2u ? r.gxs2 : r.gxs;
+        a.xq_in = r.gq; a.xs_in = r.gxs;
         if (k == ROUTE_FRAG_G6) return launch_gemm_q80_g6(a, st);
         if (k == ROUTE_FRAG_G7) return launch_gemm_q80_g7(a, st);
         // the classifier of a batched step: GC (persistent waves, the activation fragments staged in LDS once per workgroup)
-        if (r.use_cls && !a.frag_out && gemm_q80_cls_supports(a)) return launch_gemm_q80_cls(a, st);
-        if (r.use_g5 && gemm_q80_g5_supports(a)) return launch_gemm_q80_g5(a, a.frag_out, a.frag_scale_out, st);
-        if (a.frag_out) return hipErrorInvalidValue;               // the caller checked gemm_q80_g5_can_quantize_outputs()
+        if (gemm_q80_cls_supports(a)) return launch_gemm_q80_cls(a, st);
         return launch_gemm_q80_g2(a, st);
     }
     case ROUTE_GEMV_SLICED:

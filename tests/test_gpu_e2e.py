@@ -128,7 +128,7 @@ def test_large_batch_mfma_gemm_path(model_dir, B):
 def test_small_batch_on_large_layers_takes_the_gemm_with_a_split_attention(model_dir):
     """Qwen3-4B's layer sizes, 3 sequences per step, positions past 64: the weight launches take the batched GEMM from 2
     sequences on, the attention is split, so its partials are combined by the kernel that also writes Wo's Q80 fragments.
-    Same bits with the general GEMM kernel and with a quantizer launch of its own; one-by-one decoding within the Q80 bar."""
+    The same steps through the GEMV kernels (NANO_MFMA_MIN_NB=65) stay within the Q80 bar."""
     path, spec = synth_model(model_dir, "wide-qwen3", "q80", 64)
     from nano_amd import modelfile as mf
     B, T = 3, 70
@@ -150,11 +150,6 @@ def test_small_batch_on_large_layers_takes_the_gemm_with_a_split_attention(model
         m.close()
         return out
     a = run()
-    # round 3's kernels (G5 with the canonical fold + quantizer launches, NANO_GEMM_G6=0) and a quantizer launch instead of the
-    # attention kernel's fragment output: other kernels, the same arithmetic
-    for other in (run(NANO_GEMM_G6="0"), run(NANO_ATTN_QUANT="0"), run(NANO_GEMM_G6="0", NANO_W2_QUANT="0")):
-        for x, y in zip(a, other):
-            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     gemv = run(NANO_MFMA_MIN_NB="65")                          # every launch through the GEMV kernels
     worst = max(rel_err(x, y) for x, y in zip(a, gemv))
     print(f"3 sequences on wide rows past position 64: GEMM path vs GEMV path worst {worst:.3e}")
@@ -247,11 +242,10 @@ def test_q4k_batch_on_rows_too_long_for_one_launch(model_dir):
 
 
 @pytest.mark.parametrize("B", [3, 9, 16, 33, 64])
-def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
-    """gemm_q80_g5.hip (row length split over a chained team of waves) against the general G2 kernel (NANO_GEMM_G5=0) on
-    Qwen3-4B's row lengths (2560 / 4096 / 9728: 5, 8 and 19 half chunks, several per wave) -- integer group sums and the
-    ascending fp32 group order are the same arithmetic, so logits and KV rows must agree bit for bit; and against
-    one-by-one decoding through the GEMV kernels."""
+def test_batched_steps_on_wide_rows_equal_one_by_one_decoding(model_dir, B):
+    """Batched steps on Qwen3-4B's row lengths (2560 / 4096 / 9728) -- G6 at 3..16 sequences, G7 / G6 at 17..64, G2 + GC in strict
+    mode -- against one-by-one decoding: strict mode (the reference's order whatever the kernel) bit for bit, the fast path (the
+    canonical fold whatever the kernel; the rmsnorm tree of a wide matrix follows the launch, kernels.h) within the Q80 bar."""
     path, spec = synth_model(model_dir, "wide-qwen3", "q80", 64)
     from nano_amd import modelfile as mf
     T = 3
@@ -272,26 +266,23 @@ def test_chained_gemm_equals_the_general_gemm_kernel_on_wide_rows(model_dir, B):
         m.close()
         return out, kv
     a, akv = run()
-    # FAST path: G6 (<= 16 tokens) / G5 beyond against G5 everywhere (NANO_GEMM_G6=0) -- the canonical fold is one shape whatever
-    # the split; Wo's / W2's input quantized by a launch of its own instead of by the attention kernel / the W1|W3 GEMM's epilogue
-    for b, bkv in (run(NANO_GEMM_G6="0"), run(NANO_ATTN_QUANT="0"), run(NANO_GEMM_G6="0", NANO_W2_QUANT="0")):
-        for pos in range(T):
-            assert np.array_equal(a[pos].view(np.uint32), b[pos].view(np.uint32)), pos
-        assert np.array_equal(akv.view(np.uint32), bkv.view(np.uint32))
-    # STRICT mode (the reference's ascending group order): the chained G5 against the general G2 kernel
-    s5, s5kv = run(strict=True)
-    s2, s2kv = run(strict=True, NANO_GEMM_G5="0")
-    for pos in range(T):
-        assert np.array_equal(s5[pos].view(np.uint32), s2[pos].view(np.uint32)), pos
-    assert np.array_equal(s5kv.view(np.uint32), s2kv.view(np.uint32))
+    s, skv = run(strict=True)
     m1 = nb.load_model_file(path, max_seq_len=16, max_batch=1)
     worst, exact = 0.0, True
-    for bi in (0, B // 2, B - 1):
-        for pos in range(T):
-            lg, _ = m1.forward([int(seqs[bi][pos])], [pos])
-            worst = max(worst, rel_err(a[pos][bi], lg[0])); exact = exact and np.array_equal(lg[0], a[pos][bi])
+    for strict, got in ((False, a), (True, s)):
+        m1.set_strict(strict)
+        for bi in (0, B // 2, B - 1):
+            for pos in range(T):
+                lg, _ = m1.forward([int(seqs[bi][pos])], [pos])
+                if strict:
+                    assert np.array_equal(lg[0].view(np.uint32), got[pos][bi].view(np.uint32)), (bi, pos)
+                else:
+                    worst = max(worst, rel_err(got[pos][bi], lg[0])); exact = exact and np.array_equal(lg[0], got[pos][bi])
+        if strict:
+            one_kv = m1.read_state("v", spec.kv_dim, slot=0, layer=0, pos=T - 1).copy()
+            assert np.array_equal(one_kv.view(np.uint32), skv.view(np.uint32))
     m1.close()
-    print(f"wide rows, batch {B}: G6/G5 == G5 (fast), G5 == G2 (strict) bit for bit; vs one-by-one decoding worst {worst:.3e}, bit-identical {exact}")
+    print(f"wide rows, batch {B}: strict == one-by-one strict bit for bit; fast path vs one-by-one worst {worst:.3e}, bit-identical {exact}")
     assert worst < TOL["q80"]
 
 

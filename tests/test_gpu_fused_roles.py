@@ -1,8 +1,8 @@
 """GPU parity tests of the FUSED decode launches exactly as a step issues them (nano_hip_op_fused_gemv, routed by the step's own
 router nano_amd/csrc/route.hip): K1 (rmsnorm + quantize + q|k|v), K3 / K5 (quantize [+ split-attention combine] + projection +
 residual add) and K4 (rmsnorm + quantize + W1|W3 + SwiGLU) -- the role-specialised SLAB GEMV kernels at Qwen3-0.6B shapes, the
-split-K kernel G6 (MODE P: norm / combine + quantization in its prologue) at Qwen3-4B shapes, and their batched forms (GEMV
-kernels for 2..8 sequences, G6 MODE F up to 16 tokens, G5 up to 64, GC for the classifier).
+same kernels in their large plans at Qwen3-4B shapes, and their batched forms (GEMV
+kernels for 2..8 sequences, G6 up to 64 tokens, G7 at 17..64 where it pays, GC for the classifier).
 
 TWO BARS (round 4):
   * strict mode (ordered=True): every fp32 group fold in the reference's ascending order -> the oracle's restatement of the
@@ -20,9 +20,6 @@ normalised values, quantized activations, integer group sums, products, the resi
 (device vs libm, <= 2 ulp) keeps a tolerance.
 Reference lines: rmsnorm infer.c:601-614, quantize tensor.c:21-46 / 144-242, matmul_quant infer.c:654-679, matmul_q4k
 tensor.c:438-471, residual adds infer.c:906-908 / 963-965, SwiGLU infer.c:937-944."""
-import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -59,10 +56,7 @@ def ref_q80(oracle, act, segs, n, gs, canon=False):
     return np.concatenate([oracle.matmul_q80(xq, xs, wq, ws, n, rows, gs) for wq, ws, rows in segs])
 
 
-ROUTES_FREE = os.environ.get("NANO_GEMM_G6") == "0"        # round 3's routes (A/B knob): the expected-route assertions do not apply
-G7_OFF = os.environ.get("NANO_GEMM_G7") == "0"             # 17..64 tokens through G6 MODE F / G5 instead of G7 (A/B knob)
-# one sequence on Qwen3-4B's matrices: the SLAB GEMV (leaner, measured faster); NANO_G6P_B1=1 sends it through G6 MODE P
-W1 = "g6p" if os.environ.get("NANO_G6P_B1") == "1" else "gemv"
+W1 = "gemv"        # one sequence on Qwen3-4B's matrices: the SLAB GEMV
 
 
 def check_q80(oracle, kind, n, segs, x, nw, old, nb_, *, attn=None, act_of=None, use_gemm=False, routes=None, strict_too=True):
@@ -80,7 +74,7 @@ def check_q80(oracle, kind, n, segs, x, nw, old, nb_, *, attn=None, act_of=None,
             assert np.array_equal(bits(strict[b]), bits(ref)), ("strict", b, float(np.abs(strict[b] - ref).max()))
         assert np.array_equal(bits(fast[b]), bits(cref)), ("fast", route, b, float(np.abs(fast[b] - cref).max()))
         assert float(np.abs(fast[b] - ref).max()) <= 1e-5 * scale, ("tier ii", route, b)
-    if routes is not None and not ROUTES_FREE:
+    if routes is not None:
         assert route in routes, route
     return route
 
@@ -90,7 +84,7 @@ def silu_mul(a, b):
     return (a * (np.float32(1) / (np.float32(1) + np.exp(-a.astype(np.float64)).astype(np.float32))) * b).astype(np.float32)
 
 
-# (name, n, rows of the weight tensors, the fast path's route): Qwen3-0.6B (SLAB GEMV) and Qwen3-4B (G6 MODE P) per-layer shapes
+# (name, n, rows of the weight tensors, the fast path's route): Qwen3-0.6B and Qwen3-4B per-layer shapes (SLAB GEMV)
 K1_SHAPES = [("q06", 1024, (2048, 1024, 1024), "gemv"), ("4b", 2560, (4096, 1024, 1024), W1)]
 K3_SHAPES = [("q06", 2048, 1024, "gemv"), ("4b", 4096, 2560, W1)]
 K4_SHAPES = [("q06", 1024, 3072, "gemv"), ("4b", 2560, 9728, W1)]
@@ -118,7 +112,7 @@ def test_k3_k5_residual_q80(oracle, name, n, rows, route):
 @pytest.mark.parametrize("n_head,n,rows,route", [(16, 2048, 1024, "gemv"), (32, 4096, 2560, W1)])
 @pytest.mark.parametrize("nsplit,ls", [(2, (3, 5)), (4, (1, 3, 2, 2)), (8, (1, 1, 2, 4, 2, 2, 1, 3))])
 def test_k3_split_attention_combine_q80(oracle, nsplit, ls, n_head, n, rows, route):
-    """Wo launch whose prologue combines split-attention partials (gemv_common.h combine_weights; G6 MODE P at Qwen3-4B's shape):
+    """Wo launch whose prologue combines split-attention partials (gemv_common.h combine_weights):
     equal split maxima make every exp() an exact 1, the split sums add up to a power of two, the partials are order-free -> the
     combined activation is exact on both sides and the launch is pinned like the others."""
     hd = 128
@@ -170,8 +164,8 @@ def test_batched_gemv_roles_q80(oracle, nb_, kind):
 
 @pytest.mark.parametrize("nb_", [2, 3, 4, 8])
 @pytest.mark.parametrize("kind", [0, 1, 2])
-def test_batched_g6_prologue_roles_q80(oracle, nb_, kind):
-    """Qwen3-4B's shapes, 2..8 sequences: two sequences through the balanced SLAB GEMV (round 5: faster than G6's MODE P there), more take
+def test_batched_wide_roles_q80(oracle, nb_, kind):
+    """Qwen3-4B's shapes, 2..8 sequences: two sequences through the balanced SLAB GEMV (capacity 2), more take
     fragment-order activations from a quantizer launch (G6 MODE F / S)"""
     n, rows = [(2560, (4096, 1024, 1024)), (4096, (2560,)), (2560, (9728, 9728))][kind]
     rng = np.random.default_rng(nb_ * 7 + kind)
@@ -234,9 +228,9 @@ def gemm_route_case(oracle, nb_, kind, n, rows):
             ref = ref_q80(oracle, oracle.rmsnorm(x[b], nw), segs, n, 64)
             assert np.array_equal(bits(out[b]), bits(ref)), (b, float(np.abs(out[b] - ref).max()))
         return "frag_old"
-    # 17..64 tokens: G7 where it pays (several row tiles per CU, or very short rows: gemm_q80_g7_supports), else G6 MODE F / G5
-    g7 = nb_ >= 17 and not G7_OFF and n % 256 == 0 and g7_pays(n, rows, nb_, kind)
-    want = ("frag_old",) if n % 256 else ("frag_g7",) if g7 else ("frag_g6", "frag_old") if nb_ >= 17 else ("frag_g6",)
+    # 17..64 tokens: G7 where it pays (several row tiles per CU, or very short rows: gemm_q80_g7_supports), else G6 MODE F
+    g7 = nb_ >= 17 and n % 256 == 0 and g7_pays(n, rows, nb_, kind)
+    want = ("frag_old",) if n % 256 else ("frag_g7",) if g7 else ("frag_g6",)
     return check_q80(oracle, kind, n, segs, x, nw, old, nb_, use_gemm=True, routes=want)
 
 
@@ -249,7 +243,7 @@ def test_g7_swiglu_epilogue(oracle, nb_, n, rows):
     nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
     segs = [(*q80_weights(rng, rows, n, 64), rows) for _ in range(2)]
     out, r = nb.op_fused_gemv(Q80, 2, n, segs, x, nw, gs=64, nb=nb_, use_gemm=True, want_route=True)
-    assert G7_OFF or r == "frag_g7", r
+    assert r == "frag_g7", r
     for b in range(nb_):
         xn = oracle.rmsnorm(x[b], nw)
         want = silu_mul(ref_q80(oracle, xn, segs[:1], n, 64, canon=True), ref_q80(oracle, xn, segs[1:], n, 64, canon=True))
@@ -270,29 +264,9 @@ def test_g6_ragged_segments(oracle):
 
 @pytest.mark.parametrize("nb_,kind,n,rows", GEMM_CASES)
 def test_mfma_gemm_route_q80(oracle, nb_, kind, n, rows):
-    """the batched route of a step: quant_rows_frag_kernel (fragment-order activations) + the int8 MFMA GEMM (G6 MODE F up to 16
-    tokens, G5 beyond, GC for tall matrices; strict mode: G5 / GC in the reference's order)"""
+    """the batched route of a step: quant_rows_frag_kernel (fragment-order activations) + the int8 MFMA GEMM (G6 up to 64 tokens,
+    G7 at 17..64 where it pays, GC for tall matrices; strict mode: G2 / GC in the reference's order)"""
     gemm_route_case(oracle, nb_, kind, n, rows)
-
-
-def test_one_sequence_through_g6_mode_p():
-    """NANO_G6P_B1=1: the one-sequence launches of Qwen3-4B's shapes through G6 MODE P (capacity 1, the split-attention combine in its
-    prologue) instead of the SLAB GEMV -- same bits (the knob is read once per process)"""
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k", "test_k1 or test_k3 or test_k4"],
-                       env=dict(os.environ, NANO_G6P_B1="1"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-1500:]
-
-
-def test_mfma_gemm_route_older_kernels():
-    """NANO_GEMM_G6=0 (round 3's routes: G5 for every batched launch, its fold canonical in the fast path too) and NANO_GEMM_G5=0
-    (the general kernel G2, the reference's order only: strict mode); the knobs are read per call / per process"""
-    for env in ({"NANO_GEMM_G7": "0"}, {"NANO_GEMM_G6": "0"}, {"NANO_GEMM_G6": "0", "NANO_G5_BALANCED": "1"}):
-        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);\n"
-                "import test_gpu_fused_roles as t; from oracle import binding as ob; o = ob.load_oracle()\n"
-                "import canon\n"
-                "for c in t.GEMM_CASES:\n    t.gemm_route_case(o, *c)\nprint('older ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "older ok" in r.stdout, (env, r.stderr[-800:])
 
 
 # ---- Q4K: the whole-workgroup block quantizer inside the fused launches ---------------------------------------------------

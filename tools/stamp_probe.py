@@ -34,13 +34,10 @@ for p in range(0, pos):                                     # some KV history (v
     m.forward([1] * B, [p] * B, want_logits=False)
 names = {1: "qkv", 2: "attention", 3: "wo", 4: "w1w3", 5: "w2"}
 phases = {1: ["issue", "x arrives(+norm sum)", "quantize", "w arrive+dots", "barrier", "fold+store"], 2: ["issue", "q/k norm+rope", "KV+softmax", "partials", "combine+store"]}
-G6 = quant == "q80" and (B >= 9 or (B >= 2 and model in ("qwen3-4b", "wide-qwen3")) or os.environ.get("NANO_G6P_B1") == "1") and os.environ.get("NANO_GEMM_G6") != "0"     # gemm_q80_g6.hip's stamps
+G6 = quant == "q80" and (B >= 9 or (B >= 3 and model in ("qwen3-4b", "wide-qwen3")))     # gemm_q80_g6.hip's stamps
 g6_phases = ["issue", "x arrives, norm, quantize (P)", "first weights land", "first item multiplied", "this wave's other items", "finish tiles + last wave"]
-G5 = B > 1 and quant == "q80" and not G6          # batched Q80 steps of large matrices run the G5 GEMM: its first wave stamps entry, weights of its first half chunk
-                                        # landed, scales + fragments landed and products done, its first chain link folded; the last phase = the rest of the chain
-g5_phases = ["first weights land", "scales+fragments land, products", "first link folded", "-", "-", "rest of the chain + epilogue"]
 # gemm_q80_g7.hip (17..64 tokens, q|k|v and W1|W3): consumer wave 0's stamps
-G7 = quant == "q80" and B >= 17 and os.environ.get("NANO_GEMM_G7") != "0"
+G7 = quant == "q80" and B >= 17                  # (where gemm_q80_g7_supports() says it pays; the other launches stay G6's)
 g7_phases = ["prologue (fragments of step 0 parked)", "first weights land", "step 0 multiplied", "the other steps", "stores issued", "last wave"]
 agg = {}
 tl = {}
@@ -69,8 +66,9 @@ for rep in range(1 if GRAPH else 3):
         ends = s[:, nph]
         ok = ends > 0                                       # (fold threads exist in every workgroup)
         # (the shader clock is per XCD: only differences INSIDE a workgroup mean anything)
-        if G5 and k != 2:
-            s[:, 4] = s[:, 3]; s[:, 5] = s[:, 3]            # G5 stamps slots 0..3 and the end
+        for j in range(1, nph):                             # a slot this kernel does not stamp (or stamped by a wave that ran ahead) is a
+            s[:, j] = np.maximum(s[:, j], s[:, j - 1])      # phase of length 0, not a negative one
+        s[:, nph] = np.maximum(s[:, nph], s[:, nph - 1])
         if LIGHT:
             s[:, 1:nph] = s[:, :1]                          # no phase stamps in this build: everything is "the last phase"
         d = np.diff(s[:, :nph + 1], axis=1)[ok] / (GHZ * 1e3)
@@ -91,6 +89,6 @@ for k in sorted(agg):
     mean = np.mean([r[1] for r in rows], axis=0); mx = np.mean([r[2] for r in rows], axis=0)
     print(f"{names.get(k, k):10s} wgs {wg:6.0f}  entry -> end of a workgroup's first wave: mean {np.mean([r[3] for r in rows]):5.2f}  max {np.mean([r[4] for r in rows]):5.2f}")
     if not LIGHT:
-        print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(g7_phases if (G7 and k in (1, 4)) else g6_phases if (G6 and k != 2) else g5_phases if (G5 and k != 2) else phases[1 if k != 2 else 2], mean, mx)))
+        print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(g7_phases if (G7 and k in (1, 4)) else g6_phases if (G6 and k != 2) else phases[1 if k != 2 else 2], mean, mx)))
     t = np.array(tl[k]); print(f"           device clock: entry ramp {t[:, 0].mean():.2f}  span {t[:, 1].mean():.2f}  gap to the next launch {np.nanmean(t[:, 2]):.2f}")
 m.close()
