@@ -201,14 +201,39 @@ __device__ __forceinline__ float unit_sum(const float4 &t0, const float4 &t1) {
     float s = t0.x; s += t0.y; s += t0.z; s += t0.w; s += t1.x; s += t1.y; s += t1.z; s += t1.w;
     return s;
 }
+// One fp32 add the optimizer cannot pair: the SLP vectorizer turned two neighbouring unit sums into v_pk_add_f32 behind a shuffle of
+// v_mov and let the scheduler sink the LDS reads next to them (three LDS round trips per row).  Same instruction the compiler emits for
+// a + b, same rounding; not volatile, so it schedules freely.
+__device__ __forceinline__ float fadd(float a, float b) { float r; asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// the NU = NQ / 2 unit sums of a row in lock step: NU independent add chains of depth 7 (a wave issues them back to back), then the
+// NU - 1 adds of the units -- depth 7 + NU - 1 where the ordered chain has 8 NU - 1
+template <int NU> __device__ __forceinline__ void unit_sums(const float4 *t, float *s) {
+#pragma unroll
+    for (int u = 0; u < NU; u++) s[u] = fadd(t[2 * u].x, t[2 * u].y);
+#pragma unroll
+    for (int u = 0; u < NU; u++) s[u] = fadd(s[u], t[2 * u].z);
+#pragma unroll
+    for (int u = 0; u < NU; u++) s[u] = fadd(s[u], t[2 * u].w);
+#pragma unroll
+    for (int u = 0; u < NU; u++) s[u] = fadd(s[u], t[2 * u + 1].x);
+#pragma unroll
+    for (int u = 0; u < NU; u++) s[u] = fadd(s[u], t[2 * u + 1].y);
+#pragma unroll
+    for (int u = 0; u < NU; u++) s[u] = fadd(s[u], t[2 * u + 1].z);
+#pragma unroll
+    for (int u = 0; u < NU; u++) s[u] = fadd(s[u], t[2 * u + 1].w);
+}
 template <int NQ> __device__ __forceinline__ float fold_row_canon(const float *p) {
     static_assert(NQ % 2 == 0, "whole units");
     float4 t[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) t[q] = *reinterpret_cast<const float4 *>(p + 4 * q);
-    float v = unit_sum(t[0], t[1]);
+    __builtin_amdgcn_sched_barrier(0);          // every LDS read of the row goes out before the first add (one round trip, not one per unit pair)
+    float s[NQ / 2];
+    unit_sums<NQ / 2>(t, s);
+    float v = s[0];
 #pragma unroll
-    for (int q = 2; q < NQ; q += 2) v += unit_sum(t[q], t[q + 1]);
+    for (int u = 1; u < NQ / 2; u++) v = fadd(v, s[u]);
     return v;
 }
 // any group count that is a multiple of 4 (the last unit may hold 4 groups); two units per trip, their reads first
@@ -235,9 +260,12 @@ template <int NQ> __device__ __forceinline__ void fold_row2_canon(const float *p
     float4 t[NQ], u[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) { t[q] = *reinterpret_cast<const float4 *>(p0 + 4 * q); u[q] = *reinterpret_cast<const float4 *>(p1 + 4 * q); }
-    v0 = unit_sum(t[0], t[1]); v1 = unit_sum(u[0], u[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    float s0[NQ / 2], s1[NQ / 2];
+    unit_sums<NQ / 2>(t, s0); unit_sums<NQ / 2>(u, s1);
+    v0 = s0[0]; v1 = s1[0];
 #pragma unroll
-    for (int q = 2; q < NQ; q += 2) { v0 += unit_sum(t[q], t[q + 1]); v1 += unit_sum(u[q], u[q + 1]); }
+    for (int k = 1; k < NQ / 2; k++) { v0 = fadd(v0, s0[k]); v1 = fadd(v1, s1[k]); }
 }
 __device__ __forceinline__ void fold_row2_canon_ng(const float *p0, const float *p1, uint32_t ng, float &v0, float &v1) {
     if (ng == 16u) { fold_row2_canon<4>(p0, p1, v0, v1); return; }

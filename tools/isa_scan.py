@@ -42,10 +42,22 @@ def scan(asm: str, pat: str = ""):
     return out
 
 
+def file_flags(src: str) -> list:
+    """the per-file flags the product's Makefile gives this source (FLAGS_<stem> := ...)"""
+    mk = os.path.join(os.path.dirname(os.path.abspath(src)), "Makefile")
+    stem = os.path.splitext(os.path.basename(src))[0]
+    if os.path.exists(mk):
+        for ln in open(mk):
+            m = re.match(r"FLAGS_%s\s*:=\s*(.*)" % re.escape(stem), ln)
+            if m:
+                return m.group(1).split()
+    return []
+
+
 def compile_to_asm(src: str) -> str:
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-o", out, src], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *file_flags(src), "-o", out, src], check=True, stderr=subprocess.DEVNULL)
         return open(out).read()
 
 
