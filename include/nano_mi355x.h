@@ -156,8 +156,10 @@ int nano_hip_lora_enable(NanoHipModel *m, int on);
  * nucleus, one draw with `coin` (the caller's xorshift64* float, infer/utils.c:959-970).  temperature == 0 gives the
  * penalised arg-max (infer.c:1169-1171).  The sampled token is the one the host code returns for the same logits
  * (expf, the index-order float sum, the stable sort and the cut are evaluated in the reference's order).
- * status NANO_SAMPLE_FALLBACK: the nucleus does not fit the device's sorter (more than NANO_SAMPLE_MAX_CANDIDATES tokens
- * down to the power of two below the cut: near-uniform distributions); `token` is not valid and the caller samples on the host from the logits of this step
+ * A nucleus that does not fit the LDS sorter (more than NANO_SAMPLE_MAX_CANDIDATES tokens down to the bin of the cut: near-uniform
+ * distributions) is sampled by a second device phase (every candidate through a device radix sort, the same sequential cut and draw):
+ * n_sorted == n_candidates then.  status NANO_SAMPLE_FALLBACK is left for the cases the device declines (no candidate at all, or no memory
+ * for the second phase's scratch): `token` is not valid and the caller samples on the host from the logits of this step
  * (nano_hip_read_state(m, 0, 4, ...)); nothing else has to be redone.
  * Replaces: the D2H copy of V logits plus the host loops of generate_next_token (infer.c:1156-1189). */
 #define NANO_SAMPLE_OK        0u

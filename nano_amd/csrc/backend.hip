@@ -60,6 +60,7 @@ struct SamplerState {
     uint8_t *seen = nullptr;
     uint32_t *hist = nullptr, hist_cap = 0;
     uint32_t *h_hist = nullptr; NanoHipSample *h_res = nullptr;
+    uint8_t *wide = nullptr; void *wide_temp = nullptr; size_t wide_temp_bytes = 0;      // second phase (wide nuclei), allocated on first need
     std::vector<uint32_t> applied;                        // ids already marked in `seen`, in history order
 };
 
@@ -200,6 +201,7 @@ static void destroy(NanoHipModel *m) {
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (m->smp) {
         if (m->smp->block) (void)hipFree(m->smp->block);
+        if (m->smp->wide) (void)hipFree(m->smp->wide);
         if (m->smp->h_hist) (void)hipHostFree(m->smp->h_hist);
         if (m->smp->h_res) (void)hipHostFree(m->smp->h_res);
         delete m->smp;
@@ -1067,6 +1069,23 @@ static int sample_run(NanoHipModel *m, const float *logits, const uint32_t *hist
     HIP_TRY(launch_sample(a, m->st));
     HIP_TRY(hipMemcpyAsync(sp->h_res, a.res, sizeof(NanoHipSample), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    if (sp->h_res->status == NANO_SAMPLE_FALLBACK && sp->h_res->n_candidates != 0) {
+        // The nucleus does not fit the LDS sorter (near-uniform distributions): second phase on the device (sampler_wide.hip) from the
+        // numerators and the denominator the first phase left there -- every candidate sorted by a device radix sort, the same cut and draw.
+        if (!sp->wide) {
+            const size_t npad = (size_t)a.nch * SAMPLE_CHUNK;
+            sp->wide_temp_bytes = sample_wide_temp_bytes((uint32_t)npad);
+            const size_t tb = (sp->wide_temp_bytes + 255) & ~(size_t)255;
+            if (!sp->wide_temp_bytes || hipMalloc(&sp->wide, npad * 20 + tb) != hipSuccess) { sp->wide = nullptr; *out = *sp->h_res; return 0; }   // (the caller's host loops)
+            sp->a.wide_in = (unsigned long long *)sp->wide; sp->a.wide_out = sp->a.wide_in + npad;
+            sp->a.wide_p = (float *)(sp->a.wide_out + npad); sp->a.wide_cap = (uint32_t)npad;
+            sp->wide_temp = sp->wide + npad * 20;
+        }
+        a.wide_in = sp->a.wide_in; a.wide_out = sp->a.wide_out; a.wide_p = sp->a.wide_p; a.wide_cap = sp->a.wide_cap;
+        HIP_TRY(launch_sample_wide(a, sp->wide_temp, sp->wide_temp_bytes, m->st));
+        HIP_TRY(hipMemcpyAsync(sp->h_res, a.res, sizeof(NanoHipSample), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+    }
     *out = *sp->h_res;
     return 0;
 }

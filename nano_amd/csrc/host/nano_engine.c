@@ -610,8 +610,8 @@ uint32_t generate_next_token(Nano_Context *ctx, uint32_t *output_ids, uint32_t p
             }
             return r.token;
         }
-        /* more candidates than the device nucleus holds (near-uniform distribution): same logits, host loops; after two
-         * such tokens in a row the next 32 skip the device attempt (its ~0.1 ms would be wasted) */
+        /* the device declined (round 5: only when there is no candidate at all or no memory for the wide-nucleus phase; rounds 2-4:
+         * every near-uniform distribution): same logits, host loops; after two such tokens in a row the next 32 skip the device attempt */
         if (++me->fallback_streak >= 2) me->host_turns = 32;
         logits = llm->state.logits;
         if (nano_hip_read_state(dev, 0, 4, 0, 0, logits, (size_t)V) != NANO_HIP_OK) die_hip("generate_next_token");

@@ -268,9 +268,14 @@ struct SampleArgs {
     float *sum;
     unsigned long long *cand; uint32_t cap;
     NanoHipSample *res;
+    // second phase, wide nuclei (sampler_wide.hip): every candidate as a key, the sorted keys, the sorted probabilities
+    unsigned long long *wide_in, *wide_out; float *wide_p; uint32_t wide_cap;
 };
 hipError_t launch_seen_set(const uint32_t *ids, uint32_t n, uint8_t *seen, hipStream_t st);
 hipError_t launch_sample_prep(const SampleArgs &a, hipStream_t st);   // penalty (and temperature) only
 hipError_t launch_sample(const SampleArgs &a, hipStream_t st);
+size_t sample_wide_temp_bytes(uint32_t n);                            // scratch of the device sort of n keys
+hipError_t launch_sample_wide(const SampleArgs &a, void *temp, size_t temp_bytes, hipStream_t st);
+hipError_t launch_sample_wide_cut(const SampleArgs &a, hipStream_t st);   // (its last three kernels: sampler.hip)   // after launch_sample reported NANO_SAMPLE_FALLBACK
 
 }  // namespace nano

@@ -343,6 +343,138 @@ __global__ __launch_bounds__(1024) void samp_pick_kernel(const SampleArgs a) {
     for (uint32_t i = 0; i < 6; i++) a.res->top[i] = i < n0 ? 0xffffffffu - (uint32_t)key[i] : 0u;
 }
 
+// ---- wide nuclei (second phase, sampler_wide.hip): the cut and the draw over ALL candidates, sorted by a device radix sort ---------------
+// The reference's two sequential loops (infer.c:1078-1084, 1096-1108) walk the sorted probabilities with one float running sum.  That sum
+// is the same kind of object as the softmax denominator above: inside a binade it is integer arithmetic, so the chunk functions of
+// exact_math.h apply unchanged -- 256 sorted probabilities per chunk, one wave scans 64 chunk functions per step and records the EXACT
+// running sum at every chunk boundary; only the chunk in which the sum passes top_p (and the one in which it passes r = coin * sum) is
+// added element by element.  (First build of the round: one thread adding all ~137 k probabilities of a flat Qwen3 distribution in
+// order, 1.3 ms per token -- 546 tokens/s at temperature 1 against 77 through the host loops; this form: see profiles/r05_sample_decode_probe.txt.)
+
+// W3: probabilities of the sorted keys (zeros behind the last candidate) + one approximate float sum per chunk
+__global__ __launch_bounds__(256) void samp_wide_unpack_kernel(const SampleArgs a) {
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= a.nch) return;
+    const ulonglong2 *k = reinterpret_cast<const ulonglong2 *>(a.wide_out + (size_t)c * CH + lane * 4);
+    const ulonglong2 k0 = k[0], k1 = k[1];
+    float4 p;
+    p.x = __uint_as_float((uint32_t)(k0.x >> 32)); p.y = __uint_as_float((uint32_t)(k0.y >> 32));
+    p.z = __uint_as_float((uint32_t)(k1.x >> 32)); p.w = __uint_as_float((uint32_t)(k1.y >> 32));
+    reinterpret_cast<float4 *>(a.wide_p)[c * 64 + lane] = p;
+    float s = (p.x + p.y) + (p.z + p.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) a.approx[c] = s;
+}
+
+// one chunk element by element, every running sum kept: lane k gets the sums after its four elements (4k .. 4k+3)
+__device__ __attribute__((noinline)) uint32_t samp_walk_chunk_sums(const float *e, uint32_t c, uint32_t lane, uint32_t sb, float &r0, float &r1, float &r2, float &r3) {
+    const float4 v = reinterpret_cast<const float4 *>(e)[c * 64 + lane];
+    float s = __uint_as_float(sb);
+    r0 = r1 = r2 = r3 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        const bool mine = lane == (uint32_t)k;
+        s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), k)); r0 = mine ? s : r0;
+        s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), k)); r1 = mine ? s : r1;
+        s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), k)); r2 = mine ? s : r2;
+        s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.w), k)); r3 = mine ? s : r3;
+    }
+    return __builtin_amdgcn_readfirstlane(__float_as_uint(s));
+}
+// index (0..255) of the first running sum of the chunk above `thr`, or 256; *at = that sum
+__device__ __forceinline__ uint32_t first_above(float r0, float r1, float r2, float r3, float thr, uint32_t lane, float *at) {
+    const uint32_t j = r0 > thr ? 0u : r1 > thr ? 1u : r2 > thr ? 2u : r3 > thr ? 3u : 4u;
+    const unsigned long long m = __ballot(j < 4u);
+    if (m == 0) return 256u;
+    const int L = __builtin_ctzll(m);
+    const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)j, L);
+    const float v = jl == 0 ? r0 : jl == 1 ? r1 : jl == 2 ? r2 : r3;
+    *at = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L));
+    return (uint32_t)L * 4u + jl;
+}
+
+// W5: one wave: exact running sums at the chunk boundaries of the sorted list, the cut, the draw
+__global__ __launch_bounds__(64) void samp_wide_cut_kernel(const SampleArgs a) {
+    __shared__ uint32_t s_dE[SAMPLE_MAX_CHUNKS + 64], s_dO[SAMPLE_MAX_CHUNKS + 64], s_spec[SAMPLE_MAX_CHUNKS + 64], s_bound[SAMPLE_MAX_CHUNKS + 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n0 = *a.ncand;
+    for (uint32_t c = lane; c < a.nch + 64; c += 64) {
+        const bool in = c < a.nch;
+        const uint2 f = in ? a.fn[c] : make_uint2(0u, 0u);
+        s_dE[c] = f.x; s_dO[c] = f.y; s_spec[c] = in ? a.spec[c] : 0xffffffffu;
+    }
+    if (lane == 0) { *a.ncand = 0; a.res->n_candidates = n0; a.res->n_sorted = n0; }
+    if (n0 == 0 || n0 > a.wide_cap) { if (lane == 0) { a.res->status = NANO_SAMPLE_FALLBACK; a.res->token = 0; } return; }
+    __syncthreads();
+    const uint32_t nchw = (n0 + CH - 1) / CH;                        // chunks that hold candidates (the rest are zeros)
+    const float *p = a.wide_p;
+    uint32_t sb = 0, cur = 0;
+    while (cur < nchw && !(__uint_as_float(sb) > a.top_p)) {
+        const uint32_t E = sum_exp(sb), M = sum_man(sb);
+        ChunkFn f{s_dE[cur + lane], s_dO[cur + lane]};
+        uint32_t valid = s_spec[cur + lane] == E ? 1u : 0u;
+        wave_scan_fn(f, valid);
+        const uint32_t tot = M + ((M & 1u) ? f.dO : f.dE);
+        const unsigned long long ok = __ballot(valid != 0u && tot < (1u << 24));
+        const uint32_t n = ok == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ok);
+        if (lane < n) s_bound[cur + lane] = ((E - 1u) << 23) + tot;  // the exact sum behind chunk cur + lane
+        if (n) { sb = ((E - 1u) << 23) + (uint32_t)__builtin_amdgcn_readlane((int)tot, (int)n - 1); cur += n; }
+        if (n < 64 && cur < nchw && !(__uint_as_float(sb) > a.top_p)) {
+            sb = samp_walk_chunk(p, cur, lane, sb);
+            if (lane == 0) s_bound[cur] = sb;
+            cur++;
+        }
+        sb = __builtin_amdgcn_readfirstlane(sb); cur = __builtin_amdgcn_readfirstlane(cur);
+    }
+    __syncthreads();
+    const uint32_t ncov = cur < nchw ? cur : nchw;                   // s_bound[0 .. ncov) are exact
+    auto first_chunk_above = [&](float thr, uint32_t upto) {         // first c < upto with the sum behind chunk c above thr, or upto
+        for (uint32_t c0 = 0; c0 < upto; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const unsigned long long m = __ballot(c < upto && __uint_as_float(s_bound[c]) > thr);
+            if (m) return c0 + (uint32_t)__builtin_ctzll(m);
+        }
+        return upto;
+    };
+    // the cut (infer.c:1078-1084): the first running sum above top_p; without one the whole list and its total
+    uint32_t last = n0 - 1u;
+    float cum = __uint_as_float(s_bound[ncov - 1u]);
+    float r0, r1, r2, r3;
+    const uint32_t cstar = first_chunk_above(a.top_p, ncov);
+    if (cstar < ncov) {
+        (void)samp_walk_chunk_sums(p, cstar, lane, cstar ? s_bound[cstar - 1u] : 0u, r0, r1, r2, r3);
+        float at = 0.0f;
+        const uint32_t k = first_above(r0, r1, r2, r3, a.top_p, lane, &at);
+        if (k < 256u) { last = cstar * CH + k; cum = at; }
+    }
+    // the draw (infer.c:1096-1108): the first running sum above r among entries 0 .. last, else entry `last`
+    const float r = a.coin * cum;
+    const uint32_t clast = last / CH;
+    uint32_t pick = last;
+    uint32_t cr = first_chunk_above(r, clast);                       // whole chunks in front of the one that holds `last`
+    {
+        if (cr != cstar || cstar >= ncov) (void)samp_walk_chunk_sums(p, cr, lane, cr ? s_bound[cr - 1u] : 0u, r0, r1, r2, r3);
+        float at = 0.0f;
+        const uint32_t k = first_above(r0, r1, r2, r3, r, lane, &at);
+        if (k < 256u && cr * CH + k <= last) pick = cr * CH + k;
+    }
+    if (lane != 0) return;
+    a.res->token = 0xffffffffu - (uint32_t)a.wide_out[pick];
+    a.res->status = NANO_SAMPLE_OK;
+    a.res->nucleus = last + 1u;
+    for (uint32_t i = 0; i < 6; i++) a.res->top[i] = i < n0 ? 0xffffffffu - (uint32_t)a.wide_out[i] : 0u;
+}
+
+hipError_t launch_sample_wide_cut(const SampleArgs &a, hipStream_t st) {
+    SampleArgs w = a;
+    w.e = a.wide_p;                                                  // the chunk-function kernel reads its addends from `e`
+    hipLaunchKernelGGL(samp_wide_unpack_kernel, dim3(a.nch / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(samp_chunkfn_kernel, dim3(a.nch / 4), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(samp_wide_cut_kernel, dim3(1), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_seen_set(const uint32_t *ids, uint32_t n, uint8_t *seen, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(seen_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, seen);

@@ -23,10 +23,11 @@ def bigvocab(model_dir):
 
 def test_op_sample_vs_reference_golden(bigvocab):
     """Qwen3-vocabulary logits: tokens, candidate counts and the softmax denominator's bits equal the compiled
-    reference's (tests/golden/sampler_logits.npz); > CAP candidates is reported as a fall-back, never as a token."""
+    reference's (tests/golden/sampler_logits.npz).  A nucleus that does not fit the LDS sorter (> CAP tokens: the near-uniform case)
+    goes through the second phase (sampler_wide.hip: every candidate through a device radix sort) -- same token, never a fall-back."""
     g = np.load(os.path.join(GOLD, "sampler_logits.npz"))
     assert [repr(c) for c in sc.CASES] == [str(c) for c in g["cases"]]
-    on_device = 0
+    on_device = wide = 0
     for ci, (seed, sigma, mode, rp, temp, top_p, nh) in enumerate(sc.CASES):
         l, h = sc.logits_of(seed, sigma, mode), sc.history_of(seed, nh)
         n_ref = int(g["n_candidates"][ci])
@@ -37,15 +38,35 @@ def test_op_sample_vs_reference_golden(bigvocab):
                 continue
             assert r.n_candidates == n_ref, (ci, ki, r.n_candidates, n_ref)
             assert r.sum_bits == int(g["denominator_bits"][ci]), (ci, ki)
+            assert r.status == 0, (ci, ki)
             if n_ref <= CAP:
-                assert r.status == 0 and r.n_sorted == n_ref, (ci, ki)
+                assert r.n_sorted == n_ref, (ci, ki)
             if mode == "plain" and sigma < 1.0:
-                assert r.status == 1, (ci, ki)                # near-uniform: the nucleus itself is > CAP tokens
-            if r.status == 0:
-                assert r.token == int(g["tokens"][ci, ki]), (ci, ki, r.token)
-                assert r.n_sorted <= CAP
-                on_device += 1
-    assert on_device >= 24
+                assert r.n_sorted == n_ref and n_ref > CAP, (ci, ki)      # near-uniform: the nucleus itself is > CAP tokens -> wide phase
+            assert r.token == int(g["tokens"][ci, ki]), (ci, ki, r.token)
+            on_device += 1
+            wide += r.n_sorted > CAP
+    assert on_device >= 44 and wide >= 4, (on_device, wide)
+
+
+def test_wide_nucleus_vs_oracle(oracle, bigvocab):
+    """The second phase (sampler_wide.hip) against the oracle's sampler at V = 151 936 on distributions whose nucleus is far beyond the
+    LDS sorter: all logits equal (136 k equal probabilities: the stable order IS the index order, and the sequential float sum of equal
+    addends changes its increment at every binade), a flat distribution with a penalty history, temperature 2, top_p near 1."""
+    V = sc.V_QWEN3
+    rng = np.random.default_rng(5)
+    flat = np.zeros(V, np.float32)
+    two = np.where(rng.random(V) < 0.5, np.float32(0.0), np.float32(0.25)).astype(np.float32)
+    noisy = (0.3 * rng.standard_normal(V)).astype(np.float32)
+    h = rng.integers(0, V, size=100).astype(np.uint32)
+    none = np.zeros(0, np.uint32)
+    for l, hist, rp, temp, top_p in ((flat, none, 1.0, 1.0, 0.9), (two, none, 1.0, 1.0, 0.5), (noisy, h, 1.2, 1.0, 0.9), (noisy, none, 1.0, 2.0, 0.999),
+                                     (two, h, 1.3, 0.7, 0.95)):
+        for coin in (0.0, 0.31, 0.77, 0.99999994):
+            tok, n = oracle.sample_logits(l, hist, rp, temp, top_p, coin)
+            r = bigvocab.op_sample(l, hist, rp, temp, top_p, coin)
+            assert r.status == 0 and r.n_candidates == n and r.n_sorted == n and n > CAP, (temp, top_p, coin, r.status, r.n_candidates, n)
+            assert r.token == tok, (temp, top_p, coin, r.token, tok)
 
 
 @pytest.mark.parametrize("preset", ["tiny-nano", "tiny-qwen3"])
@@ -94,10 +115,10 @@ def test_forward_sample_follows_history(oracle, model_dir):
     m.close()
 
 
-def test_engine_flat_distribution_falls_back_to_host_loops(oracle, model_dir):
-    """Random weights at temperature 1 under Qwen3's vocabulary: ~152 k candidates, the nucleus does not fit the device
-    sorter, so generate_next_token runs the host loops on the device's logits (and, after two such tokens, skips the
-    device attempt for a while).  The ids are the oracle engine's for the same seed."""
+def test_engine_flat_distribution_stays_on_the_device(oracle, model_dir):
+    """Random weights at temperature 1 under Qwen3's vocabulary: ~152 k candidates, the nucleus does not fit the LDS sorter;
+    generate_next_token gets its token from the sampler's second phase (rounds 2-4: the host loops on the device's logits).
+    The ids are the oracle engine's for the same seed."""
     from oracle import binding as ob
     path, spec = synth_model(model_dir, "bigvocab-qwen3", "f32", 0)
     from nano_amd import modelfile as mf
