@@ -355,12 +355,14 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
         auto ready = [&](unsigned long long x0, unsigned long long x1) { return __all((uint32_t)(x0 >> 32) == 1u && (uint32_t)(x1 >> 32) == 1u) != 0; };
         unsigned long long a0, a1, b0, b1;
         sweep(a0, a1);
-        for (uint32_t spin = 0; spin < (1u << 13); spin++) {   // (bounded, ~10 ms: a projection that never arrives must not hang the device -- the tests see the garbage)
+        bool got = false;
+        for (uint32_t spin = 0; spin < (1u << 13); spin++) {   // (bounded, ~10 ms: a projection that never arrives must not hang the device)
             sweep(b0, b1);
-            if (ready(a0, a1)) { g0 = a0; g1 = a1; break; }
+            if (ready(a0, a1)) { g0 = a0; g1 = a1; got = true; break; }
             sweep(a0, a1);
-            if (ready(b0, b1)) { g0 = b0; g1 = b1; break; }
+            if (ready(b0, b1)) { g0 = b0; g1 = b1; got = true; break; }
         }
+        if (!got && tid == 0 && a.err) __hip_atomic_fetch_or(a.err, NANO_DEVERR_HANDOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((uint32_t)tid < 128u) { qh[t7] = __uint_as_float((uint32_t)g0); vh[t7] = __uint_as_float((uint32_t)g1); }
         else kh[t7] = __uint_as_float((uint32_t)g0);
         __syncthreads();

@@ -95,6 +95,7 @@ struct NanoHipModel {
     uint32_t nsplit_cap = 8;                             // the partial buffers are sized for it (32 beyond 2048 positions)
     // pinned host staging
     uint32_t *h_tokens = nullptr, *h_pos = nullptr, *h_amax = nullptr;
+    uint32_t *h_err = nullptr, *dev_err = nullptr;        // sticky error word: host-mapped, written by kernels that give up a bounded wait (kernels.h NANO_DEVERR_*)
     float *h_logits = nullptr;
     std::map<uint64_t, hipGraphExec_t> graphs;
     std::vector<uint64_t> pf_graph_keys;                  // prefill-chunk graphs in creation order (bounded: PF_GRAPH_CAP)
@@ -199,6 +200,7 @@ static void destroy(NanoHipModel *m) {
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
+    if (m->h_err) (void)hipHostFree(m->h_err);
     if (m->smp) {
         if (m->smp->block) (void)hipFree(m->smp->block);
         if (m->smp->wide) (void)hipFree(m->smp->wide);
@@ -420,6 +422,9 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     ok = hipHostMalloc(&m->h_tokens, Bs * 4) == hipSuccess && hipHostMalloc(&m->h_pos, Bs * 4) == hipSuccess &&
          hipHostMalloc(&m->h_amax, (size_t)m->trace_cap * 4) == hipSuccess && hipHostMalloc(&m->h_logits, B * V * 4) == hipSuccess;
     if (!ok) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipHostMalloc failed"); }
+    if (hipHostMalloc(reinterpret_cast<void **>(&m->h_err), 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&m->dev_err), m->h_err, 0) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipHostMalloc (mapped) failed"); }
+    *m->h_err = 0;
     if (hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
         hipEventCreate(&m->ev1) != hipSuccess || hipEventCreate(&m->ev2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "stream/event creation failed"); }
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
@@ -527,8 +532,18 @@ static Q80Route route_of(const NanoHipModel *m) {
 }
 static RouteKind kind_of(const NanoHipModel *m, GemvArgs a) { a.ordered = m->strict ? 1u : 0u; a.cus = (uint32_t)m->cus; return route_kind(route_of(m), a); }
 
+// A kernel gave up a bounded wait since the last check (G6's finisher, the fused launch's hand-off): the results of the call are not
+// valid.  Read after a stream synchronisation; the word lives in host-mapped memory, so the check is one load.
+static int dev_err_check(NanoHipModel *m) {
+    const uint32_t c = m->h_err ? *reinterpret_cast<volatile uint32_t *>(m->h_err) : 0u;
+    if (!c) return 0;
+    *reinterpret_cast<volatile uint32_t *>(m->h_err) = 0;
+    FAIL(NANO_HIP_ERUNTIME, "a kernel gave up waiting for its producers (code %u: 1 = G6 tile counter, 2 = q|k|v hand-off): the results of this call are not valid", c);
+}
+
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     a.ordered = m->strict ? 1u : 0u;                                   // strict mode: the reference's group order in every kernel
+    a.err = m->dev_err;
     return route_projection(route_of(m), a, m->st);
 }
 
@@ -631,6 +646,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         qa.norm_w = m->rms_attn + (size_t)l * E; qa.pos = (m->kv_paged && !m->kv_half) ? m->kvrow : m->pos;     // (the only position-indexed output)
         // qk-norm, rope, k-cache write, attention   reference infer.c:810-879
         AttnArgs a{};
+        a.err = m->dev_err;
         a.q = m->q; a.q_out = nullptr; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
         a.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
         a.k_norm = m->k_norm ? m->k_norm + (size_t)l * m->hd : nullptr;
@@ -939,7 +955,7 @@ extern "C" int nano_hip_sync(NanoHipModel *m) {
     if (!m) FAIL(NANO_HIP_EINVAL, "null model");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->st));
-    return 0;
+    return dev_err_check(m);
 }
 
 static int check_batch(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, uint32_t extra_steps) {
@@ -981,6 +997,7 @@ extern "C" int nano_hip_forward_end(NanoHipModel *m, float *logits_out, uint32_t
     if (!m) FAIL(NANO_HIP_EINVAL, "null model");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->st));
+    { const int rc_err = dev_err_check(m); if (rc_err) { m->pending_batch = 0; return rc_err; } }
     const size_t V = m->d.vocab_size, batch = m->pending_batch;
     if (logits_out) memcpy(logits_out, m->h_logits, batch * V * 4);
     if (argmax_out) memcpy(argmax_out, m->h_amax, batch * 4);
@@ -1087,7 +1104,7 @@ static int sample_run(NanoHipModel *m, const float *logits, const uint32_t *hist
         HIP_TRY(hipStreamSynchronize(m->st));
     }
     *out = *sp->h_res;
-    return 0;
+    return dev_err_check(m);
 }
 
 extern "C" int nano_hip_forward_sample(NanoHipModel *m, uint32_t token, uint32_t pos, const uint32_t *history, uint32_t n_history,
@@ -1229,7 +1246,7 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
         HIP_TRY(hipStreamSynchronize(m->st));                              // h_tokens / h_pos are reused by the next chunk
         done += nb;
     }
-    return 0;
+    return dev_err_check(m);
 }
 
 extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
@@ -1259,7 +1276,7 @@ extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, c
     } else {
         HIP_TRY(hipStreamSynchronize(m->st));
     }
-    return 0;
+    return dev_err_check(m);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -305,8 +305,10 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
                 for (int i = 0; i < 4; i++) if (rr0 + (uint32_t)i < hh && orow0 + (uint32_t)i < t.rows0) oldv[i] = o[i];
             }
         }
-        // (bounded: a miscounted tile must not hang the device -- 2^24 naps are ~0.5 s, the results are then wrong and the tests say so)
-        for (uint32_t spin = 0; g6_lds_load_acq(cnt + tl) != ipt && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
+        // (bounded: a miscounted tile must not hang the device -- 2^24 naps are ~0.5 s; giving up is reported through the sticky error word)
+        uint32_t spin = 0;
+        for (; g6_lds_load_acq(cnt + tl) != ipt && spin < (1u << 24); spin++) __builtin_amdgcn_s_sleep(1);
+        if (spin == (1u << 24) && d.g.err) __hip_atomic_fetch_or(d.g.err, NANO_DEVERR_G6_TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const float *tp = T + ((size_t)tl * nu * NT + tt) * 256u + lane * 4u;
         float4 acc = *reinterpret_cast<const float4 *>(tp);
         for (uint32_t u0 = 1; u0 < nu; u0 += 4) {                      // units ascending; the reads of four units go out together

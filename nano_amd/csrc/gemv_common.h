@@ -86,6 +86,7 @@ struct GemvDev {
     unsigned long long *stamps;     // measurement builds only (-DNANO_STAMPS=1, tools/stamp_probe.py): [workgroup][8] shader-clock stamps, or nullptr
     uint32_t dbg;                   // measurement builds only: experiment bits (NANO_DBG): 1 = no norm-weight load, 2 = weights issued before the activation
     uint32_t canon;                 // 1: the fast path's canonical fold (kernels.h q80_canonical()), 0: the reference's ascending group order
+    uint32_t *err;                  // sticky error word (host-mapped; nullptr in operator tests): a kernel that gives up a bounded wait ORs its code in
 };
 
 template <int ROLE> __device__ __forceinline__ bool has_flag(const GemvDev &a, uint32_t f) {
@@ -231,6 +232,7 @@ static GemvDev to_dev(const GemvArgs &a) {
     d.resid_add = a.resid_add; d.resid_add_bstride = a.resid_add_bstride;
     d.stamps = a.stamps;
     d.canon = q80_canonical(a) ? 1u : 0u;
+    d.err = a.err;
 #if NANO_STAMPS
     { static const uint32_t dbg = getenv("NANO_DBG") ? (uint32_t)strtoul(getenv("NANO_DBG"), nullptr, 0) : 0u; d.dbg = dbg; }      // measurement builds only
 #endif

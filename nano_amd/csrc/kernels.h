@@ -51,8 +51,14 @@ struct GemvArgs {
     uint32_t cus;           // compute units of the device the launch goes to (0: assume 256); sizes the work split
     uint32_t ordered;       // 1: strict mode -- every fp32 group fold in the reference's ascending order (infer.c:668-674); 0: the fast
                             // path's CANONICAL fold where it applies (q80_canonical(): unit sums of 8 groups, units ascending)
+    uint32_t *err;          // sticky error word of the model (device pointer to host-mapped memory), or nullptr: see NANO_DEVERR_*
     unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
+
+// Bounded waits inside kernels (G6's finisher on its tile counter, the fused launch's attention workgroups on their q | k | v granules) must
+// not hang the device; a wait that gives up ORs its code into the model's sticky error word and the next synchronising C-ABI call returns
+// NANO_HIP_ERUNTIME instead of results computed from whatever was there (round-4 advice).
+constexpr uint32_t NANO_DEVERR_G6_TILE = 1u, NANO_DEVERR_HANDOFF = 2u;
 
 // The fast path's reduction shape of a Q80 projection (group size 64, row length a multiple of 256; not the classifier-like tall
 // STORE launches, whose kernels hold whole rows per wave and keep the reference's order): row = ((S_0 + S_1) + ...), S_u = the 8
@@ -169,6 +175,7 @@ struct AttnArgs {
     const uint32_t *kvrow;          // [nb] pool row of position pos[b] (staged by the embed kernel next to the RoPE row)
     uint32_t pt_stride, pt_bstride; // entries per slot; entries between the sequences of this launch (0: batched prefill, one slot)
     uint32_t pool_rows, _pad6;      // rows of one layer plane = pages * 64
+    uint32_t *err;          // sticky error word (as GemvArgs::err)
     unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
