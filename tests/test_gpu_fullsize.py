@@ -72,9 +72,13 @@ def test_device_sampler_at_full_vocabulary(q3, oracle):
         assert r.token == want, (p, r.token, want)
         on_device += 1
         ids.append(int(r.token))
-    # temperature 1 on random weights: a near-uniform distribution, the nucleus does not fit the device sorter
-    r = m.forward_sample(ids[29], 29, ids[:29], 1.0, 1.0, 0.9, 0.5)
-    assert r.status == 1 and r.n_candidates > 100000
+    # temperature 1 on random weights: a near-uniform distribution, the nucleus does not fit the LDS sorter -- the sampler's second phase
+    # (sampler_wide.hip, round 5) draws the oracle's token from > 100 000 sorted candidates (rounds 2-4: status 1, the host loops)
+    logits, _ = m.forward([ids[29]], [29])
+    want, n_ref = oracle.sample_logits(logits[0], np.array(ids[:29], np.uint32), 1.1, 1.0, 0.9, 0.5)
+    r = m.forward_sample(ids[29], 29, ids[:29], 1.1, 1.0, 0.9, 0.5)
+    assert r.status == 0 and r.n_candidates == n_ref and r.n_sorted == n_ref and n_ref > 100000, (r.status, r.n_candidates, n_ref)
+    assert r.token == want, (r.token, want)
 
 
 def test_c_abi_rejects_bad_arguments(q3):
