@@ -88,6 +88,7 @@ struct NanoHipModel {
     const float *lora_t[8] = {nullptr};                   // qa qb ka kb va vb oa ob, each [L][...]
     uint32_t lora_rank = 0, lora_alpha = 0; bool lora_on = false;
     int8_t *gq = nullptr; float *gxs = nullptr;           // MFMA GEMM path (batch > 8, Q80): quantized activations of all sequences
+    uint8_t *q4x = nullptr; size_t q4x_bytes = 0;         // Q4K, 2 .. 8 sequences: the staged activation groups (gemv_q4k_chunk.hip)
     float *rope_cur = nullptr;                            // RoPE rows of the current positions [B][2][hd/2], staged by the embed kernel
     float *kcache = nullptr, *vcache = nullptr;
     uint32_t *tokens = nullptr, *pos = nullptr, *amax = nullptr, *trace = nullptr, *pos0 = nullptr;
@@ -200,6 +201,7 @@ static void destroy(NanoHipModel *m) {
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
+    if (m->q4x) (void)hipFree(m->q4x);
     if (m->h_err) (void)hipHostFree(m->h_err);
     if (m->smp) {
         if (m->smp->block) (void)hipFree(m->smp->block);
@@ -404,6 +406,11 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
         size_t nmax = E > QD ? E : QD; if (H > nmax) nmax = H;
         ok = hipMalloc(&m->gq, Bs * ((nmax + 15) & ~(size_t)15)) == hipSuccess && hipMalloc(&m->gxs, Bs * (nmax / d.group_size) * 4) == hipSuccess;
     }
+    if (ok && Bs > 1 && d.quant_type == NANO_QUANT_Q4K) {
+        size_t nmax = E > QD ? E : QD; if (H > nmax) nmax = H;
+        m->q4x_bytes = 8 * ((nmax + 255) & ~(size_t)255);                 // 32 bytes per 32-value group, up to 8 sequences per launch
+        ok = hipMalloc(&m->q4x, m->q4x_bytes) == hipSuccess;
+    }
     if (ok && m->kv_paged) {
         const size_t ptn = B * m->pt_stride;
         ok = hipMalloc(&m->pt, ptn * 4) == hipSuccess && hipMalloc(&m->kvrow, Bs * 4) == hipSuccess && hipHostMalloc(&m->h_pt, ptn * 4) == hipSuccess &&
@@ -527,7 +534,7 @@ static GemvSeg mkseg(const TensorRef &t, float *out, uint32_t rows, uint32_t bst
 static Q80Route route_of(const NanoHipModel *m) {
     Q80Route r{};
     r.quant = m->d.quant_type; r.cus = m->cus; r.mfma_min_nb = m->mfma_min_nb;
-    r.gq = m->gq; r.gxs = m->gxs;
+    r.gq = m->gq; r.gxs = m->gxs; r.q4x = m->q4x; r.q4x_bytes = m->q4x_bytes;
     return r;
 }
 static RouteKind kind_of(const NanoHipModel *m, GemvArgs a) { a.ordered = m->strict ? 1u : 0u; a.cus = (uint32_t)m->cus; return route_kind(route_of(m), a); }
@@ -544,6 +551,7 @@ static int dev_err_check(NanoHipModel *m) {
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
     a.ordered = m->strict ? 1u : 0u;                                   // strict mode: the reference's group order in every kernel
     a.err = m->dev_err;
+    a.q4_scratch = m->q4x; a.q4_scratch_bytes = m->q4x_bytes;
     return route_projection(route_of(m), a, m->st);
 }
 
@@ -557,6 +565,7 @@ static GemvArgs classifier_args(const NanoHipModel *m, uint32_t nb) {
 
 static hipError_t enqueue_classifier(NanoHipModel *m, uint32_t nb, uint32_t *ntiles_out = nullptr) {
     GemvArgs a = classifier_args(m, nb);
+    a.q4_scratch = m->q4x; a.q4_scratch_bytes = m->q4x_bytes;           // (what gemv() will set: the partial count must match the launch)
     if (ntiles_out && nb <= 8 && !route_takes_fragments(kind_of(m, a)) &&
         (m->d.quant_type != NANO_QUANT_Q4K || nb <= (nb > 1 ? gemv_q4k_fit_batch(a) : 1u))) {      // per-tile arg-max partials for the sampler (Q4K: not for sliced launches)
         a.tile_max = m->tile_max;

@@ -310,8 +310,19 @@ static hipError_t launch_q4k_r(const GemvDev &d, const Q4kPlan &p, uint32_t rows
 }  // namespace
 // (max, row) arg-max partials a STORE launch with tile_max writes per sequence: one per workgroup of a one-segment launch
 // (the classifier); 0 = none, the arg-max kernel scans the logits
+// 2 .. 8 sequences: which kernel takes the launch.  The chunk kernel's several-sequence form pays an extra launch (the quantizer) and
+// wins where the weights are what the step moves or where this file's kernel cannot hold the sequences in LDS; measured on one box
+// (round 5, ms per step, this file's kernel -> the chunk form): Qwen3-4B 2 / 4 / 8 sequences 3.96 -> 2.13, 6.85 -> 2.60, 13.46 -> 3.54
+// (its rows fit one or two sequences per launch here: no weight sharing); Qwen3-0.6B 0.89 -> 1.18, 1.13 -> 1.30, 1.73 -> 1.49.
+bool gemv_q4k_chunk_takes(const GemvArgs &a) {
+    if (a.nb <= 1) return gemv_q4k_chunk_supports(a);
+    if (a.nb > 8 || !gemv_q4k_chunk_supports(a)) return false;
+    return a.nb >= 5u || route_is_wide(a) || gemv_q4k_fit_batch(a) < a.nb;
+}
+
 uint32_t gemv_q4k_partials(const GemvArgs &a) {
     if (a.nb == 1 && gemv_q4k_chunk_supports(a)) return gemv_q4k_chunk_partials(a);
+    if (a.nb > 1 && gemv_q4k_chunk_takes(a)) return 0;                 // (the several-sequence chunk launch writes no partials: the arg-max kernel scans the logits)
     if (!a.tile_max || a.epi != GEMV_EPI_STORE || a.nseg != 1 || a.nb == 0 || a.nb > 8 || a.seg[0].out_pstride) return 0;
     const int B = a.nb <= 1 ? 1 : a.nb <= 2 ? 2 : a.nb <= 4 ? 4 : 8;
     const Q4kPlan p = plan_q4k(a, B);
@@ -351,7 +362,7 @@ uint32_t gemv_q4k_fit_batch(const GemvArgs &a) {
 
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st) {
     (void)max_wg;
-    if (a.nb == 1 && gemv_q4k_chunk_supports(a)) return launch_gemv_q4k_chunk(a, st);     // one sequence, whole blocks: gemv_q4k_chunk.hip
+    if (a.nb >= 1 && a.nb <= 8 && gemv_q4k_chunk_takes(a)) return launch_gemv_q4k_chunk(a, st);     // whole blocks: gemv_q4k_chunk.hip (2 .. 8 sequences: with scratch)
     if (a.nb == 0 || a.nb > 8 || a.n % 4 || a.nseg == 0 || a.nseg > 3) return hipErrorInvalidValue;
     if (a.attn_part && (a.norm_w || a.attn_nsplit > 8 || a.attn_hd % 4)) return hipErrorInvalidValue;
     if (a.epi != GEMV_EPI_SWIGLU && a.nseg > 1)

@@ -38,6 +38,7 @@ struct GemvArgs {
     const int8_t *xq_in;    // Q80 int8[n] (batched GEMM path with frag_ready: all tokens, MFMA B-fragment order)
     const float *xs_in;     // Q80 float[n/gs]
     const uint8_t *x4_in;   // Q4K blocks[ceil(n/256)*160]
+    uint8_t *q4_scratch; size_t q4_scratch_bytes;   // Q4K, 2 .. 8 sequences: room for the staged groups of every sequence (nb * n bytes), or nullptr
     // input = combination of split attention partials (attn.hip) instead of xin:
     //   x[b][i] = sum_s part[b][s][i] * w[b][head(i)][s],  w from the (max, sum) pairs in attn_ml
     const float *attn_part; // [nb][nsplit][n] unnormalised partial outputs, or nullptr
@@ -78,6 +79,7 @@ uint32_t gemv_tiles(uint32_t quant, const GemvArgs &a);   // tiles launch_gemv()
 hipError_t launch_gemv(uint32_t quant, GemvArgs &a, uint32_t max_wg, hipStream_t st);
 hipError_t launch_gemv_q4k(GemvArgs &a, uint32_t max_wg, hipStream_t st);
 bool gemv_q4k_chunk_supports(const GemvArgs &a);            // gemv_q4k_chunk.hip: one sequence, whole 256-value blocks
+bool gemv_q4k_chunk_takes(const GemvArgs &a);               // ... or 2 .. 8 sequences where the chunk form is the faster one (gemv_q4k.hip)
 bool gemv_q4k_chunk_loops(const GemvArgs &a);               // ... and the launch is the looping (classifier) variant
 uint32_t gemv_q4k_chunk_partials(const GemvArgs &a);
 hipError_t launch_gemv_q4k_chunk(GemvArgs &a, hipStream_t st);
@@ -125,6 +127,7 @@ struct Q80Route {
     uint32_t quant; int cus;
     uint32_t mfma_min_nb;  // sequences from which the small Q80 matrices take the batched route (9; NANO_MFMA_MIN_NB)
     int8_t *gq; float *gxs;  // fragment-order activation scratch (nullptr: no batched route)
+    uint8_t *q4x; size_t q4x_bytes;   // Q4K: scratch for the staged groups of 2 .. 8 sequences (gemv_q4k_chunk.hip), or nullptr
 };
 RouteKind route_kind(const Q80Route &r, const GemvArgs &a);
 hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st);

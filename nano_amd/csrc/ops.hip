@@ -233,6 +233,11 @@ extern "C" int nano_hip_op_fused_gemv(int device, const NanoFusedGemvDesc *dp) {
         r.gq = B.alloc<int8_t>(tt * 16 * n16); r.gxs = B.alloc<float>(tt * 16 * (d.n / d.gs));
         OP_CHECK(r.gq && r.gxs, "device alloc failed");
     }
+    if (d.quant == NANO_QUANT_Q4K && d.nb > 1) {                       // the several-sequence chunk launch's staged groups
+        r.q4x_bytes = (size_t)8 * ((d.n + 255) & ~(size_t)255);
+        r.q4x = B.alloc<uint8_t>(r.q4x_bytes);
+        OP_CHECK(r.q4x, "device alloc failed");
+    }
     if (d.use_gemm && (d.quant != NANO_QUANT_Q80 || !route_takes_fragments(route_kind(r, a)))) { nano_hip_set_error_("the batched GEMM route does not take this launch"); return NANO_HIP_EINVAL; }
     if (d.route_out) *d.route_out = (uint32_t)route_kind(r, a);
     const hipError_t e = route_projection(r, a, 0);

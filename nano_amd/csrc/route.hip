@@ -85,7 +85,12 @@ hipError_t route_projection(const Q80Route &r, GemvArgs &a, hipStream_t st) {
     case ROUTE_Q4K: {
         // every workgroup stages the whole quantized activation of each sequence in LDS: long rows (Qwen3-4B's hidden size)
         // take fewer sequences per launch
-        const uint32_t fit = a.nb > 1 ? gemv_q4k_fit_batch(a) : 1u;
+        a.q4_scratch = r.q4x; a.q4_scratch_bytes = r.q4x_bytes;
+        uint32_t fit = a.nb > 1 ? gemv_q4k_fit_batch(a) : 1u;
+        if (a.nb > 1) {                                                  // round 5: whole-block launches share every weight byte among up to 8 sequences
+            GemvArgs probe = a; probe.nb = a.nb < 8u ? a.nb : 8u;
+            if (gemv_q4k_chunk_takes(probe)) fit = 8u;
+        }
         if (a.nb <= fit) return launch_gemv_q4k(a, max_wg, st);
         for (uint32_t b0 = 0; b0 < a.nb; b0 += fit) {
             GemvArgs s = gemv_slice(a, b0, a.nb - b0 < fit ? a.nb - b0 : fit);

@@ -347,6 +347,36 @@ def test_q4k_block_quantizer_ties_bit_exact(oracle, nb_):
     assert np.array_equal(bits(out), bits(ref)), [(b, int((bits(out[b]) != bits(ref[b])).sum()), float(np.abs(out[b] - ref[b]).max())) for b in range(nb_)]
 
 
+@pytest.mark.parametrize("nb_", [2, 3, 4, 8])
+@pytest.mark.parametrize("kind,n,rows", [(0, 1024, (2048, 1024, 1024)), (0, 2560, (4096, 1024, 1024)), (1, 3072, (1024,)), (1, 9728, (2560,)), (1, 4096, (2560,)),
+                                         (2, 1024, (3072, 3072)), (2, 2560, (9728, 9728)), (0, 1024, (1000, 40, 36)), (0, 1024, (65536 + 37,))])
+def test_batched_roles_q4k_bit_exact(oracle, nb_, kind, n, rows):
+    """2 .. 8 sequences through gemv_q4k_chunk.hip's several-sequence form (round 5: one quantizer launch -- a workgroup per sequence running
+    the one-sequence kernel's prologue -- then ONE projection launch that reads every weight byte once for all sequences): every fused
+    launch of a step at Qwen3-0.6B and Qwen3-4B shapes (q|k|v, Wo / W2 with the residual, W1|W3 with SwiGLU, ragged segments, the looping
+    classifier) bit for bit the oracle's, and bit for bit what each sequence gets alone."""
+    rng = np.random.default_rng(nb_ * 31 + n + kind)
+    x = order_free(rng, (nb_, n))
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32) if kind != 1 else None
+    WTs = [(q4k_weights(oracle, rng, r, n), r) for r in rows]
+    segs = [(WT[44:], None, r) for WT, r in WTs]
+    old = rng.standard_normal((nb_, sum(rows))).astype(np.float32) if kind == 1 else None
+    out, route = nb.op_fused_gemv(Q4K, kind, n, segs, x, nw, nb=nb_, resid=old, want_route=True)
+    assert route == "q4k"
+    for b in range(nb_):
+        act = oracle.rmsnorm(x[b], nw) if nw is not None else x[b]
+        if kind == 2:
+            h1, h3 = ref_q4k(oracle, act, WTs[:1], n), ref_q4k(oracle, act, WTs[1:], n)
+            assert np.allclose(out[b], silu_mul(h1, h3), rtol=3e-6, atol=1e-9), b
+        else:
+            ref = ref_q4k(oracle, act, WTs, n)
+            if kind == 1:
+                ref = (old[b] + ref).astype(np.float32)
+            assert np.array_equal(bits(out[b]), bits(ref)), (b, float(np.abs(out[b] - ref).max()))
+        alone = nb.op_fused_gemv(Q4K, kind, n, segs, x[b:b + 1], nw, nb=1, resid=old[b:b + 1] if old is not None else None)[0]
+        assert np.array_equal(bits(out[b]), bits(alone)), ("alone", b)
+
+
 def test_classifier_q4k_persistent_workgroups_bit_exact(oracle):
     # rows >= 65536, one STORE segment: gemv_q4k_chunk.hip's looping workgroups (ring of 8 loads per wave), last workgroup ragged
     n, rows = 1024, 65536 + 37
