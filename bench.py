@@ -623,7 +623,7 @@ def main():
         fam = [r for r in table if r["kernel"] in ("qkv_gemv", "wo_gemv", "w1w3_gemv", "w2_gemv")]
         us = sum(r["us_per_step"] for r in fam); by = sum(r["bytes_per_step"] for r in fam)
         if us > 0:
-            dominant = {"kernel": "per-layer weight projections (QKV, Wo, W1|W3, W2 launches: SLAB GEMV at 1..8 sequences, G6 / G5 GEMM beyond)",
+            dominant = {"kernel": "per-layer weight projections (QKV, Wo, W1|W3, W2 launches: SLAB GEMV at 1..8 sequences, G6 / G7 GEMM beyond)",
                         "launches_per_step": 4 * spec.n_layer, "bytes_per_step": int(by), "us_per_step": round(us, 2), "share_of_step": round(us / full_us, 3),
                         "us_per_launch": round(us / (4 * spec.n_layer), 3), "GBps": round(by / (us * 1e-6) / 1e9, 1), "frac": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                         "how": "sum of the four kinds' in-situ marginals (kernels table): a LOWER bound of their time, so this fraction is an upper bound"}
@@ -643,7 +643,8 @@ def main():
                 "kernels": table, "kernels_how": None if table is None else
                 f"in-situ: graph replays of the step at position {pos_mid} minus replays with the launch kind left out; full step {full_us:.1f} us, sum of the kinds {sum_us:.1f} us. "
                 "The marginals are LOWER bounds of a kind's time (leaving a launch out also removes its boundary and lets its neighbours' weights stay cached): a row's "
-                "GB/s is an upper bound and can exceed peak_measured",
+                "GB/s is an upper bound and can exceed peak_measured.  One-sequence Q80 steps issue q|k|v and the attention as ONE launch "
+                "(qkv_attn_fused_kernel); leaving either kind out falls back to the two-launch form, so the qkv / attention rows are the two kernels' own",
                 "dominant_kernel": dominant, "best_kernel": cls}
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tokens / elapsed, 2), "unit": "tokens/s",
