@@ -103,8 +103,10 @@ struct NanoHipModel {
     uint64_t weight_bytes_per_step = 0;
     bool use_graph = true;
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
-    bool fuse_qkv_attn = true;                            // one sequence, Q80 gs 64, Qwen3 head_dim 128: q|k|v projection + attention in one launch; NANO_FUSE_QKV_ATTN=0: two launches (same bits)
+    bool fuse_qkv_attn = true;                            // one sequence, Q80 gs 64, Qwen3 head_dim 128: q|k|v projection + attention in one launch; NANO_FUSE_LAUNCHES bit 0
     unsigned long long *hand[2] = {nullptr, nullptr};     // its two granule buffers (q_dim + 2 kv_dim entries each)
+    bool fuse_wo_w13 = true, fuse_wo_w13_always = false;  // Wo + W1|W3 in one launch (x as granules) where it pays / wherever the shapes allow; NANO_FUSE_LAUNCHES bits 1 / 2
+    unsigned long long *hand2[2] = {nullptr, nullptr};    // its two granule buffers (n_embd entries each)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // nano_hip_time_step_masked (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
@@ -197,7 +199,7 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att, m->vraw, m->stamps, m->pt, m->kvrow, m->hand[0], m->hand[1] };
+                    m->xn, m->hb2, m->att, m->vraw, m->stamps, m->pt, m->kvrow, m->hand[0], m->hand[1], m->hand2[0], m->hand2[1] };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -436,11 +438,14 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
         hipEventCreate(&m->ev1) != hipSuccess || hipEventCreate(&m->ev2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ERUNTIME, "stream/event creation failed"); }
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
-    if (const char *fz = getenv("NANO_FUSE_QKV_ATTN")) m->fuse_qkv_attn = *fz && *fz != '0';
+    // NANO_FUSE_LAUNCHES: bit 0 = q | k | v + attention in one launch, bit 1 = Wo + W1|W3 in one launch where it pays, bit 2 = ... wherever the
+    // shapes allow (default 3; 0 = the five launches per layer; same bits in every setting)
+    if (const char *fz = getenv("NANO_FUSE_LAUNCHES")) { const uint32_t v = (uint32_t)strtoul(fz, nullptr, 0); m->fuse_qkv_attn = (v & 1u) != 0; m->fuse_wo_w13 = (v & 2u) != 0; m->fuse_wo_w13_always = (v & 4u) != 0; }
     if (m->d.quant_type == NANO_QUANT_Q80 && m->d.group_size == 64) {
         for (int i = 0; i < 2; i++) {
-            const size_t hb = (size_t)(m->QD + 2 * m->KD) * 8;
-            if (hipMalloc(reinterpret_cast<void **>(&m->hand[i]), hb) != hipSuccess || hipMemset(m->hand[i], 0, hb) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off granules failed"); }
+            const size_t hb = (size_t)(m->QD + 2 * m->KD) * 8, hb2 = (size_t)m->d.n_embd * 8;
+            if (hipMalloc(reinterpret_cast<void **>(&m->hand[i]), hb) != hipSuccess || hipMemset(m->hand[i], 0, hb) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void **>(&m->hand2[i]), hb2) != hipSuccess || hipMemset(m->hand2[i], 0, hb2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off granules failed"); }
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -712,6 +717,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         {
             if (pf_combine && (e = launch_attn_combine_tokens(m->attn_part, m->attn_ml, m->xba, d.n_head, m->hd, nsplit, nb, wo_frag ? m->gq : nullptr, wo_frag ? m->gxs : nullptr, m->st)) != hipSuccess) return e;
         }
+        bool wo13_done = false;
         {   // x += Wo . xba   reference infer.c:885-908
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[WO][l], m->x, E, E);
@@ -725,17 +731,33 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             }
             if (nsplit > 1 && !pf_combine) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
             a.frag_ready = (wo_frag && !(skip & 2)) ? 1u : 0u;
-            a.stamps = next_stamps(m, 3);
-            if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
+            // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
+            GemvArgs b{};
+            b.nseg = 2; b.seg[0] = mkseg(m->W[W1][l], m->hb, H, H); b.seg[1] = mkseg(m->W[W3][l], m->hb, H, H);
+            b.n = E; b.gs = d.group_size; b.nb = nb; b.xin = m->x; b.xin_bstride = E; b.epi = GEMV_EPI_SWIGLU;
+            b.norm_w = m->rms_ffn + (size_t)l * E; b.pos = m->pos;
+            // ONE launch for both (one sequence, Q80 group size 64; gemv_q80_impl.h wo_w13_fused_kernel): W1|W3's workgroups take x from Wo's as
+            // granules of the same launch.  Two granule buffers alternate by layer like the q | k | v + attention launch's.
+            a.ordered = 0; a.cus = (uint32_t)m->cus; a.err = m->dev_err; b.ordered = 0; b.cus = (uint32_t)m->cus; b.err = m->dev_err;
+            // Where it is used (round 5, same-box A/B, profiles/r05_wo_w13_fused.txt): the all-gather costs about what the boundary does -- on
+            // Qwen3-0.6B 1847-1855 vs 1850-1861 tok/s while Wo is the plain role, 1772 vs 1742 over positions 31..510, where Wo also combines the
+            // attention splits (a longer first body hides more of W1|W3's loads); on Qwen3-4B's matrices it LOSES (1.531 vs 1.473 ms per
+            // step: 1024-thread workgroups whose polls queue behind their own 207 KB of weight loads).  So: split attention, not the wide matrices;
+            // NANO_FUSE_LAUNCHES bit 2 (value 4) forces it wherever the shapes allow (the parity test; the measurement).
+            const bool fuse13_shape = m->hand2[0] && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && (L % 2u) == 0u && !(skip & 12u) &&
+                                      d.quant_type == NANO_QUANT_Q80 && kind_of(m, a) == ROUTE_GEMV && kind_of(m, b) == ROUTE_GEMV && wo_w13_fused_supports(a, b);
+            const bool fuse13 = fuse13_shape && (m->fuse_wo_w13_always || (m->fuse_wo_w13 && a.attn_part != nullptr && !route_is_wide(b)));
+            if (fuse13) {
+                if ((e = launch_wo_w13_fused(a, b, m->hand2[l & 1u], m->hand2[(l + 1u) & 1u], m->st)) != hipSuccess) return e;
+                wo13_done = true;
+            } else {
+                a.stamps = next_stamps(m, 3);
+                if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
+                b.stamps = next_stamps(m, 4);
+                if (!(skip & 8) && (e = gemv(m, b)) != hipSuccess) return e;
+            }
         }
-        {   // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
-            GemvArgs a{};
-            a.nseg = 2; a.seg[0] = mkseg(m->W[W1][l], m->hb, H, H); a.seg[1] = mkseg(m->W[W3][l], m->hb, H, H);
-            a.n = E; a.gs = d.group_size; a.nb = nb; a.xin = m->x; a.xin_bstride = E; a.epi = GEMV_EPI_SWIGLU;
-            a.norm_w = m->rms_ffn + (size_t)l * E; a.pos = m->pos;
-            a.stamps = next_stamps(m, 4);
-            if (!(skip & 8) && (e = gemv(m, a)) != hipSuccess) return e;
-        }
+        (void)wo13_done;
         {   // x += W2 . hb   reference infer.c:950-965
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[W2][l], m->x, E, E);

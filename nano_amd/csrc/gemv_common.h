@@ -157,6 +157,20 @@ __device__ __forceinline__ void stage_issue(const GemvDev &a, Staged<B, NV> &r) 
     }
 }
 
+// the norm weights of a launch whose activation values arrive another way (granules of the same launch: gemv_q80_slab_body.inc SLAB_XHAND)
+template <int ROLE, int B, int NV>
+__device__ __forceinline__ void stage_issue_nw(const GemvDev &a, Staged<B, NV> &r) {
+    if constexpr (NV == 0) { (void)a; (void)r; return; } else {
+    const uint32_t tid = threadIdx.x, nthr = a.nthr, n = a.n;
+    const __amdgpu_buffer_rsrc_t rn = mkrsrc(a.norm_w, has_flag<ROLE>(a, F_NORM) ? n * 4u : 0u);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const uint32_t i = (tid + (uint32_t)j * nthr) * 4u;
+        if (has_flag<ROLE>(a, F_NORM)) r.nw[j] = bload_f4(rn, (i < n) ? i * 4u : OOB);
+    }
+    }
+}
+
 // x[b][i] = sum_s part[b][s][i] * wgt[b][head(i)][s]  (attn.hip split partials), wgt from (max, sum) pairs
 // PRE: the (max, sum) pair of thread (head, split) came with the kernel's first loads (pm, pl) -- one pass, no load in the
 // loop (a runtime flag left a load on the other path, and the wait the compiler put at the join was for EVERY load in flight,

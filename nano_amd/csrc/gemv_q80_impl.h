@@ -291,13 +291,19 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #define SLAB_A a
 #define SLAB_BID blockIdx.x
-#define SLAB_HAND false
+#define SLAB_HAND 0
 #define SLAB_HANDV (SlabHand{})
+#define SLAB_XHAND 0
+#define SLAB_XHANDV ((const unsigned long long *)nullptr)
+#define SLAB_PART 0
 #include "gemv_q80_slab_body.inc"
 #undef SLAB_A
 #undef SLAB_BID
 #undef SLAB_HAND
 #undef SLAB_HANDV
+#undef SLAB_XHAND
+#undef SLAB_XHANDV
+#undef SLAB_PART
 }
 
 #if NANO_Q80_GS == 64
@@ -324,13 +330,80 @@ __global__ __launch_bounds__(256) void qkv_attn_fused_kernel(const FusedArgs fa)
     constexpr int ROLE = R_NORM_STORE, GS = 64, B = 1;
 #define SLAB_A fa.g
 #define SLAB_BID (blockIdx.x - fa.n_attn)
-#define SLAB_HAND true
+#define SLAB_HAND 1
 #define SLAB_HANDV fa.hand
+#define SLAB_XHAND 0
+#define SLAB_XHANDV ((const unsigned long long *)nullptr)
+#define SLAB_PART 0
 #include "gemv_q80_slab_body.inc"
 #undef SLAB_A
 #undef SLAB_BID
 #undef SLAB_HAND
 #undef SLAB_HANDV
+#undef SLAB_XHAND
+#undef SLAB_XHANDV
+#undef SLAB_PART
+}
+
+// ---- Wo + W1|W3 in ONE launch (round 5): the first all-to-all edge of the block as an in-launch all-gather -------------------------------
+// Wo's epilogue produces the residual stream x; W1|W3 needs ALL of x (rmsnorm, then every row times the whole vector): an all-to-all edge,
+// a kernel boundary in every earlier build.  Here the launch has W1|W3's grid; its first `wo_wgs` workgroups run Wo's body first (results
+// stored as usual AND as 8-byte {tag, value} granules), then EVERY workgroup runs W1|W3's body with the activation polled from the granules
+// (gemv_q80_slab_body.inc SLAB_XHAND).  W1|W3's weight and norm-weight loads go out at kernel entry (SLAB_PART 1), BEFORE Wo's body: they are
+// in LDS-distance when the granules arrive, and -- younger than Wo's own loads -- do not hold up Wo's wait counts.  What the boundary cost
+// (the gap, the entry ramp, the activation's round trip behind a cold launch) is traded for the polls.  Deadlock: producers are the first
+// workgroups of the grid and never wait for consumers; a grid of <= one workgroup per CU is resident as a whole.  Same bodies, same bits
+// (test_fused_wo_w13_launch_equals_the_two_launches).  Reference: infer/infer.c:885-944.
+struct Wo13Args { GemvDev wo; GemvDev w13; SlabHand hand; uint32_t wo_wgs, _pad; };
+template <int ROLE_A, int NV_A, int UPW_A, int NV_B, int UPW_B, int NT>
+__global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int GS = 64, B = 1;
+    // Order of issue: Wo's loads, W1|W3's loads, Wo's arithmetic, W1|W3's.  (vmcnt counts in order: loads issued BEFORE Wo's would have to
+    // land before Wo may use its own -- the first build had W1|W3's in front and Wo waited for the whole 64 MB of Qwen3-4B's two matrices.)
+    // Workgroups beyond Wo's grid run Wo's part 1 on rows past the matrix (out-of-range buffer loads: no traffic) and skip its part 2.
+    {
+        constexpr int ROLE = ROLE_A, NV = NV_A, UPW = UPW_A;
+#define SLAB_BID blockIdx.x
+#define SLAB_XHANDV fa.hand.cur
+#define SLAB_A fa.wo
+#define SLAB_HAND 1
+#define SLAB_HANDV fa.hand
+#define SLAB_XHAND 0
+#define SLAB_PART 1
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_PART
+        auto wo_rest = [&]() __attribute__((always_inline)) {
+#define SLAB_PART 2
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_PART
+        };
+#undef SLAB_A
+#undef SLAB_HAND
+#undef SLAB_HANDV
+#undef SLAB_XHAND
+        {
+            constexpr int ROLE = R_NORM_SWIGLU, NV = NV_B, UPW = UPW_B;
+#define SLAB_A fa.w13
+#define SLAB_HAND 0
+#define SLAB_HANDV (SlabHand{})
+#define SLAB_XHAND 1
+#define SLAB_PART 1
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_PART
+            if (blockIdx.x < fa.wo_wgs) wo_rest();
+            __syncthreads();                // (LDS is W1|W3's from here)
+#define SLAB_PART 2
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_PART
+#undef SLAB_A
+#undef SLAB_HAND
+#undef SLAB_HANDV
+#undef SLAB_XHAND
+        }
+#undef SLAB_BID
+#undef SLAB_XHANDV
+    }
 }
 #endif
 
@@ -656,6 +729,45 @@ static bool fused_shape(const GemvArgs &ga, const AttnArgs &aa, SlabPlan &p) {
     if (aa.q_dim != ga.seg[0].rows || aa.kv_dim != ga.seg[1].rows || aa.kv_dim != ga.seg[2].rows || aa.q_dim != aa.n_head * aa.hd) return false;
     return true;
 }
+
+// ---- the fused Wo + W1|W3 launch: host side ----------------------------------------------------------------------------------------------
+// Both bodies run on the launch's threads = W1|W3's own plan (its rmsnorm tree follows the thread count; Wo has no tree: any count gives its
+// bits).  Instantiated: Qwen3-0.6B's shapes (256 threads) and Qwen3-4B's (1024 threads, every W1|W3 weight load of a workgroup in flight
+// while Wo computes).
+struct Wo13Plan { SlabPlan a, b; uint32_t nw, nv_a, upw_a, wa, wb; int sig; };
+static bool wo13_shape(const GemvArgs &wo, const GemvArgs &w13, Wo13Plan &q) {
+    if (wo.gs != 64 || w13.gs != 64 || wo.nb != 1 || w13.nb != 1 || !q80_canonical(wo) || !q80_canonical(w13)) return false;
+    if (wo.nseg != 1 || wo.epi != GEMV_EPI_RESID || wo.norm_w || wo.xq_in || wo.tile_max || wo.resid_add || wo.seg[0].out_pstride) return false;
+    if (wo.attn_part && (wo.attn_nsplit > 8u || wo.attn_hd % 4u)) return false;
+    if (w13.nseg != 2 || w13.epi != GEMV_EPI_SWIGLU || !w13.norm_w || w13.xq_in || w13.attn_part || w13.tile_max || w13.resid_add) return false;
+    if (use_stream(wo) || use_stream(w13) || w13.n != wo.seg[0].rows || w13.xin != wo.seg[0].out || w13.n % 4u) return false;
+    q.a = plan_slab(wo, 1); q.b = plan_slab(w13, 1);
+    q.nw = q.b.nw;
+    const uint32_t units_a = ((q.a.rw + 3) / 4) * ((wo.n + 1023) / 1024);
+    q.upw_a = (units_a + q.nw - 1) / q.nw;
+    q.nv_a = (wo.n / 4 + 64 * q.nw - 1) / (64 * q.nw);
+    q.wa = (wo.seg[0].rows + q.a.rw - 1) / q.a.rw; q.wb = (w13.seg[0].rows + q.b.rw - 1) / q.b.rw;
+    const uint32_t cus = w13.cus ? w13.cus : 256u;
+    if (q.wa > q.wb || q.wb > cus) return false;                                                // one workgroup per CU: the whole grid is resident
+    if (q.a.rw > 64 * q.nw || q.b.rw > 64 * q.nw) return false;                                 // one fold thread per row
+    q.sig = 0;
+    if (q.nw == 4u && q.nv_a == 2u && q.upw_a == 1u && q.b.nv == 1u && q.b.upw == 2u) q.sig = 1;       // Qwen3-0.6B
+    if (q.nw == 16u && q.nv_a == 1u && q.upw_a == 1u && q.b.nv == 1u && q.b.upw == 4u) q.sig = 2;      // Qwen3-4B
+    return q.sig != 0;
+}
+static void slab_dev_fill(GemvDev &d, const GemvArgs &a, const SlabPlan &p, uint32_t nthr) {
+    d.tile_max = nullptr;
+    d.rw = p.rw; d.tpw = (p.rw + 3) / 4; d.magic_rw = 65536u / p.rw + 1u; d.log2_tiles = 0;
+    d.units = d.tpw * d.nchunk * (a.epi == GEMV_EPI_SWIGLU ? 2u : 1u);
+    d.wg_c0 = 0xffffffffu; d.wg_c1 = 0xffffffffu;
+    d.nthr = nthr;
+}
+static size_t slab_lds(const GemvDev &d) {
+    const uint32_t nmat = d.epi == GEMV_EPI_SWIGLU ? 2 : 1;
+    const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u, pitch = ((d.ng + 47) / 64) * 64 + 16;
+    return n16 + ng4 * 4 + 64 + ((d.flags & F_COMBINE) ? (size_t)d.attn_n_head * 32 : 0) + (size_t)nmat * (d.tpw * 4) * pitch * 4;
+}
+
 #endif
 
 template <int GS, int B>
@@ -716,6 +828,31 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
     FUSED_NV(4);
 #undef FUSED_NV
 #undef FUSED_GO
+}
+
+bool wo_w13_fused_supports(const GemvArgs &wo, const GemvArgs &w13) { Wo13Plan q; return wo13_shape(wo, w13, q); }
+
+hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st) {
+    Wo13Plan q;
+    if (!hand_cur || !hand_nxt || !wo13_shape(wo, w13, q)) return hipErrorInvalidValue;
+    Wo13Args fa{};
+    fa.wo = to_dev(wo); fa.w13 = to_dev(w13);
+    slab_dev_fill(fa.wo, wo, q.a, 64 * q.nw); slab_dev_fill(fa.w13, w13, q.b, 64 * q.nw);
+    fa.wo_wgs = q.wa;
+    SlabHand h{};
+    h.cur = hand_cur; h.nxt = hand_nxt;
+    h.base[0] = 0; h.base[1] = 0; h.base[2] = 0; h.total = wo.seg[0].rows;
+    h.zper = (h.total + fa.wo_wgs - 1) / fa.wo_wgs;                   // (the producers zero the other buffer for the launch after this one)
+    if (h.zper > 64 * q.nw) return hipErrorInvalidValue;
+    fa.hand = h;
+    const size_t la = slab_lds(fa.wo), lb = slab_lds(fa.w13), lds = la > lb ? la : lb;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const bool comb = (fa.wo.flags & F_COMBINE) != 0;
+#define WO13_GO(RA_, NVA_, UA_, NVB_, UB_, NT_) do { hipLaunchKernelGGL((wo_w13_fused_kernel<RA_, NVA_, UA_, NVB_, UB_, NT_>), dim3(q.wb), dim3(NT_), lds, st, fa); return hipGetLastError(); } while (0)
+    if (q.sig == 1) { if (comb) WO13_GO(R_RESID_COMBINE, 2, 1, 1, 2, 256); WO13_GO(R_RESID, 2, 1, 1, 2, 256); }
+    if (comb) WO13_GO(R_RESID_COMBINE, 1, 1, 1, 4, 1024);
+    WO13_GO(R_RESID, 1, 1, 1, 4, 1024);
+#undef WO13_GO
 }
 #endif
 

@@ -186,6 +186,9 @@ hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 // for q / k / v as 8-byte granules in hand_cur (q_dim + 2 kv_dim entries, all-zero at launch), the projection's workgroups zero hand_nxt
 bool qkv_attn_fused_supports(const GemvArgs &ga, const AttnArgs &aa);
 hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st);
+// Wo + W1|W3 of one sequence in ONE launch (gemv_q80_impl.h wo_w13_fused_kernel): x reaches W1|W3 as granules of the same launch
+bool wo_w13_fused_supports(const GemvArgs &wo, const GemvArgs &w13);
+hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
 hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb,

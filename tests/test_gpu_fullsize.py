@@ -286,17 +286,21 @@ def test_nano56m_strict_equals_the_oracle_bit_for_bit(model_dir, oracle, quant, 
     assert worst_fast <= {"f32": 1e-4, "q80": 5e-2, "q4k": 0.5}[quant]
 
 
-def test_fused_qkv_attention_launch_equals_the_two_launches(model_dir):
+@pytest.mark.parametrize("preset", ["qwen3-0.6b", "wide-qwen3-2l"])
+def test_fused_launches_equal_the_five_launches_per_layer(model_dir, preset):
     """One sequence on Qwen3-0.6B Q80: the q|k|v projection and the attention run as ONE launch (qkv_attn_fused_kernel: the attention
-    workgroups take q / k / v from the projection's workgroups as write-through granules inside the launch).  Same two kernel bodies, so
-    every logit of every step -- one split and several (positions beyond 64), eager first use and graph replays, the greedy loop -- must be
-    BIT-IDENTICAL to the two-launch form (NANO_FUSE_QKV_ATTN=0, read at model creation: a child process)."""
+    workgroups take q / k / v from the projection's workgroups as write-through granules inside the launch), and so do Wo and W1|W3
+    (wo_w13_fused_kernel: W1|W3's workgroups take the residual stream from Wo's as granules -- an all-gather inside the launch).  Same
+    kernel bodies, so every logit of every step -- one split and several (positions beyond 64: Wo combines the partials), eager first use
+    and graph replays, the greedy loop -- must be BIT-IDENTICAL whichever of them are on (NANO_FUSE_LAUNCHES = 3 (default: Wo + W1|W3 fused where Wo combines splits on
+    small matrices) | 0 | 1 | 5 (Wo + W1|W3 fused wherever the shapes allow), read at model creation: child processes).  wide-qwen3-2l = two layers of Qwen3-4B's shapes (1024-thread workgroups, every W1|W3 weight load of a workgroup in
+    flight while Wo computes)."""
     import os
     import subprocess
     import sys
     import zlib
     from conftest import ROOT
-    path, spec = synth_model(model_dir, "qwen3-0.6b", "q80", 64)
+    path, spec = synth_model(model_dir, preset, "q80", 64)
     code = ("import sys, zlib, numpy as np; sys.path.insert(0, %r)\n"
             "from nano_amd import binding as nb, modelfile as mf\n"
             "m = nb.load_model_file(%r, max_seq_len=256, max_batch=1)\n"
@@ -308,9 +312,9 @@ def test_fused_qkv_attention_launch_equals_the_two_launches(model_dir):
             "out = m.decode_greedy([int(ids[-1])], [150], 40)\n"
             "print('CRC', crc & 0xffffffff, zlib.crc32(out.tobytes()) & 0xffffffff)\n" % (ROOT, path, spec.vocab_size))
     res = []
-    for fuse in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NANO_FUSE_QKV_ATTN=fuse), capture_output=True, text=True, timeout=900)
+    for fuse in ("3", "0", "1", "5"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NANO_FUSE_LAUNCHES=fuse), capture_output=True, text=True, timeout=900)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("CRC")]
         assert r.returncode == 0 and lines, r.stderr[-2000:]
         res.append(lines[-1])
-    assert res[0] == res[1], res
+    assert res[0] == res[1] == res[2] == res[3], res

@@ -40,14 +40,15 @@ case "$1" in
 hab)   # headline A/B on ONE box at the driver's flags: round 3's tree (05d885c, its library built from a worktree) vs HEAD without and with the fused launch
   for r in $(seq 1 ${HAB_REPEATS:-3}); do
     NANO_LIB=$R/nano_amd/lib/libnano_mi355x_r3.so bench hab_r3_$r --steps 20 --warmup 5 --no-kernel-table
-    NANO_FUSE_QKV_ATTN=0 bench hab_two_$r --steps 20 --warmup 5 --no-kernel-table
+    NANO_FUSE_LAUNCHES=0 bench hab_two_$r --steps 20 --warmup 5 --no-kernel-table
     [ -f $R/nano_amd/lib/libnano_mi355x_alt.so ] && NANO_LIB=$R/nano_amd/lib/libnano_mi355x_alt.so bench hab_alt_$r --steps 20 --warmup 5 --no-kernel-table
+    NANO_FUSE_LAUNCHES=1 bench hab_qa_$r --steps 20 --warmup 5 --no-kernel-table
     bench hab_fused_$r --steps 20 --warmup 5 --no-kernel-table
   done
   python3 - <<'PY' | tee $O/headline_ab.txt
 import json, glob
 print("Qwen3-0.6B Q80 gs=64, one sequence, python bench.py --steps 20 --warmup 5 (the driver's flags), one box, interleaved repeats")
-for t, what in (("r3", "round 3's tree (05d885c)"), ("alt", "alternate build of HEAD (nano_amd/lib/libnano_mi355x_alt.so)"), ("two", "HEAD, q|k|v and attention as two launches (NANO_FUSE_QKV_ATTN=0)"), ("fused", "HEAD (q|k|v + attention in one launch)")):
+for t, what in (("r3", "round 3's tree (05d885c)"), ("alt", "alternate build of HEAD (nano_amd/lib/libnano_mi355x_alt.so)"), ("two", "HEAD, five launches per layer (NANO_FUSE_LAUNCHES=0)"), ("qa", "HEAD, q|k|v + attention in one launch only (NANO_FUSE_LAUNCHES=1)"), ("fused", "HEAD (q|k|v + attention in one launch, Wo + W1|W3 in one launch)")):
     v = [json.loads(open(f).read().strip().splitlines()[-1]) for f in sorted(glob.glob("gpurun_out/r5/hab_%s_*.json" % t))]
     if v: print(f"{what:70s} tokens/s {[d['value'] for d in v]}  full window {[d['value_full_window']['value'] for d in v if d.get('value_full_window')]}")
 PY
@@ -55,12 +56,12 @@ PY
 kt)    # per-launch-kind in-situ marginals, round 3's library against HEAD's (two launches), interleaved
   for r in 1 2 3; do
     NANO_LIB=$R/nano_amd/lib/libnano_mi355x_r3.so bench kt_r3_$r --steps 20 --warmup 5
-    NANO_FUSE_QKV_ATTN=0 bench kt_two_$r --steps 20 --warmup 5
+    NANO_FUSE_LAUNCHES=0 bench kt_two_$r --steps 20 --warmup 5
   done
   ;;
 kp)    # eager kernel-trace durations, round 3's library against HEAD's
   NANO_LIB=$R/nano_amd/lib/libnano_mi355x_r3.so prof kp_r3 --steps 100 --warmup 4
-  NANO_FUSE_QKV_ATTN=0 prof kp_two --steps 100 --warmup 4
+  NANO_FUSE_LAUNCHES=0 prof kp_two --steps 100 --warmup 4
   prof kp_fused --steps 100 --warmup 4
   ;;
 chk)   # the pruned tree: the suites its routes changed under
