@@ -36,3 +36,21 @@ def test_two_ranks_share_the_gpu_over_gloo_and_agree_with_one_rank():
     # six prompts, eight timed steps each: the all-gathered ids of the sharded run == the ids of the unsharded run
     assert two["config"]["timed_ids_crc32"] == one["config"]["timed_ids_crc32"], (one["config"], two["config"])
     assert two["value"] > 0 and two["steps"] == 8
+
+
+def test_one_rank_through_rccl_is_the_unsharded_run():
+    """The RCCL (backend "nccl") path itself with the one rank a 1-GPU box allows: started the way the driver starts ranks
+    (python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1), NANO_BENCH_FORCE_DIST=1 makes the single rank take the
+    distributed code -- init_process_group("nccl"), the device-side broadcast of the model file's bytes, the barriers, the all-reduce of the
+    window times, the all-gather of the ids.  Same ids as the plain run."""
+    one = run_bench(["--gpus", "1"], {"NANO_BENCH_NO_TRAFFIC": "1"})
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"NANO_BENCH_NO_TRAFFIC": "1", "NANO_BENCH_FORCE_DIST": "1"})
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29577",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--total-seqs", "6", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-table"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln[ln.index('{"metric"'):] for ln in r.stdout.strip().splitlines() if '{"metric"' in ln]
+    assert r.returncode == 0 and lines, (r.returncode, r.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["config"]["collectives"] == "nccl" and d["config"]["windows_all_reduced"] is True and d["n_gpus"] == 1
+    assert d["config"]["timed_ids_crc32"] == one["config"]["timed_ids_crc32"]
