@@ -53,6 +53,7 @@ struct G7Dev {
     uint32_t b_base, b_stage, b_xs;     // the two fragment stages: LDS offset of the first, bytes of one, offset of the activation scales inside
 };
 
+typedef float g7f2 __attribute__((ext_vector_type(2)));
 template <int AUX> __device__ __forceinline__ void g7_dma16(const void *gsrc, unsigned char *lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, AUX);
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
     const uint32_t gpt = (ttl + (uint32_t)PP - 1u) / (uint32_t)PP;    // waves per row tile
     const bool active = wid < ntl * gpt;
     const uint32_t wtile = active ? wid / gpt : 0u, tt0 = active ? (wid - wtile * gpt) * (uint32_t)PP : 0u;
-    float acc[PP][4], S[PP][4], oldv[PP][4];
+    float acc[PP][4], oldv[PP][4];
+    g7f2 S01[PP], S23[PP];                                            // the running unit sums of rows 0 | 1 and 2 | 3 of each pair
     uint32_t opos[PP];
     const TI wt = decode(wtile);
     const uint32_t orow0 = wt.lrow0 + half * halfoff + rr0;           // output row of c[0] (SwiGLU: lanes kq < 2 write, half 0)
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
     for (int i = 0; i < PP; i++) {
         opos[i] = 0u;
 #pragma unroll
-        for (int r = 0; r < 4; r++) { acc[i][r] = 0.0f; S[i][r] = 0.0f; oldv[i][r] = 0.0f; }
+        for (int r = 0; r < 4; r++) { acc[i][r] = 0.0f; oldv[i][r] = 0.0f; }
+        S01[i] = g7f2{0.0f, 0.0f}; S23[i] = g7f2{0.0f, 0.0f};
         // what the epilogue needs from memory (the old residual values, the position of a position-indexed output): asked for now
         const uint32_t tok = (tt0 + (uint32_t)i) * 16u + m;
         if (active && tok < nb && (epi == GEMV_EPI_RESID || wt.ops != 0u)) {
@@ -264,20 +267,27 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
                 xsc[j] = XS[j * 16];
                 cv[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[j], fb, v4i{0, 0, 0, 0}, 0, 0, 0);
             }
+            // infer.c:672 per output: ((float)ival * ws) * xs, then the running unit sum -- as PACKED fp32 (two rows per instruction:
+            // v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar forms): 4 conversions + 6 packed operations per group where
+            // the scalar form took 16; this VALU work, not the matrix cores, is what bounds the kernel at 3-4 token tiles
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float p = ((float)cv[j][r] * wr[r][j]) * xsc[j];              // infer.c:672
-                    if (j == 0) S[i][r] = first ? p : S[i][r] + p; else S[i][r] += p;
-                }
+            for (int j = 0; j < 4; j++) {
+                const g7f2 c01 = {(float)cv[j][0], (float)cv[j][1]}, c23 = {(float)cv[j][2], (float)cv[j][3]};
+                const g7f2 w01 = {wr[0][j], wr[1][j]}, w23 = {wr[2][j], wr[3][j]};
+                const g7f2 x2 = {xsc[j], xsc[j]};
+                const g7f2 p01 = (c01 * w01) * x2, p23 = (c23 * w23) * x2;
+                if (j == 0) { S01[i] = first ? p01 : S01[i] + p01; S23[i] = first ? p23 : S23[i] + p23; }
+                else { S01[i] += p01; S23[i] += p23; }
+            }
         }
     };
     auto fold = [&](uint32_t u) {
 #pragma unroll
-        for (int i = 0; i < PP; i++)
+        for (int i = 0; i < PP; i++) {                                                              // units ascending
+            const float sv_[4] = {S01[i].x, S01[i].y, S23[i].x, S23[i].y};
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[i][r] = u == 0u ? S[i][r] : acc[i][r] + S[i][r];          // units ascending
+            for (int r = 0; r < 4; r++) acc[i][r] = u == 0u ? sv_[r] : acc[i][r] + sv_[r];
+        }
     };
     // prologue: the first G7_BD steps' fragments are asked for, step 0's parked (behind the first barrier everyone may read them)
     g7_static_for<0, G7_BD>([&](auto SL) { b_issue(SL, (uint32_t)decltype(SL)::value); });
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
         b_issue(SI, k + (uint32_t)G7_BD);                              // slot si was parked at step k - 1
         if (active) step((k & 1u) == 0u, smem + sta * d.a_stage, smem + d.b_base + (k & 1u) * d.b_stage);
         sta = sta + 1u == nsa ? 0u : sta + 1u;
-        if (k == 0u) NANO_STAMP(a.stamps, 3, S[0][0]);                 // step 0 multiplied
+        if (k == 0u) NANO_STAMP(a.stamps, 3, S01[0].x);                 // step 0 multiplied
     };
     uint32_t k4 = 0;
     for (; k4 + (uint32_t)G7_BD <= nk; k4 += (uint32_t)G7_BD)          // whole rounds of G7_BD steps: straight-line code
