@@ -37,9 +37,9 @@ prof() {   # prof TAG bench-args... : eager kernel-trace stats of a short bench 
 case "$1" in
 # (modes g7a / g7b / g7c / g7s / fz / bis -- G7's bring-up, its parts switched off, the fused launch's A/B, the round-4 bisect -- used
 #  A/B knobs and per-commit libraries the pruned tree no longer has: they are in this file's history, their outputs under profiles/r05_*)
-hab)   # headline A/B on ONE box at the driver's flags: round 3's tree (05d885c, its library built from a worktree) vs HEAD without and with the fused launch
+hab)   # headline A/B on ONE box at the driver's flags: round 3's tree (05d885c: git worktree add /tmp/r3 05d885c && make -C /tmp/r3/nano_amd/csrc && cp .../libnano_mi355x.so nano_amd/lib/libnano_mi355x_r3.so) vs HEAD, launches fused and not
   for r in $(seq 1 ${HAB_REPEATS:-3}); do
-    NANO_LIB=$R/nano_amd/lib/libnano_mi355x_r3.so bench hab_r3_$r --steps 20 --warmup 5 --no-kernel-table
+    [ -f $R/nano_amd/lib/libnano_mi355x_r3.so ] && NANO_LIB=$R/nano_amd/lib/libnano_mi355x_r3.so bench hab_r3_$r --steps 20 --warmup 5 --no-kernel-table
     NANO_FUSE_LAUNCHES=0 bench hab_two_$r --steps 20 --warmup 5 --no-kernel-table
     [ -f $R/nano_amd/lib/libnano_mi355x_alt.so ] && NANO_LIB=$R/nano_amd/lib/libnano_mi355x_alt.so bench hab_alt_$r --steps 20 --warmup 5 --no-kernel-table
     NANO_FUSE_LAUNCHES=1 bench hab_qa_$r --steps 20 --warmup 5 --no-kernel-table
