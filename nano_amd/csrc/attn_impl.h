@@ -161,7 +161,7 @@ constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight 
 // launch before): one sweep per wave until every tag is set, the values go through LDS into the registers the loads used to fill.
 template <int LPR, int QV, int KVM, int MODE, bool KVH, bool PG, int NPT, bool W16, bool FUSE>
 __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char *smem, const uint32_t grp, const uint32_t b, const uint32_t split,
-                                               const unsigned long long *hand, const uint32_t hand_k0, const uint32_t hand_v0) {
+                                               const unsigned long long *hand, const uint32_t hand_k0, const uint32_t hand_v0, const uint32_t hand_wait16 = 0u) {
     static_assert(!W16 || (KVH && QV % 4 == 0), "16-byte FP16 loads: two float4 slots per load");
     static_assert(!FUSE || (MODE == 1 && KVM == 1 && !KVH && !PG && LPR * QV * 4 == 128), "the fused launch: Qwen3 decode, head_dim 128, FP32 contiguous cache");
     constexpr int R = 256 / LPR;                 // timesteps per block
@@ -354,6 +354,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
         };
         auto ready = [&](unsigned long long x0, unsigned long long x1) { return __all((uint32_t)(x0 >> 32) == 1u && (uint32_t)(x1 >> 32) == 1u) != 0; };
         unsigned long long a0, a1, b0, b1;
+        for (uint32_t w_ = 0; w_ < hand_wait16; w_++) __builtin_amdgcn_s_sleep(16);      // (the projection needs ~3 us: polls before that only compete with it)
         sweep(a0, a1);
         bool got = false;
         for (uint32_t spin = 0; spin < (1u << 13); spin++) {   // (bounded, ~10 ms: a projection that never arrives must not hang the device)

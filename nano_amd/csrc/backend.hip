@@ -739,14 +739,14 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             // ONE launch for both (one sequence, Q80 group size 64; gemv_q80_impl.h wo_w13_fused_kernel): W1|W3's workgroups take x from Wo's as
             // granules of the same launch.  Two granule buffers alternate by layer like the q | k | v + attention launch's.
             a.ordered = 0; a.cus = (uint32_t)m->cus; a.err = m->dev_err; b.ordered = 0; b.cus = (uint32_t)m->cus; b.err = m->dev_err;
-            // Where it is used (round 5, same-box A/B, profiles/r05_wo_w13_fused.txt): the all-gather costs about what the boundary does -- on
-            // Qwen3-0.6B 1847-1855 vs 1850-1861 tok/s while Wo is the plain role, 1772 vs 1742 over positions 31..510, where Wo also combines the
-            // attention splits (a longer first body hides more of W1|W3's loads); on Qwen3-4B's matrices it LOSES (1.531 vs 1.473 ms per
-            // step: 1024-thread workgroups whose polls queue behind their own 207 KB of weight loads).  So: split attention, not the wide matrices;
-            // NANO_FUSE_LAUNCHES bit 2 (value 4) forces it wherever the shapes allow (the parity test; the measurement).
+            // Where it is used (round 5, same-box A/Bs, profiles/r05_wo_w13_fused.txt): with the polls backed off (workgroups that produce nothing
+            // nap ~2 us before their first sweep) the fused launch wins on Qwen3-0.6B's matrices at every position (1882-1887 vs 1859-1871 tok/s at
+            // positions 20..39, 1789-1795 vs 1750-1753 over 31..510); on Qwen3-4B's it LOSES (1.531 vs 1.473 ms per step: 1024-thread workgroups
+            // that spill, polls queued behind their own 207 KB of weight loads).  So: not on the wide matrices; NANO_FUSE_LAUNCHES bit 2 (value 4)
+            // forces it wherever the shapes allow (the parity test; the measurement).
             const bool fuse13_shape = m->hand2[0] && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && (L % 2u) == 0u && !(skip & 12u) &&
                                       d.quant_type == NANO_QUANT_Q80 && kind_of(m, a) == ROUTE_GEMV && kind_of(m, b) == ROUTE_GEMV && wo_w13_fused_supports(a, b);
-            const bool fuse13 = fuse13_shape && (m->fuse_wo_w13_always || (m->fuse_wo_w13 && a.attn_part != nullptr && !route_is_wide(b)));
+            const bool fuse13 = fuse13_shape && (m->fuse_wo_w13_always || (m->fuse_wo_w13 && !route_is_wide(b)));
             if (fuse13) {
                 if ((e = launch_wo_w13_fused(a, b, m->hand2[l & 1u], m->hand2[(l + 1u) & 1u], m->st)) != hipSuccess) return e;
                 wo13_done = true;

@@ -318,13 +318,13 @@ namespace {
 // GEMV (role: rmsnorm + quantize + store), whose fold threads also store every result as a granule.  What the boundary between the two
 // kernels cost -- the gap, the attention's entry ramp and its K / V round trip -- now overlaps the projection.  Bits: the same two bodies.
 // Reference: infer/infer.c:758-879.
-struct FusedArgs { GemvDev g; AttnArgs a; SlabHand hand; uint32_t n_attn, head_wgs; };
+struct FusedArgs { GemvDev g; AttnArgs a; SlabHand hand; uint32_t n_attn, head_wgs, wait16, _pad; };
 template <int NV, int UPW>
 __global__ __launch_bounds__(256) void qkv_attn_fused_kernel(const FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x < fa.n_attn) {
         const uint32_t split = blockIdx.x / fa.head_wgs, grp = blockIdx.x - split * fa.head_wgs;
-        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand.cur, fa.hand.base[1], fa.hand.base[2]);
+        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand.cur, fa.hand.base[1], fa.hand.base[2], fa.wait16);
         return;
     }
     constexpr int ROLE = R_NORM_STORE, GS = 64, B = 1;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void qkv_attn_fused_kernel(const FusedArgs fa)
 // (the gap, the entry ramp, the activation's round trip behind a cold launch) is traded for the polls.  Deadlock: producers are the first
 // workgroups of the grid and never wait for consumers; a grid of <= one workgroup per CU is resident as a whole.  Same bodies, same bits
 // (test_fused_wo_w13_launch_equals_the_two_launches).  Reference: infer/infer.c:885-944.
-struct Wo13Args { GemvDev wo; GemvDev w13; SlabHand hand; uint32_t wo_wgs, _pad; };
+struct Wo13Args { GemvDev wo; GemvDev w13; SlabHand hand; uint32_t wo_wgs, wait16; };   // wait16: naps of 16 x 64 cycles before a non-producer workgroup starts polling
 template <int ROLE_A, int NV_A, int UPW_A, int NV_B, int UPW_B, int NT>
 __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -388,6 +388,8 @@ __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
 #define SLAB_HAND 0
 #define SLAB_HANDV (SlabHand{})
 #define SLAB_XHAND 1
+#define SLAB_XHAND_WAIT (blockIdx.x >= fa.wo_wgs ? fa.wait16 : 0u)
+#define SLAB_XHAND_NAP 2
 #define SLAB_PART 1
 #include "gemv_q80_slab_body.inc"
 #undef SLAB_PART
@@ -400,6 +402,8 @@ __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
 #undef SLAB_HAND
 #undef SLAB_HANDV
 #undef SLAB_XHAND
+#undef SLAB_XHAND_WAIT
+#undef SLAB_XHAND_NAP
         }
 #undef SLAB_BID
 #undef SLAB_XHANDV
@@ -821,6 +825,10 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
     const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
     FusedArgs fa{};
     fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = n_attn; fa.head_wgs = a.n_head;
+    // the attention workgroups nap 3 x 16 x 64 cycles (~1.5 us) between asking for their K / V rows and the first poll: the projection needs
+    // ~3 us, earlier polls only compete with it.  Same box, driver's flags: 1881-1887 tok/s without, 1893-1899 with 2, 1899-1901 with 3,
+    // 1893-1898 with 4, 1851 with 5 (late), 1813 with 6.
+    fa.wait16 = 3u;
 #define FUSED_GO(NV_, UPW_) do { hipLaunchKernelGGL((qkv_attn_fused_kernel<NV_, UPW_>), dim3(n_attn + ngemv), dim3(256), lds, st, fa); return hipGetLastError(); } while (0)
 #define FUSED_NV(NV_) do { if (upw == 1) FUSED_GO(NV_, 1); if (upw == 2) FUSED_GO(NV_, 2); FUSED_GO(NV_, 4); } while (0)
     if (p.nv == 1u) FUSED_NV(1);
@@ -839,6 +847,9 @@ hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned
     fa.wo = to_dev(wo); fa.w13 = to_dev(w13);
     slab_dev_fill(fa.wo, wo, q.a, 64 * q.nw); slab_dev_fill(fa.w13, w13, q.b, 64 * q.nw);
     fa.wo_wgs = q.wa;
+    // workgroups that produce nothing nap 4 x 16 x 64 cycles (~2 us) before their first poll, every workgroup 128 cycles between sweeps: same
+    // box, driver's flags, Qwen3-0.6B: 1846-1852 tok/s without, 1855-1865 with 2, 1879-1889 with 3, 1882-1887 with 4, 1847-1852 with 5, 1806-1817 with 6
+    fa.wait16 = 4u;
     SlabHand h{};
     h.cur = hand_cur; h.nxt = hand_nxt;
     h.base[0] = 0; h.base[1] = 0; h.base[2] = 0; h.total = wo.seg[0].rows;
