@@ -643,8 +643,9 @@ def main():
                 "kernels": table, "kernels_how": None if table is None else
                 f"in-situ: graph replays of the step at position {pos_mid} minus replays with the launch kind left out; full step {full_us:.1f} us, sum of the kinds {sum_us:.1f} us. "
                 "The marginals are LOWER bounds of a kind's time (leaving a launch out also removes its boundary and lets its neighbours' weights stay cached): a row's "
-                "GB/s is an upper bound and can exceed peak_measured.  One-sequence Q80 steps issue q|k|v and the attention as ONE launch "
-                "(qkv_attn_fused_kernel); leaving either kind out falls back to the two-launch form, so the qkv / attention rows are the two kernels' own",
+                "GB/s is an upper bound and can exceed peak_measured.  One-sequence Q80 steps on small matrices issue q|k|v + attention as ONE launch and Wo + W1|W3 as ONE launch "
+                "(qkv_attn_fused_kernel, wo_w13_fused_kernel); leaving a kind out falls back to the separate launches, so the qkv / attention / wo / w1w3 rows "
+                "are the separate kernels' own marginals",
                 "dominant_kernel": dominant, "best_kernel": cls}
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tokens / elapsed, 2), "unit": "tokens/s",
