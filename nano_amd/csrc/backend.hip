@@ -107,6 +107,8 @@ struct NanoHipModel {
     unsigned long long *hand[2] = {nullptr, nullptr};     // its two granule buffers (q_dim + 2 kv_dim entries each)
     bool fuse_wo_w13 = true, fuse_wo_w13_always = false;  // Wo + W1|W3 in one launch (x as granules) where it pays / wherever the shapes allow; NANO_FUSE_LAUNCHES bits 1 / 2
     unsigned long long *hand2[2] = {nullptr, nullptr};    // its two granule buffers (n_embd entries each)
+    bool fuse_w2_qkv = false;                             // W2 + the next layer's q|k|v + attention in one launch (measured break-even: opt-in); NANO_FUSE_LAUNCHES bit 3
+    unsigned long long *hand3[2] = {nullptr, nullptr};    // its two granule buffers for x (n_embd entries each)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // nano_hip_time_step_masked (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
@@ -199,7 +201,7 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att, m->vraw, m->stamps, m->pt, m->kvrow, m->hand[0], m->hand[1], m->hand2[0], m->hand2[1] };
+                    m->xn, m->hb2, m->att, m->vraw, m->stamps, m->pt, m->kvrow, m->hand[0], m->hand[1], m->hand2[0], m->hand2[1], m->hand3[0], m->hand3[1] };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -439,13 +441,15 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (getenv("NANO_HIP_NO_GRAPH")) m->use_graph = false;
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
     // NANO_FUSE_LAUNCHES: bit 0 = q | k | v + attention in one launch, bit 1 = Wo + W1|W3 in one launch where it pays, bit 2 = ... wherever the
-    // shapes allow (default 3; 0 = the five launches per layer; same bits in every setting)
-    if (const char *fz = getenv("NANO_FUSE_LAUNCHES")) { const uint32_t v = (uint32_t)strtoul(fz, nullptr, 0); m->fuse_qkv_attn = (v & 1u) != 0; m->fuse_wo_w13 = (v & 2u) != 0; m->fuse_wo_w13_always = (v & 4u) != 0; }
+    // shapes allow, bit 3 = W2 + the next layer's q | k | v + attention in one launch (two launches per layer: measured break-even, opt-in).
+    // Default 3; 0 = the five launches per layer; same bits in every setting
+    if (const char *fz = getenv("NANO_FUSE_LAUNCHES")) { const uint32_t v = (uint32_t)strtoul(fz, nullptr, 0); m->fuse_qkv_attn = (v & 1u) != 0; m->fuse_wo_w13 = (v & 2u) != 0; m->fuse_wo_w13_always = (v & 4u) != 0; m->fuse_w2_qkv = (v & 8u) != 0; }
     if (m->d.quant_type == NANO_QUANT_Q80 && m->d.group_size == 64) {
         for (int i = 0; i < 2; i++) {
             const size_t hb = (size_t)(m->QD + 2 * m->KD) * 8, hb2 = (size_t)m->d.n_embd * 8;
             if (hipMalloc(reinterpret_cast<void **>(&m->hand[i]), hb) != hipSuccess || hipMemset(m->hand[i], 0, hb) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void **>(&m->hand2[i]), hb2) != hipSuccess || hipMemset(m->hand2[i], 0, hb2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off granules failed"); }
+                hipMalloc(reinterpret_cast<void **>(&m->hand2[i]), hb2) != hipSuccess || hipMemset(m->hand2[i], 0, hb2) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void **>(&m->hand3[i]), hb2) != hipSuccess || hipMemset(m->hand3[i], 0, hb2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off granules failed"); }
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -644,10 +648,10 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     const uint32_t skip = m->skip_mask;
     if (!(skip & 128) && !(m->skip_embed && mode == MODE_LOOP) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
 
-    for (uint32_t l = 0; l < L; l++) {
+    // the q | k | v launch and the attention launch of layer l (arguments only)
+    auto build_qkv_attn = [&](const uint32_t l, GemvArgs &qa, AttnArgs &a) {
         const size_t layer_rows = (size_t)l * S;                    // cache row offset of this layer within a slot
         // q | raw k | v (straight into the cache row)   reference infer.c:758-786
-        GemvArgs qa{};
         qa.nseg = 3;
         qa.seg[0] = mkseg(m->W[WQ][l], m->q, QD, QD);
         qa.seg[1] = mkseg(m->W[WK][l], m->kraw, KD, KD);
@@ -659,7 +663,6 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         qa.n = E; qa.gs = d.group_size; qa.nb = nb; qa.xin = m->x; qa.xin_bstride = E; qa.epi = GEMV_EPI_STORE;
         qa.norm_w = m->rms_attn + (size_t)l * E; qa.pos = (m->kv_paged && !m->kv_half) ? m->kvrow : m->pos;     // (the only position-indexed output)
         // qk-norm, rope, k-cache write, attention   reference infer.c:810-879
-        AttnArgs a{};
         a.err = m->dev_err;
         a.q = m->q; a.q_out = nullptr; a.kraw = m->kraw; a.kcache = m->kcache; a.vcache = m->vcache; a.pos = m->pos;
         a.q_norm = m->q_norm ? m->q_norm + (size_t)l * m->hd : nullptr;
@@ -671,14 +674,26 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         a.kv_half = m->kv_half ? 1u : 0u; a.vraw = m->kv_half ? m->vraw : nullptr;
         if (wo_frag && nsplit == 1) { a.xf_out = m->gq; a.xsf_out = m->gxs; }
         if (m->kv_paged) { a.pt_rows = pt_base; a.kvrow = m->kvrow; a.pt_stride = m->pt_stride; a.pt_bstride = pt_bstride; a.pool_rows = m->kv_pages * 64u; }
+        qa.ordered = 0; qa.cus = (uint32_t)m->cus; qa.err = m->dev_err;
+    };
+    bool qkv_prelaunched = false;       // layer l's q | k | v + attention already ran inside the previous layer's last launch (w2_qkv_attn_fused_kernel)
+    for (uint32_t l = 0; l < L; l++) {
+        const size_t layer_rows = (size_t)l * S;                    // cache row offset of this layer within a slot
+        GemvArgs qa{};
+        AttnArgs a{};
+        build_qkv_attn(l, qa, a);
         // ONE launch for both (one sequence, Q80 group size 64, Qwen3 attention at head_dim 128: gemv_q80_impl.h qkv_attn_fused_kernel): the
         // attention workgroups start with the projection's, ask for their K / V rows and take q / k / v from it as write-through granules.
         // Two granule buffers alternate by layer (each launch zeroes the one the next launch fills): an even layer count keeps the
         // alternation across steps.
-        qa.ordered = 0; qa.cus = (uint32_t)m->cus;
-        const bool fused = m->fuse_qkv_attn && m->hand[0] && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && (L % 2u) == 0u && !(skip & 3u) &&
-                           d.quant_type == NANO_QUANT_Q80 && kind_of(m, qa) == ROUTE_GEMV && qkv_attn_fused_supports(qa, a);
-        if (fused) {
+        auto qkv_attn_fusable = [&](const GemvArgs &qa_, const AttnArgs &a_) {
+            return m->fuse_qkv_attn && m->hand[0] && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && (L % 2u) == 0u && !(skip & 3u) &&
+                   d.quant_type == NANO_QUANT_Q80 && kind_of(m, qa_) == ROUTE_GEMV && qkv_attn_fused_supports(qa_, a_);
+        };
+        const bool fused = qkv_attn_fusable(qa, a);
+        if (qkv_prelaunched) {
+            qkv_prelaunched = false;                                   // (done by the launch that ended the previous layer)
+        } else if (fused) {
             if ((e = launch_qkv_attn_fused(qa, a, m->hand[l & 1u], m->hand[(l + 1u) & 1u], m->st)) != hipSuccess) return e;
         } else {
             qa.stamps = next_stamps(m, 1);
@@ -762,8 +777,24 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             GemvArgs a{};
             a.nseg = 1; a.seg[0] = mkseg(m->W[W2][l], m->x, E, E);
             a.n = H; a.gs = d.group_size; a.nb = nb; a.xin = m->hb; a.xin_bstride = H; a.epi = GEMV_EPI_RESID; a.pos = m->pos;
-            a.stamps = next_stamps(m, 5);
-            if (!(skip & 16) && (e = gemv(m, a)) != hipSuccess) return e;
+            // W2 of this layer + q | k | v + attention of the NEXT one in ONE launch (gemv_q80_impl.h w2_qkv_attn_fused_kernel): the residual stream
+            // reaches the next layer's projection as granules of the same launch, q / k / v its attention workgroups as before
+            bool tripled = false;
+            // (not for the last pair of layers: the x-granule buffers alternate by launch and each launch zeroes the one the next will fill --
+            //  an EVEN number of such launches per step, L - 2, keeps the alternation across steps and graph replays)
+            if (m->fuse_w2_qkv && m->hand3[0] && l + 2u < L && !(skip & 16u)) {
+                GemvArgs qn{}; AttnArgs an{};
+                build_qkv_attn(l + 1u, qn, an);
+                a.ordered = 0; a.cus = (uint32_t)m->cus; a.err = m->dev_err;
+                if (qkv_attn_fusable(qn, an) && kind_of(m, a) == ROUTE_GEMV && w2_qkv_attn_fused_supports(a, qn, an)) {
+                    if ((e = launch_w2_qkv_attn_fused(a, qn, an, m->hand3[l & 1u], m->hand3[(l + 1u) & 1u], m->hand[(l + 1u) & 1u], m->hand[l & 1u], m->st)) != hipSuccess) return e;
+                    tripled = true; qkv_prelaunched = true;
+                }
+            }
+            if (!tripled) {
+                a.stamps = next_stamps(m, 5);
+                if (!(skip & 16) && (e = gemv(m, a)) != hipSuccess) return e;
+            }
         }
     }
     if (mode == MODE_NOCLS) return hipSuccess;

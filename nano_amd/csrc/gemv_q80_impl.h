@@ -409,6 +409,70 @@ __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
 #undef SLAB_XHANDV
     }
 }
+
+// ---- W2 of layer l + q | k | v + attention of layer l + 1 in ONE launch (round 5) ---------------------------------------------------------
+// The third hand-off: the residual stream x = x + W2 . hb reaches the NEXT layer's q | k | v projection as granules of the same launch (an
+// all-gather, like Wo -> W1|W3 above), and q / k / v reach that layer's attention workgroups as in qkv_attn_fused_kernel.  With it a
+// one-sequence step on the small matrices is TWO launches per layer.  The projection workgroups run W2's rows first (every one of them is a
+// producer), the attention workgroups come first in the grid, ask for their K / V rows, nap (the q / k / v of the next layer are two bodies
+// away) and poll.  Issue order: W2's loads, q|k|v's weight loads, W2's arithmetic, q|k|v's.  Reference: infer/infer.c:950-965, 758-879.
+struct W2QkvArgs { GemvDev w2; GemvDev g; AttnArgs a; SlabHand xh; SlabHand hand; uint32_t n_attn, head_wgs, wait16, w2_wgs, xwait, _pad; };
+template <int NV_A, int UPW_A, int NV_B, int UPW_B>
+__global__ __launch_bounds__(256) void w2_qkv_attn_fused_kernel(const W2QkvArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x < fa.n_attn) {
+        const uint32_t split = blockIdx.x / fa.head_wgs, grp = blockIdx.x - split * fa.head_wgs;
+        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand.cur, fa.hand.base[1], fa.hand.base[2], fa.wait16);
+        return;
+    }
+    constexpr int GS = 64, B = 1;
+    {
+        constexpr int ROLE = R_RESID, NV = NV_A, UPW = UPW_A;
+#define SLAB_BID (blockIdx.x - fa.n_attn)
+#define SLAB_XHANDV fa.xh.cur
+#define SLAB_A fa.w2
+#define SLAB_HAND 1
+#define SLAB_HANDV fa.xh
+#define SLAB_XHAND 0
+#define SLAB_PART 1
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_PART
+        auto w2_rest = [&]() __attribute__((always_inline)) {
+#define SLAB_PART 2
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_PART
+        };
+#undef SLAB_A
+#undef SLAB_HAND
+#undef SLAB_HANDV
+#undef SLAB_XHAND
+        {
+            constexpr int ROLE = R_NORM_STORE, NV = NV_B, UPW = UPW_B;
+#define SLAB_A fa.g
+#define SLAB_HAND 1
+#define SLAB_HANDV fa.hand
+#define SLAB_XHAND 1
+#define SLAB_XHAND_WAIT fa.xwait
+#define SLAB_XHAND_NAP 2
+#define SLAB_PART 1
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_PART
+            if ((blockIdx.x - fa.n_attn) < fa.w2_wgs) w2_rest();
+            __syncthreads();
+#define SLAB_PART 2
+#include "gemv_q80_slab_body.inc"
+#undef SLAB_PART
+#undef SLAB_A
+#undef SLAB_HAND
+#undef SLAB_HANDV
+#undef SLAB_XHAND
+#undef SLAB_XHAND_WAIT
+#undef SLAB_XHAND_NAP
+        }
+#undef SLAB_BID
+#undef SLAB_XHANDV
+    }
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
@@ -836,6 +900,70 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
     FUSED_NV(4);
 #undef FUSED_NV
 #undef FUSED_GO
+}
+
+// W2 (layer l) + q | k | v + attention (layer l + 1)
+struct W2QkvPlan { SlabPlan a, b; uint32_t nv_a, upw_a, wa; };
+static bool w2qkv_shape(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa, W2QkvPlan &q) {
+    if (!fused_shape(ga, aa, q.b)) return false;
+    if (w2.gs != 64 || w2.nb != 1 || !q80_canonical(w2) || w2.nseg != 1 || w2.epi != GEMV_EPI_RESID || w2.norm_w || w2.xq_in || w2.attn_part || w2.tile_max ||
+        w2.resid_add || w2.seg[0].out_pstride || use_stream(w2)) return false;
+    if (ga.n != w2.seg[0].rows || ga.xin != w2.seg[0].out) return false;              // the projection's input is what W2 writes
+    q.a = plan_slab(w2, 1);
+    const uint32_t units_a = ((q.a.rw + 3) / 4) * ((w2.n + 1023) / 1024);
+    q.upw_a = (units_a + 3u) / 4u;                                                   // on the launch's 256 threads
+    q.nv_a = (w2.n / 4 + 255u) / 256u;
+    q.wa = (w2.seg[0].rows + q.a.rw - 1) / q.a.rw;
+    uint32_t ngemv = 0;
+    for (uint32_t s2 = 0; s2 < 3; s2++) ngemv += (ga.seg[s2].rows + q.b.rw - 1) / q.b.rw;
+    if (q.wa > ngemv || q.a.rw > 256u) return false;
+    // instantiated: Qwen3-0.6B's shapes (W2: three float4 items per thread -> NV 4, one unit per wave; q|k|v: NV 1, UPW 1)
+    return q.upw_a == 1u && q.nv_a >= 3u && q.nv_a <= 4u && q.b.nv == 1u && q.b.upw == 1u;
+}
+
+bool w2_qkv_attn_fused_supports(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa) { W2QkvPlan q; return w2qkv_shape(w2, ga, aa, q); }
+
+hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa, unsigned long long *x_cur, unsigned long long *x_nxt,
+                                    unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st) {
+    W2QkvPlan q;
+    if (!x_cur || !x_nxt || !hand_cur || !hand_nxt || !w2qkv_shape(w2, ga, aa, q)) return hipErrorInvalidValue;
+    W2QkvArgs fa{};
+    fa.w2 = to_dev(w2); slab_dev_fill(fa.w2, w2, q.a, 256u);
+    GemvDev d = to_dev(ga);
+    d.tile_max = nullptr;
+    d.rw = q.b.rw; d.tpw = (q.b.rw + 3) / 4; d.magic_rw = 65536u / q.b.rw + 1u; d.log2_tiles = 0;
+    d.units = d.tpw * d.nchunk;
+    uint32_t wg[3];
+    for (uint32_t s2 = 0; s2 < 3; s2++) wg[s2] = (ga.seg[s2].rows + q.b.rw - 1) / q.b.rw;
+    d.wg_c0 = wg[0]; d.wg_c1 = wg[0] + wg[1];
+    const uint32_t ngemv = wg[0] + wg[1] + wg[2];
+    d.nthr = 256;
+    fa.g = d;
+    AttnArgs a = aa;
+    { uint32_t l2 = 0; while ((1u << l2) < a.n_kv_head) l2++; a.kv_log2 = l2; }
+    { const uint32_t kv_mul = a.n_head / a.n_kv_head; uint32_t l2 = 0; while ((1u << l2) < kv_mul) l2++; a.kvmul_log2 = l2; }
+    fa.a = a;
+    SlabHand h{};
+    h.cur = hand_cur; h.nxt = hand_nxt;
+    h.base[0] = 0; h.base[1] = a.q_dim; h.base[2] = a.q_dim + a.kv_dim; h.total = a.q_dim + 2u * a.kv_dim;
+    h.zper = (h.total + ngemv - 1) / ngemv;
+    SlabHand xh{};
+    xh.cur = x_cur; xh.nxt = x_nxt;
+    xh.base[0] = 0; xh.base[1] = 0; xh.base[2] = 0; xh.total = w2.seg[0].rows;
+    xh.zper = (xh.total + q.wa - 1) / q.wa;
+    if (h.zper > 256u || xh.zper > 256u) return hipErrorInvalidValue;
+    fa.hand = h; fa.xh = xh;
+    fa.n_attn = a.n_head * a.nsplit; fa.head_wgs = a.n_head; fa.w2_wgs = q.wa;
+    // naps (x 16 x 64 cycles) before the first polls: the attention workgroups' q / k / v are two bodies away (swept 3 .. 11: 7-8 best),
+    // the projection workgroups all finish W2 together and nap ~1 us before asking for the others' rows (swept 0 .. 3: 2 best).  Measured
+    // against the default (two fused launches + W2) on one box: 1879-1898 vs 1877-1920 tok/s -- break-even, hence opt-in.
+    fa.wait16 = 7u; fa.xwait = 2u;
+    const size_t la = slab_lds(fa.w2), lb = slab_lds(fa.g);
+    const size_t hd4 = a.hd, lds_a = (hd4 + hd4 + 4 + 4 + 4 * hd4 + hd4) * sizeof(float);
+    size_t lds = la > lb ? la : lb; if (lds_a > lds) lds = lds_a;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((w2_qkv_attn_fused_kernel<4, 1, 1, 1>), dim3(fa.n_attn + ngemv), dim3(256), lds, st, fa);
+    return hipGetLastError();
 }
 
 bool wo_w13_fused_supports(const GemvArgs &wo, const GemvArgs &w13) { Wo13Plan q; return wo13_shape(wo, w13, q); }

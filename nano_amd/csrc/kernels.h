@@ -189,6 +189,10 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
 // Wo + W1|W3 of one sequence in ONE launch (gemv_q80_impl.h wo_w13_fused_kernel): x reaches W1|W3 as granules of the same launch
 bool wo_w13_fused_supports(const GemvArgs &wo, const GemvArgs &w13);
 hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st);
+// W2 of a layer + q | k | v + attention of the next one in ONE launch (w2_qkv_attn_fused_kernel): x as granules, then q / k / v as granules
+bool w2_qkv_attn_fused_supports(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa);
+hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa, unsigned long long *x_cur, unsigned long long *x_nxt,
+                                    unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
 hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb,
