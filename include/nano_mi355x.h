@@ -220,6 +220,22 @@ int nano_hip_time_step_masked(NanoHipModel *m, uint32_t batch, uint32_t pos, uin
 /* Device read-bandwidth microbenchmark: streams `bytes` of device memory `iters` times; GB/s out. */
 int nano_hip_membw(int device, size_t bytes, uint32_t iters, float *gbps);
 
+/* ---- in-launch hand-offs: state, switches, fault injection -----------------------------------------
+ * One-sequence Q80 steps fuse launches whose workgroups hand results to each other INSIDE a launch (q|k|v -> attention, Wo -> W1|W3;
+ * DESIGN.md section 3), batched Q80 steps run the activation quantizer inside the GEMM launch that consumes it.  Every such wait is
+ * bounded; when one gives up (the chip shared with work that kept the producers off the CUs) the engine switches the fusions off for
+ * this model and RE-ISSUES the call through the plain launches -- the caller gets the results, `fallbacks` counts the event.
+ * nano_hip_handoff_state: fused_mask = the NANO_FUSE_LAUNCHES bits in force (1 q|k|v + attention, 2 Wo + W1|W3 on small matrices, 4 ...
+ * everywhere, 8 W2 + next q|k|v, 16 in-launch quantizer), fallbacks = re-issues so far, last_code = code bits of the last give-up.
+ * nano_hip_set_fusion: set those bits (drops the captured graphs).
+ * nano_hip_debug_fault (tests): bit 0 = the producers of every hand-off publish with a wrong tag, so each consumer gives up (the
+ * give-up path on demand); bit 1 = no re-issue: the call returns NANO_HIP_ERUNTIME.  0 restores both.
+ * nano_hip_background_load (tests): a competing streaming reader on the XCDs of `xcd_mask`, see backend.hip. */
+int nano_hip_handoff_state(const NanoHipModel *m, uint32_t *fused_mask, uint32_t *fallbacks, uint32_t *last_code);
+int nano_hip_set_fusion(NanoHipModel *m, uint32_t mask);
+int nano_hip_debug_fault(NanoHipModel *m, uint32_t flags);
+int nano_hip_background_load(int device, size_t bytes, uint32_t iters, uint32_t xcd_mask, uint32_t wgs);
+
 /* ---- debugging / parity access -----------------------------------------------------------------
  * Copy a scratch tensor of slot `slot` to the host after a forward.  which: 0=x 1=q 2=xba 3=hb
  * 4=logits 5=k cache row (layer,pos) 6=v cache row (layer,pos).  n floats are copied. */

@@ -103,6 +103,10 @@ def lib() -> C.CDLL:
     fn("nano_hip_op_fused_gemv", C.c_int, [C.c_int, C.POINTER(NanoFusedGemvDesc)])
     fn("nano_hip_kv_release", C.c_int, [vp, C.c_uint32])
     fn("nano_hip_kv_pages", C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
+    fn("nano_hip_handoff_state", C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
+    fn("nano_hip_set_fusion", C.c_int, [vp, C.c_uint32])
+    fn("nano_hip_debug_fault", C.c_int, [vp, C.c_uint32])
+    fn("nano_hip_background_load", C.c_int, [C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32])
     fn("nano_hip_stamps_begin", C.c_int, [vp])
     fn("nano_hip_stamps_read", C.c_int, [vp, vp, u32p, C.c_uint32, C.POINTER(C.c_uint32)])
     _lib = L
@@ -135,6 +139,11 @@ def membw(device: int = 0, nbytes: int = 1 << 30, iters: int = 10) -> float:
     g = C.c_float(0)
     check(lib().nano_hip_membw(device, nbytes, iters, C.byref(g)))
     return float(g.value)
+
+
+def background_load(device: int = 0, nbytes: int = 1 << 30, iters: int = 10, xcd_mask: int = 0xff, wgs: int = 2048):
+    """A competing streaming reader on the XCDs of xcd_mask (blocks until done: run it in a thread)."""
+    check(lib().nano_hip_background_load(device, nbytes, iters, xcd_mask, wgs))
 
 
 STATE_IDS = {"x": 0, "q": 1, "xba": 2, "hb": 3, "logits": 4, "k": 5, "v": 6}
@@ -279,6 +288,18 @@ class DeviceModel:
         a, b = C.c_uint32(0), C.c_uint32(0)
         check(lib().nano_hip_kv_pages(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def handoff_state(self):
+        """(fusion bits in force, re-issues after a hand-off gave up, code bits of the last give-up)"""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        check(lib().nano_hip_handoff_state(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    def set_fusion(self, mask: int):
+        check(lib().nano_hip_set_fusion(self.h, mask))
+
+    def debug_fault(self, flags: int):
+        check(lib().nano_hip_debug_fault(self.h, flags))
 
     def stamps_begin(self):
         check(lib().nano_hip_stamps_begin(self.h))

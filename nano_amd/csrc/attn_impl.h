@@ -157,11 +157,12 @@ constexpr int NP = 2;            // timestep blocks a workgroup keeps in flight 
 // The RoPE partner of slot q stays slot q + QV / 2 of the same lane (f + 2 LPR = half a head further for QV = 4).
 // FUSE (qkv_attn_fused_kernel, gemv_q80_impl.h): the workgroup runs INSIDE the launch that computes q | k | v -- its K / V rows are
 // asked for at entry as always, q, the raw k row and the fresh v row then arrive as 8-byte {value, tag} granules that the projection's
-// workgroups store write-through (hand[]: q at 0, k at hand_k0, v at hand_v0; tag 1 = written in this launch, the buffer was zeroed by the
-// launch before): one sweep per wave until every tag is set, the values go through LDS into the registers the loads used to fill.
+// workgroups store write-through (hh.buf: q at 0, k at hh.base[1], v at hh.base[2]; tag = hand_tag, the epoch of this step and layer --
+// device_common.h): one sweep per wave until every tag matches, the values go through LDS into the registers the loads used to fill.
+// A workgroup that gives up (bounded wait) reports it and stores NOTHING: no k row, no output (round-5 advice).
 template <int LPR, int QV, int KVM, int MODE, bool KVH, bool PG, int NPT, bool W16, bool FUSE>
 __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char *smem, const uint32_t grp, const uint32_t b, const uint32_t split,
-                                               const unsigned long long *hand, const uint32_t hand_k0, const uint32_t hand_v0, const uint32_t hand_wait16 = 0u) {
+                                               const SlabHand &hh, const uint32_t hand_tag = 0u, const uint32_t hand_wait16 = 0u) {
     static_assert(!W16 || (KVH && QV % 4 == 0), "16-byte FP16 loads: two float4 slots per load");
     static_assert(!FUSE || (MODE == 1 && KVM == 1 && !KVH && !PG && LPR * QV * 4 == 128), "the fused launch: Qwen3 decode, head_dim 128, FP32 contiguous cache");
     constexpr int R = 256 / LPR;                 // timesteps per block
@@ -343,16 +344,18 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
         // of this KV group.  Relaxed agent-scope 8-byte loads (sc1: past the L1) of granules stored the same way: the data is the flag.
         float *vh = part + 4 * KVM * hd4;                       // (an LDS row of its own behind the partials)
         const uint32_t t7 = (uint32_t)tid & 127u;
-        const unsigned long long *g0p = (uint32_t)tid < 128u ? hand + (size_t)h0 * hd + t7 : hand + hand_k0 + (size_t)g * hd + t7;
-        const unsigned long long *g1p = hand + hand_v0 + (size_t)g * hd + t7;
+        const unsigned long long *hand = hh.buf;
+        const unsigned long long *g0p = (uint32_t)tid < 128u ? hand + (size_t)h0 * hd + t7 : hand + hh.base[1] + (size_t)g * hd + t7;
+        const unsigned long long *g1p = hand + hh.base[2] + (size_t)g * hd + t7;
+        const unsigned long long tag_done = (unsigned long long)hand_tag << 32;
         // TWO sweeps in flight (A, B): a sweep is a memory round trip (~1 us), the next one is on its way while this one is looked at
         unsigned long long g0 = 0, g1 = 0;
         const bool two = (uint32_t)tid < 128u;
         auto sweep = [&](unsigned long long &x0, unsigned long long &x1) {
             x0 = __hip_atomic_load(g0p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            x1 = two ? __hip_atomic_load(g1p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 32);
+            x1 = two ? __hip_atomic_load(g1p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag_done;
         };
-        auto ready = [&](unsigned long long x0, unsigned long long x1) { return __all((uint32_t)(x0 >> 32) == 1u && (uint32_t)(x1 >> 32) == 1u) != 0; };
+        auto ready = [&](unsigned long long x0, unsigned long long x1) { return __all((uint32_t)(x0 >> 32) == hand_tag && (uint32_t)(x1 >> 32) == hand_tag) != 0; };
         unsigned long long a0, a1, b0, b1;
         for (uint32_t w_ = 0; w_ < hand_wait16; w_++) __builtin_amdgcn_s_sleep(16);      // (the projection needs ~3 us: polls before that only compete with it)
         sweep(a0, a1);
@@ -362,11 +365,14 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
             if (ready(a0, a1)) { g0 = a0; g1 = a1; got = true; break; }
             sweep(a0, a1);
             if (ready(b0, b1)) { g0 = b0; g1 = b1; got = true; break; }
+            if ((spin & 63u) == 63u && hand_aborted(hh)) break;   // (somebody in this step already gave up: the call is lost)
         }
-        if (!got && tid == 0 && a.err) __hip_atomic_fetch_or(a.err, NANO_DEVERR_HANDOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((uint32_t)tid < 128u) { qh[t7] = __uint_as_float((uint32_t)g0); vh[t7] = __uint_as_float((uint32_t)g1); }
         else kh[t7] = __uint_as_float((uint32_t)g0);
-        __syncthreads();
+        if (__syncthreads_or(got ? 0 : 1)) {                   // (the staging barrier; a wave that gave up takes the whole workgroup out)
+            if (!got && lane == 0) hand_give_up(hh, a.err);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < QV; q++) {
             const uint32_t f = fidx(q);
@@ -635,7 +641,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
 template <int LPR, int QV, int KVM, int MODE, bool KVH, bool PG, int NPT, bool W16>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    attention_body<LPR, QV, KVM, MODE, KVH, PG, NPT, W16, false>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z, nullptr, 0u, 0u);
+    attention_body<LPR, QV, KVM, MODE, KVH, PG, NPT, W16, false>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z, SlabHand{});
 }
 
 

@@ -104,11 +104,17 @@ struct NanoHipModel {
     bool use_graph = true;
     uint32_t mfma_min_nb = 9;                             // sequences per step from which Q80 GEMVs go to the MFMA GEMM (NANO_MFMA_MIN_NB: measurement)
     bool fuse_qkv_attn = true;                            // one sequence, Q80 gs 64, Qwen3 head_dim 128: q|k|v projection + attention in one launch; NANO_FUSE_LAUNCHES bit 0
-    unsigned long long *hand[2] = {nullptr, nullptr};     // its two granule buffers (q_dim + 2 kv_dim entries each)
+    unsigned long long *hand = nullptr;                   // its granule buffer (q_dim + 2 kv_dim entries of {tag, value}; tags are epochs: device_common.h)
     bool fuse_wo_w13 = true, fuse_wo_w13_always = false;  // Wo + W1|W3 in one launch (x as granules) where it pays / wherever the shapes allow; NANO_FUSE_LAUNCHES bits 1 / 2
-    unsigned long long *hand2[2] = {nullptr, nullptr};    // its two granule buffers (n_embd entries each)
+    unsigned long long *hand2 = nullptr;                  // its granule buffer (n_embd entries)
     bool fuse_w2_qkv = false;                             // W2 + the next layer's q|k|v + attention in one launch (measured break-even: opt-in); NANO_FUSE_LAUNCHES bit 3
-    unsigned long long *hand3[2] = {nullptr, nullptr};    // its two granule buffers for x (n_embd entries each)
+    unsigned long long *hand3 = nullptr;                  // its granule buffer for x (n_embd entries)
+    bool fuse_quant = true;                               // batched Q80 steps: the activation quantizer runs INSIDE the GEMM launch that consumes it (gemm_q80_inq.h); NANO_FUSE_LAUNCHES bit 4
+    uint32_t *tick = nullptr;                             // device words of the in-launch hand-offs: [0] step counter (the epoch), [1] fault word, [2] abort flag, [3] spare
+    uint32_t handoff_fallbacks = 0;                       // times a hand-off gave up and the call was re-issued through the plain launches (fusion stays off after the first)
+    bool reissue = true;                                  // (nano_hip_debug_fault bit 1 clears it: the give-up then surfaces as NANO_HIP_ERUNTIME)
+    uint32_t last_dev_err = 0;                            // the code bits of the last give-up (diagnostics)
+    std::vector<uint32_t> fw_tokens, fw_pos; uint32_t fw_causal = 0; int fw_logits = 0, fw_argmax = 0;   // the step queued by nano_hip_forward_begin (for its re-issue)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
     uint32_t skip_mask = 0;       // nano_hip_time_step_masked (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
@@ -201,7 +207,7 @@ static void destroy(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     void *dev[] = { m->arena, m->x, m->q, m->kraw, m->xba, m->hb, m->logits, m->kcache, m->vcache,
                     m->tokens, m->pos, m->amax, m->trace, m->pos0, m->attn_part, m->attn_ml, m->tile_max, m->rope_cur, m->gq, m->gxs, m->lora_buf, m->lora_o1,
-                    m->xn, m->hb2, m->att, m->vraw, m->stamps, m->pt, m->kvrow, m->hand[0], m->hand[1], m->hand2[0], m->hand2[1], m->hand3[0], m->hand3[1] };
+                    m->xn, m->hb2, m->att, m->vraw, m->stamps, m->pt, m->kvrow, m->hand, m->hand2, m->hand3, m->tick };
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -442,15 +448,15 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
     // NANO_FUSE_LAUNCHES: bit 0 = q | k | v + attention in one launch, bit 1 = Wo + W1|W3 in one launch where it pays, bit 2 = ... wherever the
     // shapes allow, bit 3 = W2 + the next layer's q | k | v + attention in one launch (two launches per layer: measured break-even, opt-in).
-    // Default 3; 0 = the five launches per layer; same bits in every setting
-    if (const char *fz = getenv("NANO_FUSE_LAUNCHES")) { const uint32_t v = (uint32_t)strtoul(fz, nullptr, 0); m->fuse_qkv_attn = (v & 1u) != 0; m->fuse_wo_w13 = (v & 2u) != 0; m->fuse_wo_w13_always = (v & 4u) != 0; m->fuse_w2_qkv = (v & 8u) != 0; }
+    // bit 4 = batched Q80 steps quantize their activations inside the GEMM launch (round 6).  Default 19; 0 = the plain launches; same bits in every setting
+    if (const char *fz = getenv("NANO_FUSE_LAUNCHES")) { const uint32_t v = (uint32_t)strtoul(fz, nullptr, 0); m->fuse_qkv_attn = (v & 1u) != 0; m->fuse_wo_w13 = (v & 2u) != 0; m->fuse_wo_w13_always = (v & 4u) != 0; m->fuse_w2_qkv = (v & 8u) != 0; m->fuse_quant = (v & 16u) != 0; }
+    if (hipMalloc(reinterpret_cast<void **>(&m->tick), 64) != hipSuccess || hipMemset(m->tick, 0, 64) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off words failed"); }
     if (m->d.quant_type == NANO_QUANT_Q80 && m->d.group_size == 64) {
-        for (int i = 0; i < 2; i++) {
-            const size_t hb = (size_t)(m->QD + 2 * m->KD) * 8, hb2 = (size_t)m->d.n_embd * 8;
-            if (hipMalloc(reinterpret_cast<void **>(&m->hand[i]), hb) != hipSuccess || hipMemset(m->hand[i], 0, hb) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void **>(&m->hand2[i]), hb2) != hipSuccess || hipMemset(m->hand2[i], 0, hb2) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void **>(&m->hand3[i]), hb2) != hipSuccess || hipMemset(m->hand3[i], 0, hb2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off granules failed"); }
-        }
+        // granule buffers of the fused one-sequence launches: tag 0 (the memset) is no epoch -- the first step's tick is 1
+        const size_t hb = (size_t)(m->QD + 2 * m->KD) * 8, hb2 = (size_t)m->d.n_embd * 8;
+        if (hipMalloc(reinterpret_cast<void **>(&m->hand), hb) != hipSuccess || hipMemset(m->hand, 0, hb) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&m->hand2), hb2) != hipSuccess || hipMemset(m->hand2, 0, hb2) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&m->hand3), hb2) != hipSuccess || hipMemset(m->hand3, 0, hb2) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off granules failed"); }
     }
     HIP_TRY(hipDeviceSynchronize());
     *out = m;
@@ -548,13 +554,43 @@ static Q80Route route_of(const NanoHipModel *m) {
 }
 static RouteKind kind_of(const NanoHipModel *m, GemvArgs a) { a.ordered = m->strict ? 1u : 0u; a.cus = (uint32_t)m->cus; return route_kind(route_of(m), a); }
 
-// A kernel gave up a bounded wait since the last check (G6's finisher, the fused launch's hand-off): the results of the call are not
-// valid.  Read after a stream synchronisation; the word lives in host-mapped memory, so the check is one load.
-static int dev_err_check(NanoHipModel *m) {
+// A kernel gave up a bounded wait since the last check (G6's finisher, a fused launch's hand-off, the in-launch activation quantizer):
+// the results of the call are not valid.  Read after a stream synchronisation; the word lives in host-mapped memory, so the check
+// is one load.  dev_err_take() returns the code bits and clears the word (m->last_dev_err keeps them); dev_err_check() turns
+// them into NANO_HIP_ERUNTIME.  Every public entry point that synchronises ends with one of the two (round-5 advice: the
+// arg-max sampling path and an allocation-failure exit of sample_run() returned without looking).
+static uint32_t dev_err_take(NanoHipModel *m) {
     const uint32_t c = m->h_err ? *reinterpret_cast<volatile uint32_t *>(m->h_err) : 0u;
-    if (!c) return 0;
+    if (!c) return 0u;
     *reinterpret_cast<volatile uint32_t *>(m->h_err) = 0;
-    FAIL(NANO_HIP_ERUNTIME, "a kernel gave up waiting for its producers (code %u: 1 = G6 tile counter, 2 = q|k|v hand-off): the results of this call are not valid", c);
+    m->last_dev_err = c;
+    if (m->tick) (void)hipMemsetAsync(m->tick + 2, 0, 4, m->st);         // the abort flag of the lost step (device_common.h)
+    return c;
+}
+static int dev_err_fail(uint32_t c) {
+    FAIL(NANO_HIP_ERUNTIME, "a kernel gave up waiting for its producers (code %u: 1 = G6 tile counter, 2 = in-launch hand-off of a fused launch, 4 = in-launch activation quantizer): the results of this call are not valid", c);
+}
+static int dev_err_check(NanoHipModel *m) {
+    const uint32_t c = dev_err_take(m);
+    return c ? dev_err_fail(c) : 0;
+}
+// The in-launch hand-offs (fused one-sequence launches, the batched GEMMs' in-launch quantizer) are an optimisation over launches
+// that need nothing from each other but stream order.  When one of them gives up -- the chip shared with other work that kept
+// its producers off the CUs for longer than the bound -- the engine switches them off for this model, drops the graphs that
+// contain them and RE-ISSUES the call through the plain launches, once; the caller sees the results, not an error.
+static bool handoff_recoverable(const NanoHipModel *m, uint32_t code) {
+    return m->reissue && code && (code & ~(NANO_DEVERR_HANDOFF | NANO_DEVERR_QSYNC)) == 0u;
+}
+static void drop_graphs(NanoHipModel *m) {
+    for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    m->graphs.clear(); m->pf_graph_keys.clear();
+}
+static void handoff_fallback(NanoHipModel *m) {
+    (void)hipStreamSynchronize(m->st);
+    m->fuse_qkv_attn = m->fuse_wo_w13 = m->fuse_wo_w13_always = m->fuse_w2_qkv = false;
+    m->fuse_quant = false;
+    drop_graphs(m);
+    m->handoff_fallbacks++;
 }
 
 static hipError_t gemv(NanoHipModel *m, GemvArgs &a) {
@@ -645,6 +681,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     const uint32_t pt_bstride = (m->kv_paged && !m->pf) ? m->pt_stride : 0u;
     const size_t plane = (size_t)m->kv_pages * 64 * KD;                      // elements of one layer plane of the pool
     if (m->kv_paged) { ea.pt_rows = pt_base; ea.kvrow = m->kvrow; ea.pt_bstride = pt_bstride; ea.pt_entries = m->pt_stride; }
+    ea.tick = m->tick;                                                       // the step's first kernel opens a new hand-off epoch
     const uint32_t skip = m->skip_mask;
     if (!(skip & 128) && !(m->skip_embed && mode == MODE_LOOP) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
 
@@ -683,18 +720,17 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         AttnArgs a{};
         build_qkv_attn(l, qa, a);
         // ONE launch for both (one sequence, Q80 group size 64, Qwen3 attention at head_dim 128: gemv_q80_impl.h qkv_attn_fused_kernel): the
-        // attention workgroups start with the projection's, ask for their K / V rows and take q / k / v from it as write-through granules.
-        // Two granule buffers alternate by layer (each launch zeroes the one the next launch fills): an even layer count keeps the
-        // alternation across steps.
+        // attention workgroups start with the projection's, ask for their K / V rows and take q / k / v from it as write-through granules
+        // tagged with the epoch of this step and layer (tick * 128 + l + 1: at most 126 layers).
         auto qkv_attn_fusable = [&](const GemvArgs &qa_, const AttnArgs &a_) {
-            return m->fuse_qkv_attn && m->hand[0] && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && (L % 2u) == 0u && !(skip & 3u) &&
+            return m->fuse_qkv_attn && m->hand && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && L <= 126u && !(skip & (3u | 128u)) &&
                    d.quant_type == NANO_QUANT_Q80 && kind_of(m, qa_) == ROUTE_GEMV && qkv_attn_fused_supports(qa_, a_);
         };
         const bool fused = qkv_attn_fusable(qa, a);
         if (qkv_prelaunched) {
             qkv_prelaunched = false;                                   // (done by the launch that ended the previous layer)
         } else if (fused) {
-            if ((e = launch_qkv_attn_fused(qa, a, m->hand[l & 1u], m->hand[(l + 1u) & 1u], m->st)) != hipSuccess) return e;
+            if ((e = launch_qkv_attn_fused(qa, a, m->hand, m->tick, l + 1u, m->st)) != hipSuccess) return e;
         } else {
             qa.stamps = next_stamps(m, 1);
             if (!(skip & 1) && (e = gemv(m, qa)) != hipSuccess) return e;
@@ -752,18 +788,18 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             b.n = E; b.gs = d.group_size; b.nb = nb; b.xin = m->x; b.xin_bstride = E; b.epi = GEMV_EPI_SWIGLU;
             b.norm_w = m->rms_ffn + (size_t)l * E; b.pos = m->pos;
             // ONE launch for both (one sequence, Q80 group size 64; gemv_q80_impl.h wo_w13_fused_kernel): W1|W3's workgroups take x from Wo's as
-            // granules of the same launch.  Two granule buffers alternate by layer like the q | k | v + attention launch's.
+            // granules of the same launch (epoch tags like the q | k | v + attention launch's).
             a.ordered = 0; a.cus = (uint32_t)m->cus; a.err = m->dev_err; b.ordered = 0; b.cus = (uint32_t)m->cus; b.err = m->dev_err;
             // Where it is used (round 5, same-box A/Bs, profiles/r05_wo_w13_fused.txt): with the polls backed off (workgroups that produce nothing
             // nap ~2 us before their first sweep) the fused launch wins on Qwen3-0.6B's matrices at every position (1882-1887 vs 1859-1871 tok/s at
             // positions 20..39, 1789-1795 vs 1750-1753 over 31..510); on Qwen3-4B's it LOSES (1.531 vs 1.473 ms per step: 1024-thread workgroups
             // that spill, polls queued behind their own 207 KB of weight loads).  So: not on the wide matrices; NANO_FUSE_LAUNCHES bit 2 (value 4)
             // forces it wherever the shapes allow (the parity test; the measurement).
-            const bool fuse13_shape = m->hand2[0] && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && (L % 2u) == 0u && !(skip & 12u) &&
+            const bool fuse13_shape = m->hand2 && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && L <= 126u && !(skip & (12u | 128u)) &&
                                       d.quant_type == NANO_QUANT_Q80 && kind_of(m, a) == ROUTE_GEMV && kind_of(m, b) == ROUTE_GEMV && wo_w13_fused_supports(a, b);
             const bool fuse13 = fuse13_shape && (m->fuse_wo_w13_always || (m->fuse_wo_w13 && !route_is_wide(b)));
             if (fuse13) {
-                if ((e = launch_wo_w13_fused(a, b, m->hand2[l & 1u], m->hand2[(l + 1u) & 1u], m->st)) != hipSuccess) return e;
+                if ((e = launch_wo_w13_fused(a, b, m->hand2, m->tick, l + 1u, m->st)) != hipSuccess) return e;
                 wo13_done = true;
             } else {
                 a.stamps = next_stamps(m, 3);
@@ -780,14 +816,12 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             // W2 of this layer + q | k | v + attention of the NEXT one in ONE launch (gemv_q80_impl.h w2_qkv_attn_fused_kernel): the residual stream
             // reaches the next layer's projection as granules of the same launch, q / k / v its attention workgroups as before
             bool tripled = false;
-            // (not for the last pair of layers: the x-granule buffers alternate by launch and each launch zeroes the one the next will fill --
-            //  an EVEN number of such launches per step, L - 2, keeps the alternation across steps and graph replays)
-            if (m->fuse_w2_qkv && m->hand3[0] && l + 2u < L && !(skip & 16u)) {
+            if (m->fuse_w2_qkv && m->hand3 && l + 1u < L && !(skip & 16u)) {
                 GemvArgs qn{}; AttnArgs an{};
                 build_qkv_attn(l + 1u, qn, an);
                 a.ordered = 0; a.cus = (uint32_t)m->cus; a.err = m->dev_err;
                 if (qkv_attn_fusable(qn, an) && kind_of(m, a) == ROUTE_GEMV && w2_qkv_attn_fused_supports(a, qn, an)) {
-                    if ((e = launch_w2_qkv_attn_fused(a, qn, an, m->hand3[l & 1u], m->hand3[(l + 1u) & 1u], m->hand[(l + 1u) & 1u], m->hand[l & 1u], m->st)) != hipSuccess) return e;
+                    if ((e = launch_w2_qkv_attn_fused(a, qn, an, m->hand3, m->hand, m->tick, l + 1u, m->st)) != hipSuccess) return e;
                     tripled = true; qkv_prelaunched = true;
                 }
             }
@@ -1041,6 +1075,8 @@ extern "C" int nano_hip_forward_begin(NanoHipModel *m, const uint32_t *tokens, c
     if ((rc = check_batch(m, tokens, pos, batch, 0))) return rc;
     HIP_TRY(hipSetDevice(m->device));
     if ((rc = kv_ensure_batch(m, pos, batch, 0, !is_causal))) return rc;
+    if (tokens != m->fw_tokens.data()) { m->fw_tokens.assign(tokens, tokens + batch); m->fw_pos.assign(pos, pos + batch); }    // (what a re-issue needs)
+    m->fw_causal = is_causal; m->fw_logits = want_logits; m->fw_argmax = want_argmax;
     memcpy(m->h_tokens, tokens, batch * 4); memcpy(m->h_pos, pos, batch * 4);
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, batch * 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, batch * 4, hipMemcpyHostToDevice, m->st));
@@ -1059,7 +1095,15 @@ extern "C" int nano_hip_forward_end(NanoHipModel *m, float *logits_out, uint32_t
     if (!m) FAIL(NANO_HIP_EINVAL, "null model");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->st));
-    { const int rc_err = dev_err_check(m); if (rc_err) { m->pending_batch = 0; return rc_err; } }
+    uint32_t code = dev_err_take(m);
+    if (handoff_recoverable(m, code) && m->pending_batch && m->fw_tokens.size() == m->pending_batch) {
+        handoff_fallback(m);                                                // the same step again, through the plain launches
+        const int rc = nano_hip_forward_begin(m, m->fw_tokens.data(), m->fw_pos.data(), m->pending_batch, m->fw_causal, m->fw_logits, m->fw_argmax);
+        if (rc) { m->pending_batch = 0; return rc; }
+        HIP_TRY(hipStreamSynchronize(m->st));
+        code = dev_err_take(m);
+    }
+    if (code) { m->pending_batch = 0; return dev_err_fail(code); }
     const size_t V = m->d.vocab_size, batch = m->pending_batch;
     if (logits_out) memcpy(logits_out, m->h_logits, batch * V * 4);
     if (argmax_out) memcpy(argmax_out, m->h_amax, batch * 4);
@@ -1110,7 +1154,9 @@ static int sampler_init(NanoHipModel *m) {
     return 0;
 }
 
-// queue the sampler behind whatever produced `logits` (device pointer) on the model's stream, wait, fill *out
+// queue the sampler behind whatever produced `logits` (device pointer) on the model's stream, wait, fill *out.  Returns SAMPLE_RC_CHECK
+// (> 0) on every exit that synchronised the stream: the caller then looks at the sticky error word (and may re-issue the forward).
+constexpr int SAMPLE_RC_CHECK = 1;
 static int sample_run(NanoHipModel *m, const float *logits, const uint32_t *history, uint32_t n_history,
                       float penalty, float temperature, float top_p, float coin, NanoHipSample *out) {
     SamplerState *sp = m->smp;
@@ -1143,7 +1189,7 @@ static int sample_run(NanoHipModel *m, const float *logits, const uint32_t *hist
         HIP_TRY(hipStreamSynchronize(m->st));
         memset(out, 0, sizeof *out);
         out->token = m->h_amax[0]; out->status = NANO_SAMPLE_OK;
-        return 0;
+        return SAMPLE_RC_CHECK;
     }
     HIP_TRY(launch_sample(a, m->st));
     HIP_TRY(hipMemcpyAsync(sp->h_res, a.res, sizeof(NanoHipSample), hipMemcpyDeviceToHost, m->st));
@@ -1155,7 +1201,7 @@ static int sample_run(NanoHipModel *m, const float *logits, const uint32_t *hist
             const size_t npad = (size_t)a.nch * SAMPLE_CHUNK;
             sp->wide_temp_bytes = sample_wide_temp_bytes((uint32_t)npad);
             const size_t tb = (sp->wide_temp_bytes + 255) & ~(size_t)255;
-            if (!sp->wide_temp_bytes || hipMalloc(&sp->wide, npad * 20 + tb) != hipSuccess) { sp->wide = nullptr; *out = *sp->h_res; return 0; }   // (the caller's host loops)
+            if (!sp->wide_temp_bytes || hipMalloc(&sp->wide, npad * 20 + tb) != hipSuccess) { sp->wide = nullptr; *out = *sp->h_res; return SAMPLE_RC_CHECK; }   // (the caller's host loops)
             sp->a.wide_in = (unsigned long long *)sp->wide; sp->a.wide_out = sp->a.wide_in + npad;
             sp->a.wide_p = (float *)(sp->a.wide_out + npad); sp->a.wide_cap = (uint32_t)npad;
             sp->wide_temp = sp->wide + npad * 20;
@@ -1166,7 +1212,7 @@ static int sample_run(NanoHipModel *m, const float *logits, const uint32_t *hist
         HIP_TRY(hipStreamSynchronize(m->st));
     }
     *out = *sp->h_res;
-    return dev_err_check(m);
+    return SAMPLE_RC_CHECK;
 }
 
 extern "C" int nano_hip_forward_sample(NanoHipModel *m, uint32_t token, uint32_t pos, const uint32_t *history, uint32_t n_history,
@@ -1180,8 +1226,17 @@ extern "C" int nano_hip_forward_sample(NanoHipModel *m, uint32_t token, uint32_t
     m->h_tokens[0] = token; m->h_pos[0] = pos;
     HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, 4, hipMemcpyHostToDevice, m->st));
-    if ((rc = run_step(m, 1, 1u, MODE_LOGITS, pos))) return rc;
-    return sample_run(m, m->logits, history, n_history, repetition_penalty, temperature, top_p, coin, out);
+    for (int attempt = 0;; attempt++) {
+        if ((rc = run_step(m, 1, 1u, MODE_LOGITS, pos))) return rc;
+        rc = sample_run(m, m->logits, history, n_history, repetition_penalty, temperature, top_p, coin, out);
+        if (rc != SAMPLE_RC_CHECK) return rc;
+        const uint32_t code = dev_err_take(m);
+        if (!code) return 0;
+        if (attempt || !handoff_recoverable(m, code)) return dev_err_fail(code);
+        handoff_fallback(m);                                                // the same step again, through the plain launches
+        HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, 4, hipMemcpyHostToDevice, m->st));
+    }
 }
 
 extern "C" int nano_hip_op_sample(NanoHipModel *m, const float *logits, const uint32_t *history, uint32_t n_history,
@@ -1193,7 +1248,8 @@ extern "C" int nano_hip_op_sample(NanoHipModel *m, const float *logits, const ui
     const size_t V = m->d.vocab_size;
     memcpy(m->h_logits, logits, V * 4);
     HIP_TRY(hipMemcpyAsync(m->logits, m->h_logits, V * 4, hipMemcpyHostToDevice, m->st));
-    return sample_run(m, m->logits, history, n_history, repetition_penalty, temperature, top_p, coin, out);
+    const int rc2 = sample_run(m, m->logits, history, n_history, repetition_penalty, temperature, top_p, coin, out);
+    return rc2 == SAMPLE_RC_CHECK ? dev_err_check(m) : rc2;
 }
 
 // ---- LoRA ---------------------------------------------------------------------------------------------
@@ -1311,8 +1367,22 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
     return dev_err_check(m);
 }
 
+static int decode_greedy_once(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, uint32_t steps, uint32_t *out_ids, uint32_t *code_out);
 extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch,
                                       uint32_t steps, uint32_t *out_ids) {
+    uint32_t code = 0;
+    int rc = decode_greedy_once(m, tokens, pos, batch, steps, out_ids, &code);
+    if (rc || !code) return rc;
+    if (!handoff_recoverable(m, code)) return dev_err_fail(code);
+    // a hand-off gave up somewhere in the loop: every later step of it ran on garbage.  The whole call again (same tokens, same
+    // positions: the KV rows are rewritten), through the plain launches.
+    handoff_fallback(m);
+    code = 0;
+    rc = decode_greedy_once(m, tokens, pos, batch, steps, out_ids, &code);
+    if (rc || !code) return rc;
+    return dev_err_fail(code);
+}
+static int decode_greedy_once(NanoHipModel *m, const uint32_t *tokens, const uint32_t *pos, uint32_t batch, uint32_t steps, uint32_t *out_ids, uint32_t *code_out) {
     int rc;
     if (steps == 0) return 0;
     if ((rc = check_batch(m, tokens, pos, batch, steps))) return rc;
@@ -1338,7 +1408,37 @@ extern "C" int nano_hip_decode_greedy(NanoHipModel *m, const uint32_t *tokens, c
     } else {
         HIP_TRY(hipStreamSynchronize(m->st));
     }
-    return dev_err_check(m);
+    *code_out = dev_err_take(m);
+    return 0;
+}
+
+// ---- the in-launch hand-offs: state, switches, fault injection (tests; tools) ----------------------------------------------------------
+extern "C" int nano_hip_handoff_state(const NanoHipModel *m, uint32_t *fused_mask, uint32_t *fallbacks, uint32_t *last_code) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    if (fused_mask) *fused_mask = (m->fuse_qkv_attn ? 1u : 0u) | (m->fuse_wo_w13 ? 2u : 0u) | (m->fuse_wo_w13_always ? 4u : 0u) | (m->fuse_w2_qkv ? 8u : 0u) | (m->fuse_quant ? 16u : 0u);
+    if (fallbacks) *fallbacks = m->handoff_fallbacks;
+    if (last_code) *last_code = m->last_dev_err;
+    return 0;
+}
+extern "C" int nano_hip_set_fusion(NanoHipModel *m, uint32_t mask) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    if (mask & ~31u) FAIL(NANO_HIP_EINVAL, "unknown fusion bits 0x%x", mask);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    m->fuse_qkv_attn = (mask & 1u) != 0; m->fuse_wo_w13 = (mask & 2u) != 0; m->fuse_wo_w13_always = (mask & 4u) != 0; m->fuse_w2_qkv = (mask & 8u) != 0;
+    m->fuse_quant = (mask & 16u) != 0;
+    drop_graphs(m);                                                        // (graphs carry the launches of the setting they were captured under)
+    return 0;
+}
+extern "C" int nano_hip_debug_fault(NanoHipModel *m, uint32_t flags) {
+    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
+    if (flags & ~3u) FAIL(NANO_HIP_EINVAL, "unknown fault bits 0x%x", flags);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    const uint32_t words[2] = { (flags & 1u) ? 0x5a5au : 0u, 0u };          // tick[1]: XORed into every producer's tag; tick[2]: the abort flag, cleared
+    HIP_TRY(hipMemcpy(m->tick + 1, words, 8, hipMemcpyHostToDevice));
+    m->reissue = (flags & 2u) == 0;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1414,7 +1514,7 @@ extern "C" int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos,
     HIP_TRY(hipEventSynchronize(m->ev1));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
     if (ms_per_step) *ms_per_step = ms / iters;
-    return 0;
+    return dev_err_check(m);                                             // (a step whose kernels gave up is no measurement)
 }
 
 // Measurement: the step with some kernel kinds left out (mask bits: 1 QKV GEMV, 2 attention, 4 Wo GEMV, 8 W1|W3 GEMV,
@@ -1445,6 +1545,25 @@ extern "C" int nano_hip_membw(int device, size_t bytes, uint32_t iters, float *g
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     if (gbps) *gbps = (float)((double)bytes * iters / (ms * 1e-3) / 1e9);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(buf); (void)hipFree(sink);
+    return 0;
+}
+
+// Competing load for the hand-off tests: `iters` launches of a streaming reader of `bytes` on a stream of its own, on the workgroup slots of
+// the XCDs in `xcd_mask` only (uneven load), `wgs` workgroups of 256 threads each launch.  Blocks until they are done: call it from a thread
+// of its own while the model under test decodes.
+extern "C" int nano_hip_background_load(int device, size_t bytes, uint32_t iters, uint32_t xcd_mask, uint32_t wgs) {
+    if (!iters || bytes < (1u << 20) || !wgs || wgs > 65535u) FAIL(NANO_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    void *buf = nullptr; float *sink = nullptr; hipStream_t st = nullptr;
+    HIP_TRY(hipMalloc(&buf, bytes));
+    HIP_TRY(hipMalloc(&sink, 4));
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipMemsetAsync(buf, 1, bytes, st));
+    hipError_t e = hipSuccess;
+    for (uint32_t i = 0; i < iters && e == hipSuccess; i++) e = launch_stream_read_masked(buf, bytes, sink, xcd_mask, wgs, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st); (void)hipFree(buf); (void)hipFree(sink);
+    HIP_TRY(e); HIP_TRY(e2);
     return 0;
 }
 

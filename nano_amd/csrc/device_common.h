@@ -42,6 +42,28 @@ namespace nano {
 // waited for once, while nothing else could run anyway.
 template <class T> __device__ __forceinline__ void karg_touch(const T &v) { asm volatile("" :: "s"(v)); }
 
+// ---- in-launch hand-offs (the fused decode launches, gemv_q80_impl.h / attn_impl.h) -----------------------------------------------
+// Results travel between workgroups of ONE launch as 8-byte {tag, value} granules (one relaxed agent-scope store / load each: the
+// data is the flag -- MI355X guide, Guideline 16 R2).  The tag is an EPOCH: tick * 128 + (layer + 1), where `tick` is a device
+// word the step's first kernel (embed_kernel, or the arg-max kernel that embeds the next token) increments -- read from memory,
+// never a launch argument (those are frozen under graph replay).  A granule left by any earlier launch carries another tag: a
+// consumer that meets it WAITS (round 5 tagged with a constant 1 and relied on the other buffer of a pair being zeroed by the
+// launch before: an aborted step could flip that parity and stale values were then taken for fresh ones -- round-5 advice).
+// No buffer is ever zeroed, one buffer per edge, no restriction on the layer count's parity.
+// tick[0] = the step counter, tick[1] = fault word XORed into the PRODUCERS' tag (0; nano_hip_debug_fault sets it so that every
+// hand-off of a step fails: the test of the give-up path), tick[2] = abort flag: set by the first consumer that gives up, polled by
+// the others so that a lost step does not sit out the bound once per launch; cleared by the host.
+constexpr uint32_t NANO_DEVERR_G6_TILE = 1u, NANO_DEVERR_HANDOFF = 2u, NANO_DEVERR_QSYNC = 4u;
+struct SlabHand { unsigned long long *buf; uint32_t *tick; uint32_t base[3], layer1; };
+__device__ __forceinline__ uint2 hand_tick(const SlabHand &h) { return *reinterpret_cast<const uint2 *>(h.tick); }
+__device__ __forceinline__ uint32_t hand_ctag(const uint2 t, const SlabHand &h) { return t.x * 128u + h.layer1; }              // what a consumer waits for
+__device__ __forceinline__ uint32_t hand_ptag(const uint2 t, const SlabHand &h) { return (t.x * 128u + h.layer1) ^ t.y; }      // what a producer writes
+__device__ __forceinline__ bool hand_aborted(const SlabHand &h) { return __hip_atomic_load(h.tick + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
+__device__ __forceinline__ void hand_give_up(const SlabHand &h, uint32_t *err) {
+    __hip_atomic_store(h.tick + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err) __hip_atomic_fetch_or(err, NANO_DEVERR_HANDOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- x / C for the quantizers' constant divisors (15, 63, 127) -----------------------------------------
 // Three operations (multiply by RN(1/C), exact remainder by FMA, one correction) instead of the ~12 of the IEEE division
 // expansion.  The result is the correctly rounded quotient -- bit-identical to x / C -- for EVERY finite float x (denormals

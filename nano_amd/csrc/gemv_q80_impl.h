@@ -281,11 +281,8 @@ __device__ __forceinline__ float fold_row_canon_ng(const float *p, uint32_t ng) 
 // ------------------------------------------------------------------------------------------------------------
 // SLAB kernel
 // ------------------------------------------------------------------------------------------------------------
-// Hand-off of a launch's results to consumers INSIDE the same launch (the fused q | k | v + attention kernel below): every result is
-// also stored as an 8-byte {value, tag 1} granule (ONE write-through store: the data is the flag), and each workgroup zeroes its share
-// of the OTHER granule buffer -- the one the next launch of this kind will fill.
-struct SlabHand { unsigned long long *cur, *nxt; uint32_t base[3], total, zper; };
-
+// Hand-off of a launch's results to consumers INSIDE the same launch (the fused kernels below): every result is also stored as an 8-byte
+// {tag, value} granule (ONE write-through store: the data is the flag); SlabHand and the epoch tags: device_common.h.
 template <int ROLE, int GS, int B, int NV, int UPW>
 __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -293,16 +290,20 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
 #define SLAB_BID blockIdx.x
 #define SLAB_HAND 0
 #define SLAB_HANDV (SlabHand{})
+#define SLAB_PTAG 0u
 #define SLAB_XHAND 0
-#define SLAB_XHANDV ((const unsigned long long *)nullptr)
+#define SLAB_XHANDV (SlabHand{})
+#define SLAB_CTAG 0u
 #define SLAB_PART 0
 #include "gemv_q80_slab_body.inc"
 #undef SLAB_A
 #undef SLAB_BID
 #undef SLAB_HAND
 #undef SLAB_HANDV
+#undef SLAB_PTAG
 #undef SLAB_XHAND
 #undef SLAB_XHANDV
+#undef SLAB_CTAG
 #undef SLAB_PART
 }
 
@@ -313,35 +314,43 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
 namespace nano {
 namespace {
 // ---- q | k | v projection + attention in ONE launch (Qwen3 decode, one sequence, head_dim 128; round 5) --------------------------------------
-// The first `n_attn` workgroups are the attention's (head x split): they ask for their K / V rows at entry, exactly as the attention kernel
-// does, and then wait for q, the raw k row and the fresh v row of their KV group as granules; the other workgroups are the projection's SLAB
-// GEMV (role: rmsnorm + quantize + store), whose fold threads also store every result as a granule.  What the boundary between the two
+// The LAST `n_attn` workgroups are the attention's (head x split): they ask for their K / V rows at entry, exactly as the attention kernel
+// does, and then wait for q, the raw k row and the fresh v row of their KV group as granules; the first `ngemv` workgroups are the projection's
+// SLAB GEMV (role: rmsnorm + quantize + store), whose fold threads also store every result as a granule.  What the boundary between the two
 // kernels cost -- the gap, the attention's entry ramp and its K / V round trip -- now overlaps the projection.  Bits: the same two bodies.
-// Reference: infer/infer.c:758-879.
-struct FusedArgs { GemvDev g; AttnArgs a; SlabHand hand; uint32_t n_attn, head_wgs, wait16, _pad; };
+// Round 6: the PRODUCERS come first in the grid (round-5 advice: with the consumers in front, a chip that other work keeps busy could seat
+// the pollers and leave the projection waiting for their slots); granules carry epoch tags (device_common.h), a consumer that gives up
+// skips its stores.  Reference: infer/infer.c:758-879.
+struct FusedArgs { GemvDev g; AttnArgs a; SlabHand hand; uint32_t n_attn, head_wgs, wait16, ngemv; };
 template <int NV, int UPW>
 __global__ __launch_bounds__(256) void qkv_attn_fused_kernel(const FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (blockIdx.x < fa.n_attn) {
-        const uint32_t split = blockIdx.x / fa.head_wgs, grp = blockIdx.x - split * fa.head_wgs;
-        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand.cur, fa.hand.base[1], fa.hand.base[2], fa.wait16);
+    const uint2 tk_ = hand_tick(fa.hand);                       // the step's epoch: the first load of every workgroup
+    if (blockIdx.x >= fa.ngemv) {
+        const uint32_t ab = blockIdx.x - fa.ngemv;
+        const uint32_t split = ab / fa.head_wgs, grp = ab - split * fa.head_wgs;
+        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand, hand_ctag(tk_, fa.hand), fa.wait16);
         return;
     }
     constexpr int ROLE = R_NORM_STORE, GS = 64, B = 1;
 #define SLAB_A fa.g
-#define SLAB_BID (blockIdx.x - fa.n_attn)
+#define SLAB_BID blockIdx.x
 #define SLAB_HAND 1
 #define SLAB_HANDV fa.hand
+#define SLAB_PTAG hand_ptag(tk_, fa.hand)
 #define SLAB_XHAND 0
-#define SLAB_XHANDV ((const unsigned long long *)nullptr)
+#define SLAB_XHANDV (SlabHand{})
+#define SLAB_CTAG 0u
 #define SLAB_PART 0
 #include "gemv_q80_slab_body.inc"
 #undef SLAB_A
 #undef SLAB_BID
 #undef SLAB_HAND
 #undef SLAB_HANDV
+#undef SLAB_PTAG
 #undef SLAB_XHAND
 #undef SLAB_XHANDV
+#undef SLAB_CTAG
 #undef SLAB_PART
 }
 
@@ -359,17 +368,20 @@ template <int ROLE_A, int NV_A, int UPW_A, int NV_B, int UPW_B, int NT>
 __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int GS = 64, B = 1;
+    const uint2 tk_ = hand_tick(fa.hand);
     // Order of issue: Wo's loads, W1|W3's loads, Wo's arithmetic, W1|W3's.  (vmcnt counts in order: loads issued BEFORE Wo's would have to
     // land before Wo may use its own -- the first build had W1|W3's in front and Wo waited for the whole 64 MB of Qwen3-4B's two matrices.)
     // Workgroups beyond Wo's grid run Wo's part 1 on rows past the matrix (out-of-range buffer loads: no traffic) and skip its part 2.
     {
         constexpr int ROLE = ROLE_A, NV = NV_A, UPW = UPW_A;
 #define SLAB_BID blockIdx.x
-#define SLAB_XHANDV fa.hand.cur
 #define SLAB_A fa.wo
 #define SLAB_HAND 1
 #define SLAB_HANDV fa.hand
+#define SLAB_PTAG hand_ptag(tk_, fa.hand)
 #define SLAB_XHAND 0
+#define SLAB_XHANDV (SlabHand{})
+#define SLAB_CTAG 0u
 #define SLAB_PART 1
 #include "gemv_q80_slab_body.inc"
 #undef SLAB_PART
@@ -381,13 +393,19 @@ __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
 #undef SLAB_A
 #undef SLAB_HAND
 #undef SLAB_HANDV
+#undef SLAB_PTAG
 #undef SLAB_XHAND
+#undef SLAB_XHANDV
+#undef SLAB_CTAG
         {
             constexpr int ROLE = R_NORM_SWIGLU, NV = NV_B, UPW = UPW_B;
 #define SLAB_A fa.w13
 #define SLAB_HAND 0
 #define SLAB_HANDV (SlabHand{})
+#define SLAB_PTAG 0u
 #define SLAB_XHAND 1
+#define SLAB_XHANDV fa.hand
+#define SLAB_CTAG hand_ctag(tk_, fa.hand)
 #define SLAB_XHAND_WAIT (blockIdx.x >= fa.wo_wgs ? fa.wait16 : 0u)
 #define SLAB_XHAND_NAP 2
 #define SLAB_PART 1
@@ -401,12 +419,14 @@ __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
 #undef SLAB_A
 #undef SLAB_HAND
 #undef SLAB_HANDV
+#undef SLAB_PTAG
 #undef SLAB_XHAND
+#undef SLAB_XHANDV
+#undef SLAB_CTAG
 #undef SLAB_XHAND_WAIT
 #undef SLAB_XHAND_NAP
         }
 #undef SLAB_BID
-#undef SLAB_XHANDV
     }
 }
 
@@ -414,26 +434,30 @@ __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
 // The third hand-off: the residual stream x = x + W2 . hb reaches the NEXT layer's q | k | v projection as granules of the same launch (an
 // all-gather, like Wo -> W1|W3 above), and q / k / v reach that layer's attention workgroups as in qkv_attn_fused_kernel.  With it a
 // one-sequence step on the small matrices is TWO launches per layer.  The projection workgroups run W2's rows first (every one of them is a
-// producer), the attention workgroups come first in the grid, ask for their K / V rows, nap (the q / k / v of the next layer are two bodies
+// producer), the attention workgroups come LAST in the grid, ask for their K / V rows, nap (the q / k / v of the next layer are two bodies
 // away) and poll.  Issue order: W2's loads, q|k|v's weight loads, W2's arithmetic, q|k|v's.  Reference: infer/infer.c:950-965, 758-879.
-struct W2QkvArgs { GemvDev w2; GemvDev g; AttnArgs a; SlabHand xh; SlabHand hand; uint32_t n_attn, head_wgs, wait16, w2_wgs, xwait, _pad; };
+struct W2QkvArgs { GemvDev w2; GemvDev g; AttnArgs a; SlabHand xh; SlabHand hand; uint32_t n_attn, head_wgs, wait16, w2_wgs, xwait, ngemv; };
 template <int NV_A, int UPW_A, int NV_B, int UPW_B>
 __global__ __launch_bounds__(256) void w2_qkv_attn_fused_kernel(const W2QkvArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (blockIdx.x < fa.n_attn) {
-        const uint32_t split = blockIdx.x / fa.head_wgs, grp = blockIdx.x - split * fa.head_wgs;
-        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand.cur, fa.hand.base[1], fa.hand.base[2], fa.wait16);
+    const uint2 tk_ = hand_tick(fa.hand);
+    if (blockIdx.x >= fa.ngemv) {
+        const uint32_t ab = blockIdx.x - fa.ngemv;
+        const uint32_t split = ab / fa.head_wgs, grp = ab - split * fa.head_wgs;
+        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand, hand_ctag(tk_, fa.hand), fa.wait16);
         return;
     }
     constexpr int GS = 64, B = 1;
     {
         constexpr int ROLE = R_RESID, NV = NV_A, UPW = UPW_A;
-#define SLAB_BID (blockIdx.x - fa.n_attn)
-#define SLAB_XHANDV fa.xh.cur
+#define SLAB_BID blockIdx.x
 #define SLAB_A fa.w2
 #define SLAB_HAND 1
 #define SLAB_HANDV fa.xh
+#define SLAB_PTAG hand_ptag(tk_, fa.xh)
 #define SLAB_XHAND 0
+#define SLAB_XHANDV (SlabHand{})
+#define SLAB_CTAG 0u
 #define SLAB_PART 1
 #include "gemv_q80_slab_body.inc"
 #undef SLAB_PART
@@ -445,19 +469,25 @@ __global__ __launch_bounds__(256) void w2_qkv_attn_fused_kernel(const W2QkvArgs 
 #undef SLAB_A
 #undef SLAB_HAND
 #undef SLAB_HANDV
+#undef SLAB_PTAG
 #undef SLAB_XHAND
+#undef SLAB_XHANDV
+#undef SLAB_CTAG
         {
             constexpr int ROLE = R_NORM_STORE, NV = NV_B, UPW = UPW_B;
 #define SLAB_A fa.g
 #define SLAB_HAND 1
 #define SLAB_HANDV fa.hand
+#define SLAB_PTAG hand_ptag(tk_, fa.hand)
 #define SLAB_XHAND 1
+#define SLAB_XHANDV fa.xh
+#define SLAB_CTAG hand_ctag(tk_, fa.xh)
 #define SLAB_XHAND_WAIT fa.xwait
 #define SLAB_XHAND_NAP 2
 #define SLAB_PART 1
 #include "gemv_q80_slab_body.inc"
 #undef SLAB_PART
-            if ((blockIdx.x - fa.n_attn) < fa.w2_wgs) w2_rest();
+            if (blockIdx.x < fa.w2_wgs) w2_rest();
             __syncthreads();
 #define SLAB_PART 2
 #include "gemv_q80_slab_body.inc"
@@ -465,12 +495,14 @@ __global__ __launch_bounds__(256) void w2_qkv_attn_fused_kernel(const W2QkvArgs 
 #undef SLAB_A
 #undef SLAB_HAND
 #undef SLAB_HANDV
+#undef SLAB_PTAG
 #undef SLAB_XHAND
+#undef SLAB_XHANDV
+#undef SLAB_CTAG
 #undef SLAB_XHAND_WAIT
 #undef SLAB_XHAND_NAP
         }
 #undef SLAB_BID
-#undef SLAB_XHANDV
     }
 }
 #endif
@@ -860,9 +892,9 @@ hipError_t NANO_Q80_ENTRY(const GemvArgs &a, hipStream_t st) { return launch_gs<
 #if NANO_Q80_GS == 64
 bool qkv_attn_fused_supports(const GemvArgs &ga, const AttnArgs &aa) { SlabPlan p; return fused_shape(ga, aa, p); }
 
-hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st) {
+hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st) {
     SlabPlan p;
-    if (!hand_cur || !hand_nxt || !fused_shape(ga, aa, p)) return hipErrorInvalidValue;
+    if (!hand || !tick || !layer1 || layer1 > 127u || !fused_shape(ga, aa, p)) return hipErrorInvalidValue;
     GemvDev d = to_dev(ga);
     d.tile_max = nullptr;
     d.rw = p.rw; d.tpw = (p.rw + 3) / 4; d.magic_rw = 65536u / p.rw + 1u; d.log2_tiles = 0;
@@ -876,10 +908,8 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
     { uint32_t l2 = 0; while ((1u << l2) < a.n_kv_head) l2++; a.kv_log2 = l2; }
     { const uint32_t kv_mul = a.n_head / a.n_kv_head; uint32_t l2 = 0; while ((1u << l2) < kv_mul) l2++; a.kvmul_log2 = l2; }
     SlabHand h{};
-    h.cur = hand_cur; h.nxt = hand_nxt;
-    h.base[0] = 0; h.base[1] = a.q_dim; h.base[2] = a.q_dim + a.kv_dim; h.total = a.q_dim + 2u * a.kv_dim;
-    h.zper = (h.total + ngemv - 1) / ngemv;
-    if (h.zper > 256u) return hipErrorInvalidValue;
+    h.buf = hand; h.tick = tick; h.layer1 = layer1;
+    h.base[0] = 0; h.base[1] = a.q_dim; h.base[2] = a.q_dim + a.kv_dim;
     const uint32_t n_attn = a.n_head * a.nsplit;
     const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u, pitch = ((d.ng + 47) / 64) * 64 + 16;
     const size_t lds_g = n16 + ng4 * 4 + 64 + (size_t)(d.tpw * 4) * pitch * 4;
@@ -888,7 +918,7 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
     FusedArgs fa{};
-    fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = n_attn; fa.head_wgs = a.n_head;
+    fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = n_attn; fa.head_wgs = a.n_head; fa.ngemv = ngemv;
     // the attention workgroups nap 3 x 16 x 64 cycles (~1.5 us) between asking for their K / V rows and the first poll: the projection needs
     // ~3 us, earlier polls only compete with it.  Same box, driver's flags: 1881-1887 tok/s without, 1893-1899 with 2, 1899-1901 with 3,
     // 1893-1898 with 4, 1851 with 5 (late), 1813 with 6.
@@ -923,10 +953,10 @@ static bool w2qkv_shape(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &
 
 bool w2_qkv_attn_fused_supports(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa) { W2QkvPlan q; return w2qkv_shape(w2, ga, aa, q); }
 
-hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa, unsigned long long *x_cur, unsigned long long *x_nxt,
-                                    unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st) {
+hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa, unsigned long long *xhand, unsigned long long *hand,
+                                    uint32_t *tick, uint32_t layer1, hipStream_t st) {
     W2QkvPlan q;
-    if (!x_cur || !x_nxt || !hand_cur || !hand_nxt || !w2qkv_shape(w2, ga, aa, q)) return hipErrorInvalidValue;
+    if (!xhand || !hand || !tick || !layer1 || layer1 > 126u || !w2qkv_shape(w2, ga, aa, q)) return hipErrorInvalidValue;
     W2QkvArgs fa{};
     fa.w2 = to_dev(w2); slab_dev_fill(fa.w2, w2, q.a, 256u);
     GemvDev d = to_dev(ga);
@@ -944,16 +974,13 @@ hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, cons
     { const uint32_t kv_mul = a.n_head / a.n_kv_head; uint32_t l2 = 0; while ((1u << l2) < kv_mul) l2++; a.kvmul_log2 = l2; }
     fa.a = a;
     SlabHand h{};
-    h.cur = hand_cur; h.nxt = hand_nxt;
-    h.base[0] = 0; h.base[1] = a.q_dim; h.base[2] = a.q_dim + a.kv_dim; h.total = a.q_dim + 2u * a.kv_dim;
-    h.zper = (h.total + ngemv - 1) / ngemv;
+    h.buf = hand; h.tick = tick; h.layer1 = layer1 + 1u;                // q / k / v of the NEXT layer
+    h.base[0] = 0; h.base[1] = a.q_dim; h.base[2] = a.q_dim + a.kv_dim;
     SlabHand xh{};
-    xh.cur = x_cur; xh.nxt = x_nxt;
-    xh.base[0] = 0; xh.base[1] = 0; xh.base[2] = 0; xh.total = w2.seg[0].rows;
-    xh.zper = (xh.total + q.wa - 1) / q.wa;
-    if (h.zper > 256u || xh.zper > 256u) return hipErrorInvalidValue;
+    xh.buf = xhand; xh.tick = tick; xh.layer1 = layer1;
+    xh.base[0] = 0; xh.base[1] = 0; xh.base[2] = 0;
     fa.hand = h; fa.xh = xh;
-    fa.n_attn = a.n_head * a.nsplit; fa.head_wgs = a.n_head; fa.w2_wgs = q.wa;
+    fa.n_attn = a.n_head * a.nsplit; fa.head_wgs = a.n_head; fa.w2_wgs = q.wa; fa.ngemv = ngemv;
     // naps (x 16 x 64 cycles) before the first polls: the attention workgroups' q / k / v are two bodies away (swept 3 .. 11: 7-8 best),
     // the projection workgroups all finish W2 together and nap ~1 us before asking for the others' rows (swept 0 .. 3: 2 best).  Measured
     // against the default (two fused launches + W2) on one box: 1879-1898 vs 1877-1920 tok/s -- break-even, hence opt-in.
@@ -968,9 +995,9 @@ hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, cons
 
 bool wo_w13_fused_supports(const GemvArgs &wo, const GemvArgs &w13) { Wo13Plan q; return wo13_shape(wo, w13, q); }
 
-hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st) {
+hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st) {
     Wo13Plan q;
-    if (!hand_cur || !hand_nxt || !wo13_shape(wo, w13, q)) return hipErrorInvalidValue;
+    if (!hand || !tick || !layer1 || layer1 > 127u || !wo13_shape(wo, w13, q)) return hipErrorInvalidValue;
     Wo13Args fa{};
     fa.wo = to_dev(wo); fa.w13 = to_dev(w13);
     slab_dev_fill(fa.wo, wo, q.a, 64 * q.nw); slab_dev_fill(fa.w13, w13, q.b, 64 * q.nw);
@@ -979,10 +1006,8 @@ hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned
     // box, driver's flags, Qwen3-0.6B: 1846-1852 tok/s without, 1855-1865 with 2, 1879-1889 with 3, 1882-1887 with 4, 1847-1852 with 5, 1806-1817 with 6
     fa.wait16 = 4u;
     SlabHand h{};
-    h.cur = hand_cur; h.nxt = hand_nxt;
-    h.base[0] = 0; h.base[1] = 0; h.base[2] = 0; h.total = wo.seg[0].rows;
-    h.zper = (h.total + fa.wo_wgs - 1) / fa.wo_wgs;                   // (the producers zero the other buffer for the launch after this one)
-    if (h.zper > 64 * q.nw) return hipErrorInvalidValue;
+    h.buf = hand; h.tick = tick; h.layer1 = layer1;
+    h.base[0] = 0; h.base[1] = 0; h.base[2] = 0;
     fa.hand = h;
     const size_t la = slab_lds(fa.wo), lb = slab_lds(fa.w13), lds = la > lb ? la : lb;
     if (lds > 64 * 1024) return hipErrorInvalidValue;

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "../../include/nano_mi355x.h"
+#include "device_common.h"
 
 namespace nano {
 
@@ -56,10 +57,10 @@ struct GemvArgs {
     unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
 
-// Bounded waits inside kernels (G6's finisher on its tile counter, the fused launch's attention workgroups on their q | k | v granules) must
-// not hang the device; a wait that gives up ORs its code into the model's sticky error word and the next synchronising C-ABI call returns
-// NANO_HIP_ERUNTIME instead of results computed from whatever was there (round-4 advice).
-constexpr uint32_t NANO_DEVERR_G6_TILE = 1u, NANO_DEVERR_HANDOFF = 2u;
+// Bounded waits inside kernels (G6's finisher on its tile counter, the fused launches' consumers on their granules, the batched GEMMs on the
+// in-launch activation quantizer) must not hang the device; a wait that gives up ORs its code (device_common.h NANO_DEVERR_*) into the model's
+// sticky error word: the next synchronising C-ABI call re-issues the work through the plain launches (hand-offs) or returns NANO_HIP_ERUNTIME
+// instead of results computed from whatever was there (round-4 / round-5 advice).
 
 // The fast path's reduction shape of a Q80 projection (group size 64, row length a multiple of 256; not the classifier-like tall
 // STORE launches, whose kernels hold whole rows per wave and keep the reference's order): row = ((S_0 + S_1) + ...), S_u = the 8
@@ -183,16 +184,17 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs &a, uint32_t nb, hipStream_t st);
 // q | k | v projection (Q80 group size 64, one sequence) + Qwen3 decode attention as ONE launch (gemv_q80_impl.h): the attention workgroups wait
-// for q / k / v as 8-byte granules in hand_cur (q_dim + 2 kv_dim entries, all-zero at launch), the projection's workgroups zero hand_nxt
+// for q / k / v as 8-byte {tag, value} granules in `hand` (q_dim + 2 kv_dim entries); tag = the step's tick * 128 + layer1 (device_common.h)
 bool qkv_attn_fused_supports(const GemvArgs &ga, const AttnArgs &aa);
-hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st);
+hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st);
 // Wo + W1|W3 of one sequence in ONE launch (gemv_q80_impl.h wo_w13_fused_kernel): x reaches W1|W3 as granules of the same launch
 bool wo_w13_fused_supports(const GemvArgs &wo, const GemvArgs &w13);
-hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st);
-// W2 of a layer + q | k | v + attention of the next one in ONE launch (w2_qkv_attn_fused_kernel): x as granules, then q / k / v as granules
+hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st);
+// W2 of a layer + q | k | v + attention of the next one in ONE launch (w2_qkv_attn_fused_kernel): x as granules (xhand, tag of layer1), then
+// q / k / v as granules (hand, tag of layer1 + 1)
 bool w2_qkv_attn_fused_supports(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa);
-hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa, unsigned long long *x_cur, unsigned long long *x_nxt,
-                                    unsigned long long *hand_cur, unsigned long long *hand_nxt, hipStream_t st);
+hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa, unsigned long long *xhand, unsigned long long *hand,
+                                    uint32_t *tick, uint32_t layer1, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
 hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb,
@@ -243,6 +245,8 @@ struct EmbedArgs {
     const float *rope_cos; const float *rope_sin; const uint32_t *pos; float *rope_cur; uint32_t half, _pad;
     // paged KV cache: kvrow[b] = pt_rows[b * pt_bstride + pos[b] / 64] + pos[b] % 64 (the pool row the step writes), or nullptr
     const uint32_t *pt_rows; uint32_t *kvrow; uint32_t pt_bstride, pt_entries;   // pt_entries: table entries per slot (a position beyond them stages nothing)
+    // the step's first kernel also advances the model's hand-off epoch (device_common.h: tick[0] += 1, workgroup 0), or nullptr
+    uint32_t *tick;
 };
 hipError_t launch_embed(const EmbedArgs &a, uint32_t nb, hipStream_t st);
 
@@ -266,6 +270,7 @@ hipError_t launch_quantize_q4k(const float *x, uint32_t n, uint8_t *blocks, hipS
 hipError_t launch_swiglu(float *hb, const float *hb2, uint32_t n, hipStream_t st);
 hipError_t launch_rope(float *head, uint32_t hd, const float *fcr, const float *fci, int qwen3, hipStream_t st);
 hipError_t launch_stream_read(const void *buf, size_t bytes, float *sink, hipStream_t st);
+hipError_t launch_stream_read_masked(const void *buf, size_t bytes, float *sink, uint32_t xcd_mask, uint32_t wgs, hipStream_t st);
 
 // ---- device-side sampler (sampler.hip) ----
 constexpr uint32_t SAMPLE_CHUNK = 256;            // softmax numerators per chunk function (one wave x float4)

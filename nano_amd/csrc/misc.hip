@@ -63,6 +63,7 @@ __device__ __forceinline__ void embed_row(const EmbedArgs &a, uint32_t b, uint32
 
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     const int b = blockIdx.x;
+    if (a.tick && b == 0 && threadIdx.x == 0) a.tick[0] = a.tick[0] + 1u;       // a new step: a new epoch for its in-launch hand-offs
     embed_row(a, (uint32_t)b, a.tokens[b], a.pos ? a.pos[b] : 0u, true);
 }
 
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
     if (a.tokens && a.emb.x) {                                // greedy loop: embed the picked token at its next position right here
         __syncthreads();
         const uint32_t np = s_next[1];
+        if (a.emb.tick && b == 0 && tid == 0) a.emb.tick[0] = a.emb.tick[0] + 1u;      // (this kernel is the next step's first)
         embed_row(a.emb, (uint32_t)b, s_next[0], np, np < a.rope_rows);
     }
 }
@@ -227,6 +229,19 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const u32x4 *buf, size
     }
     for (; i < n16; i += stride) acc ^= buf[i];
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) *sink = 1.0f;   // keep the loads alive
+}
+// the same reader on SOME of the chip only (tests of the in-launch hand-offs under uneven load): workgroup b runs on XCD b % 8 (observed
+// placement); the workgroups of the XCDs outside `xcd_mask` leave at once
+__global__ __launch_bounds__(256) void stream_read_masked_kernel(const u32x4 *buf, size_t n16, float *sink, uint32_t xcd_mask) {
+    if (!((xcd_mask >> (blockIdx.x & 7u)) & 1u)) return;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) acc ^= __builtin_nontemporal_load(buf + i);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) *sink = 1.0f;
+}
+hipError_t launch_stream_read_masked(const void *buf, size_t bytes, float *sink, uint32_t xcd_mask, uint32_t wgs, hipStream_t st) {
+    hipLaunchKernelGGL(stream_read_masked_kernel, dim3(wgs), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(buf), bytes / 16, sink, xcd_mask);
+    return hipGetLastError();
 }
 hipError_t launch_stream_read(const void *buf, size_t bytes, float *sink, hipStream_t st) {
     hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(buf), bytes / 16, sink);

@@ -104,7 +104,8 @@ def preset(name: str, quant: str = "f32", group_size: int = 0, block_size: Optio
         # one layer with Qwen3-4B's row lengths (2560 / 4096 / 9728: partial 1 KiB chunks, many chunks per row,
         # 4 q heads per KV head) and a vocabulary tall enough for the classifier's STREAM kernel
         "wide-qwen3": (ARCH_QWEN3, 128, 20000, 1, 2560, 32, 8, 9728, 128),
-        "wide-qwen3-2l": (ARCH_QWEN3, 256, 20000, 2, 2560, 32, 8, 9728, 128),      # two such layers (an even count: the fused launches' granule buffers alternate by layer)
+        "wide-qwen3-2l": (ARCH_QWEN3, 256, 20000, 2, 2560, 32, 8, 9728, 128),      # two such layers
+        "qwen3-0.6b-3l": (ARCH_QWEN3, 256, 20000, 3, 1024, 16, 8, 3072, 128),       # Qwen3-0.6B's layer shapes, an ODD layer count (round 5's granule buffers alternated by layer parity)
         # a toy network under Qwen3's full vocabulary: the sampler's 151 936-entry softmax / nucleus at real size
         "bigvocab-qwen3": (ARCH_QWEN3, 64, 151936, 1, 64, 2, 1, 128, 32),
     }

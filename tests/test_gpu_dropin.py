@@ -43,7 +43,22 @@ def test_reference_nano_cli_generates(tmp_path):
     import dataclasses
     from nano_amd import modelfile as mf
     hard_coded = "/home/bd4sur/ai/_model/Nano/qwen3-0b6-q4ks.bin"
-    os.makedirs(os.path.dirname(hard_coded), exist_ok=True)
+    cli = need("nano_cli")
+    try:
+        os.makedirs(os.path.dirname(hard_coded), exist_ok=True)
+    except PermissionError:
+        # an ordinary user cannot create /home/bd4sur (the GPU box): the same binary with the path LITERAL re-pointed, byte for byte the
+        # same length, at a scratch directory -- the front-end's code is untouched, only where its string constant points
+        scratch = "/tmp/nano_dropin_" + "x" * 64
+        alt = (scratch[:len(os.path.dirname(hard_coded))] + "/" + os.path.basename(hard_coded))
+        assert len(alt) == len(hard_coded)
+        blob = open(cli, "rb").read()
+        assert blob.count(hard_coded.encode()) == 1
+        cli = str(tmp_path / "nano_cli")
+        open(cli, "wb").write(blob.replace(hard_coded.encode(), alt.encode()))
+        os.chmod(cli, 0o755)
+        hard_coded = alt
+        os.makedirs(os.path.dirname(hard_coded), exist_ok=True)
     spec = dataclasses.replace(mf.preset("tiny-nano", "q80", group_size=32), block_size=2048)   # the CLI asks for max_seq_len 2048
     # vocabulary: ids 0..3 unreachable private-use characters (0 and 3 end a Nano generation, infer.c:1292), the ASCII
     # characters of the CLI's prompt template, the two template marks as 17-character special tokens (they go through
@@ -58,7 +73,7 @@ def test_reference_nano_cli_generates(tmp_path):
     out_path = tmp_path / "cli.out"
     try:
         with open(out_path, "wb") as out:
-            p = subprocess.Popen([need("nano_cli")], env=ENV, stdin=subprocess.PIPE, stdout=out, stderr=subprocess.STDOUT)
+            p = subprocess.Popen([cli], env=ENV, stdin=subprocess.PIPE, stdout=out, stderr=subprocess.STDOUT)
             p.stdin.write(prompt.encode("utf-8")); p.stdin.close()       # EOF submits the prompt (and later picks random default prompts)
             deadline = time.time() + 90
             text = ""

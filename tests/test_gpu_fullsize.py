@@ -286,7 +286,7 @@ def test_nano56m_strict_equals_the_oracle_bit_for_bit(model_dir, oracle, quant, 
     assert worst_fast <= {"f32": 1e-4, "q80": 5e-2, "q4k": 0.5}[quant]
 
 
-@pytest.mark.parametrize("preset", ["qwen3-0.6b", "wide-qwen3-2l"])
+@pytest.mark.parametrize("preset", ["qwen3-0.6b", "wide-qwen3-2l", "qwen3-0.6b-3l"])
 def test_fused_launches_equal_the_five_launches_per_layer(model_dir, preset):
     """One sequence on Qwen3-0.6B Q80: the q|k|v projection and the attention run as ONE launch (qkv_attn_fused_kernel: the attention
     workgroups take q / k / v from the projection's workgroups as write-through granules inside the launch), and so do Wo and W1|W3
@@ -294,7 +294,7 @@ def test_fused_launches_equal_the_five_launches_per_layer(model_dir, preset):
     kernel bodies, so every logit of every step -- one split and several (positions beyond 64: Wo combines the partials), eager first use
     and graph replays, the greedy loop -- must be BIT-IDENTICAL whichever of them are on (NANO_FUSE_LAUNCHES bits: 1 q|k|v + attention, 2 Wo + W1|W3 on small matrices, 4 ... wherever the shapes
     allow, 8 W2 + the next layer's q|k|v + attention; values 15 | 0 | 1 | 5 | 11, read at model creation: child processes).  wide-qwen3-2l = two layers of Qwen3-4B's shapes (1024-thread workgroups, every W1|W3 weight load of a workgroup in
-    flight while Wo computes)."""
+    flight while Wo computes); qwen3-0.6b-3l = an odd layer count (round 6: the granules carry epoch tags, no buffer pair alternates by layer)."""
     import os
     import subprocess
     import sys
