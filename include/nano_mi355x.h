@@ -222,11 +222,11 @@ int nano_hip_membw(int device, size_t bytes, uint32_t iters, float *gbps);
 
 /* ---- in-launch hand-offs: state, switches, fault injection -----------------------------------------
  * One-sequence Q80 steps fuse launches whose workgroups hand results to each other INSIDE a launch (q|k|v -> attention, Wo -> W1|W3;
- * DESIGN.md section 3), batched Q80 steps run the activation quantizer inside the GEMM launch that consumes it.  Every such wait is
+ * DESIGN.md section 3).  Every such wait is
  * bounded; when one gives up (the chip shared with work that kept the producers off the CUs) the engine switches the fusions off for
  * this model and RE-ISSUES the call through the plain launches -- the caller gets the results, `fallbacks` counts the event.
  * nano_hip_handoff_state: fused_mask = the NANO_FUSE_LAUNCHES bits in force (1 q|k|v + attention, 2 Wo + W1|W3 on small matrices, 4 ...
- * everywhere, 8 W2 + next q|k|v, 16 in-launch quantizer), fallbacks = re-issues so far, last_code = code bits of the last give-up.
+ * everywhere, 8 W2 + next q|k|v), fallbacks = re-issues so far, last_code = code bits of the last give-up.
  * nano_hip_set_fusion: set those bits (drops the captured graphs).
  * nano_hip_debug_fault (tests): bit 0 = the producers of every hand-off publish with a wrong tag, so each consumer gives up (the
  * give-up path on demand); bit 1 = no re-issue: the call returns NANO_HIP_ERUNTIME.  0 restores both.

@@ -237,7 +237,15 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
     // RoPE partner of float4 f (f + head_dim/8 for the half-split style, the same float4 for adjacent pairs) lives in
     // the same lane, so rmsnorm + RoPE need one DPP reduction and no LDS / barrier; every sub-group does it redundantly.
     constexpr bool REGQK = MODE != 0;
+    // SHARE (round 6; decode modes with several q heads per workgroup = the batched steps): the KVM q heads and the k row are loaded,
+    // normalised and rotated ONCE per workgroup -- sub-group v of wave 0 takes vector v (v < KVM: q head h0 + v; v == KVM: the k row) with
+    // exactly the per-lane arithmetic below (same slots per lane, same DPP tree: same bits), parks it in LDS, and every lane reads the
+    // finished vectors back.  Round 5 had all 32 sub-groups of a workgroup do all KVM + 1 vectors: at KVM = 4 that was 36 of a lane's 52
+    // load instructions and ~500 of a wave's ~2300 VALU instructions in a launch that is VALU bound at 64 sequences (SQ_ACTIVE_INST_VALU
+    // 64 % of the SIMD cycles, profiles/r06_4b_b64_pmc_before.txt).
+    constexpr bool SHARE = REGQK && !FUSE && KVM > 1;
     float4 qv[KVM][QV], kfresh[QV], vfresh[QV];
+    float4 sv[SHARE ? QV : 1], snw[SHARE ? QV : 1];            // SHARE: this sub-group's vector and its norm weight
     float4 qnw[QV], knw[QV], rcs[QV], rsn[QV];
     const __amdgpu_buffer_rsrc_t rq = mkrsrc(a.q + (size_t)b * a.q_dim, a.q_dim * 4u);
     const __amdgpu_buffer_rsrc_t rkr = mkrsrc(fresh_k ? a.kraw + (size_t)b * a.kv_dim : nullptr, fresh_k ? a.kv_dim * 4u : 0u);
@@ -249,7 +257,34 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
     float e0[VR][JJ], e1[VR][JJ], nw0[VR][JJ], nw1[VR][JJ];     // generic path: [vector round][jj]
     float rc[JJ], rs[JJ];
     const bool rope_staged = G ? (a.rope_cur != nullptr && fresh_k) : true;
-    if constexpr (REGQK) {
+    if constexpr (SHARE) {
+        if (wid == 0) {                                         // (wave-uniform: the other waves ask for none of this)
+            const __amdgpu_buffer_rsrc_t rr = mkrsrc(a.rope_cur + (size_t)b * 2 * half, 2 * half * 4u);
+            const bool isq = sub < (uint32_t)KVM, isk = sub == (uint32_t)KVM;
+#pragma unroll
+            for (int q = 0; q < QV; q++) {
+                const uint32_t f = fidx(q);
+                const uint32_t fo = (f * 4u < hd) ? f * 16u : OOB;
+                const float4 xq = bload_f4(rq, (isq && fo != OOB) ? (h0 + sub) * hd * 4u + fo : OOB), xk = bload_f4(rkr, (isk && fo != OOB) ? g * hd * 4u + fo : OOB);
+                sv[q] = isq ? xq : xk;
+                if (MODE == 1) {
+                    const float4 nq = bload_f4(rqn, isq ? fo : OOB), nk = bload_f4(rkn, isk ? fo : OOB);
+                    snw[q] = isq ? nq : nk;
+                    const uint32_t fr = f & (uint32_t)(QV * LPR / 2 - 1);
+                    rcs[q] = bload_f4(rr, fo == OOB ? OOB : fr * 16u);
+                    rsn[q] = bload_f4(rr, fo == OOB ? OOB : (half + fr * 4u) * 4u);
+                } else {
+                    const float c0 = bload_f(rr, fo == OOB ? OOB : (2u * f) * 4u), c1 = bload_f(rr, fo == OOB ? OOB : (2u * f + 1u) * 4u);
+                    const float s0 = bload_f(rr, fo == OOB ? OOB : (half + 2u * f) * 4u), s1 = bload_f(rr, fo == OOB ? OOB : (half + 2u * f + 1u) * 4u);
+                    rcs[q] = make_float4(c0, c1, 0.f, 0.f); rsn[q] = make_float4(s0, s1, 0.f, 0.f);
+                }
+            }
+        }
+        if constexpr (KVH) {                                    // FP16 cache: every lane keeps the fresh v row (it is not in the cache yet)
+#pragma unroll
+            for (int q = 0; q < QV; q++) { const uint32_t f = fidx(q); vfresh[q] = bload_f4(rvr, (f * 4u < hd) ? g * hd * 4u + f * 16u : OOB); }
+        }
+    } else if constexpr (REGQK) {
         const __amdgpu_buffer_rsrc_t rr = mkrsrc(a.rope_cur + (size_t)b * 2 * half, 2 * half * 4u);
 #pragma unroll
         for (int q = 0; q < QV; q++) {
@@ -386,7 +421,65 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
     const uint32_t pos = fixed_range ? (fixed_range - 1) : pos_ld;
     const uint32_t prow = paged ? prow_ld : pos;               // the cache row position pos is written to
     const uint32_t range = fixed_range ? fixed_range : (causal ? (pos + 1) : a.S);
-    if constexpr (REGQK) {
+    if constexpr (SHARE) {
+        if (wid == 0) {
+            const bool isq = sub < (uint32_t)KVM, isk = sub == (uint32_t)KVM;
+            if (MODE == 1) {                     // rmsnorm over the head (infer.c:601-614, 824-835), tree order: the per-lane sums and the DPP tree of the code below
+                float ssq = 0.0f;
+#pragma unroll
+                for (int q = 0; q < QV; q++) { ssq += sv[q].x * sv[q].x; ssq += sv[q].y * sv[q].y; ssq += sv[q].z * sv[q].z; ssq += sv[q].w * sv[q].w; }
+                ssq = group_sum_t<LPR>(ssq); ssq /= (float)hd; ssq += 1e-5f; ssq = 1.0f / sqrtf(ssq);
+#pragma unroll
+                for (int q = 0; q < QV; q++) {
+                    sv[q].x = snw[q].x * (ssq * sv[q].x); sv[q].y = snw[q].y * (ssq * sv[q].y); sv[q].z = snw[q].z * (ssq * sv[q].z); sv[q].w = snw[q].w * (ssq * sv[q].w);
+                }
+#pragma unroll
+                for (int q = 0; q < QV / 2; q++) {   // half-split RoPE (rope_qwen3, infer.c:692-706)
+                    const float4 l = sv[q], h = sv[q + QV / 2], c = rcs[q], sn = rsn[q];
+                    sv[q].x = l.x * c.x - h.x * sn.x; sv[q + QV / 2].x = h.x * c.x + l.x * sn.x;
+                    sv[q].y = l.y * c.y - h.y * sn.y; sv[q + QV / 2].y = h.y * c.y + l.y * sn.y;
+                    sv[q].z = l.z * c.z - h.z * sn.z; sv[q + QV / 2].z = h.z * c.z + l.z * sn.z;
+                    sv[q].w = l.w * c.w - h.w * sn.w; sv[q + QV / 2].w = h.w * c.w + l.w * sn.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < QV; q++) {       // adjacent-pair RoPE (rope, infer.c:681-690)
+                    const float4 t = sv[q], c = rcs[q], sn = rsn[q];
+                    sv[q].x = t.x * c.x - t.y * sn.x; sv[q].y = t.x * sn.x + t.y * c.x;
+                    sv[q].z = t.z * c.y - t.w * sn.y; sv[q].w = t.z * sn.y + t.w * c.y;
+                }
+            }
+            if (isk) {
+#pragma unroll
+                for (int q = 0; q < QV; q++) sv[q] = kv_round<KVH>(sv[q]);                          // what the cache holds
+            }
+            if (isq || isk) {
+                float *dst = isq ? qh + sub * hd4 : kh;
+#pragma unroll
+                for (int q = 0; q < QV; q++) { const uint32_t f = fidx(q); if (f * 4u < hd) *reinterpret_cast<float4 *>(dst + 4u * f) = sv[q]; }
+            }
+            if (isk && split == 0 && first_of_group) {            // the finished k row (FP16 cache: and the v row) -> cache row pos
+                float *krow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(kc)) + (size_t)prow * a.kv_dim * ESZ);
+                float *vrow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(const_cast<float *>(vc)) + (size_t)prow * a.kv_dim * ESZ);
+#pragma unroll
+                for (int q = 0; q < QV; q++) {
+                    const uint32_t f = fidx(q);
+                    if (f * 4u < hd) { kv_store4<KVH>(krow, 4u * f, sv[q]); if (KVH && fresh_v) kv_store4<KVH>(vrow, 4u * f, kv_round<KVH>(vfresh[q])); }
+                }
+            }
+        }
+        if (a.prep_only) return;                                  // batched prefill, pass 1: the k row is all that was wanted
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < QV; q++) {
+            const uint32_t f = fidx(q);
+            const bool ok = f * 4u < hd;
+#pragma unroll
+            for (int m = 0; m < KVM; m++) qv[m][q] = ok ? *reinterpret_cast<const float4 *>(qh + m * hd4 + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            kfresh[q] = ok ? *reinterpret_cast<const float4 *>(kh + 4 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KVH) vfresh[q] = kv_round<KVH>(vfresh[q]);
+        }
+    } else if constexpr (REGQK) {
         if (MODE == 1) {                         // rmsnorm over the head (infer.c:601-614, 824-835), tree order
             float sk = 0.0f, sq[KVM];
 #pragma unroll

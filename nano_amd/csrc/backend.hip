@@ -109,7 +109,6 @@ struct NanoHipModel {
     unsigned long long *hand2 = nullptr;                  // its granule buffer (n_embd entries)
     bool fuse_w2_qkv = false;                             // W2 + the next layer's q|k|v + attention in one launch (measured break-even: opt-in); NANO_FUSE_LAUNCHES bit 3
     unsigned long long *hand3 = nullptr;                  // its granule buffer for x (n_embd entries)
-    bool fuse_quant = true;                               // batched Q80 steps: the activation quantizer runs INSIDE the GEMM launch that consumes it (gemm_q80_inq.h); NANO_FUSE_LAUNCHES bit 4
     uint32_t *tick = nullptr;                             // device words of the in-launch hand-offs: [0] step counter (the epoch), [1] fault word, [2] abort flag, [3] spare
     uint32_t handoff_fallbacks = 0;                       // times a hand-off gave up and the call was re-issued through the plain launches (fusion stays off after the first)
     bool reissue = true;                                  // (nano_hip_debug_fault bit 1 clears it: the give-up then surfaces as NANO_HIP_ERUNTIME)
@@ -448,8 +447,8 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     if (const char *mm = getenv("NANO_MFMA_MIN_NB")) { const uint32_t v = (uint32_t)strtoul(mm, nullptr, 0); if (v >= 2) m->mfma_min_nb = v; }
     // NANO_FUSE_LAUNCHES: bit 0 = q | k | v + attention in one launch, bit 1 = Wo + W1|W3 in one launch where it pays, bit 2 = ... wherever the
     // shapes allow, bit 3 = W2 + the next layer's q | k | v + attention in one launch (two launches per layer: measured break-even, opt-in).
-    // bit 4 = batched Q80 steps quantize their activations inside the GEMM launch (round 6).  Default 19; 0 = the plain launches; same bits in every setting
-    if (const char *fz = getenv("NANO_FUSE_LAUNCHES")) { const uint32_t v = (uint32_t)strtoul(fz, nullptr, 0); m->fuse_qkv_attn = (v & 1u) != 0; m->fuse_wo_w13 = (v & 2u) != 0; m->fuse_wo_w13_always = (v & 4u) != 0; m->fuse_w2_qkv = (v & 8u) != 0; m->fuse_quant = (v & 16u) != 0; }
+    // Default 3; 0 = the five launches per layer; same bits in every setting
+    if (const char *fz = getenv("NANO_FUSE_LAUNCHES")) { const uint32_t v = (uint32_t)strtoul(fz, nullptr, 0); m->fuse_qkv_attn = (v & 1u) != 0; m->fuse_wo_w13 = (v & 2u) != 0; m->fuse_wo_w13_always = (v & 4u) != 0; m->fuse_w2_qkv = (v & 8u) != 0; }
     if (hipMalloc(reinterpret_cast<void **>(&m->tick), 64) != hipSuccess || hipMemset(m->tick, 0, 64) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off words failed"); }
     if (m->d.quant_type == NANO_QUANT_Q80 && m->d.group_size == 64) {
         // granule buffers of the fused one-sequence launches: tag 0 (the memset) is no epoch -- the first step's tick is 1
@@ -554,7 +553,7 @@ static Q80Route route_of(const NanoHipModel *m) {
 }
 static RouteKind kind_of(const NanoHipModel *m, GemvArgs a) { a.ordered = m->strict ? 1u : 0u; a.cus = (uint32_t)m->cus; return route_kind(route_of(m), a); }
 
-// A kernel gave up a bounded wait since the last check (G6's finisher, a fused launch's hand-off, the in-launch activation quantizer):
+// A kernel gave up a bounded wait since the last check (G6's finisher, a fused launch's hand-off):
 // the results of the call are not valid.  Read after a stream synchronisation; the word lives in host-mapped memory, so the check
 // is one load.  dev_err_take() returns the code bits and clears the word (m->last_dev_err keeps them); dev_err_check() turns
 // them into NANO_HIP_ERUNTIME.  Every public entry point that synchronises ends with one of the two (round-5 advice: the
@@ -568,18 +567,18 @@ static uint32_t dev_err_take(NanoHipModel *m) {
     return c;
 }
 static int dev_err_fail(uint32_t c) {
-    FAIL(NANO_HIP_ERUNTIME, "a kernel gave up waiting for its producers (code %u: 1 = G6 tile counter, 2 = in-launch hand-off of a fused launch, 4 = in-launch activation quantizer): the results of this call are not valid", c);
+    FAIL(NANO_HIP_ERUNTIME, "a kernel gave up waiting for its producers (code %u: 1 = G6 tile counter, 2 = in-launch hand-off of a fused launch): the results of this call are not valid", c);
 }
 static int dev_err_check(NanoHipModel *m) {
     const uint32_t c = dev_err_take(m);
     return c ? dev_err_fail(c) : 0;
 }
-// The in-launch hand-offs (fused one-sequence launches, the batched GEMMs' in-launch quantizer) are an optimisation over launches
+// The in-launch hand-offs of the fused one-sequence launches are an optimisation over launches
 // that need nothing from each other but stream order.  When one of them gives up -- the chip shared with other work that kept
 // its producers off the CUs for longer than the bound -- the engine switches them off for this model, drops the graphs that
 // contain them and RE-ISSUES the call through the plain launches, once; the caller sees the results, not an error.
 static bool handoff_recoverable(const NanoHipModel *m, uint32_t code) {
-    return m->reissue && code && (code & ~(NANO_DEVERR_HANDOFF | NANO_DEVERR_QSYNC)) == 0u;
+    return m->reissue && code == NANO_DEVERR_HANDOFF;
 }
 static void drop_graphs(NanoHipModel *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -588,7 +587,6 @@ static void drop_graphs(NanoHipModel *m) {
 static void handoff_fallback(NanoHipModel *m) {
     (void)hipStreamSynchronize(m->st);
     m->fuse_qkv_attn = m->fuse_wo_w13 = m->fuse_wo_w13_always = m->fuse_w2_qkv = false;
-    m->fuse_quant = false;
     drop_graphs(m);
     m->handoff_fallbacks++;
 }
@@ -1415,18 +1413,17 @@ static int decode_greedy_once(NanoHipModel *m, const uint32_t *tokens, const uin
 // ---- the in-launch hand-offs: state, switches, fault injection (tests; tools) ----------------------------------------------------------
 extern "C" int nano_hip_handoff_state(const NanoHipModel *m, uint32_t *fused_mask, uint32_t *fallbacks, uint32_t *last_code) {
     if (!m) FAIL(NANO_HIP_EINVAL, "null model");
-    if (fused_mask) *fused_mask = (m->fuse_qkv_attn ? 1u : 0u) | (m->fuse_wo_w13 ? 2u : 0u) | (m->fuse_wo_w13_always ? 4u : 0u) | (m->fuse_w2_qkv ? 8u : 0u) | (m->fuse_quant ? 16u : 0u);
+    if (fused_mask) *fused_mask = (m->fuse_qkv_attn ? 1u : 0u) | (m->fuse_wo_w13 ? 2u : 0u) | (m->fuse_wo_w13_always ? 4u : 0u) | (m->fuse_w2_qkv ? 8u : 0u);
     if (fallbacks) *fallbacks = m->handoff_fallbacks;
     if (last_code) *last_code = m->last_dev_err;
     return 0;
 }
 extern "C" int nano_hip_set_fusion(NanoHipModel *m, uint32_t mask) {
     if (!m) FAIL(NANO_HIP_EINVAL, "null model");
-    if (mask & ~31u) FAIL(NANO_HIP_EINVAL, "unknown fusion bits 0x%x", mask);
+    if (mask & ~15u) FAIL(NANO_HIP_EINVAL, "unknown fusion bits 0x%x", mask);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->st));
     m->fuse_qkv_attn = (mask & 1u) != 0; m->fuse_wo_w13 = (mask & 2u) != 0; m->fuse_wo_w13_always = (mask & 4u) != 0; m->fuse_w2_qkv = (mask & 8u) != 0;
-    m->fuse_quant = (mask & 16u) != 0;
     drop_graphs(m);                                                        // (graphs carry the launches of the setting they were captured under)
     return 0;
 }

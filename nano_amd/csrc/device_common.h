@@ -53,7 +53,7 @@ template <class T> __device__ __forceinline__ void karg_touch(const T &v) { asm 
 // tick[0] = the step counter, tick[1] = fault word XORed into the PRODUCERS' tag (0; nano_hip_debug_fault sets it so that every
 // hand-off of a step fails: the test of the give-up path), tick[2] = abort flag: set by the first consumer that gives up, polled by
 // the others so that a lost step does not sit out the bound once per launch; cleared by the host.
-constexpr uint32_t NANO_DEVERR_G6_TILE = 1u, NANO_DEVERR_HANDOFF = 2u, NANO_DEVERR_QSYNC = 4u;
+constexpr uint32_t NANO_DEVERR_G6_TILE = 1u, NANO_DEVERR_HANDOFF = 2u;
 struct SlabHand { unsigned long long *buf; uint32_t *tick; uint32_t base[3], layer1; };
 __device__ __forceinline__ uint2 hand_tick(const SlabHand &h) { return *reinterpret_cast<const uint2 *>(h.tick); }
 __device__ __forceinline__ uint32_t hand_ctag(const uint2 t, const SlabHand &h) { return t.x * 128u + h.layer1; }              // what a consumer waits for

@@ -111,14 +111,20 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     };
 
     // ---- the ring: D items of this wave in flight ---------------------------------------------------------------------------------
-    struct Slot { int4 w[8]; float4 s0, s1; i32x4 b[MODE == G6_F ? 8 : 1]; float4 xs; };
+    // MODE F with several token tiles per item (TT > 1; 17..64 tokens): the fragments of this wave's (item, token tile) BLOCKS run through a
+    // register queue of their own -- the next block in flight behind the one being multiplied, across item boundaries (round 6, below);
+    // the slots then hold weights only.  (A three-deep queue measured the same step time -- the blocks come from L2 in ~300 cycles,
+    // TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ -- and its 32 registers make the 3-round variants spill.)
+    constexpr bool STREAM_B = MODE == G6_F && TT > 1;
+    constexpr int QD = 2;
+    struct Slot { int4 w[8]; float4 s0, s1; i32x4 b[(MODE == G6_F && !STREAM_B) ? 8 : 1]; float4 xs; };
     Slot ring[D];
     auto issue = [&](auto J, uint32_t it) {
         constexpr int sl = decltype(J)::value;
         const bool live = it < nitems;
         const uint32_t tl = (it * d.magic_nu) >> 16, rem = it - tl * ipt, u = rem >> tsh, tk = rem & (tts - 1u);
         const TI t = decode(tl);
-        if constexpr (MODE == G6_F) {               // the item's activation fragments FIRST (loads return in issue order)
+        if constexpr (MODE == G6_F && !STREAM_B) {  // the item's activation fragments FIRST (loads return in issue order)
             const uint32_t g0 = u * 8u;
             const bool lvb = live && tk * 16u < nb;  // (spread token tiles: tile tk of this item; serial ones: tile 0 here, the others in consume)
             const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf + ((size_t)tk * ng + g0) * 1024u, lvb ? (ng - g0) * 1024u : 0u);     // groups >= ng: out of range -> 0
@@ -180,8 +186,29 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     // ---- the first items go out.  MODE F: every round that has a slot, right away (its one barrier -- arming the counters -- is behind
     //      it: nothing waits on a wave that the memory pipeline holds up while it issues).  MODE S: ROUND 0 ONLY -- the staging below has a
     //      barrier, and a wave stuck issuing 30 KB into a full memory pipeline keeps the whole workgroup from its first multiply ---------
+    // STREAM_B: block s of this wave = (its round s / TT, token tile s % TT) -> queue slot s % QD.  Every load of the stream is unconditional
+    // (a block of a dead item or of a token tile beyond the batch reads through a zero-sized descriptor: zeros, no memory access) and sits
+    // OUTSIDE the branches around the arithmetic, so the compiler's vmcnt counts stay exact: multiplying block s waits for block s alone.
+    constexpr int NBLK = STREAM_B ? R * TT : 0;
+    i32x4 fq[STREAM_B ? QD : 1][8]; float4 fx[STREAM_B ? QD : 1];
+    auto fissue = [&](auto S) {
+        constexpr int sb_ = decltype(S)::value, qi = sb_ % QD, r = sb_ / TT, t = sb_ % TT;
+        const uint32_t it = wid + (uint32_t)r * NW;
+        const uint32_t tl = (it * d.magic_nu) >> 16, u = it - tl * ipt, g0 = u * 8u;          // (serial token tiles: ipt = nu)
+        const bool lv = it < nitems && (uint32_t)t * 16u < nb;
+        const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf + ((size_t)t * ng + g0) * 1024u, lv ? (ng - g0) * 1024u : 0u);      // groups >= ng: out of range -> 0
+        const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf + ((size_t)t * ng + g0) * 16u, lv ? (ng - g0) * 64u : 0u);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) fq[qi][j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)(lane * 16u + j * 1024u), 0, 0);
+        fx[qi] = bload_f4(rxs, lane < 32u ? lane * 16u : OOB);                      // lanes 0..31: group g0 + l/4, tokens 4 (l%4) .. +3
+    };
     if (tid < d.tpw) cnt[tid] = 0u;
     if constexpr (MODE == G6_F) __syncthreads();
+    if constexpr (STREAM_B) {                                          // block 0, round 0's weights, round 1's weights: in the order they are needed
+        fissue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 0>{}, wid);
+        if constexpr (R > 1) issue(std::integral_constant<int, 1>{}, wid + NW);
+    } else
     g6_static_for<0, (MODE == G6_F ? (R < D ? R : D) : 1)>([&](auto K) { issue(K, wid + (uint32_t)decltype(K)::value * NW); });
     NANO_STAMP(a.stamps, 1, opos0);                                 // the loads of the first round(s) issued
 
@@ -215,64 +242,27 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
         }
         if constexpr (MODE == G6_F) { if (lane < 32u) *reinterpret_cast<float4 *>(xslw + lane * 4u) = ring[sl].xs; }
         if constexpr (first) NANO_STAMP(a.stamps, 3, (float)ring[sl].w[7].x + ring[sl].s1.x);     // this wave's first weights (and scales) arrived
-        // 2. per token tile: eight groups -- A fragment from LDS, one MFMA, products, the unit sum in ascending group order (groups >= ng
-        //    of a row's last unit: zero activation bytes and scales -> products +0.0f); the sum goes to the tile's table
-        i32x4 nb_[MODE == G6_F && TT > 1 ? 8 : 1]; float4 nxs = make_float4(0.f, 0.f, 0.f, 0.f);       // the NEXT token tile's fragments and scales
-        const uint32_t ntt = (nb + 15u) >> 4;
+        // 2. eight groups -- A fragment from LDS, one MFMA, products, the unit sum in ascending group order (groups >= ng of a row's last
+        //    unit: zero activation bytes and scales -> products +0.0f); the sum goes to the tile's table
+        float S[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (uint32_t t = 0; t < (uint32_t)TT; t++) {
-            if constexpr (MODE == G6_F && TT > 1) {
-                if (t > 0u) { if (lane < 32u) *reinterpret_cast<float4 *>(xslw + lane * 4u) = nxs; }
-                if (t + 1u < (uint32_t)TT) {        // token tile t + 1 of this unit: asked for now (unconditional loads; a tile beyond the batch reads through a zero-sized descriptor)
-                    const bool lv = t + 1u < ntt;
-                    const __amdgpu_buffer_rsrc_t rxf = mkrsrc(d.xf + ((size_t)(t + 1u) * ng + g0) * 1024u, lv ? (ng - g0) * 1024u : 0u);
-                    const __amdgpu_buffer_rsrc_t rxs = mkrsrc(d.xsf + ((size_t)(t + 1u) * ng + g0) * 16u, lv ? (ng - g0) * 64u : 0u);
-                    i32x4 tmp[8];
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) tmp[j] = __builtin_amdgcn_raw_buffer_load_b128(rxf, (int)(lane * 16u + j * 1024u), 0, 0);
-                    const float4 txs = bload_f4(rxs, lane < 32u ? lane * 16u : OOB);
-                    // (the loads above are in flight while the MFMAs below read the CURRENT tile's registers)
-                    float S[4];
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) {
-                        const i32x4 fa = *reinterpret_cast<const i32x4 *>(wb_r + j * 64u);
-                        const i32x4 fb = t == 0u ? ring[sl].b[j] : nb_[j];
-                        const float xsc = xslw[j * 16u + m];
-                        const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
-                        const float4 wv = *reinterpret_cast<const float4 *>(wsl_r + j * 16u);
-                        const float p0 = ((float)cv[0] * wv.x) * xsc, p1 = ((float)cv[1] * wv.y) * xsc;      // infer.c:672
-                        const float p2 = ((float)cv[2] * wv.z) * xsc, p3 = ((float)cv[3] * wv.w) * xsc;
-                        if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
-                        else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
-                    }
-                    if constexpr (first) { if (t == 0u) NANO_STAMP(a.stamps, 4, S[3]); }     // ... multiplied (token tile 0)
-                    *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * NT + t) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) nb_[j] = tmp[j];
-                    nxs = txs;
-                    continue;
-                }
+        for (uint32_t j = 0; j < 8; j++) {
+            const i32x4 fa = *reinterpret_cast<const i32x4 *>(wb_r + j * 64u);
+            i32x4 fb; float xsc;
+            if constexpr (MODE == G6_F) { fb = ring[sl].b[j]; xsc = xslw[j * 16u + m]; }
+            else {
+                fb = *reinterpret_cast<const i32x4 *>(xqc + pb_off + (g0 + j) * pb_str);
+                xsc = xs_l[px_off + (g0 + j) * px_str];
             }
-            float S[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) {
-                const i32x4 fa = *reinterpret_cast<const i32x4 *>(wb_r + j * 64u);
-                i32x4 fb; float xsc;
-                if constexpr (MODE == G6_F) { fb = (TT == 1 || t == 0u) ? ring[sl].b[j] : nb_[j]; xsc = xslw[j * 16u + m]; }
-                else {
-                    fb = *reinterpret_cast<const i32x4 *>(xqc + pb_off + (g0 + j) * pb_str);
-                    xsc = xs_l[px_off + (g0 + j) * px_str];
-                }
-                const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
-                const float4 wv = *reinterpret_cast<const float4 *>(wsl_r + j * 16u);
-                const float p0 = ((float)cv[0] * wv.x) * xsc, p1 = ((float)cv[1] * wv.y) * xsc;      // infer.c:672
-                const float p2 = ((float)cv[2] * wv.z) * xsc, p3 = ((float)cv[3] * wv.w) * xsc;
-                if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
-                else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
-            }
-            if constexpr (first && TT == 1) { if (t == 0u) NANO_STAMP(a.stamps, 4, S[3]); }   // ... multiplied
-            *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * NT + (TT == 1 ? tk : t)) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
+            const v4i cv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, v4i{0, 0, 0, 0}, 0, 0, 0);
+            const float4 wv = *reinterpret_cast<const float4 *>(wsl_r + j * 16u);
+            const float p0 = ((float)cv[0] * wv.x) * xsc, p1 = ((float)cv[1] * wv.y) * xsc;      // infer.c:672
+            const float p2 = ((float)cv[2] * wv.z) * xsc, p3 = ((float)cv[3] * wv.w) * xsc;
+            if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
+            else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
         }
+        if constexpr (first) NANO_STAMP(a.stamps, 4, S[3]);            // ... multiplied
+        *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * NT + tk) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
         // 3. arrive
         if (lane == 0u) __hip_atomic_fetch_add(cnt + tl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
@@ -280,6 +270,61 @@ __global__ __launch_bounds__(512, 2) void gemm_q80_g6_kernel(const G6Dev d) {
     // round r's slot is free.  MODES P / S (four slots): LOOK-AHEAD of two rounds -- round r + 2 is requested right before round r is
     // multiplied.  (Round 4 first issued every round that had a slot at once: a wave then sits ~3 us in a full memory pipeline issuing
     // 30 loads while its first item has long landed -- W1|W3's first multiply 6.2 us after entry, profiles/r04_g6_stamps.txt.)
+    if constexpr (STREAM_B) {
+        // Round 6 -- 17..64 tokens.  Round 5 fetched token tile t + 1 of an item while it multiplied tile t: one 8-KB block in flight per wave,
+        // asked for ~0.3 us before it was needed, and every tile waited out the rest of an L2 round trip (W2 of Qwen3-4B at 64 tokens: twelve
+        // blocks per wave, 19.8 us where the weights stream in 4.4; SQ_WAIT_ANY + SQ_WAIT_INST_ANY 72 % of the wave cycles, profiles/
+        // r06_4b_b64_pmc_before.txt).  Now the blocks form ONE stream per wave, the next one in flight behind the one being multiplied across
+        // item boundaries too (64 registers where the slot copies + look-ahead pair took 128), and what the freed registers buy is below:
+        // the item's A fragments and weight scales held in registers over its token tiles, eight matrix instructions back to back.
+        g6_static_for<0, R>([&](auto K) {
+            constexpr int r = decltype(K)::value;
+            const uint32_t it = wid + (uint32_t)r * NW;
+            const bool live = it < nitems;
+            const uint32_t tl = (it * d.magic_nu) >> 16, u = it - tl * ipt;
+            // the item's weight pieces -> transposition buffer, its weight scales -> LDS (a dead item's registers hold zeros)
+#pragma unroll
+            for (int r8 = 0; r8 < 8; r8++) *reinterpret_cast<int4 *>(wb_w + (size_t)(2 * r8) * G6_PITCH) = ring[r % D].w[r8];
+            if (lane < 16u) {
+                wsl_w[0] = ring[r % D].s0.x; wsl_w[16] = ring[r % D].s0.y; wsl_w[32] = ring[r % D].s0.z; wsl_w[48] = ring[r % D].s0.w;
+                wsl_w[8] = ring[r % D].s1.x; wsl_w[24] = ring[r % D].s1.y; wsl_w[40] = ring[r % D].s1.z; wsl_w[56] = ring[r % D].s1.w;
+            }
+            if constexpr (r == 0) NANO_STAMP(a.stamps, 3, (float)ring[0].w[7].x + ring[0].s1.x);     // this wave's first weights (and scales) arrived
+            // the item's A fragments and weight scales are the same for every token tile: read from LDS ONCE per item (round 5 re-read them per
+            // tile: 16 KB of LDS reads and their latency in front of every tile's first matrix instruction; with two waves per SIMD nothing
+            // covered it -- 3600 cycles per tile where the instructions need ~900, profiles/r06_4b_b64_pmc_before.txt)
+            i32x4 fa[8]; float4 wv[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) fa[j] = *reinterpret_cast<const i32x4 *>(wb_r + j * 64u);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) wv[j] = *reinterpret_cast<const float4 *>(wsl_r + j * 16u);
+            g6_static_for<0, TT>([&](auto TK) {
+                constexpr int t = decltype(TK)::value, sblk = r * TT + t, qi = sblk % QD;
+                if (lane < 32u) *reinterpret_cast<float4 *>(xslw + lane * 4u) = fx[qi];          // this block's activation scales [8 groups][16 tokens]
+                if constexpr (sblk + QD - 1 < NBLK) fissue(std::integral_constant<int, sblk + QD - 1>{});     // the next block: into the slot block sblk - 1 left
+                if (live && (uint32_t)t * 16u < nb) {                                              // (wave-uniform; no load inside)
+                    float xsc[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) xsc[j] = xslw[j * 16u + m];
+                    v4i cv[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) cv[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[j], fq[qi][j], v4i{0, 0, 0, 0}, 0, 0, 0);     // eight matrix instructions back to back
+                    float S[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) {
+                        const float p0 = ((float)cv[j][0] * wv[j].x) * xsc[j], p1 = ((float)cv[j][1] * wv[j].y) * xsc[j];      // infer.c:672
+                        const float p2 = ((float)cv[j][2] * wv[j].z) * xsc[j], p3 = ((float)cv[j][3] * wv[j].w) * xsc[j];
+                        if (j == 0) { S[0] = p0; S[1] = p1; S[2] = p2; S[3] = p3; }
+                        else { S[0] += p0; S[1] += p1; S[2] += p2; S[3] += p3; }
+                    }
+                    if constexpr (sblk == 0) NANO_STAMP(a.stamps, 4, S[3]);                          // ... multiplied (token tile 0)
+                    *reinterpret_cast<float4 *>(T + (((size_t)tl * nu + u) * NT + (uint32_t)t) * 256u + lane * 4u) = make_float4(S[0], S[1], S[2], S[3]);
+                }
+            });
+            if (live && lane == 0u) __hip_atomic_fetch_add(cnt + tl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (r + D < R) issue(std::integral_constant<int, r % D>{}, it + (uint32_t)D * NW);
+        });
+    } else
     g6_static_for<0, R>([&](auto K) {
         constexpr int r = decltype(K)::value;
         const uint32_t it = wid + (uint32_t)r * NW;

@@ -48,7 +48,7 @@ struct G7Dev {
     uint32_t hh;                        // live rows per half tile (1..8)
     uint32_t ntiles, tc0, tc1;          // tiles; tiles up to the end of segment 0 / 1
     uint32_t grid, tpw, full;           // workgroups; tiles per workgroup (max); workgroups that own tpw tiles (the others: tpw - 1)
-    uint32_t nk, ttl, nsa;              // steps (256 B of a row each); live token tiles; weight-ring stages
+    uint32_t nk, ttl, nsa, pre;         // steps (256 B of a row each); live token tiles; weight-ring stages; steps asked for before the first barrier
     uint32_t a_stage, a_ws;             // bytes of a weight stage (tiles' weights at 0, their scales at a_ws)
     uint32_t b_base, b_stage, b_xs;     // the two fragment stages: LDS offset of the first, bytes of one, offset of the activation scales inside
 };
@@ -169,13 +169,20 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
         // read); after it step k + nsa - 1 may go out.  `mine` = steps THIS loader has issued; its step k is its (k / 2)-th.
         const uint32_t la = wid - G7_NCW;
         uint32_t mine = 0;
-        const uint32_t pre = nsa - 1u < nk ? nsa - 1u : nk;
+        // Round 6: only d.pre steps (one per loader) go out before the first barrier -- a DMA instruction costs ~150 cycles of issue, and
+        // the consumers' first multiply waited for the loaders to finish ISSUING nsa - 1 steps (Qwen3-4B's W1|W3 at 64 tokens: "first weights
+        // land" 4.8 us after entry, profiles/r06_stamps_wide_b64_before.txt); the ring then fills two steps per barrier until it is nsa - 1 deep.
+        const uint32_t pre = d.pre;
         for (uint32_t j = 0; j < pre; j++) if ((j & 1u) == la) { issue(j, smem + (j % nsa) * d.a_stage); mine++; }
         uint32_t jn = pre, stn = pre % nsa;                                // the next step to go out and its stage
         for (uint32_t k = 0; k < nk; k++) {
             if ((k & 1u) == la) g7_wait_vm((mine - 1u - (k >> 1)) * ips);      // step k has landed (this loader's later steps may still fly)
             g7_loader_barrier();
-            if (jn < nk) { if ((jn & 1u) == la) { issue(jn, smem + stn * d.a_stage); mine++; } jn++; stn = stn + 1u == nsa ? 0u : stn + 1u; }
+            // stage (k - 1) % nsa is free again: steps up to k + nsa - 1 may be in the ring
+            for (uint32_t c = 0; c < 2u && jn < nk && jn < k + nsa; c++) {
+                if ((jn & 1u) == la) { issue(jn, smem + stn * d.a_stage); mine++; }
+                jn++; stn = stn + 1u == nsa ? 0u : stn + 1u;
+            }
         }
         return;
     }
@@ -435,6 +442,8 @@ hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st) {
     d.hh = p.hh; d.ntiles = p.ntiles; d.tc0 = p.tc0; d.tc1 = p.tc1; d.grid = p.grid; d.tpw = p.tpw;
     d.full = p.ntiles - (p.tpw - 1u) * p.grid;
     d.nk = p.nk; d.ttl = p.ttl; d.nsa = p.nsa;
+    d.pre = p.nsa - 1u < p.nk ? p.nsa - 1u : p.nk;
+    if (d.pre > 3u) d.pre = 3u;         // (2 / 3 / all nsa - 1 before the first barrier: 3.249 / 3.248 / 3.279 ms per 64-sequence Qwen3-4B step, one box, two runs each)
     d.a_stage = p.a_stage; d.a_ws = p.a_ws; d.b_base = p.b_base; d.b_stage = p.b_stage; d.b_xs = p.b_xs;
 #define G7_GO(TP_, PP_) do { return p.ms ? g7_launch_t<TP_, PP_, true>(d, p.lds, st) : g7_launch_t<TP_, PP_, false>(d, p.lds, st); } while (0)
 #define G7_TP(PP_) do { if (p.tp == 1u) G7_GO(1, PP_); if (p.tp == 2u) G7_GO(2, PP_); if (p.tp == 3u) G7_GO(3, PP_); if (p.tp == 5u) G7_GO(5, PP_); G7_GO(8, PP_); } while (0)

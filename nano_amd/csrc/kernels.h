@@ -57,8 +57,7 @@ struct GemvArgs {
     unsigned long long *stamps;   // measurement builds only (NANO_STAMPS): per-workgroup phase stamps, or nullptr
 };
 
-// Bounded waits inside kernels (G6's finisher on its tile counter, the fused launches' consumers on their granules, the batched GEMMs on the
-// in-launch activation quantizer) must not hang the device; a wait that gives up ORs its code (device_common.h NANO_DEVERR_*) into the model's
+// Bounded waits inside kernels (G6's finisher on its tile counter, the fused launches' consumers on their granules) must not hang the device; a wait that gives up ORs its code (device_common.h NANO_DEVERR_*) into the model's
 // sticky error word: the next synchronising C-ABI call re-issues the work through the plain launches (hand-offs) or returns NANO_HIP_ERUNTIME
 // instead of results computed from whatever was there (round-4 / round-5 advice).
 

@@ -44,6 +44,7 @@ def test_reference_nano_cli_generates(tmp_path):
     from nano_amd import modelfile as mf
     hard_coded = "/home/bd4sur/ai/_model/Nano/qwen3-0b6-q4ks.bin"
     cli = need("nano_cli")
+    env = ENV
     try:
         os.makedirs(os.path.dirname(hard_coded), exist_ok=True)
     except PermissionError:
@@ -57,6 +58,7 @@ def test_reference_nano_cli_generates(tmp_path):
         cli = str(tmp_path / "nano_cli")
         open(cli, "wb").write(blob.replace(hard_coded.encode(), alt.encode()))
         os.chmod(cli, 0o755)
+        env = dict(ENV, LD_LIBRARY_PATH=os.path.join(ROOT, "nano_amd", "lib") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))   # (the copy left its $ORIGIN rpath behind)
         hard_coded = alt
         os.makedirs(os.path.dirname(hard_coded), exist_ok=True)
     spec = dataclasses.replace(mf.preset("tiny-nano", "q80", group_size=32), block_size=2048)   # the CLI asks for max_seq_len 2048
@@ -73,7 +75,7 @@ def test_reference_nano_cli_generates(tmp_path):
     out_path = tmp_path / "cli.out"
     try:
         with open(out_path, "wb") as out:
-            p = subprocess.Popen([cli], env=ENV, stdin=subprocess.PIPE, stdout=out, stderr=subprocess.STDOUT)
+            p = subprocess.Popen([cli], env=env, stdin=subprocess.PIPE, stdout=out, stderr=subprocess.STDOUT)
             p.stdin.write(prompt.encode("utf-8")); p.stdin.close()       # EOF submits the prompt (and later picks random default prompts)
             deadline = time.time() + 90
             text = ""
