@@ -213,10 +213,6 @@ int nano_hip_time_classifier_in_step(NanoHipModel *m, uint32_t batch, uint32_t p
                                      uint64_t *bytes_per_launch, float *ms_empty_pair);
 /* Same for one whole decode step (graph replay), `iters` replays between two events. */
 int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, float *ms_per_step);
-/* The same with some kernel kinds left out of the step (mask bits: 1 QKV GEMV, 2 attention, 4 Wo GEMV, 8 W1|W3 GEMV,
- * 16 W2 GEMV, 32 classifier, 64 arg-max, 128 embedding): step(0) - step(mask) is the in-situ cost of those launches
- * inside the dependent chain (bench.py's per-kernel roofline table).  Measurement only. */
-int nano_hip_time_step_masked(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, uint32_t skip_mask, float *ms_per_step);
 /* Device read-bandwidth microbenchmark: streams `bytes` of device memory `iters` times; GB/s out. */
 int nano_hip_membw(int device, size_t bytes, uint32_t iters, float *gbps);
 

@@ -87,7 +87,6 @@ def lib() -> C.CDLL:
     fn("nano_hip_time_classifier", C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64)])
     fn("nano_hip_time_classifier_in_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_float)])
     fn("nano_hip_time_step", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)])
-    fn("nano_hip_time_step_masked", C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)])
     fn("nano_hip_membw", C.c_int, [C.c_int, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)])
     fn("nano_hip_read_state", C.c_int, [vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, f32p, C.c_size_t])
     fn("nano_hip_op_rmsnorm", C.c_int, [C.c_int, f32p, f32p, f32p, C.c_uint32])
@@ -271,12 +270,6 @@ class DeviceModel:
     def time_step(self, batch: int = 1, pos: int = 0, iters: int = 20) -> float:
         ms = C.c_float(0)
         check(lib().nano_hip_time_step(self.h, batch, pos, iters, C.byref(ms)))
-        return float(ms.value)
-
-    def time_step_masked(self, batch: int, pos: int, iters: int, skip_mask: int) -> float:
-        """ms per step with the kernel kinds of `skip_mask` left out (1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed)."""
-        ms = C.c_float(0)
-        check(lib().nano_hip_time_step_masked(self.h, batch, pos, iters, skip_mask, C.byref(ms)))
         return float(ms.value)
 
     def kv_release(self, slot: int):

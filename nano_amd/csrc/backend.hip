@@ -115,7 +115,6 @@ struct NanoHipModel {
     uint32_t last_dev_err = 0;                            // the code bits of the last give-up (diagnostics)
     std::vector<uint32_t> fw_tokens, fw_pos; uint32_t fw_causal = 0; int fw_logits = 0, fw_argmax = 0;   // the step queued by nano_hip_forward_begin (for its re-issue)
     struct SamplerState *smp = nullptr;                   // device-side sampler scratch, created on first use
-    uint32_t skip_mask = 0;       // nano_hip_time_step_masked (measurement only): drop kernels from the step: 1 qkv 2 attn 4 wo 8 w13 16 w2 32 cls 64 argmax 128 embed
     uint32_t rope_rows = 0;       // rows of the RoPE tables on the device: positions >= rope_rows are rejected
     uint32_t pending_batch = 0;   // sequences of the step queued by nano_hip_forward_begin
     bool kv_half = false;         // opt-in FP16 KV cache: rows hold __half, v passes through vraw like k through kraw
@@ -680,8 +679,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     const size_t plane = (size_t)m->kv_pages * 64 * KD;                      // elements of one layer plane of the pool
     if (m->kv_paged) { ea.pt_rows = pt_base; ea.kvrow = m->kvrow; ea.pt_bstride = pt_bstride; ea.pt_entries = m->pt_stride; }
     ea.tick = m->tick;                                                       // the step's first kernel opens a new hand-off epoch
-    const uint32_t skip = m->skip_mask;
-    if (!(skip & 128) && !(m->skip_embed && mode == MODE_LOOP) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
+    if (!(m->skip_embed && mode == MODE_LOOP) && (e = launch_embed(ea, nb, m->st)) != hipSuccess) return e;
 
     // the q | k | v launch and the attention launch of layer l (arguments only)
     auto build_qkv_attn = [&](const uint32_t l, GemvArgs &qa, AttnArgs &a) {
@@ -721,7 +719,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         // attention workgroups start with the projection's, ask for their K / V rows and take q / k / v from it as write-through granules
         // tagged with the epoch of this step and layer (tick * 128 + l + 1: at most 126 layers).
         auto qkv_attn_fusable = [&](const GemvArgs &qa_, const AttnArgs &a_) {
-            return m->fuse_qkv_attn && m->hand && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && L <= 126u && !(skip & (3u | 128u)) &&
+            return m->fuse_qkv_attn && m->hand && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && L <= 126u &&
                    d.quant_type == NANO_QUANT_Q80 && kind_of(m, qa_) == ROUTE_GEMV && qkv_attn_fused_supports(qa_, a_);
         };
         const bool fused = qkv_attn_fusable(qa, a);
@@ -731,7 +729,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             if ((e = launch_qkv_attn_fused(qa, a, m->hand, m->tick, l + 1u, m->st)) != hipSuccess) return e;
         } else {
             qa.stamps = next_stamps(m, 1);
-            if (!(skip & 1) && (e = gemv(m, qa)) != hipSuccess) return e;
+            if ((e = gemv(m, qa)) != hipSuccess) return e;
             if (m->lora_on) {       // q / k / v += (alpha/rank) B (A xb)   reference infer.c:792-808
                 const size_t la = (size_t)l * m->lora_rank * E, lbq = (size_t)l * E * m->lora_rank, lbk = (size_t)l * KD * m->lora_rank;
                 LoraArgs la_{};
@@ -761,7 +759,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 a.prep_only = 0;
             }
             a.stamps = next_stamps(m, 2);
-            if (!(skip & 2) && (e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
+            if ((e = launch_attention(a, nb, m->st)) != hipSuccess) return e;
         }
         {
             if (pf_combine && (e = launch_attn_combine_tokens(m->attn_part, m->attn_ml, m->xba, d.n_head, m->hd, nsplit, nb, wo_frag ? m->gq : nullptr, wo_frag ? m->gxs : nullptr, m->st)) != hipSuccess) return e;
@@ -779,7 +777,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 a.resid_add = m->lora_o1; a.resid_add_bstride = E;
             }
             if (nsplit > 1 && !pf_combine) { a.attn_part = m->attn_part; a.attn_ml = m->attn_ml; a.attn_nsplit = nsplit; a.attn_n_head = d.n_head; a.attn_hd = m->hd; }
-            a.frag_ready = (wo_frag && !(skip & 2)) ? 1u : 0u;
+            a.frag_ready = wo_frag ? 1u : 0u;
             // hb = silu(W1 . xn) * (W3 . xn)   reference infer.c:914-944
             GemvArgs b{};
             b.nseg = 2; b.seg[0] = mkseg(m->W[W1][l], m->hb, H, H); b.seg[1] = mkseg(m->W[W3][l], m->hb, H, H);
@@ -793,7 +791,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             // positions 20..39, 1789-1795 vs 1750-1753 over 31..510); on Qwen3-4B's it LOSES (1.531 vs 1.473 ms per step: 1024-thread workgroups
             // that spill, polls queued behind their own 207 KB of weight loads).  So: not on the wide matrices; NANO_FUSE_LAUNCHES bit 2 (value 4)
             // forces it wherever the shapes allow (the parity test; the measurement).
-            const bool fuse13_shape = m->hand2 && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && L <= 126u && !(skip & (12u | 128u)) &&
+            const bool fuse13_shape = m->hand2 && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && L <= 126u &&
                                       d.quant_type == NANO_QUANT_Q80 && kind_of(m, a) == ROUTE_GEMV && kind_of(m, b) == ROUTE_GEMV && wo_w13_fused_supports(a, b);
             const bool fuse13 = fuse13_shape && (m->fuse_wo_w13_always || (m->fuse_wo_w13 && !route_is_wide(b)));
             if (fuse13) {
@@ -801,9 +799,9 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                 wo13_done = true;
             } else {
                 a.stamps = next_stamps(m, 3);
-                if (!(skip & 4) && (e = gemv(m, a)) != hipSuccess) return e;
+                if ((e = gemv(m, a)) != hipSuccess) return e;
                 b.stamps = next_stamps(m, 4);
-                if (!(skip & 8) && (e = gemv(m, b)) != hipSuccess) return e;
+                if ((e = gemv(m, b)) != hipSuccess) return e;
             }
         }
         (void)wo13_done;
@@ -814,7 +812,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             // W2 of this layer + q | k | v + attention of the NEXT one in ONE launch (gemv_q80_impl.h w2_qkv_attn_fused_kernel): the residual stream
             // reaches the next layer's projection as granules of the same launch, q / k / v its attention workgroups as before
             bool tripled = false;
-            if (m->fuse_w2_qkv && m->hand3 && l + 1u < L && !(skip & 16u)) {
+            if (m->fuse_w2_qkv && m->hand3 && l + 1u < L) {
                 GemvArgs qn{}; AttnArgs an{};
                 build_qkv_attn(l + 1u, qn, an);
                 a.ordered = 0; a.cus = (uint32_t)m->cus; a.err = m->dev_err;
@@ -825,7 +823,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             }
             if (!tripled) {
                 a.stamps = next_stamps(m, 5);
-                if (!(skip & 16) && (e = gemv(m, a)) != hipSuccess) return e;
+                if ((e = gemv(m, a)) != hipSuccess) return e;
             }
         }
     }
@@ -841,7 +839,7 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
     }
     if (probe_ext) { g_q80_probe_start = m->ev0; g_q80_probe_stop = m->ev1; }
     else if (m->probe_cls && (e = hipEventRecord(m->ev0, m->st)) != hipSuccess) return e;
-    if (!(skip & 32) && (e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;
+    if ((e = enqueue_classifier(m, nb, sample ? &ntiles : nullptr)) != hipSuccess) return e;
     g_q80_probe_start = g_q80_probe_stop = nullptr;
     if (m->probe_cls) {
         if (!probe_ext && (e = hipEventRecord(m->ev1, m->st)) != hipSuccess) return e;
@@ -853,9 +851,9 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
                        ntiles ? m->tile_max : nullptr, ntiles };
         if (mode == MODE_LOOP) {
             aa.tokens = m->tokens; aa.trace = m->trace;
-            if (!m->pf && !(skip & (64 | 128))) { aa.emb = ea; aa.rope_rows = m->rope_rows; }      // ... and embeds the token it picked for the next step
+            if (!m->pf) { aa.emb = ea; aa.rope_rows = m->rope_rows; }      // ... and embeds the token it picked for the next step
         }
-        if (!(skip & 64) && (e = launch_argmax(aa, nb, m->st)) != hipSuccess) return e;
+        if ((e = launch_argmax(aa, nb, m->st)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -1019,7 +1017,7 @@ static int run_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal, uint32_t m
     constexpr bool stamps_graph = false;
 #endif
     if (!m->use_graph || (m->stamps_on && !stamps_graph)) { HIP_TRY(enqueue_step(m, nb, is_causal, mode, range_hint)); m->nsplit = xba_nsplit(m, nb, range_hint); return 0; }
-    const uint64_t key = ((uint64_t)(m->skip_mask & 0xffu) << 52) | ((uint64_t)(m->stamps_on ? 1 : 0) << 50) | ((uint64_t)((m->skip_embed && mode == MODE_LOOP) ? 1 : 0) << 49) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) |
+    const uint64_t key = ((uint64_t)(m->stamps_on ? 1 : 0) << 50) | ((uint64_t)((m->skip_embed && mode == MODE_LOOP) ? 1 : 0) << 49) | ((uint64_t)(m->lora_on ? 1 : 0) << 48) |
                          ((uint64_t)range_hint << 16) | ((uint64_t)nb << 8) | ((uint64_t)is_causal << 4) | mode;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
@@ -1322,7 +1320,7 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
         if (range_hint > m->S) range_hint = m->S;
         m->pf = true; m->pf_slot = slot;
         hipError_t e = hipSuccess;
-        if (m->use_graph && nb == chunk_max && chunk_max == 64u && !m->skip_mask) {
+        if (m->use_graph && nb == chunk_max && chunk_max == 64u) {
             // a full 64-token chunk recurs in every long prompt: one HIP graph per (KV slot, range bucket) -- positions and
             // tokens are device data, the slot's cache addresses are baked into the nodes.  Other chunk lengths run eagerly
             // (a capture costs more than the ~300 launches it would save once).
@@ -1512,18 +1510,6 @@ extern "C" int nano_hip_time_step(NanoHipModel *m, uint32_t batch, uint32_t pos,
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
     if (ms_per_step) *ms_per_step = ms / iters;
     return dev_err_check(m);                                             // (a step whose kernels gave up is no measurement)
-}
-
-// Measurement: the step with some kernel kinds left out (mask bits: 1 QKV GEMV, 2 attention, 4 Wo GEMV, 8 W1|W3 GEMV,
-// 16 W2 GEMV, 32 classifier, 64 arg-max, 128 embedding).  step(0) - step(mask) = what those launches cost where they
-// run: inside the dependent chain of a graph replay.  The results of a masked step are meaningless.
-extern "C" int nano_hip_time_step_masked(NanoHipModel *m, uint32_t batch, uint32_t pos, uint32_t iters, uint32_t skip_mask, float *ms_per_step) {
-    if (!m) FAIL(NANO_HIP_EINVAL, "null model");
-    const uint32_t keep = m->skip_mask;
-    m->skip_mask = skip_mask & 0xffu;
-    const int rc = nano_hip_time_step(m, batch, pos, iters, ms_per_step);
-    m->skip_mask = keep;
-    return rc;
 }
 
 extern "C" int nano_hip_membw(int device, size_t bytes, uint32_t iters, float *gbps) {

@@ -429,6 +429,18 @@ __global__ __launch_bounds__(64) void samp_wide_cut_kernel(const SampleArgs a) {
     }
     __syncthreads();
     const uint32_t ncov = cur < nchw ? cur : nchw;                   // s_bound[0 .. ncov) are exact
+    if (ncov == 0u) {
+        // top_p below zero: the loop above never ran (0 > top_p) and there is no boundary to read (round-5 advice: s_bound[ncov - 1] was an
+        // out-of-bounds LDS read).  The reference's cut (infer.c:1078-1081) stops at the FIRST entry -- its probability already exceeds
+        // top_p -- and the draw over that one entry returns it (infer.c:1096-1108).
+        if (lane == 0) {
+            a.res->token = 0xffffffffu - (uint32_t)a.wide_out[0];
+            a.res->status = NANO_SAMPLE_OK;
+            a.res->nucleus = 1u;
+            for (uint32_t i = 0; i < 6; i++) a.res->top[i] = i < n0 ? 0xffffffffu - (uint32_t)a.wide_out[i] : 0u;
+        }
+        return;
+    }
     auto first_chunk_above = [&](float thr, uint32_t upto) {         // first c < upto with the sum behind chunk c above thr, or upto
         for (uint32_t c0 = 0; c0 < upto; c0 += 64) {
             const uint32_t c = c0 + lane;

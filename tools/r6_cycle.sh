@@ -84,6 +84,18 @@ mem64)
   pmc 4b_b64_tcp "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" --model qwen3-4b --batch 64 --steps 6
   pmc 4b_b64_tcc "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum" --model qwen3-4b --batch 64 --steps 6
   pmc 4b_b64_ta "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" --model qwen3-4b --batch 64 --steps 6 ;;
+line)  # the driver's line, whole (counter pass + kernel trace table included)
+  ( unset NANO_BENCH_NO_TRAFFIC; timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err ); tail -2 $O/bench_line.err
+  python3 - $O/bench_line.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
+print("value", d["value"], "ms", d["ms_per_step"], "frac", r["frac"], "traffic", r["traffic"], "x", r["traffic_over_algorithmic"], "peak_measured", r["peak_measured"])
+print("dominant", {k: v for k, v in (r["dominant_kernel"] or {}).items() if k not in ("how", "kernel")})
+print("best", {k: v for k, v in (r["best_kernel"] or {}).items() if k not in ("how",)})
+for k in (r["kernels"] or [])[:9]: print("  ", k)
+print("cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("cores"))
+PY
+  ;;
 head2l) for r in 1 2 3; do NANO_FUSE_LAUNCHES=11 bench head_two_launches_$r --steps 20 --warmup 5 --no-kernel-table; bench head_default_$r --steps 20 --warmup 5 --no-kernel-table; done ;;
 *) echo "unknown mode $mode";;
 esac
