@@ -40,7 +40,8 @@ constexpr uint32_t G7_NLA = 2;                      // weight loader waves (step
 constexpr uint32_t G7_NW = G7_NCW + G7_NLA;         // 16 waves: four per SIMD (<= 128 registers each)
 constexpr uint32_t G7_MAXNSA = 32;
 constexpr uint32_t G7_LDS = 160u * 1024u;
-constexpr int G7_BD = 3;                            // steps of activation fragments a consumer wave keeps in flight (registers)
+constexpr int G7_BD = 2;                            // steps of activation fragments a consumer wave keeps in flight (registers): asked for one whole step (>= 0.6 us: an
+                                                    // L2 round trip is ~0.15 us) before they are parked; 2 = the steps of a unit, so slot and unit phase unroll together
 
 struct G7Dev {
     GemvDev g;                          // segments, n, ng, epi, nb, pos
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
     }
     // ---- the activation fragments: the step's 1-KB chunks -- c = 4 tt + j: token tile tt, group j of the step; c = 4 ttl: the step's
     //      activation scales (256 B per token tile) -- are fetched and parked by wave c % 14 (<= two chunks per wave).  A chunk sits in
-    //      registers for G7_BD steps: asked for at step k - 2, parked in LDS stage (k + 1) % 2 at step k, multiplied at step k + 1.
+    //      registers for G7_BD steps: asked for at step k - 1, parked in LDS stage (k + 1) % 2 at step k, multiplied at step k + 1.
     // The step loop below has NO branch around a load or an LDS store (a chunk that does not exist is read through an out-of-range offset
     // -- zeros, no memory access -- and parked in a dummy kilobyte): every s_waitcnt the compiler places is then the exact count (the
     // younger steps stay in flight), where a merge point made it wait for everything (the first build: vmcnt(0)).
@@ -253,15 +254,20 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
         *reinterpret_cast<i32x4 *>(smem + (c_dst[1] != 0xffffffffu ? bs + c_dst[1] : dummy)) = breg[sl][1];
     };
     // one step of this wave's pairs: FIRST = the step opens a unit (its group 0 starts the unit sum)
-    auto step = [&](const bool first, const unsigned char *st, const unsigned char *bs) {
+    // FIRST (compile time): the step opens a unit.  Round 6: two fragment slots instead of three, so that the step loop unrolls over one unit
+    // and neither the slot nor "does this step open a unit" is a run-time select (round 5: 20 v_cndmask + 16 v_mov among a step's 142 VALU
+    // instructions in a kernel whose consumers are VALU bound -- SQ_ACTIVE_INST_VALU 45 % of the SIMD cycles, profiles/
+    // r06_4b_b64_pmc_before.txt), and the weight scales are read as the (row r, row r + 1) pairs the packed products take.
+    auto step = [&](auto FIRST, const unsigned char *st, const unsigned char *bs) {
+        constexpr bool first = decltype(FIRST)::value;
         const unsigned char *A = st + wtile * 4096u;
         const float *WS = reinterpret_cast<const float *>(st + d.a_ws + wtile * 256u) + kq * 16u;              // rows 4 kq .. + 3: [row][4 groups]
         i32x4 fa[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) fa[j] = *reinterpret_cast<const i32x4 *>(A + a_off[j]);
-        const float4 w0 = *reinterpret_cast<const float4 *>(WS), w1 = *reinterpret_cast<const float4 *>(WS + 4);
-        const float4 w2 = *reinterpret_cast<const float4 *>(WS + 8), w3 = *reinterpret_cast<const float4 *>(WS + 12);
-        const float wr[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}, {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
+        g7f2 w01[4], w23[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { w01[j] = g7f2{WS[j], WS[4 + j]}; w23[j] = g7f2{WS[8 + j], WS[12 + j]}; }      // (ds_read2_b32: the pair lands in adjacent registers)
 #pragma unroll
         for (int i = 0; i < PP; i++) {                                 // per token tile: 4 fragment reads, 4 matrix instructions back to back, then the VALU work
             const unsigned char *B = bs + (tt0 + (uint32_t)i) * 4096u + lane * 16u;
@@ -280,20 +286,20 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const g7f2 c01 = {(float)cv[j][0], (float)cv[j][1]}, c23 = {(float)cv[j][2], (float)cv[j][3]};
-                const g7f2 w01 = {wr[0][j], wr[1][j]}, w23 = {wr[2][j], wr[3][j]};
                 const g7f2 x2 = {xsc[j], xsc[j]};
-                const g7f2 p01 = (c01 * w01) * x2, p23 = (c23 * w23) * x2;
-                if (j == 0) { S01[i] = first ? p01 : S01[i] + p01; S23[i] = first ? p23 : S23[i] + p23; }
+                const g7f2 p01 = (c01 * w01[j]) * x2, p23 = (c23 * w23[j]) * x2;
+                if (first && j == 0) { S01[i] = p01; S23[i] = p23; }
                 else { S01[i] += p01; S23[i] += p23; }
             }
         }
     };
-    auto fold = [&](uint32_t u) {
+    auto fold = [&](auto FIRSTU) {                                     // units ascending; the first unit is the row's starting value (not 0 + S_0: -0.0)
+        constexpr bool firstu = decltype(FIRSTU)::value;
 #pragma unroll
-        for (int i = 0; i < PP; i++) {                                                              // units ascending
+        for (int i = 0; i < PP; i++) {
             const float sv_[4] = {S01[i].x, S01[i].y, S23[i].x, S23[i].y};
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[i][r] = u == 0u ? sv_[r] : acc[i][r] + sv_[r];
+            for (int r = 0; r < 4; r++) acc[i][r] = firstu ? sv_[r] : acc[i][r] + sv_[r];
         }
     };
     // prologue: the first G7_BD steps' fragments are asked for, step 0's parked (behind the first barrier everyone may read them)
@@ -301,23 +307,26 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
     b_park(std::integral_constant<int, 0>{}, 0u);
     NANO_STAMP(a.stamps, 1, breg[0][0].x);                          // prologue done: step 0's fragments arrived and are parked
     uint32_t sta = 0;                                                  // weight stage of the current step
-    auto one_step = [&](auto SI, uint32_t k) {                         // step k, k % G7_BD == SI
+    auto one_step = [&](auto SI, auto FIRST, uint32_t k) {             // step k: fragment slot k % G7_BD == SI, FIRST = k is even
         constexpr int si = decltype(SI)::value;
         __syncthreads();                                               // weights of step k landed (the loaders), fragments of step k parked; everyone is done with step k - 1
         if (k == 0u) NANO_STAMP(a.stamps, 2, sta);                     // the first weights have landed
         b_park(std::integral_constant<int, (si + 1) % G7_BD>{}, k + 1u);       // stage (k + 1) % 2 was last read at step k - 1
         b_issue(SI, k + (uint32_t)G7_BD);                              // slot si was parked at step k - 1
-        if (active) step((k & 1u) == 0u, smem + sta * d.a_stage, smem + d.b_base + (k & 1u) * d.b_stage);
+        if (active) step(FIRST, smem + sta * d.a_stage, smem + d.b_base + (k & 1u) * d.b_stage);
         sta = sta + 1u == nsa ? 0u : sta + 1u;
         if (k == 0u) NANO_STAMP(a.stamps, 3, S01[0].x);                 // step 0 multiplied
     };
-    uint32_t k4 = 0;
-    for (; k4 + (uint32_t)G7_BD <= nk; k4 += (uint32_t)G7_BD)          // whole rounds of G7_BD steps: straight-line code
-        g7_static_for<0, G7_BD>([&](auto SI) { const uint32_t k = k4 + (uint32_t)decltype(SI)::value; one_step(SI, k); if ((k & 1u) || k + 1u == nk) fold(k >> 1); });
-    g7_static_for<0, G7_BD - 1>([&](auto SI) {                         // the last nk % G7_BD steps
-        const uint32_t k = k4 + (uint32_t)decltype(SI)::value;
-        if (k < nk) { one_step(SI, k); if ((k & 1u) || k + 1u == nk) fold(k >> 1); }
-    });
+    static_assert(G7_BD == 2, "the step loop is unrolled over one unit = two steps = the two fragment slots");
+    using T_ = std::true_type; using F_ = std::false_type;
+    using S0_ = std::integral_constant<int, 0>; using S1_ = std::integral_constant<int, 1>;
+    // unit 0 (steps 0 and 1) gives the rows their starting values; then unit by unit, straight-line code per unit
+    one_step(S0_{}, T_{}, 0u);
+    if (nk > 1u) one_step(S1_{}, F_{}, 1u);
+    fold(T_{});
+    uint32_t k2 = 2;
+    for (; k2 + 2u <= nk; k2 += 2u) { one_step(S0_{}, T_{}, k2); one_step(S1_{}, F_{}, k2 + 1u); fold(F_{}); }
+    if (k2 < nk) { one_step(S0_{}, T_{}, k2); fold(F_{}); }             // a row of an odd number of steps: its last unit is one step
     NANO_STAMP(a.stamps, 4, acc[0][0]);                             // every step done
     // ---- epilogue: store | residual add | SwiGLU -----------------------------------------------------------------------------------------
     if (!active) return;

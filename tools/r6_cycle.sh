@@ -96,6 +96,14 @@ for k in (r["kernels"] or [])[:9]: print("  ", k)
 print("cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("cores"))
 PY
   ;;
+ab)    # A/B of nano_amd/lib/libnano_mi355x_prev.so (a build of an earlier commit) against the tree's library, interleaved on one box
+  for r in 1 2 3; do
+    for cfg in "4b_b64 --model qwen3-4b --batch 64" "q06_b64 --batch 64"; do
+      set -- $cfg; tag=$1; shift
+      NANO_LIB=$R/nano_amd/lib/libnano_mi355x_prev.so bench ${tag}_prev_$r "$@" --steps 32 --warmup 4 --no-kernel-table
+      bench ${tag}_new_$r "$@" --steps 32 --warmup 4 --no-kernel-table
+    done
+  done ;;
 head2l) for r in 1 2 3; do NANO_FUSE_LAUNCHES=11 bench head_two_launches_$r --steps 20 --warmup 5 --no-kernel-table; bench head_default_$r --steps 20 --warmup 5 --no-kernel-table; done ;;
 *) echo "unknown mode $mode";;
 esac
