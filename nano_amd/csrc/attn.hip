@@ -29,7 +29,8 @@ static hipError_t launch_mode_kv(const AttnArgs &a_in, uint32_t nb, hipStream_t 
     const uint32_t kv_mul = a_in.n_head / a_in.n_kv_head;
     const uint32_t hd4 = (a_in.hd + 3) & ~3u;
     constexpr uint32_t R = 256 / LPR;                          // timesteps per block
-    auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + 4 * kvm + (size_t)4 * kvm * hd4) * sizeof(float); };
+    // (+ several heads per workgroup: the waves' transposition blocks of the sub-group combine, 4 waves x 64 / LPR sub-groups x LPR * QV * 4 floats)
+    auto lds_for = [&](uint32_t kvm) { return (size_t)(kvm * hd4 + hd4 + 4 * kvm + 4 * kvm + (size_t)4 * kvm * hd4 + (kvm > 1 ? (size_t)4 * (64 / LPR) * (LPR * QV * 4) : 0)) * sizeof(float); };
     // q heads per workgroup (KVM; h0 = KVM grp, KV head h0 / kv_mul): fewer heads = more workgroups with less dependent work each,
     // the K/V rows' repeated reads come from L2 (and the KV head's fresh k row is written by each of its workgroups: same
     // bits).  Same per-head arithmetic whatever the choice.  One head per workgroup while that leaves at most one workgroup

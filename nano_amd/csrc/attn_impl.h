@@ -679,6 +679,40 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
     //     l % LPR, so the wave's maximum, its exp-sum and its weighted-V slices are three cross-lane steps each (VALU only);
     // (b) across the four waves through LDS: 4 partial rows per head instead of one per sub-group.
     // (round 3: the former layout -- every sub-group's row through LDS, 32-term sums -- cost 1.7 of the kernel's 4.8 us)
+    if constexpr (KVM > 1) {
+        // Round 6, several heads per workgroup (the batched steps): the weighted accumulators of a wave's sub-groups meet through a
+        // wave-private LDS block instead of three cross-lane steps per value (KVM x QV x 4 values x ~7 instructions = ~450 of a wave's VALU
+        // instructions at KVM = 4, in a launch that is VALU bound): every lane parks its KVM x QV float4 products acc * w, then a lane
+        // adds the NS sub-groups' values of two output elements in the SAME association the cross-lane tree has --
+        // ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)), fp addition commutes -- so the bits are those of the KVM = 1 kernels.
+        constexpr int NS = 64 / LPR, HP = LPR * QV * 4;          // sub-groups per wave; floats a sub-group holds per head (>= head_dim)
+        float *tr = part + 4 * KVM * hd4 + (size_t)wid * NS * HP; // [sub-group][HP], wave-private: no barrier (a wave's LDS operations are in order)
+        const uint32_t sw = (uint32_t)lane / LPR;                 // sub-group inside the wave
+#pragma unroll
+        for (int m = 0; m < KVM; m++) {
+            const float Mw = xsub_max<LPR>(mrun[m]);
+            const float w = (mrun[m] == -INFINITY) ? 0.0f : expf(mrun[m] - Mw);
+            const float lw = xsub_sum<LPR>(lrun[m] * w);
+#pragma unroll
+            for (int q = 0; q < QV; q++)
+                *reinterpret_cast<float4 *>(tr + sw * HP + 4u * fidx(q)) = make_float4(acc[m][q].x * w, acc[m][q].y * w, acc[m][q].z * w, acc[m][q].w * w);
+            for (uint32_t o = (uint32_t)lane * 2u; o < (uint32_t)HP; o += 128u) {
+                float2 v[NS];
+#pragma unroll
+                for (int k = 0; k < NS; k++) v[k] = *reinterpret_cast<const float2 *>(tr + k * HP + o);
+                float2 t;
+                if constexpr (NS == 8) {
+                    t.x = ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+                    t.y = ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+                } else {
+                    t.x = (v[0].x + v[1].x) + (v[2].x + v[3].x);
+                    t.y = (v[0].y + v[1].y) + (v[2].y + v[3].y);
+                }
+                if (o < hd) *reinterpret_cast<float2 *>(part + ((size_t)wid * KVM + m) * hd4 + o) = t;
+            }
+            if (lane == 0) { redm[m * 4 + wid] = Mw; redl[m * 4 + wid] = lw; }
+        }
+    } else {
 #pragma unroll
     for (int m = 0; m < KVM; m++) {
         const float Mw = xsub_max<LPR>(mrun[m]);
@@ -691,6 +725,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
             if (lane < LPR && f * 4u < hd) *reinterpret_cast<float4 *>(part + ((size_t)wid * KVM + m) * hd4 + 4 * f) = t;
         }
         if (lane == 0) { redm[m * 4 + wid] = Mw; redl[m * 4 + wid] = lw; }
+    }
     }
     __syncthreads();
     NANO_STAMP(a.stamps, 4, redl[0]);                          // the four waves' partials are in LDS
