@@ -82,7 +82,8 @@ struct GemvDev {
     const float *attn_part; const float *attn_ml;
     uint32_t attn_nsplit, attn_n_head, attn_hd, ntiles;
     float *tile_max;
-    const float *resid_add; uint32_t resid_add_bstride, _pad1;
+    const float *resid_add; uint32_t resid_add_bstride;
+    uint32_t early;                 // SLAB launches of the wide matrices: units of a wave's weights asked for BEFORE the activation is normalised + quantized (0 = all)
     unsigned long long *stamps;     // measurement builds only (-DNANO_STAMPS=1, tools/stamp_probe.py): [workgroup][8] shader-clock stamps, or nullptr
     uint32_t dbg;                   // measurement builds only: experiment bits (NANO_DBG): 1 = no norm-weight load, 2 = weights issued before the activation
     uint32_t canon;                 // 1: the fast path's canonical fold (kernels.h q80_canonical()), 0: the reference's ascending group order

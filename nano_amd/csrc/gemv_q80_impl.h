@@ -283,9 +283,10 @@ __device__ __forceinline__ float fold_row_canon_ng(const float *p, uint32_t ng) 
 // ------------------------------------------------------------------------------------------------------------
 // Hand-off of a launch's results to consumers INSIDE the same launch (the fused kernels below): every result is also stored as an 8-byte
 // {tag, value} granule (ONE write-through store: the data is the flag); SlabHand and the epoch tags: device_common.h.
-template <int ROLE, int GS, int B, int NV, int UPW>
+template <int ROLE, int GS, int B, int NV, int UPW, int EARLY = 0>
 __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#define SLAB_EARLY EARLY
 #define SLAB_A a
 #define SLAB_BID blockIdx.x
 #define SLAB_HAND 0
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(1024) void gemv_q80_slab_kernel(const GemvDev a) {
 #undef SLAB_XHANDV
 #undef SLAB_CTAG
 #undef SLAB_PART
+#undef SLAB_EARLY
 }
 
 #if NANO_Q80_GS == 64
@@ -737,9 +739,17 @@ static hipError_t launch_slab_t(const GemvDev &d, const SlabPlan &p, uint32_t nw
     const size_t n16 = (d.n + 15) & ~15u, ng4 = (d.ng + 3) & ~3u;
     const size_t pitch = (1024 / GS == 16) ? (((d.ng + 47) / 64) * 64 + 16) : (ng4 + 4);
     const size_t lds = B * n16 + B * ng4 * 4 + B * 64 + ((d.flags & F_COMBINE) ? (size_t)B * d.attn_n_head * 32 : 0) + (size_t)B * nmat * (d.tpw * 4) * pitch * 4;
+    GemvDev dd = d; dd.nthr = 64 * p.nw;
+    // the matrices of >= 8 M weights (d.early, one or two sequences, group size 64): the first unit of every wave before the activation is
+    // quantized, the others after (gemv_q80_slab_body.inc SLAB_EARLY)
+    if constexpr (GS == 64 && B <= 2 && UPW >= 2 && NV >= 1) if (d.early) {
+        auto kern = &gemv_q80_slab_kernel<ROLE, GS, B, NV, UPW, 1>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * p.nw), lds, st, dd);
+        return hipGetLastError();
+    }
     auto kern = &gemv_q80_slab_kernel<ROLE, GS, B, NV, UPW>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    GemvDev dd = d; dd.nthr = 64 * p.nw;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * p.nw), lds, st, dd);
     return hipGetLastError();
 }
@@ -763,6 +773,10 @@ template <int GS, int B>
 static hipError_t launch_slab_b(GemvDev &d, const GemvArgs &a, hipStream_t st) {
     const SlabPlan p = plan_slab(a, B);
     d.rw = p.rw;
+    // the matrices of >= 8 M weights, one or two sequences: the first unit of every wave's weights before the activation is quantized, the others
+    // after (SLAB_EARLY).  Same box, interleaved (profiles/r06_slab_early_units.txt): Qwen3-4B one sequence 1.471 -> 1.427 ms per step, two
+    // sequences 1.956 -> 1.825; the first TWO units early: no gain over none (one sequence), the same as one (two sequences).
+    d.early = (B <= 2 && p.upw >= 2 && (uint64_t)total_rows(a) * a.n * (a.epi == GEMV_EPI_SWIGLU ? 2 : 1) >= (8u << 20)) ? 1u : 0u;
     d.tpw = (p.rw + 3) / 4;
     d.magic_rw = 65536u / p.rw + 1u;                                   // (tid * magic_rw) >> 16 == tid / rw for tid < 1024 <= 65536 / rw
     d.log2_tiles = 0;
