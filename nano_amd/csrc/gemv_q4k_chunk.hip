@@ -40,272 +40,73 @@ template <int ROLE, int NV, int D, bool LOOP, int NB = 1>
 __global__ __launch_bounds__(1024) void gemv_q4k_chunk_kernel(const GemvDev a) {
     static_assert(NB == 1 || (ROLE == R_GENERIC && NV == 1), "several sequences: activations arrive quantized (q4k_quant_rows_kernel), generic role");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x, nthr = a.nthr, lane = tid & 63u;
-    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = nthr >> 6;
-    const uint32_t n = a.n, bpl = n >> 8, GT = bpl * 8u, BP = bpl | 1u;    // BP: pitch of the block-sum table (odd: rows on different banks)
-    const uint32_t RW = a.rw;
-    const uint32_t epi = role_epi<ROLE>(a);
-    const bool swiglu = epi == GEMV_EPI_SWIGLU;
-    const uint32_t nmat = swiglu ? 2u : 1u;
-    // LDS: xg[NB][GT] | red[16 (+ combine weights)] | scr[NW][SL][64] (SL = D lines per wave; looping launches: 1; NB > 1: one per sequence)
-    //      | am[2 NW] | Dt[nmat][NB][RW][BP]
-    XGroup *xg = reinterpret_cast<XGroup *>(smem);
-    float *red = reinterpret_cast<float *>(smem + (size_t)NB * GT * sizeof(XGroup));
-    float *scr = red + 16 + (has_flag<ROLE>(a, F_COMBINE) ? a.attn_n_head * 8u : 0u);
-    constexpr uint32_t SL = NB > 1 ? (uint32_t)NB : LOOP ? 1u : (uint32_t)D;
-    float *am = scr + NW * SL * 64u;
-    float *Dt = am + 2u * NW;
+#define CHUNK_A a
+#define CHUNK_BID blockIdx.x
+#define CHUNK_HAND 0
+#define CHUNK_HANDV (SlabHand{})
+#define CHUNK_PTAG 0u
+#define CHUNK_XHAND 0
+#define CHUNK_XHANDV (SlabHand{})
+#define CHUNK_CTAG 0u
+#define CHUNK_XWAIT 0u
+#define CHUNK_PART 0
+#include "gemv_q4k_chunk_body.inc"
+#undef CHUNK_A
+#undef CHUNK_BID
+#undef CHUNK_HAND
+#undef CHUNK_HANDV
+#undef CHUNK_PTAG
+#undef CHUNK_XHAND
+#undef CHUNK_XHANDV
+#undef CHUNK_CTAG
+#undef CHUNK_XWAIT
+#undef CHUNK_PART
+}
 
-    // late-read arguments are fetched with the first ones (karg_touch, gemv_common.h)
-    karg_touch(a.out[0]); karg_touch(a.out_pstride[0]); karg_touch(a.magic_nchunk); karg_touch(a.tile_max); karg_touch(a.ntiles); karg_touch(a.units);
-    if (!swiglu) { karg_touch(a.out[1]); karg_touch(a.out[2]); karg_touch(a.out_pstride[1]); karg_touch(a.out_pstride[2]); }
-    karg_touch(a.pos);
-    if (ROLE == R_GENERIC || ROLE == R_RESID || ROLE == R_RESID_COMBINE) { karg_touch(a.resid_add); karg_touch(a.resid_add_bstride); }
-    NANO_STAMP(a.stamps, 0, tid);
-    Staged<1, NV> sx;
-    if constexpr (NB == 1) stage_issue<ROLE, 1, NV>(a, sx);
-
-    // this workgroup's rows: inside one segment (the last workgroup of a segment may hold fewer than RW)
-    const uint32_t bid = blockIdx.x;
-    const int sel = swiglu ? 0 : (int)(bid >= a.wg_c0) + (int)(bid >= a.wg_c1);
-    const uint8_t *w0 = reinterpret_cast<const uint8_t *>(sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2]);
-    float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
-    const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
-    const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
-    const uint32_t lrow0 = (bid - (sel == 0 ? 0u : sel == 1 ? a.wg_c0 : a.wg_c1)) * RW;
-    const uint32_t rwl = rows0 - lrow0 < RW ? rows0 - lrow0 : RW;
-    const uint32_t nblk = rwl * bpl;                                   // blocks of this workgroup, per matrix
-    const uint32_t T = ((nblk + 5u) * 43691u) >> 18;                   // wave-loads per matrix: ceil(nblk / 6) (nblk < 2^16)
-    const uint32_t TT = nmat * T;
-    const size_t run0 = (size_t)lrow0 * bpl * 160u;
-    const __amdgpu_buffer_rsrc_t rw0 = mkrsrc(w0 + run0, nblk * 160u);
-    const __amdgpu_buffer_rsrc_t rw1 = mkrsrc(swiglu ? reinterpret_cast<const uint8_t *>(a.w[1]) + run0 : nullptr, swiglu ? nblk * 160u : 0u);
-
-    const uint32_t cl = (lane * 26u) >> 8, c = lane - cl * 10u;        // lane / 10, lane % 10
-    const bool live = lane < 60u;
-    const uint32_t loff = live ? lane * 16u : OOB;
-
-    uint4 ring[D];
-    auto issue = [&](const uint32_t t) __attribute__((always_inline)) -> uint4 {
-        const bool m1 = swiglu && t >= T;                               // wave-uniform
-        const uint32_t tl = t - (m1 ? T : 0u);
-        const uint32_t off = (t < TT && live) ? tl * 960u + loff : OOB;
-        return m1 ? bload_u4(rw1, off, true) : bload_u4(rw0, off, true);
-    };
-#pragma unroll
-    for (int k = 0; k < D; k++) ring[k] = issue(wid + (uint32_t)k * NW);
-
-    // the fold threads (one per row of the workgroup): the position of a pos-indexed output (v-cache row), the old residual value
-    // and the LoRA addend are fetched now and used only by the final store
-    const bool fold_live = NB == 1 && tid < rwl;                                   // (several sequences: the fold loop below fetches its own)
-    uint32_t opos = 0;
-    if (ops && fold_live) opos = a.pos[0];
-    float oldv = 0.0f;
-    if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[lrow0 + tid];              // residual stream: never pos-indexed
-    float addv = 0.0f;                                                             // LoRA o-branch: x += (W.act + addv), reference order
-    const bool has_add = epi == GEMV_EPI_RESID && a.resid_add != nullptr;
-    if (has_add && fold_live) addv = a.resid_add[lrow0 + tid];
-
-    NANO_STAMP(a.stamps, 1, tid);                                   // every load of the first ring issued
-
-    // ---- a wave-load in two halves: what needs only the weights (pre), what needs the staged activation (post) ----------------------
-    float *scw = scr + wid * SL * 64u;                              // this wave's lines: group values of the six blocks of a wave-load
-    const int ha0 = (int)(cl * 40u), ha1 = ha0 + 4;                 // byte addresses (ds_bpermute) of this lane's two header lanes
-    const uint32_t g = (c - 2u) & 7u;                               // group of the block (lanes with c >= 2; the header lanes compute along, unused)
-    struct Pre { float sp, bp, su; };
-    auto pre = [&](const uint4 v) __attribute__((always_inline)) -> Pre {
-        // the block's header words: s_scale (chunk 0, word 3), s_bias and the 12 packed 6-bit bytes (chunk 1)
-        const float s_scale = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(ha0, (int)v.w));
-        const float s_bias = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(ha1, (int)v.x));
-        const uint32_t sb0 = (uint32_t)__builtin_amdgcn_ds_bpermute(ha1, (int)v.y);
-        const uint32_t sb1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ha1, (int)v.z);
-        const uint32_t sb2 = (uint32_t)__builtin_amdgcn_ds_bpermute(ha1, (int)v.w);
-        uint32_t s6, b6;
-        q4k_unpack6(sb0, sb1, sb2, (int)g, s6, b6);
-        const uint32_t wn[4] = { v.x, v.y, v.z, v.w };
-        uint32_t sump = 0;                                              // v_dot8_u32_u4: the weight nibbles against eight ones
-#pragma unroll
-        for (int m = 0; m < 4; m++) sump = __builtin_amdgcn_udot8(wn[m], 0x11111111u, sump, false);
-        return Pre{(float)s6 * s_scale, (float)b6 * s_bias, (float)(int)sump};
-    };
-    // post, step A: the group values of wave-load t into line `ln` of this wave's scratch; step B: the block's first lane adds the
-    // eight in order and files the block sum.  Straight-line launches run A for all their wave-loads, then B for all (the LDS round
-    // trips of D independent wave-loads overlap instead of queueing up behind one another).
-    auto post_a = [&](const uint4 v, const Pre q, const uint32_t t, float *ln, const uint32_t sq_ = 0u) __attribute__((always_inline)) {
-        const bool m1 = swiglu && t >= T;
-        const uint32_t tl = t - (m1 ? T : 0u);
-        const uint32_t b = tl * 6u + cl;                                // block of the workgroup's run
-        const bool bv = t < TT && live && b < nblk;
-        const uint32_t rl = bpl == 1u ? b : __umulhi(b, a.magic_nchunk), blk = b - rl * bpl;   // b / bpl, b % bpl (magic_nchunk = ceil(2^32 / bpl) here; 2^32 does not fit)
-        if (bv && c >= 2u) {
-            const uint32_t wn[4] = { v.x, v.y, v.z, v.w };
-            const XGroup &xq = xg[sq_ * GT + blk * 8u + g];
-            uint32_t spq = 0;                                           // ... against the activation nibbles
-#pragma unroll
-            for (int m = 0; m < 4; m++) spq = __builtin_amdgcn_udot8(wn[m], xq.pk[m], spq, false);
-            const float sp = q.sp, bp = q.bp, sq = xq.sq, bq = xq.bq;
-            // reference tensor.c:425-428, same association (whole blocks: every group has 32 values)
-            ln[cl * 8u + g] = sp * sq * (float)(int)spq - sp * bq * q.su - sq * bp * (float)xq.sumq + 32 * bp * bq;
-        }
-    };
-    auto post_b = [&](const uint32_t t, const float *ln, const uint32_t sq_ = 0u) __attribute__((always_inline)) {
-        const bool m1 = swiglu && t >= T;
-        const uint32_t tl = t - (m1 ? T : 0u);
-        const uint32_t b = tl * 6u + cl;
-        const bool bv = t < TT && live && b < nblk;
-        const uint32_t rl = bpl == 1u ? b : __umulhi(b, a.magic_nchunk), blk = b - rl * bpl;
-        if (bv && c == 0u) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(ln + cl * 8u), v1 = *reinterpret_cast<const float4 *>(ln + cl * 8u + 4u);
-            float d = 0.0f;                                             // the 8 groups of a block in order (tensor.c:359-434)
-            d += v0.x; d += v0.y; d += v0.z; d += v0.w; d += v1.x; d += v1.y; d += v1.z; d += v1.w;
-            Dt[(((m1 ? (uint32_t)NB : 0u) + sq_) * RW + rl) * BP + blk] = d;
-        }
-    };
-
-    // The activation: normalised from registers, block-quantized wave-locally into LDS.  A wave that is done with its blocks (or has
-    // none) works through the weight-only half of its wave-loads while the others still quantize; the barrier after that publishes xg.
-    Pre pq[D];
-    if constexpr (NB > 1) {
-        // the staged groups of every sequence, as q4k_quant_rows_kernel left them: [sequence][GT] x 32 bytes, copied as they are
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.xq_in);
-        uint4 *dst = reinterpret_cast<uint4 *>(xg);
-        const uint32_t cnt = a.nb * GT * 2u;
-        for (uint32_t i = tid; i < cnt; i += nthr) dst[i] = src[i];
-    } else
-    if (has_flag<ROLE>(a, F_PRE)) unpack_q4k_wg(a, xg);
-    else {
-        stage_xn<ROLE, 1, NV>(a, sx, nullptr, red, (n + 3u) & ~3u, true);
-        NANO_STAMP(a.stamps, 2, red[0]);                            // the activation arrived and is normalised
-        quantize_q4k_regs<1, NV, false>(a, sx, xg);
-    }
-    if constexpr (!LOOP) {
-#pragma unroll
-        for (int k = 0; k < D; k++) pq[k] = pre(ring[k]);
-    }
-    __syncthreads();
-    NANO_STAMP(a.stamps, 3, xg[0].sq);                              // block-quantized activation staged in LDS
-
-    if constexpr (NB > 1 && !LOOP) {
-        // several sequences: a wave-load at a time, its activation half once per sequence (one scratch line each)
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            const uint32_t t = wid + (uint32_t)k * NW;
-#pragma unroll
-            for (int b = 0; b < NB; b++) if ((uint32_t)b < a.nb) post_a(ring[k], pq[k], t, scw + b * 64, (uint32_t)b);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int b = 0; b < NB; b++) if ((uint32_t)b < a.nb) post_b(t, scw + b * 64, (uint32_t)b);
-            __builtin_amdgcn_wave_barrier();
-        }
-    } else if constexpr (NB > 1) {
-        for (uint32_t r = 0; r < a.units; r++) {
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const uint32_t t = wid + (r * (uint32_t)D + (uint32_t)k) * NW;
-                const Pre q = pre(ring[k]);
-#pragma unroll
-                for (int b = 0; b < NB; b++) if ((uint32_t)b < a.nb) post_a(ring[k], q, t, scw + b * 64, (uint32_t)b);
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int b = 0; b < NB; b++) if ((uint32_t)b < a.nb) post_b(t, scw + b * 64, (uint32_t)b);
-                __builtin_amdgcn_wave_barrier();
-                ring[k] = issue(t + (uint32_t)D * NW);
-            }
-        }
-    } else
-    if constexpr (!LOOP) {
-#pragma unroll
-        for (int k = 0; k < D; k++) post_a(ring[k], pq[k], wid + (uint32_t)k * NW, scw + k * 64);
-        __builtin_amdgcn_wave_barrier();                                // (the LDS queue of a wave is in order: the reads below see the writes above)
-#pragma unroll
-        for (int k = 0; k < D; k++) post_b(wid + (uint32_t)k * NW, scw + k * 64);
-    } else {
-        // persistent: `a.units` rounds of D wave-loads; a consumed slot is asked for again at once (loads past the end: out of range, no traffic)
-        for (uint32_t r = 0; r < a.units; r++) {
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const uint32_t t = wid + (r * (uint32_t)D + (uint32_t)k) * NW;
-                post_a(ring[k], pre(ring[k]), t, scw);
-                __builtin_amdgcn_wave_barrier();
-                post_b(t, scw);
-                __builtin_amdgcn_wave_barrier();
-                ring[k] = issue(t + (uint32_t)D * NW);
-            }
-        }
-    }
-    NANO_STAMP(a.stamps, 4, (float)ring[D - 1].x);                 // this wave's weights arrived, its block sums are in the table
-    __syncthreads();
-    NANO_STAMP(a.stamps, 5, Dt[0]);
-
-    // ---- one thread per row: the blocks of the row in order (tensor.c:438-471), epilogue --------------------------------------------
-    if constexpr (NB > 1) {
-        // a thread per (sequence, row): the blocks of the row in order, the epilogue of its sequence
-        const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
-        for (uint32_t idx = tid; idx < a.nb * rwl; idx += nthr) {
-            const uint32_t b = idx / rwl, r = idx - b * rwl;
-            float res[2] = {0.0f, 0.0f};
-            for (uint32_t mat = 0; mat < nmat; mat++) {
-                const float *f = Dt + (((size_t)mat * NB + b) * RW + r) * BP;
-                float line = 0.0f;
-                uint32_t blk = 0;
-                for (; blk + 4 <= bpl; blk += 4) {
-                    const float d0 = f[blk], d1 = f[blk + 1], d2 = f[blk + 2], d3 = f[blk + 3];
-                    line += d0; line += d1; line += d2; line += d3;
-                }
-                for (; blk < bpl; blk++) line += f[blk];
-                res[mat] = line;
-            }
-            float *o = out0 + (size_t)b * obs + (ops ? (size_t)a.pos[b] * ops : 0u) + lrow0 + r;
-            const float old = epi == GEMV_EPI_RESID ? *o : 0.0f;
-            const float add = has_add ? a.resid_add[(size_t)b * a.resid_add_bstride + lrow0 + r] : 0.0f;
-            const float v = finish_epi(epi, has_add ? res[0] + add : res[0], res[1], old);
-            __hip_atomic_store(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        NANO_STAMP_END(a.stamps, 6);
+}  // namespace
+}  // namespace nano
+#include "attn_impl.h"
+namespace nano {
+namespace {
+// ---- q | k | v projection + attention in ONE launch (Qwen3 decode, one sequence, head_dim 128; round 6: what gemv_q80_impl.h's
+//      qkv_attn_fused_kernel is for Q80) ---------------------------------------------------------------------------------------------------
+// The first `ngemv` workgroups are the projection's chunk GEMV (role: rmsnorm + block quantizer + store), whose fold threads also store every
+// result as an 8-byte {tag, value} granule; the LAST n_attn workgroups are the attention's (head x split): they ask for their K / V rows at
+// entry, nap, then poll for q, the raw k row and the fresh v row of their KV group.  256 threads for both kinds (q4k_fused_shape).  Epoch tags, give-up and re-issue: device_common.h, backend.hip.  Reference: infer/infer.c:758-879.
+struct Q4FusedArgs { GemvDev g; AttnArgs a; SlabHand hand; uint32_t n_attn, head_wgs, wait16, ngemv; };
+template <int NV, int D>
+__global__ __launch_bounds__(256) void q4k_qkv_attn_fused_kernel(const Q4FusedArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint2 tk_ = hand_tick(fa.hand);                       // the step's epoch: the first load of every workgroup
+    if (blockIdx.x >= fa.ngemv) {
+        const uint32_t ab = blockIdx.x - fa.ngemv;
+        const uint32_t split = ab / fa.head_wgs, grp = ab - split * fa.head_wgs;
+        attention_body<8, 4, 1, 1, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand, hand_ctag(tk_, fa.hand), fa.wait16);
         return;
     }
-    float val = 0.0f;
-    if (fold_live) {
-        float res[2] = {0.0f, 0.0f};
-        for (uint32_t mat = 0; mat < nmat; mat++) {
-            const float *f = Dt + ((size_t)mat * RW + tid) * BP;
-            float line = 0.0f;
-            uint32_t blk = 0;
-            for (; blk + 4 <= bpl; blk += 4) {                          // four reads go out together; the sum itself is serial (the reference's order)
-                const float d0 = f[blk], d1 = f[blk + 1], d2 = f[blk + 2], d3 = f[blk + 3];
-                line += d0; line += d1; line += d2; line += d3;
-            }
-            for (; blk < bpl; blk++) line += f[blk];
-            res[mat] = line;
-        }
-        val = finish_epi(epi, has_add ? res[0] + addv : res[0], res[1], oldv);
-        // write-through (sc1) store, see gemv_q80_impl.h: nothing is left for the write-back at the end of the kernel
-        __hip_atomic_store(out0 + (size_t)opos * ops + lrow0 + tid, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // classifier launches (one STORE segment): this workgroup's (max, first row) arg-max partial, so that the arg-max kernel scans
-    // gridDim.x pairs instead of every logit
-    if (a.tile_max) {
-        float bvv = fold_live ? val : -INFINITY;
-        uint32_t bi = fold_live ? lrow0 + tid : 0xffffffffu;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bvv, o, 64);
-            const uint32_t oi = __shfl_xor(bi, o, 64);
-            if (oi != 0xffffffffu && (bi == 0xffffffffu || ov > bvv || (ov == bvv && oi < bi))) { bvv = ov; bi = oi; }
-        }
-        if (lane == 0u) { am[2u * wid] = bvv; am[2u * wid + 1u] = __uint_as_float(bi); }
-        __syncthreads();
-        if (tid == 0u) {
-            for (uint32_t w = 1; w < NW; w++) {
-                const float ov = am[2u * w];
-                const uint32_t oi = __float_as_uint(am[2u * w + 1u]);
-                if (oi != 0xffffffffu && (bi == 0xffffffffu || ov > bvv || (ov == bvv && oi < bi))) { bvv = ov; bi = oi; }
-            }
-            float *tm = a.tile_max + (size_t)bid * 2;
-            tm[0] = bvv; tm[1] = __uint_as_float(bi);
-        }
-    }
-    NANO_STAMP_END(a.stamps, 6);
+    constexpr int ROLE = R_NORM_STORE, NB = 1;
+    constexpr bool LOOP = false;
+#define CHUNK_A fa.g
+#define CHUNK_BID blockIdx.x
+#define CHUNK_HAND 1
+#define CHUNK_HANDV fa.hand
+#define CHUNK_PTAG hand_ptag(tk_, fa.hand)
+#define CHUNK_XHAND 0
+#define CHUNK_XHANDV (SlabHand{})
+#define CHUNK_CTAG 0u
+#define CHUNK_XWAIT 0u
+#define CHUNK_PART 0
+#include "gemv_q4k_chunk_body.inc"
+#undef CHUNK_A
+#undef CHUNK_BID
+#undef CHUNK_HAND
+#undef CHUNK_HANDV
+#undef CHUNK_PTAG
+#undef CHUNK_XHAND
+#undef CHUNK_XHANDV
+#undef CHUNK_CTAG
+#undef CHUNK_XWAIT
+#undef CHUNK_PART
 }
 
 // ---- the activations of a 2 .. 8-sequence launch, normalised / combined and block-quantized once -----------------------------------------
@@ -340,7 +141,7 @@ size_t chunk_lds_bytes(uint32_t n, bool combine, uint32_t attn_n_head, uint32_t 
     return nbq * GT * sizeof(XGroup) + (16 + (combine ? (size_t)attn_n_head * 8 : 0) + (size_t)nw * sl * 64 + 2 * (size_t)nw + (size_t)nmat * nbq * rw * (bpl | 1)) * 4 + 16;
 }
 
-bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
+bool plan_chunk(const GemvArgs &a, ChunkPlan &p, uint32_t force_nw = 0) {      // force_nw: the fused launch's 256 threads (same bits: see q4k_fused_shape)
     if (a.nb == 0 || a.nb > 8 || a.n == 0 || (a.n & 255u) || a.n > 16384u || a.nseg == 0 || a.nseg > 3) return false;
     if (a.attn_part && (a.norm_w || a.attn_nsplit > 8 || a.attn_hd % 4)) return false;
     const uint32_t nbq = a.nb <= 1 ? 1u : a.nb <= 2 ? 2u : a.nb <= 4 ? 4u : 8u;     // the kernel's NB (sequences beyond a.nb are skipped)
@@ -380,6 +181,7 @@ bool plan_chunk(const GemvArgs &a, ChunkPlan &p) {
     // one wave-load per wave where the workgroup's waves allow it (<= 16): every load at kernel entry, no serial second item
     constexpr uint32_t per_want = 2u;
     if (!cls) { uint32_t m = (TT + per_want - 1) / per_want; if (m > 16) m = 16; if (nw < m) nw = m; }
+    if (force_nw) nw = force_nw;
     if (nw * 64 < best) nw = (best + 63) / 64;                           // one fold thread per row
     if (nw > 16) return false;
     uint32_t per = (TT + nw - 1) / nw;
@@ -501,6 +303,51 @@ static hipError_t launch_gemv_q4k_chunk_batched(GemvArgs &a, hipStream_t st) {
     if (a.nb <= 2) return launch_chunk_nb<2>(d, p, st);
     if (a.nb <= 4) return launch_chunk_nb<4>(d, p, st);
     return launch_chunk_nb<8>(d, p, st);
+}
+
+// ---- the fused q | k | v + attention launch: host side -----------------------------------------------------------------------------------
+static bool q4k_fused_shape(const GemvArgs &ga, const AttnArgs &aa, ChunkPlan &p) {
+    if (ga.nb != 1 || ga.nseg != 3 || ga.epi != GEMV_EPI_STORE || !ga.norm_w || ga.xq_in || ga.x4_in || ga.attn_part || ga.tile_max || ga.resid_add) return false;
+    if (ga.seg[0].out_pstride || ga.seg[1].out_pstride) return false;            // (only v is position indexed: its cache row)
+    // 256 threads, like the attention workgroups: the kernel needs ~200 registers (the attention body), i.e. two waves per SIMD, and a CU must
+    // seat a projection workgroup AND an attention workgroup (the first build ran the projection's own 384 threads: one workgroup per CU,
+    // the attention started when the projection had left -- 0.575 -> 0.626 ms per step).  Same bits as the 384-thread launch: one float4 item
+    // per thread on threads 0 .. n / 4 - 1 either way, a Q4K block is one wave's, the waves beyond add +0.0 to the norm's sum.
+    if (ga.n > 1024u || !plan_chunk(ga, p, 4u) || p.loop || p.nthr != 256u || p.nv != 1u) return false;
+    if (p.lds > 64u * 1024u) return false;
+    return fused_attn_side_ok(aa, ga.seg[0].rows, ga.seg[1].rows, ga.seg[2].rows);
+}
+bool qkv_attn_fused_q4k_supports(const GemvArgs &ga, const AttnArgs &aa) { ChunkPlan p; return q4k_fused_shape(ga, aa, p); }
+
+hipError_t launch_qkv_attn_fused_q4k(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st) {
+    ChunkPlan p;
+    if (!hand || !tick || !layer1 || layer1 > 127u || !q4k_fused_shape(ga, aa, p)) return hipErrorInvalidValue;
+    GemvDev d = to_dev(ga);
+    d.tile_max = nullptr; d.ntiles = 0;
+    const uint32_t bpl = ga.n >> 8;
+    d.rw = p.rw; d.nthr = p.nthr; d.units = p.rounds;
+    d.magic_nchunk = (uint32_t)(((1ull << 32) + bpl - 1) / bpl);
+    d.wg_c0 = p.wg[0]; d.wg_c1 = p.wg[0] + p.wg[1];
+    AttnArgs a = aa;
+    { uint32_t l2 = 0; while ((1u << l2) < a.n_kv_head) l2++; a.kv_log2 = l2; }
+    { const uint32_t kv_mul = a.n_head / a.n_kv_head; uint32_t l2 = 0; while ((1u << l2) < kv_mul) l2++; a.kvmul_log2 = l2; }
+    SlabHand h{};
+    h.buf = hand; h.tick = tick; h.layer1 = layer1;
+    h.base[0] = 0; h.base[1] = a.q_dim; h.base[2] = a.q_dim + a.kv_dim;
+    const size_t hd4 = a.hd, lds_a = (hd4 + hd4 + 4 + 4 + 4 * hd4 + hd4) * sizeof(float);            // as gemv_q80_impl.h launch_qkv_attn_fused
+    const size_t lds = p.lds > lds_a ? p.lds : lds_a;
+    Q4FusedArgs fa{};
+    fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = a.n_head * a.nsplit; fa.head_wgs = a.n_head; fa.ngemv = p.grid;
+    // naps of 16 x 64 cycles between the K / V requests and the first poll.  Same box, driver's flags (profiles/r06_q4k_fused.txt): the five
+    // launches per layer 1733 / 1755 tok/s; fused with 2 naps 1773 / 1818, 4: 1782 / 1779, 6: 1742 / 1739, 8: 1684 / 1688
+    fa.wait16 = 3u;
+#define Q4F_GO(NV_, D_) do { hipLaunchKernelGGL((q4k_qkv_attn_fused_kernel<NV_, D_>), dim3(fa.n_attn + fa.ngemv), dim3(p.nthr), lds, st, fa); return hipGetLastError(); } while (0)
+#define Q4F_NV(NV_) do { if (p.d == 1) Q4F_GO(NV_, 1); if (p.d == 2) Q4F_GO(NV_, 2); if (p.d == 4) Q4F_GO(NV_, 4); Q4F_GO(NV_, 8); } while (0)
+    if (p.nv <= 1) Q4F_NV(1);
+    if (p.nv <= 2) Q4F_NV(2);
+    Q4F_NV(4);
+#undef Q4F_NV
+#undef Q4F_GO
 }
 
 hipError_t launch_gemv_q4k_chunk(GemvArgs &a, hipStream_t st) {

@@ -833,14 +833,7 @@ static bool fused_shape(const GemvArgs &ga, const AttnArgs &aa, SlabPlan &p) {
     if (ga.seg[0].out_pstride || ga.seg[1].out_pstride) return false;            // (only v is position indexed: its cache row)
     p = plan_slab(ga, 1);
     if (p.nw != 4u || p.upw > 4u || !(p.nv == 1u || p.nv == 2u || p.nv == 4u)) return false;        // 256 threads, like the attention workgroups
-    // Qwen3 decode attention on an FP32 contiguous cache, head_dim 128, one head per workgroup, two timestep blocks in flight
-    if (aa.hd != 128u || !aa.q_norm || !aa.k_norm || !aa.rope_qwen3 || !aa.rope_cos || !aa.rope_cur || !aa.kraw || aa.fixed_range || !aa.is_causal || aa.q_out) return false;
-    if (aa.kv_half || aa.pt_rows || aa.prep_only || aa.xf_out || aa.nsplit == 0 || aa.nsplit > 8u) return false;
-    const uint32_t kv_mul = aa.n_kv_head ? aa.n_head / aa.n_kv_head : 0u;
-    if (!aa.n_kv_head || (aa.n_kv_head & (aa.n_kv_head - 1u)) || !kv_mul || (kv_mul & (kv_mul - 1u))) return false;
-    if ((uint64_t)aa.n_head * aa.nsplit > 256u) return false;                   // (beyond: the attention launcher puts several heads in a workgroup)
-    if (aa.range_hint > aa.nsplit * 2u * 32u) return false;                     // (more than one round: the launcher may pick four blocks in flight)
-    if (aa.q_dim != ga.seg[0].rows || aa.kv_dim != ga.seg[1].rows || aa.kv_dim != ga.seg[2].rows || aa.q_dim != aa.n_head * aa.hd) return false;
+    if (!fused_attn_side_ok(aa, ga.seg[0].rows, ga.seg[1].rows, ga.seg[2].rows)) return false;          // (kernels.h)
     return true;
 }
 

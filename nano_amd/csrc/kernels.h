@@ -194,6 +194,20 @@ hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned
 bool w2_qkv_attn_fused_supports(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa);
 hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, const AttnArgs &aa, unsigned long long *xhand, unsigned long long *hand,
                                     uint32_t *tick, uint32_t layer1, hipStream_t st);
+// the attention side of the fused one-sequence launches (Q80: gemv_q80_impl.h, Q4K: gemv_q4k_chunk.hip): Qwen3 decode attention on an FP32
+// contiguous cache, head_dim 128, one head per workgroup, two timestep blocks in flight; qr / kr / vr = rows of the q | k | v segments
+inline bool fused_attn_side_ok(const AttnArgs &aa, uint32_t qr, uint32_t kr, uint32_t vr) {
+    if (aa.hd != 128u || !aa.q_norm || !aa.k_norm || !aa.rope_qwen3 || !aa.rope_cos || !aa.rope_cur || !aa.kraw || aa.fixed_range || !aa.is_causal || aa.q_out) return false;
+    if (aa.kv_half || aa.pt_rows || aa.prep_only || aa.xf_out || aa.nsplit == 0 || aa.nsplit > 8u) return false;
+    const uint32_t kv_mul = aa.n_kv_head ? aa.n_head / aa.n_kv_head : 0u;
+    if (!aa.n_kv_head || (aa.n_kv_head & (aa.n_kv_head - 1u)) || !kv_mul || (kv_mul & (kv_mul - 1u))) return false;
+    if ((uint64_t)aa.n_head * aa.nsplit > 256u) return false;                   // (beyond: the attention launcher puts several heads in a workgroup)
+    if (aa.range_hint > aa.nsplit * 2u * 32u) return false;                     // (more than one round: the launcher may pick four blocks in flight)
+    return aa.q_dim == qr && aa.kv_dim == kr && aa.kv_dim == vr && aa.q_dim == aa.n_head * aa.hd;
+}
+// the same launch for Q4K (gemv_q4k_chunk.hip q4k_qkv_attn_fused_kernel, round 6)
+bool qkv_attn_fused_q4k_supports(const GemvArgs &ga, const AttnArgs &aa);
+hipError_t launch_qkv_attn_fused_q4k(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
 hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb,

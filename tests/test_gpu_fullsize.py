@@ -286,8 +286,8 @@ def test_nano56m_strict_equals_the_oracle_bit_for_bit(model_dir, oracle, quant, 
     assert worst_fast <= {"f32": 1e-4, "q80": 5e-2, "q4k": 0.5}[quant]
 
 
-@pytest.mark.parametrize("preset", ["qwen3-0.6b", "wide-qwen3-2l", "qwen3-0.6b-3l"])
-def test_fused_launches_equal_the_five_launches_per_layer(model_dir, preset):
+@pytest.mark.parametrize("preset,quant", [("qwen3-0.6b", "q80"), ("wide-qwen3-2l", "q80"), ("qwen3-0.6b-3l", "q80"), ("qwen3-0.6b", "q4k"), ("qwen3-0.6b-3l", "q4k")])
+def test_fused_launches_equal_the_five_launches_per_layer(model_dir, preset, quant):
     """One sequence on Qwen3-0.6B Q80: the q|k|v projection and the attention run as ONE launch (qkv_attn_fused_kernel: the attention
     workgroups take q / k / v from the projection's workgroups as write-through granules inside the launch), and so do Wo and W1|W3
     (wo_w13_fused_kernel: W1|W3's workgroups take the residual stream from Wo's as granules -- an all-gather inside the launch).  Same
@@ -300,7 +300,7 @@ def test_fused_launches_equal_the_five_launches_per_layer(model_dir, preset):
     import sys
     import zlib
     from conftest import ROOT
-    path, spec = synth_model(model_dir, preset, "q80", 64)
+    path, spec = synth_model(model_dir, preset, quant, 64 if quant == "q80" else 0)     # (Q4K, round 6: the q|k|v + attention launch, bit 0)
     code = ("import sys, zlib, numpy as np; sys.path.insert(0, %r)\n"
             "from nano_amd import binding as nb, modelfile as mf\n"
             "m = nb.load_model_file(%r, max_seq_len=256, max_batch=1)\n"
