@@ -109,6 +109,76 @@ __global__ __launch_bounds__(256) void q4k_qkv_attn_fused_kernel(const Q4FusedAr
 #undef CHUNK_PART
 }
 
+// ---- Wo + W1|W3 in ONE launch (round 6: what gemv_q80_impl.h's wo_w13_fused_kernel is for Q80) ---------------------------------------------
+// The launch has W1|W3's grid and thread count; its first `wo_wgs` workgroups run Wo's body first (results stored as usual AND as granules),
+// then EVERY workgroup runs W1|W3's body with the activation polled from the granules.  Issue order: Wo's loads, W1|W3's weight and
+// norm-weight loads (CHUNK_PART 1 of both bodies), Wo's arithmetic, W1|W3's.  Producers first, a grid of at most one workgroup per CU is
+// resident as a whole.  Same bodies, same bits.  Reference: infer/infer.c:885-944.
+struct Q4Wo13Args { GemvDev wo; GemvDev w13; SlabHand hand; uint32_t wo_wgs, wait16; };
+template <int ROLE_A, int NV_A, int D_A, int NV_B, int D_B>
+__global__ __launch_bounds__(1024) void q4k_wo_w13_fused_kernel(const Q4Wo13Args fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint2 tk_ = hand_tick(fa.hand);
+    constexpr int NB = 1;
+    constexpr bool LOOP = false;
+    {
+        constexpr int ROLE = ROLE_A, NV = NV_A, D = D_A;
+#define CHUNK_BID blockIdx.x
+#define CHUNK_A fa.wo
+#define CHUNK_HAND 1
+#define CHUNK_HANDV fa.hand
+#define CHUNK_PTAG hand_ptag(tk_, fa.hand)
+#define CHUNK_XHAND 0
+#define CHUNK_XHANDV (SlabHand{})
+#define CHUNK_CTAG 0u
+#define CHUNK_XWAIT 0u
+#define CHUNK_PART 1
+#include "gemv_q4k_chunk_body.inc"
+#undef CHUNK_PART
+        auto wo_rest = [&]() __attribute__((always_inline)) {
+#define CHUNK_PART 2
+#include "gemv_q4k_chunk_body.inc"
+#undef CHUNK_PART
+        };
+#undef CHUNK_A
+#undef CHUNK_HAND
+#undef CHUNK_HANDV
+#undef CHUNK_PTAG
+#undef CHUNK_XHAND
+#undef CHUNK_XHANDV
+#undef CHUNK_CTAG
+#undef CHUNK_XWAIT
+        {
+            constexpr int ROLE = R_NORM_SWIGLU, NV = NV_B, D = D_B;
+#define CHUNK_A fa.w13
+#define CHUNK_HAND 0
+#define CHUNK_HANDV (SlabHand{})
+#define CHUNK_PTAG 0u
+#define CHUNK_XHAND 1
+#define CHUNK_XHANDV fa.hand
+#define CHUNK_CTAG hand_ctag(tk_, fa.hand)
+#define CHUNK_XWAIT (blockIdx.x >= fa.wo_wgs ? fa.wait16 : 0u)
+#define CHUNK_PART 1
+#include "gemv_q4k_chunk_body.inc"
+#undef CHUNK_PART
+            if (blockIdx.x < fa.wo_wgs) wo_rest();
+            __syncthreads();                // (LDS is W1|W3's from here)
+#define CHUNK_PART 2
+#include "gemv_q4k_chunk_body.inc"
+#undef CHUNK_PART
+#undef CHUNK_A
+#undef CHUNK_HAND
+#undef CHUNK_HANDV
+#undef CHUNK_PTAG
+#undef CHUNK_XHAND
+#undef CHUNK_XHANDV
+#undef CHUNK_CTAG
+#undef CHUNK_XWAIT
+        }
+#undef CHUNK_BID
+    }
+}
+
 // ---- the activations of a 2 .. 8-sequence launch, normalised / combined and block-quantized once -----------------------------------------
 // One workgroup per sequence; its code is the one-sequence kernel's prologue (stage_issue -> stage_xn -> quantize_q4k_regs) run with the
 // thread count the one-sequence launch of the same matrix would use, so every tree (rmsnorm sum of squares, split-attention combine) and
@@ -348,6 +418,52 @@ hipError_t launch_qkv_attn_fused_q4k(const GemvArgs &ga, const AttnArgs &aa, uns
     Q4F_NV(4);
 #undef Q4F_NV
 #undef Q4F_GO
+}
+
+// ---- the fused Wo + W1|W3 launch: host side ----------------------------------------------------------------------------------------------
+struct Q4Wo13Plan { ChunkPlan a, b; };
+static bool q4k_wo13_shape(const GemvArgs &wo, const GemvArgs &w13, Q4Wo13Plan &q) {
+    if (wo.nb != 1 || w13.nb != 1) return false;
+    if (wo.nseg != 1 || wo.epi != GEMV_EPI_RESID || wo.norm_w || wo.xq_in || wo.x4_in || wo.tile_max || wo.resid_add || wo.seg[0].out_pstride) return false;
+    if (w13.nseg != 2 || w13.epi != GEMV_EPI_SWIGLU || !w13.norm_w || w13.xq_in || w13.x4_in || w13.attn_part || w13.tile_max || w13.resid_add) return false;
+    if (w13.n != wo.seg[0].rows || w13.xin != wo.seg[0].out) return false;             // W1|W3's input is what Wo writes
+    if (!plan_chunk(wo, q.a) || !plan_chunk(w13, q.b) || q.a.loop || q.b.loop) return false;
+    // both bodies on the launch's threads: the two plans must agree (Wo has no tree, but its plan's registers per thread follow the count)
+    if (q.a.nthr != q.b.nthr || q.a.grid > q.b.grid) return false;
+    const uint32_t cus = w13.cus ? w13.cus : 256u;
+    if (q.b.grid > cus) return false;                                                   // one workgroup per CU: the whole grid is resident
+    if (q.a.lds > 64u * 1024u || q.b.lds > 64u * 1024u) return false;
+    // instantiated: Qwen3-0.6B's shapes (Wo: one float4 item and one wave-load per thread / wave; W1|W3: one item, two wave-loads)
+    return q.a.nv == 1u && q.a.d == 1u && q.b.nv == 1u && q.b.d == 2u;
+}
+bool wo_w13_fused_q4k_supports(const GemvArgs &wo, const GemvArgs &w13) { Q4Wo13Plan q; return q4k_wo13_shape(wo, w13, q); }
+
+static void chunk_dev_fill(GemvDev &d, const GemvArgs &a, const ChunkPlan &p) {
+    const uint32_t bpl = a.n >> 8;
+    d.tile_max = nullptr; d.ntiles = 0;
+    d.rw = p.rw; d.nthr = p.nthr; d.units = p.rounds;
+    d.magic_nchunk = (uint32_t)(((1ull << 32) + bpl - 1) / bpl);
+    const uint32_t nseg = a.epi == GEMV_EPI_SWIGLU ? 1u : a.nseg;
+    d.wg_c0 = nseg > 1 ? p.wg[0] : 0xffffffffu;
+    d.wg_c1 = nseg > 2 ? p.wg[0] + p.wg[1] : 0xffffffffu;
+}
+
+hipError_t launch_wo_w13_fused_q4k(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st) {
+    Q4Wo13Plan q;
+    if (!hand || !tick || !layer1 || layer1 > 127u || !q4k_wo13_shape(wo, w13, q)) return hipErrorInvalidValue;
+    Q4Wo13Args fa{};
+    fa.wo = to_dev(wo); fa.w13 = to_dev(w13);
+    chunk_dev_fill(fa.wo, wo, q.a); chunk_dev_fill(fa.w13, w13, q.b);
+    fa.wo_wgs = q.a.grid;
+    fa.wait16 = 4u;                      // (workgroups that produce nothing: none on Qwen3-0.6B's shapes, where both grids are 256)
+    SlabHand h{};
+    h.buf = hand; h.tick = tick; h.layer1 = layer1;
+    fa.hand = h;
+    const size_t lds = q.a.lds > q.b.lds ? q.a.lds : q.b.lds;
+    const bool comb = (fa.wo.flags & F_COMBINE) != 0;
+    if (comb) hipLaunchKernelGGL((q4k_wo_w13_fused_kernel<R_RESID_COMBINE, 1, 1, 1, 2>), dim3(q.b.grid), dim3(q.b.nthr), lds, st, fa);
+    else hipLaunchKernelGGL((q4k_wo_w13_fused_kernel<R_RESID, 1, 1, 1, 2>), dim3(q.b.grid), dim3(q.b.nthr), lds, st, fa);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemv_q4k_chunk(GemvArgs &a, hipStream_t st) {

@@ -208,6 +208,8 @@ inline bool fused_attn_side_ok(const AttnArgs &aa, uint32_t qr, uint32_t kr, uin
 // the same launch for Q4K (gemv_q4k_chunk.hip q4k_qkv_attn_fused_kernel, round 6)
 bool qkv_attn_fused_q4k_supports(const GemvArgs &ga, const AttnArgs &aa);
 hipError_t launch_qkv_attn_fused_q4k(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st);
+bool wo_w13_fused_q4k_supports(const GemvArgs &wo, const GemvArgs &w13);
+hipError_t launch_wo_w13_fused_q4k(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st);
 uint32_t attention_nsplit(uint32_t range_hint, uint32_t hd);
 hipError_t launch_attn_combine(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, hipStream_t st);
 hipError_t launch_attn_combine_tokens(const float *part, const float *ml, float *out, uint32_t n_head, uint32_t hd, uint32_t nsplit, uint32_t nb,
