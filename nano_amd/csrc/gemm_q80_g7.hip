@@ -349,6 +349,173 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7_kernel(const G7Dev d) 
     NANO_STAMP_END(a.stamps, 6);
 }
 
+// =========================================================================================================================================
+// G7K (round 6): ONE row tile per workgroup and a LONG row (Wo, W2 of Qwen3-4B at 17..64 tokens) -- the K-phase form.
+// G7 above keeps a (row tile, token tile) pair in ONE wave for the whole row length: with one tile per CU that is `ttl` <= 4 of fourteen
+// consumer waves at work, 16 / 38 serial steps of ~0.6 us each (round 5: 13.9 / 27.9 us, so these launches stayed with G6: 10.6 / 18.7 us,
+// three 8-KB items per wave in sequence).  Here the row length is split among the waves BY UNITS (8 groups = 2 steps = the canonical fold's
+// unit sum, so no sum crosses a wave): consumer wave (token tile tt, phase j) multiplies the units u = j (mod KS); KS x ttl waves work at
+// once.  What changes with it:
+//   * the activation fragments do NOT go through LDS: with one row tile per workgroup a fragment meets exactly one wave, so every wave
+//     fetches its own units' fragments from L2 straight into registers (one unit ahead) -- no fragment stages, no parking;
+//   * ONE barrier per SUPER-STEP (KS units = 2 KS steps of weights) instead of one per step: the loaders fill a ring of `ring`
+//     super-steps by LDS-DMA exactly as above;
+//   * the unit sums S_u go to an LDS table [unit][token tile][lane]; after the last super-step the phase-0 wave of a token tile adds them
+//     in ascending order (the row's starting value is S_0) and runs the epilogue: the CANONICAL fold, bit for bit G7's / G6's.
+// Reference: matmul_quant infer/infer.c:654-679.
+constexpr uint32_t G7K_STAGE = 4096u + 256u;        // a stage: the tile's 16 rows x 256 B, then its 16 x 4 weight scales
+struct G7KDev {
+    GemvDev g;
+    const int8_t *xf; const float *xsf;
+    uint32_t hh, ntiles, nk, nu, ttl, ks, ncw, nss;     // live rows per half tile; tiles = workgroups; steps; units; token tiles; phases; consumer waves; super-steps
+    uint32_t tab, ring;                                 // LDS offset of the unit-sum table; super-steps of weights in the ring
+};
+
+__global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7k_kernel(const G7KDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const GemvDev &a = d.g;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n = a.n, ng = a.ng, hh = d.hh, nb = a.nb, nk = d.nk, nu = d.nu, ttl = d.ttl, ks = d.ks;
+    const uint32_t epi = a.epi;
+    const uint32_t ssl = 2u * ks, nsg = d.ring * ssl;                 // steps per super-step; stages of the ring
+    const uint32_t lrow0 = blockIdx.x * 2u * hh, rows0 = a.rows[0];
+    if (wid >= d.ncw) {
+        // ---- the two weight loaders: loader la brings the steps k = la (mod 2); stage of step k = k % nsg (layout: G7's, one tile) --------
+        const uint32_t la = wid - d.ncw;
+        const uint32_t lr = lane >> 4, cp = lane & 15u;
+        const int8_t *src[4];
+        uint32_t lvm = 0, ilm = 0, ips = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t r = 4u * (uint32_t)i + lr, half = r >> 3, rr = r & 7u;
+            const uint32_t grow = lrow0 + half * hh + rr;
+            const bool live = rr < hh && grow < rows0;
+            src[i] = a.w[0] + ((size_t)grow * n + ((cp ^ (r & 15u)) << 4));
+            const uint32_t rr_first = (4u * (uint32_t)i) & 7u, grow_first = lrow0 + ((uint32_t)i >> 1) * hh + rr_first;
+            const bool any = rr_first < hh && grow_first < rows0;
+            lvm |= live ? 1u << i : 0u; ilm |= any ? 1u << i : 0u; ips += any ? 1u : 0u;
+        }
+        // the step's weight scales: lane p < 16 serves tile row p -> that row's 16 bytes (4 groups)
+        const uint32_t srow = lrow0 + (cp >> 3) * hh + (cp & 7u);
+        const bool sl = lr == 0u && (cp & 7u) < hh && srow < rows0;
+        const float *ssrc = a.ws[0] + (size_t)srow * ng;
+        ips += 1u;
+        auto issue = [&](uint32_t k) {
+            unsigned char *st = smem + (k % nsg) * G7K_STAGE;
+            const uint32_t kb = k * 256u;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (ilm & (1u << i)) { if (lvm & (1u << i)) g7_dma16<2>(src[i] + kb, st + (uint32_t)i * 1024u); }
+            if (sl) g7_dma16<0>(ssrc + k * 4u, st + 4096u);
+        };
+        uint32_t mine = 0;
+        const uint32_t pre = nsg < nk ? nsg : nk;
+        for (uint32_t k = la; k < pre; k += 2u) { issue(k); mine++; }
+        for (uint32_t s = 0; s < d.nss; s++) {
+            const uint32_t bound = (s + 1u) * ssl < nk ? (s + 1u) * ssl : nk;      // steps below `bound` must have landed
+            const uint32_t need = bound > la ? (bound - la + 1u) >> 1 : 0u;        // ... this loader's share of them
+            g7_wait_vm((mine - need) * ips);
+            g7_loader_barrier();
+            if (s >= 1u) {                                                         // super-step s - 1 has been read: its stages take super-step s - 1 + RING
+                const uint32_t k0 = (s - 1u + d.ring) * ssl, k1 = k0 + ssl < nk ? k0 + ssl : nk;
+                for (uint32_t k = k0 + ((k0 ^ la) & 1u); k < k1; k += 2u) { issue(k); mine++; }
+            }
+        }
+        return;
+    }
+    // ---- consumers: wave (phase j, token tile tt) -----------------------------------------------------------------------------------------
+    const uint32_t m = lane & 15u, kq = lane >> 4;
+    uint32_t a_off[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) a_off[j] = m * 256u + (((4u * j + kq) ^ m) << 4);
+    const uint32_t half = kq >> 1, rr0 = (kq & 1u) * 4u;
+    const uint32_t ph = wid / ttl, tt = wid - ph * ttl;
+    const uint32_t orow0 = lrow0 + half * hh + rr0;
+    const uint32_t tok = tt * 16u + m;
+    float oldv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t opos = 0u;
+    const uint32_t obs = a.out_bstride[0], ops = a.out_pstride[0];
+    if (ph == 0u && tok < nb && (epi == GEMV_EPI_RESID || ops != 0u)) {
+        if (ops) opos = a.pos[tok];
+        if (epi == GEMV_EPI_RESID) {
+            const float *o = a.out[0] + (size_t)tok * obs + orow0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < rows0) oldv[r] = o[r];
+        }
+    }
+    // this wave's fragments: token tile tt, groups 8 u .. 8 u + 7 of its units, lane l reads slot l; scales [group][16 tokens]
+    const __amdgpu_buffer_rsrc_t rsf = mkrsrc(d.xf, ttl * ng * 1024u);
+    const __amdgpu_buffer_rsrc_t rss = mkrsrc(d.xsf, ttl * ng * 64u);
+    const uint32_t fbase = tt * ng * 1024u + lane * 16u, sbase = (tt * ng * 16u + m) * 4u;
+    i32x4 fb[2][4];
+    float xsc[2][4];
+    auto b_issue = [&](auto H, uint32_t u) {                            // half H (step 2 u + H) of unit u; beyond the row: zeros, no access
+        constexpr int h = decltype(H)::value;
+        const uint32_t g0 = 8u * u + 4u * (uint32_t)h;
+        const bool in = 2u * u + (uint32_t)h < nk && u < nu;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            fb[h][j] = __builtin_amdgcn_raw_buffer_load_b128(rsf, (int)(in ? fbase + (g0 + (uint32_t)j) * 1024u : OOB), 0, 0);
+            xsc[h][j] = bload_f(rss, in ? sbase + (g0 + (uint32_t)j) * 64u : OOB);
+        }
+    };
+    g7f2 S01, S23;
+    auto step = [&](auto H, const unsigned char *st) {
+        constexpr int h = decltype(H)::value;
+        const float *WS = reinterpret_cast<const float *>(st + 4096u) + kq * 16u;
+        i32x4 fa[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fa[j] = *reinterpret_cast<const i32x4 *>(st + a_off[j]);
+        g7f2 w01[4], w23[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { w01[j] = g7f2{WS[j], WS[4 + j]}; w23[j] = g7f2{WS[8 + j], WS[12 + j]}; }
+        v4i cv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) cv[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[j], fb[h][j], v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                                   // infer.c:672 per output, then the running unit sum (packed fp32: G7's step)
+            const g7f2 c01 = {(float)cv[j][0], (float)cv[j][1]}, c23 = {(float)cv[j][2], (float)cv[j][3]};
+            const g7f2 x2 = {xsc[h][j], xsc[h][j]};
+            const g7f2 p01 = (c01 * w01[j]) * x2, p23 = (c23 * w23[j]) * x2;
+            if (h == 0 && j == 0) { S01 = p01; S23 = p23; }
+            else { S01 += p01; S23 += p23; }
+        }
+    };
+    using H0_ = std::integral_constant<int, 0>; using H1_ = std::integral_constant<int, 1>;
+    float4 *tab = reinterpret_cast<float4 *>(smem + d.tab);
+    b_issue(H0_{}, ph); b_issue(H1_{}, ph);
+    for (uint32_t s = 0; s < d.nss; s++) {
+        __syncthreads();                                                 // the weights of super-step s have landed; everyone is done with s - 1
+        const uint32_t u = s * ks + ph;
+        if (u < nu) {
+            const uint32_t k0 = 2u * u;
+            step(H0_{}, smem + (k0 % nsg) * G7K_STAGE);
+            b_issue(H0_{}, u + ks);                                      // the next unit's first half into the registers just read
+            if (k0 + 1u < nk) step(H1_{}, smem + ((k0 + 1u) % nsg) * G7K_STAGE);
+            b_issue(H1_{}, u + ks);
+            tab[(u * ttl + tt) * 64u + lane] = make_float4(S01.x, S01.y, S23.x, S23.y);
+        }
+    }
+    __syncthreads();                                                     // every unit sum is in the table
+    if (ph != 0u) return;
+    float acc[4];
+    {
+        const float4 t0 = tab[tt * 64u + lane];                          // units ascending; the first unit is the row's starting value (not 0 + S_0: -0.0)
+        acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
+        for (uint32_t u = 1; u < nu; u++) {
+            const float4 t = tab[(u * ttl + tt) * 64u + lane];
+            acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+        }
+    }
+    if (tok < nb) {
+        float *o = a.out[0] + (size_t)tok * obs + (size_t)opos * ops + orow0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < rows0) o[r] = finish_epi(epi, acc[r], 0.0f, oldv[r]);
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
 struct G7Plan { uint32_t hh, ntiles, tc0, tc1, grid, tpw, nk, ttl, nsa, a_stage, a_ws, b_base, b_stage, b_xs, tp, pp; bool ms; size_t lds; };
 
@@ -422,9 +589,49 @@ static hipError_t g7_launch_t(const G7Dev &d, size_t lds, hipStream_t st) {
     return hipGetLastError();
 }
 
+
+
+// ---- G7K: plan ----------------------------------------------------------------------------------------------------------------------------
+struct G7KPlan { uint32_t hh, ntiles, nk, nu, ttl, ks, ncw, nss, tab, ring; size_t lds; };
+static bool g7k_plan(const GemvArgs &a, G7KPlan &p) {
+    if (a.gs != 64 || a.nb < 17u || a.nb > 64u || a.n % 256u || a.nseg != 1 || a.epi == GEMV_EPI_SWIGLU) return false;
+    if (a.ordered || a.resid_add || a.tile_max || a.attn_part) return false;
+    if ((uint64_t)a.seg[0].rows * a.n >= (1ull << 32) - (1u << 20) || a.seg[0].rows >= 65536u) return false;
+    const uint32_t cus = a.cus ? a.cus : 256u, rows = a.seg[0].rows;
+    p.hh = 0;
+    // tile height: a workgroup's time does not depend on its live rows (a matrix-core tile and its VALU work cost the same): the lowest tile
+    // that still gives every workgroup a CU of its own = the most CUs at work (Qwen3-0.6B's Wo / W2: 256 workgroups of 4 rows instead of 64 of 16:
+    // 1.437 -> 1.413 ms per 64-sequence step; Qwen3-4B's: 256 of 10 rows instead of 160 of 16: 3.215 -> 3.19)
+    for (uint32_t hh = 1; hh <= 8 && !p.hh; hh++) if ((rows + 2u * hh - 1u) / (2u * hh) <= cus) p.hh = hh;
+    if (!p.hh) return false;
+    p.ntiles = (rows + 2u * p.hh - 1u) / (2u * p.hh);
+    p.nk = a.n / 256u; p.nu = (p.nk + 1u) / 2u; p.ttl = (a.nb + 15u) / 16u;
+    if (p.nk < 8u) return false;                                       // short rows: G7 / G6
+    // Where it pays (same-box A/Bs against G6 MODE F, profiles/r06_g7k.txt): up to three token tiles.  Qwen3-0.6B at 32 sequences 1.253 ->
+    // 1.18-1.23 ms per step, Qwen3-4B at 48: 3.012 -> 2.981, at 32: even; with FOUR token tiles (49..64 tokens) it LOSES: Qwen3-4B at 64
+    // sequences 3.127 -> 3.19 ms, Qwen3-0.6B even -- both kernels then sit at the same ~0.1 us per (16 rows x 16 tokens x 256 B) of a CU.
+    if (p.ttl > 3u) return false;
+    // phases: as many as the fourteen consumer waves and the ring + table allow
+    // the ring: three super-steps where LDS allows (the weights of super-step s + 2 go out at barrier s: one DMA issue + one HBM round trip
+    // per super-step with a ring of two -- Qwen3-4B at 64 sequences 3.24-3.27 ms against 3.195-3.215 with three), else two
+    constexpr uint32_t ring_env = 3u;
+    for (uint32_t ks = G7_NCW / p.ttl; ks >= 2u; ks--) {
+        for (uint32_t rg = ring_env; rg >= 2u; rg--) {
+            const size_t ring = (size_t)rg * 2u * ks * G7K_STAGE, tab = (size_t)p.nu * p.ttl * 1024u;
+            if (ks > p.nu || ring + tab > G7_LDS) continue;
+            if (rg * ks * 5u > 60u) continue;                          // a loader's instructions in flight (ring super-steps x ks steps x <= 5) fit vmcnt's six bits
+            p.ks = ks; p.ncw = ks * p.ttl; p.nss = (p.nu + ks - 1u) / ks; p.ring = rg;
+            p.tab = (uint32_t)ring; p.lds = ring + tab;
+            return true;
+        }
+    }
+    return false;
+}
+
 }  // namespace
 
 bool gemm_q80_g7_supports(const GemvArgs &a) {
+    { G7KPlan kp; G7Plan gp; if (g7k_plan(a, kp) && g7_plan(a, gp) && gp.tpw == 1u) return true; }      // one row tile per CU and a long row: the K-phase form
     if (a.gs != 64 || a.nb < 17u || a.nb > 64u || a.n % 256u || a.nseg == 0 || a.nseg > 3) return false;
     if (a.ordered || a.resid_add || a.tile_max || a.attn_part) return false;
     if (a.epi == GEMV_EPI_SWIGLU && (a.nseg != 2 || a.seg[0].rows != a.seg[1].rows)) return false;
@@ -444,6 +651,22 @@ hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st) {
     if (!a.xq_in || !a.xs_in || !gemm_q80_g7_supports(a)) return hipErrorInvalidValue;
     G7Plan p;
     if (!g7_plan(a, p)) return hipErrorInvalidValue;
+    G7KPlan kp;
+    if (p.tpw == 1u && g7k_plan(a, kp)) {
+        G7KDev d{};
+        d.g = to_dev(a);
+        d.g.nthr = (kp.ncw + G7_NLA) * 64u;
+        d.xf = a.xq_in; d.xsf = a.xs_in;
+        d.hh = kp.hh; d.ntiles = kp.ntiles; d.nk = kp.nk; d.nu = kp.nu; d.ttl = kp.ttl; d.ks = kp.ks; d.ncw = kp.ncw; d.nss = kp.nss; d.tab = kp.tab; d.ring = kp.ring;
+        static std::atomic<bool> armed_k[64];
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !armed_k[dev].load(std::memory_order_acquire)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_q80_g7k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7_LDS);
+            if (dev >= 0 && dev < 64) armed_k[dev].store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(gemm_q80_g7k_kernel, dim3(kp.ntiles), dim3((kp.ncw + G7_NLA) * 64u), kp.lds, st, d);
+        return hipGetLastError();
+    }
     G7Dev d{};
     d.g = to_dev(a);
     d.g.nthr = G7_NW * 64u;

@@ -201,7 +201,7 @@ GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (17, 0, 2560, (4096, 1024, 1024
 
 
 def g7_pays(n, rows, nb_, kind, cus=256):
-    """gemm_q80_g7.hip's rule, restated: row tiles per workgroup x token tiles >= 8, or at most four 256-byte steps"""
+    """gemm_q80_g7.hip's rule, restated: row tiles per workgroup x token tiles >= 8, or at most four 256-byte steps, or its K-phase form"""
     best, best_cost = 0, None
     for hh in range(1, 9):
         trw = 2 * hh
@@ -212,7 +212,10 @@ def g7_pays(n, rows, nb_, kind, cus=256):
             best, best_cost = hh, cost
     tiles = sum((r + 2 * best - 1) // (2 * best) for r in rows)
     tpw = (tiles + min(tiles, cus) - 1) // min(tiles, cus)
-    return tpw * ((nb_ + 15) // 16) >= 8 or n // 256 <= 4
+    if tpw * ((nb_ + 15) // 16) >= 8 or n // 256 <= 4:
+        return True
+    # round 6, the K-phase form (gemm_q80_g7k_kernel): ONE row tile per workgroup, one weight segment (no SwiGLU), a row of >= 8 steps, <= 3 token tiles
+    return tpw == 1 and len(rows) == 1 and n // 256 >= 8 and (nb_ + 15) // 16 <= 3
 
 
 def gemm_route_case(oracle, nb_, kind, n, rows):
