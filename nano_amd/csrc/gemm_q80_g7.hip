@@ -367,7 +367,7 @@ constexpr uint32_t G7K_STAGE = 4096u + 256u;        // a stage: the tile's 16 ro
 struct G7KDev {
     GemvDev g;
     const int8_t *xf; const float *xsf;
-    uint32_t hh, ntiles, nk, nu, ttl, ks, ncw, nss;     // live rows per half tile; tiles = workgroups; steps; units; token tiles; phases; consumer waves; super-steps
+    uint32_t hh, ntiles, nk, nu, ttl, ks, ncw, nss, nl; // live rows per half tile; tiles = workgroups; steps; units; token tiles; phases; consumer waves; super-steps; loader waves
     uint32_t tab, ring;                                 // LDS offset of the unit-sum table; super-steps of weights in the ring
 };
 
@@ -381,8 +381,9 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7k_kernel(const G7KDev d
     const uint32_t ssl = 2u * ks, nsg = d.ring * ssl;                 // steps per super-step; stages of the ring
     const uint32_t lrow0 = blockIdx.x * 2u * hh, rows0 = a.rows[0];
     if (wid >= d.ncw) {
-        // ---- the two weight loaders: loader la brings the steps k = la (mod 2); stage of step k = k % nsg (layout: G7's, one tile) --------
-        const uint32_t la = wid - d.ncw;
+        // ---- the weight loaders (nl = the waves the consumers leave, 2..6): loader la brings the steps k = la (mod nl); stage of step k =
+        //      k % nsg (layout: G7's, one tile).  A DMA instruction costs ~150 cycles of issue: two loaders move a step per ~0.18 us ----------
+        const uint32_t la = wid - d.ncw, nl = d.nl;
         const uint32_t lr = lane >> 4, cp = lane & 15u;
         const int8_t *src[4];
         uint32_t lvm = 0, ilm = 0, ips = 0;
@@ -411,15 +412,15 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7k_kernel(const G7KDev d
         };
         uint32_t mine = 0;
         const uint32_t pre = nsg < nk ? nsg : nk;
-        for (uint32_t k = la; k < pre; k += 2u) { issue(k); mine++; }
+        for (uint32_t k = la; k < pre; k += nl) { issue(k); mine++; }
         for (uint32_t s = 0; s < d.nss; s++) {
             const uint32_t bound = (s + 1u) * ssl < nk ? (s + 1u) * ssl : nk;      // steps below `bound` must have landed
-            const uint32_t need = bound > la ? (bound - la + 1u) >> 1 : 0u;        // ... this loader's share of them
+            const uint32_t need = bound > la ? (bound - la + nl - 1u) / nl : 0u;   // ... this loader's share of them
             g7_wait_vm((mine - need) * ips);
             g7_loader_barrier();
             if (s >= 1u) {                                                         // super-step s - 1 has been read: its stages take super-step s - 1 + RING
                 const uint32_t k0 = (s - 1u + d.ring) * ssl, k1 = k0 + ssl < nk ? k0 + ssl : nk;
-                for (uint32_t k = k0 + ((k0 ^ la) & 1u); k < k1; k += 2u) { issue(k); mine++; }
+                for (uint32_t k = k0 + (la + nl - k0 % nl) % nl; k < k1; k += nl) { issue(k); mine++; }
             }
         }
         return;
@@ -592,9 +593,9 @@ static hipError_t g7_launch_t(const G7Dev &d, size_t lds, hipStream_t st) {
 
 
 // ---- G7K: plan ----------------------------------------------------------------------------------------------------------------------------
-struct G7KPlan { uint32_t hh, ntiles, nk, nu, ttl, ks, ncw, nss, tab, ring; size_t lds; };
+struct G7KPlan { uint32_t hh, ntiles, nk, nu, ttl, ks, ncw, nss, tab, ring, nl; size_t lds; };
 static bool g7k_plan(const GemvArgs &a, G7KPlan &p) {
-    if (a.gs != 64 || a.nb < 17u || a.nb > 64u || a.n % 256u || a.nseg != 1 || a.epi == GEMV_EPI_SWIGLU) return false;
+    if (a.gs != 64 || a.nb < 3u || a.nb > 64u || a.n % 256u || a.nseg != 1 || a.epi == GEMV_EPI_SWIGLU) return false;
     if (a.ordered || a.resid_add || a.tile_max || a.attn_part) return false;
     if ((uint64_t)a.seg[0].rows * a.n >= (1ull << 32) - (1u << 20) || a.seg[0].rows >= 65536u) return false;
     const uint32_t cus = a.cus ? a.cus : 256u, rows = a.seg[0].rows;
@@ -611,16 +612,20 @@ static bool g7k_plan(const GemvArgs &a, G7KPlan &p) {
     // 1.18-1.23 ms per step, Qwen3-4B at 48: 3.012 -> 2.981, at 32: even; with FOUR token tiles (49..64 tokens) it LOSES: Qwen3-4B at 64
     // sequences 3.127 -> 3.19 ms, Qwen3-0.6B even -- both kernels then sit at the same ~0.1 us per (16 rows x 16 tokens x 256 B) of a CU.
     if (p.ttl > 3u) return false;
+    // (3..16 tokens, round 6: Qwen3-0.6B at 16 sequences 1.068 -> 1.016 ms per step, Qwen3-4B at 4 / 8 / 16: -0.9 % each; the loaders are the
+    //  waves the consumers leave, up to six -- at 32..48 tokens four loaders instead of two changed nothing)
     // phases: as many as the fourteen consumer waves and the ring + table allow
     // the ring: three super-steps where LDS allows (the weights of super-step s + 2 go out at barrier s: one DMA issue + one HBM round trip
     // per super-step with a ring of two -- Qwen3-4B at 64 sequences 3.24-3.27 ms against 3.195-3.215 with three), else two
     constexpr uint32_t ring_env = 3u;
-    for (uint32_t ks = G7_NCW / p.ttl; ks >= 2u; ks--) {
+    const uint32_t ks_max = G7_NCW / p.ttl < 6u ? G7_NCW / p.ttl : 6u;
+    for (uint32_t ks = ks_max; ks >= 2u; ks--) {
+        const uint32_t nl = G7_NW - ks * p.ttl < 6u ? G7_NW - ks * p.ttl : 6u;     // the waves the consumers leave load
         for (uint32_t rg = ring_env; rg >= 2u; rg--) {
             const size_t ring = (size_t)rg * 2u * ks * G7K_STAGE, tab = (size_t)p.nu * p.ttl * 1024u;
             if (ks > p.nu || ring + tab > G7_LDS) continue;
-            if (rg * ks * 5u > 60u) continue;                          // a loader's instructions in flight (ring super-steps x ks steps x <= 5) fit vmcnt's six bits
-            p.ks = ks; p.ncw = ks * p.ttl; p.nss = (p.nu + ks - 1u) / ks; p.ring = rg;
+            if (rg * ((2u * ks + nl - 1u) / nl) * 5u > 60u) continue;  // a loader's instructions in flight (ring super-steps x its steps x <= 5) fit vmcnt's six bits
+            p.ks = ks; p.ncw = ks * p.ttl; p.nss = (p.nu + ks - 1u) / ks; p.ring = rg; p.nl = nl;
             p.tab = (uint32_t)ring; p.lds = ring + tab;
             return true;
         }
@@ -631,7 +636,7 @@ static bool g7k_plan(const GemvArgs &a, G7KPlan &p) {
 }  // namespace
 
 bool gemm_q80_g7_supports(const GemvArgs &a) {
-    { G7KPlan kp; G7Plan gp; if (g7k_plan(a, kp) && g7_plan(a, gp) && gp.tpw == 1u) return true; }      // one row tile per CU and a long row: the K-phase form
+    { G7KPlan kp; if (g7k_plan(a, kp)) return true; }                   // one row tile per CU and a long row: the K-phase form
     if (a.gs != 64 || a.nb < 17u || a.nb > 64u || a.n % 256u || a.nseg == 0 || a.nseg > 3) return false;
     if (a.ordered || a.resid_add || a.tile_max || a.attn_part) return false;
     if (a.epi == GEMV_EPI_SWIGLU && (a.nseg != 2 || a.seg[0].rows != a.seg[1].rows)) return false;
@@ -649,24 +654,24 @@ bool gemm_q80_g7_supports(const GemvArgs &a) {
 
 hipError_t launch_gemm_q80_g7(const GemvArgs &a, hipStream_t st) {
     if (!a.xq_in || !a.xs_in || !gemm_q80_g7_supports(a)) return hipErrorInvalidValue;
-    G7Plan p;
-    if (!g7_plan(a, p)) return hipErrorInvalidValue;
     G7KPlan kp;
-    if (p.tpw == 1u && g7k_plan(a, kp)) {
+    if (g7k_plan(a, kp)) {
         G7KDev d{};
         d.g = to_dev(a);
-        d.g.nthr = (kp.ncw + G7_NLA) * 64u;
+        d.g.nthr = (kp.ncw + kp.nl) * 64u;
         d.xf = a.xq_in; d.xsf = a.xs_in;
-        d.hh = kp.hh; d.ntiles = kp.ntiles; d.nk = kp.nk; d.nu = kp.nu; d.ttl = kp.ttl; d.ks = kp.ks; d.ncw = kp.ncw; d.nss = kp.nss; d.tab = kp.tab; d.ring = kp.ring;
+        d.hh = kp.hh; d.ntiles = kp.ntiles; d.nk = kp.nk; d.nu = kp.nu; d.ttl = kp.ttl; d.ks = kp.ks; d.ncw = kp.ncw; d.nss = kp.nss; d.tab = kp.tab; d.ring = kp.ring; d.nl = kp.nl;
         static std::atomic<bool> armed_k[64];
         int dev = 0; (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !armed_k[dev].load(std::memory_order_acquire)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_q80_g7k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G7_LDS);
             if (dev >= 0 && dev < 64) armed_k[dev].store(true, std::memory_order_release);
         }
-        hipLaunchKernelGGL(gemm_q80_g7k_kernel, dim3(kp.ntiles), dim3((kp.ncw + G7_NLA) * 64u), kp.lds, st, d);
+        hipLaunchKernelGGL(gemm_q80_g7k_kernel, dim3(kp.ntiles), dim3((kp.ncw + kp.nl) * 64u), kp.lds, st, d);
         return hipGetLastError();
     }
+    G7Plan p;
+    if (!g7_plan(a, p)) return hipErrorInvalidValue;
     G7Dev d{};
     d.g = to_dev(a);
     d.g.nthr = G7_NW * 64u;

@@ -182,7 +182,8 @@ def test_batched_wide_roles_q80(oracle, nb_, kind):
             assert np.allclose(out[b], want, rtol=3e-6, atol=1e-9), b
         return
     old = rng.standard_normal((nb_, sum(rows))).astype(np.float32)
-    check_q80(oracle, kind, n, segs, x, nw, old, nb_, routes=("gemv",) if nb_ <= 2 else ("frag_g6",))
+    # (round 6: one weight segment and a long row -> G7's K-phase form from three sequences on; g7k_takes is defined below)
+    check_q80(oracle, kind, n, segs, x, nw, old, nb_, routes=("gemv",) if nb_ <= 2 else ("frag_g7",) if g7k_takes(n, rows, nb_) else ("frag_g6",))
 
 
 GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (17, 0, 2560, (4096, 1024, 1024)), (32, 1, 9728, (2560,)), (64, 1, 9728, (2560,)), (48, 0, 2560, (4096, 1024, 1024)),
@@ -201,7 +202,7 @@ GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (17, 0, 2560, (4096, 1024, 1024
 
 
 def g7_pays(n, rows, nb_, kind, cus=256):
-    """gemm_q80_g7.hip's rule, restated: row tiles per workgroup x token tiles >= 8, or at most four 256-byte steps, or its K-phase form"""
+    """gemm_q80_g7.hip's rule, restated: row tiles per workgroup x token tiles >= 8, or at most four 256-byte steps"""
     best, best_cost = 0, None
     for hh in range(1, 9):
         trw = 2 * hh
@@ -212,10 +213,13 @@ def g7_pays(n, rows, nb_, kind, cus=256):
             best, best_cost = hh, cost
     tiles = sum((r + 2 * best - 1) // (2 * best) for r in rows)
     tpw = (tiles + min(tiles, cus) - 1) // min(tiles, cus)
-    if tpw * ((nb_ + 15) // 16) >= 8 or n // 256 <= 4:
-        return True
-    # round 6, the K-phase form (gemm_q80_g7k_kernel): ONE row tile per workgroup, one weight segment (no SwiGLU), a row of >= 8 steps, <= 3 token tiles
-    return tpw == 1 and len(rows) == 1 and n // 256 >= 8 and (nb_ + 15) // 16 <= 3
+    return tpw * ((nb_ + 15) // 16) >= 8 or n // 256 <= 4
+
+
+def g7k_takes(n, rows, nb_, cus=256):
+    """round 6, the K-phase form (gemm_q80_g7k_kernel), restated: 3..48 tokens, ONE weight segment (no SwiGLU), a row of >= 8 steps, and a
+    tile height <= 8 that gives every row tile a CU of its own"""
+    return 3 <= nb_ <= 48 and len(rows) == 1 and n % 256 == 0 and n // 256 >= 8 and (rows[0] + 15) // 16 <= cus
 
 
 def gemm_route_case(oracle, nb_, kind, n, rows):
@@ -232,7 +236,7 @@ def gemm_route_case(oracle, nb_, kind, n, rows):
             assert np.array_equal(bits(out[b]), bits(ref)), (b, float(np.abs(out[b] - ref).max()))
         return "frag_old"
     # 17..64 tokens: G7 where it pays (several row tiles per CU, or very short rows: gemm_q80_g7_supports), else G6 MODE F
-    g7 = nb_ >= 17 and n % 256 == 0 and g7_pays(n, rows, nb_, kind)
+    g7 = (nb_ >= 17 and n % 256 == 0 and g7_pays(n, rows, nb_, kind)) or g7k_takes(n, rows, nb_)
     want = ("frag_old",) if n % 256 else ("frag_g7",) if g7 else ("frag_g6",)
     return check_q80(oracle, kind, n, segs, x, nw, old, nb_, use_gemm=True, routes=want)
 
