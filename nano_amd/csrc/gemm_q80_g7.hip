@@ -615,21 +615,20 @@ static bool g7k_plan(const GemvArgs &a, G7KPlan &p) {
     // (3..16 tokens, round 6: Qwen3-0.6B at 16 sequences 1.068 -> 1.016 ms per step, Qwen3-4B at 4 / 8 / 16: -0.9 % each; the loaders are the
     //  waves the consumers leave, up to six -- at 32..48 tokens four loaders instead of two changed nothing)
     // phases: as many as the fourteen consumer waves and the ring + table allow
-    // the ring: three super-steps where LDS allows (the weights of super-step s + 2 go out at barrier s: one DMA issue + one HBM round trip
-    // per super-step with a ring of two -- Qwen3-4B at 64 sequences 3.24-3.27 ms against 3.195-3.215 with three), else two
-    constexpr uint32_t ring_env = 3u;
+    // the ring comes first: THREE super-steps (the weights of super-step s + 2 go out at barrier s; with two, every super-step pays a DMA issue
+    // + an HBM round trip -- Qwen3-4B at 64 sequences 3.24-3.27 ms against 3.195-3.215), then as many phases as still fit; two only when no
+    // phase count leaves room for three (the most phases first, the ring second, measured 0.6-0.8 % slower on Qwen3-4B at 8 / 16 / 32 sequences)
     const uint32_t ks_max = G7_NCW / p.ttl < 6u ? G7_NCW / p.ttl : 6u;
-    for (uint32_t ks = ks_max; ks >= 2u; ks--) {
+    auto fits = [&](uint32_t ks, uint32_t rg) {
         const uint32_t nl = G7_NW - ks * p.ttl < 6u ? G7_NW - ks * p.ttl : 6u;     // the waves the consumers leave load
-        for (uint32_t rg = ring_env; rg >= 2u; rg--) {
-            const size_t ring = (size_t)rg * 2u * ks * G7K_STAGE, tab = (size_t)p.nu * p.ttl * 1024u;
-            if (ks > p.nu || ring + tab > G7_LDS) continue;
-            if (rg * ((2u * ks + nl - 1u) / nl) * 5u > 60u) continue;  // a loader's instructions in flight (ring super-steps x its steps x <= 5) fit vmcnt's six bits
-            p.ks = ks; p.ncw = ks * p.ttl; p.nss = (p.nu + ks - 1u) / ks; p.ring = rg; p.nl = nl;
-            p.tab = (uint32_t)ring; p.lds = ring + tab;
-            return true;
-        }
-    }
+        const size_t ring = (size_t)rg * 2u * ks * G7K_STAGE, tab = (size_t)p.nu * p.ttl * 1024u;
+        if (ks > p.nu || ring + tab > G7_LDS) return false;
+        if (rg * ((2u * ks + nl - 1u) / nl) * 5u > 60u) return false;  // a loader's instructions in flight (ring super-steps x its steps x <= 5) fit vmcnt's six bits
+        p.ks = ks; p.ncw = ks * p.ttl; p.nss = (p.nu + ks - 1u) / ks; p.ring = rg; p.nl = nl;
+        p.tab = (uint32_t)ring; p.lds = ring + tab;
+        return true;
+    };
+    for (uint32_t rg = 3u; rg >= 2u; rg--) for (uint32_t ks = ks_max; ks >= 2u; ks--) if (fits(ks, rg)) return true;
     return false;
 }
 
