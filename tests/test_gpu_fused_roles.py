@@ -196,6 +196,9 @@ GEMM_CASES = [(16, 0, 1024, (2048, 1024, 1024)), (17, 0, 2560, (4096, 1024, 1024
               # ... its residual epilogue and a two-token-tile launch on shapes with several row tiles per CU
               (64, 1, 3072, (8192,)), (32, 1, 2048, (16000,)), (25, 0, 2560, (4096, 1024, 1024)),
               (3, 1, 9728, (2560,)), (1, 0, 2560, (4096, 1024, 1024)),
+              # G7's K-phase form (round 6): an odd step count (2304 = 9 steps: the last unit is half a unit) with ragged rows, the largest
+              # token count it takes with a ragged last row tile, a short batch on a matrix of 33 row tiles, the first size G7 itself starts at
+              (17, 1, 2304, (1000,)), (48, 1, 2816, (2550,)), (5, 1, 2304, (520,)), (17, 1, 4096, (2560,)), (48, 1, 9728, (2560,)),
               # tall matrices (>= 16384 rows): the classifier's kernel GC (gemm_q80_cls.hip) -- every token tile staged in LDS /
               # two staged + two from L2 (64 tokens at row length 2560), a ragged last row tile, group counts 16 / 40 / 12
               (16, 0, 1024, (16400,)), (64, 0, 1024, (16391,)), (8, 0, 2560, (16512,)), (64, 0, 2560, (16390,)), (33, 0, 768, (16384,))]
