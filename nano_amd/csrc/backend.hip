@@ -96,6 +96,7 @@ struct NanoHipModel {
     uint32_t nsplit_cap = 8;                             // the partial buffers are sized for it (32 beyond 2048 positions)
     // pinned host staging
     uint32_t *h_tokens = nullptr, *h_pos = nullptr, *h_amax = nullptr;
+    uint32_t *pf_stage = nullptr; uint32_t pf_cap = 0;    // batched prefill: the prompt's tokens | positions on the device (the chunks copy from here: no host round trip per chunk)
     uint32_t *h_err = nullptr, *dev_err = nullptr;        // sticky error word: host-mapped, written by kernels that give up a bounded wait (kernels.h NANO_DEVERR_*)
     float *h_logits = nullptr;
     std::map<uint64_t, hipGraphExec_t> graphs;
@@ -210,6 +211,7 @@ static void destroy(NanoHipModel *m) {
     void *host[] = { m->h_tokens, m->h_pos, m->h_amax, m->h_logits, m->h_pt };
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (m->q4x) (void)hipFree(m->q4x);
+    if (m->pf_stage) (void)hipFree(m->pf_stage);
     if (m->h_err) (void)hipHostFree(m->h_err);
     if (m->smp) {
         if (m->smp->block) (void)hipFree(m->smp->block);
@@ -1316,13 +1318,27 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
         return 0;
     }
     const uint32_t chunk_max = m->d.quant_type == NANO_QUANT_Q80 ? 64u : 8u;
+    // Round 6: the whole prompt's tokens and positions go to the device ONCE; a chunk takes its share by device-to-device copies on the stream
+    // and the host waits only at the end (it used to copy and wait per chunk: two small transfers + a stream synchronisation per 64 tokens).
+    if (count > m->pf_cap) {
+        if (m->pf_stage) { HIP_TRY(hipStreamSynchronize(m->st)); (void)hipFree(m->pf_stage); m->pf_stage = nullptr; m->pf_cap = 0; }
+        const uint32_t cap = count > m->S ? count : m->S;
+        if (hipMalloc(reinterpret_cast<void **>(&m->pf_stage), (size_t)cap * 8) != hipSuccess) FAIL(NANO_HIP_ENOMEM, "hipMalloc of the prompt staging buffer failed");
+        m->pf_cap = cap;
+    }
+    if (count) {
+        std::vector<uint32_t> hp(count);
+        for (uint32_t i = 0; i < count; i++) hp[i] = pos0 + i;
+        HIP_TRY(hipMemcpyAsync(m->pf_stage, tokens, (size_t)count * 4, hipMemcpyHostToDevice, m->st));          // (pageable sources: staged by the runtime before the call returns)
+        HIP_TRY(hipMemcpyAsync(m->pf_stage + m->pf_cap, hp.data(), (size_t)count * 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));                              // hp leaves scope; one wait per prompt
+    }
     for (uint32_t done = 0; done < count;) {
         uint32_t nb = (count - done < chunk_max) ? count - done : chunk_max;
         const uint32_t to_bucket_end = 64u - (pos0 + done) % 64u;          // one attention range bucket per chunk (see enqueue_step)
         if (nb > to_bucket_end) nb = to_bucket_end;
-        for (uint32_t i = 0; i < nb; i++) { m->h_tokens[i] = tokens[done + i]; m->h_pos[i] = pos0 + done + i; }
-        HIP_TRY(hipMemcpyAsync(m->tokens, m->h_tokens, nb * 4, hipMemcpyHostToDevice, m->st));
-        HIP_TRY(hipMemcpyAsync(m->pos, m->h_pos, nb * 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(m->tokens, m->pf_stage + done, nb * 4, hipMemcpyDeviceToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(m->pos, m->pf_stage + m->pf_cap + done, nb * 4, hipMemcpyDeviceToDevice, m->st));
         uint32_t range_hint = ((pos0 + done + nb + 63) / 64) * 64;
         if (range_hint > m->S) range_hint = m->S;
         m->pf = true; m->pf_slot = slot;
@@ -1364,9 +1380,9 @@ extern "C" int nano_hip_prefill(NanoHipModel *m, uint32_t slot, const uint32_t *
         m->pf = false;
         m->nsplit = 1;                                                     // a prefill chunk leaves xba final (single split or the combine kernel), replayed or not
         HIP_TRY(e);
-        HIP_TRY(hipStreamSynchronize(m->st));                              // h_tokens / h_pos are reused by the next chunk
         done += nb;
     }
+    HIP_TRY(hipStreamSynchronize(m->st));
     return dev_err_check(m);
 }
 
