@@ -380,6 +380,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7k_kernel(const G7KDev d
     const uint32_t epi = a.epi;
     const uint32_t ssl = 2u * ks, nsg = d.ring * ssl;                 // steps per super-step; stages of the ring
     const uint32_t lrow0 = blockIdx.x * 2u * hh, rows0 = a.rows[0];
+    NANO_STAMP(a.stamps, 0, tid);
     if (wid >= d.ncw) {
         // ---- the weight loaders (nl = the waves the consumers leave, 2..6): loader la brings the steps k = la (mod nl); stage of step k =
         //      k % nsg (layout: G7's, one tile).  A DMA instruction costs ~150 cycles of issue: two loaders move a step per ~0.18 us ----------
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7k_kernel(const G7KDev d
                 for (uint32_t k = k0 + (la + nl - k0 % nl) % nl; k < k1; k += nl) { issue(k); mine++; }
             }
         }
+        NANO_STAMP_END(a.stamps, 6);
         return;
     }
     // ---- consumers: wave (phase j, token tile tt) -----------------------------------------------------------------------------------------
@@ -486,8 +488,10 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7k_kernel(const G7KDev d
     using H0_ = std::integral_constant<int, 0>; using H1_ = std::integral_constant<int, 1>;
     float4 *tab = reinterpret_cast<float4 *>(smem + d.tab);
     b_issue(H0_{}, ph); b_issue(H1_{}, ph);
+    NANO_STAMP(a.stamps, 1, fb[0][0].x);                            // (measurement builds: G7's phases) the first unit's fragments arrived
     for (uint32_t s = 0; s < d.nss; s++) {
         __syncthreads();                                                 // the weights of super-step s have landed; everyone is done with s - 1
+        if (s == 0u) NANO_STAMP(a.stamps, 2, s);                         // the first weights have landed
         const uint32_t u = s * ks + ph;
         if (u < nu) {
             const uint32_t k0 = 2u * u;
@@ -497,9 +501,11 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7k_kernel(const G7KDev d
             b_issue(H1_{}, u + ks);
             tab[(u * ttl + tt) * 64u + lane] = make_float4(S01.x, S01.y, S23.x, S23.y);
         }
+        if (s == 0u) NANO_STAMP(a.stamps, 3, S01.x);                     // the first super-step multiplied
     }
     __syncthreads();                                                     // every unit sum is in the table
-    if (ph != 0u) return;
+    NANO_STAMP(a.stamps, 4, S01.x);                                  // every super-step done
+    if (ph != 0u) { NANO_STAMP_END(a.stamps, 6); return; }
     float acc[4];
     {
         const float4 t0 = tab[tt * 64u + lane];                          // units ascending; the first unit is the row's starting value (not 0 + S_0: -0.0)
@@ -515,6 +521,8 @@ __global__ __launch_bounds__(G7_NW * 64) void gemm_q80_g7k_kernel(const G7KDev d
         for (int r = 0; r < 4; r++)
             if (rr0 + (uint32_t)r < hh && orow0 + (uint32_t)r < rows0) o[r] = finish_epi(epi, acc[r], 0.0f, oldv[r]);
     }
+    NANO_STAMP(a.stamps, 5, acc[0]);                                 // stores issued
+    NANO_STAMP_END(a.stamps, 6);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------

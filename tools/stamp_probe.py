@@ -39,6 +39,9 @@ g6_phases = ["issue", "x arrives, norm, quantize (P)", "first weights land", "fi
 # gemm_q80_g7.hip (17..64 tokens, q|k|v and W1|W3): consumer wave 0's stamps
 G7 = quant == "q80" and B >= 17                  # (where gemm_q80_g7_supports() says it pays; the other launches stay G6's)
 g7_phases = ["prologue (fragments of step 0 parked)", "first weights land", "step 0 multiplied", "the other steps", "stores issued", "last wave"]
+# gemm_q80_g7k_kernel (round 6: Wo / W2 at 3..48 tokens where the batched route runs): consumer wave 0's stamps
+G7K = quant == "q80" and 3 <= B <= 48 and (B >= 9 or model in ("qwen3-4b", "wide-qwen3"))
+g7k_phases = ["first unit's fragments arrived", "first weights land", "first super-step multiplied", "the other super-steps", "table folded, stores issued", "last wave"]
 agg = {}
 tl = {}
 GRAPH = os.environ.get("NANO_STAMPS_GRAPH") == "1"          # stamp a graph replay instead of eager launches
@@ -89,6 +92,6 @@ for k in sorted(agg):
     mean = np.mean([r[1] for r in rows], axis=0); mx = np.mean([r[2] for r in rows], axis=0)
     print(f"{names.get(k, k):10s} wgs {wg:6.0f}  entry -> end of a workgroup's first wave: mean {np.mean([r[3] for r in rows]):5.2f}  max {np.mean([r[4] for r in rows]):5.2f}")
     if not LIGHT:
-        print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(g7_phases if (G7 and k in (1, 4)) else g6_phases if (G6 and k != 2) else phases[1 if k != 2 else 2], mean, mx)))
+        print("           " + "  ".join(f"{n} {a:.2f}/{b:.2f}" for n, a, b in zip(g7k_phases if (G7K and k in (3, 5)) else g7_phases if (G7 and k in (1, 4)) else g6_phases if (G6 and k != 2) else phases[1 if k != 2 else 2], mean, mx)))
     t = np.array(tl[k]); print(f"           device clock: entry ramp {t[:, 0].mean():.2f}  span {t[:, 1].mean():.2f}  gap to the next launch {np.nanmean(t[:, 2]):.2f}")
 m.close()
