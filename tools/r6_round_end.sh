@@ -78,6 +78,7 @@ elif [ "$1" = "b" ]; then
   { for a in "qwen3-0.6b q80 1 30" "wide-qwen3 q80 1 30" "wide-qwen3 q80 2 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done; } > $O/${T}_phase_stamps.txt; head -12 $O/${T}_phase_stamps.txt
   { for b in 8 32 64; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py wide-qwen3 q80 $b 30 2>&1 | tail -16; done
     NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py qwen3-0.6b q80 64 30 2>&1 | tail -16; } > $O/${T}_g6_g7_stamps.txt; head -8 $O/${T}_g6_g7_stamps.txt
+  { NANO_FUSE_LAUNCHES=0 NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py qwen3-0.6b q4k 1 30 2>&1 | tail -16; } > $O/${T}_phase_stamps_q4k.txt
   timeout 120 python tools/prefill_probe.py q80 2>&1 | tail -6 | tee $O/${T}_prefill_probe.txt
   timeout 300 python tools/long_ctx_probe.py 2>&1 | tail -10 > $O/${T}_long_ctx_probe.txt; head -5 $O/${T}_long_ctx_probe.txt
   timeout 400 python tools/sample_decode_probe.py 2>&1 | tee $O/${T}_sample_decode_probe.txt
@@ -86,7 +87,7 @@ elif [ "$1" = "c" ]; then
 import json
 for ln in open('$O/${T}_bench_all_configs.jsonl'):
     d=json.loads(ln); print(d.get('baseline_config'), d.get('value'), d.get('ms_per_step'))"
-  for b in 16 64; do NANO_BENCH_NO_TRAFFIC=1 timeout 300 python bench.py --batch $b --steps 64 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_q06_b$b.json; one $O/${T}_bench_q06_b$b.json "0.6B B=$b"; done
+  for b in 16 32 64; do NANO_BENCH_NO_TRAFFIC=1 timeout 300 python bench.py --batch $b --steps 64 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_q06_b$b.json; one $O/${T}_bench_q06_b$b.json "0.6B B=$b"; done
   timeout 300 python bench.py --replicas 2 --total-seqs 8 --steps 64 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_replicas2.json; cut -c1-160 $O/${T}_bench_replicas2.json; echo
   NANO_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --batch 4 --steps 32 --warmup 4 --no-cpu-baseline 2>/dev/null | grep -o '{"metric".*' > $O/${T}_bench_gloo_2ranks_one_gpu.json; cut -c1-200 $O/${T}_bench_gloo_2ranks_one_gpu.json; echo
   rm -f $O/${T}_bench_q06_q80_vs_q4k.jsonl; for q in q80 q4k q80 q4k; do NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --quant $q --steps 64 --warmup 8 --no-cpu-baseline --no-kernel-table 2>/dev/null >> $O/${T}_bench_q06_q80_vs_q4k.jsonl; done
@@ -95,7 +96,7 @@ import json
 for ln in open('$O/${T}_bench_q06_q80_vs_q4k.jsonl'):
     d=json.loads(ln); print(d['config']['workload'][:40], d['value'], d['ms_per_step'])"
 else
-  for b in 1 2 4 8 16 32 64; do NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_b$b.json; one $O/${T}_bench_4b_b$b.json "4B B=$b"; done
+  for b in 1 2 4 8 16 32 48 64; do NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --batch $b --steps 32 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_b$b.json; one $O/${T}_bench_4b_b$b.json "4B B=$b"; done
   NANO_BENCH_NO_TRAFFIC=1 timeout 400 python bench.py --model qwen3-4b --total-seqs 64 --steps 64 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null > $O/${T}_bench_4b_total64.json; one $O/${T}_bench_4b_total64.json "4B total-seqs 64"
   NANO_BENCH_NO_TRAFFIC=1 timeout 900 python bench.py --model qwen3-4b --quant q4k --steps 64 --warmup 4 --no-cpu-baseline 2>/dev/null > $O/${T}_bench_4b_q4k_b1.json; one $O/${T}_bench_4b_q4k_b1.json "4B q4k"
   export NANO_BENCH_NO_TRAFFIC=1
