@@ -164,7 +164,8 @@ template <int LPR, int QV, int KVM, int MODE, bool KVH, bool PG, int NPT, bool W
 __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char *smem, const uint32_t grp, const uint32_t b, const uint32_t split,
                                                const SlabHand &hh, const uint32_t hand_tag = 0u, const uint32_t hand_wait16 = 0u) {
     static_assert(!W16 || (KVH && QV % 4 == 0), "16-byte FP16 loads: two float4 slots per load");
-    static_assert(!FUSE || (MODE == 1 && KVM == 1 && !KVH && !PG && LPR * QV * 4 == 128), "the fused launch: Qwen3 decode, head_dim 128, FP32 contiguous cache");
+    static_assert(!FUSE || (((MODE == 1 && LPR * QV * 4 == 128) || MODE == 2) && KVM == 1 && !KVH && !PG && LPR * QV * 4 <= 128),
+                  "the fused launch: Qwen3 decode at head_dim 128, or the plain decode mode (no q/k norm, adjacent-pair RoPE: Nano) at head_dim <= 128; FP32 contiguous cache");
     constexpr int R = 256 / LPR;                 // timesteps per block
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -385,9 +386,11 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
         const unsigned long long tag_done = (unsigned long long)hand_tag << 32;
         // TWO sweeps in flight (A, B): a sweep is a memory round trip (~1 us), the next one is on its way while this one is looked at
         unsigned long long g0 = 0, g1 = 0;
-        const bool two = (uint32_t)tid < 128u;
+        // (MODE 2, round 6: head_dim < 128 -- the threads beyond the head have nothing to wait for)
+        const bool live7 = MODE == 1 || t7 < hd;
+        const bool two = (uint32_t)tid < 128u && live7;
         auto sweep = [&](unsigned long long &x0, unsigned long long &x1) {
-            x0 = __hip_atomic_load(g0p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x0 = live7 ? __hip_atomic_load(g0p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag_done;
             x1 = two ? __hip_atomic_load(g1p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag_done;
         };
         auto ready = [&](unsigned long long x0, unsigned long long x1) { return __all((uint32_t)(x0 >> 32) == hand_tag && (uint32_t)(x1 >> 32) == hand_tag) != 0; };
@@ -402,8 +405,10 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
             if (ready(b0, b1)) { g0 = b0; g1 = b1; got = true; break; }
             if ((spin & 63u) == 63u && hand_aborted(hh)) break;   // (somebody in this step already gave up: the call is lost)
         }
-        if ((uint32_t)tid < 128u) { qh[t7] = __uint_as_float((uint32_t)g0); vh[t7] = __uint_as_float((uint32_t)g1); }
-        else kh[t7] = __uint_as_float((uint32_t)g0);
+        if (live7) {
+            if ((uint32_t)tid < 128u) { qh[t7] = __uint_as_float((uint32_t)g0); vh[t7] = __uint_as_float((uint32_t)g1); }
+            else kh[t7] = __uint_as_float((uint32_t)g0);
+        }
         if (__syncthreads_or(got ? 0 : 1)) {                   // (the staging barrier; a wave that gave up takes the whole workgroup out)
             if (!got && lane == 0) hand_give_up(hh, a.err);
             return;
@@ -411,9 +416,11 @@ __device__ __forceinline__ void attention_body(const AttnArgs &a, unsigned char 
 #pragma unroll
         for (int q = 0; q < QV; q++) {
             const uint32_t f = fidx(q);
-            qv[0][q] = *reinterpret_cast<const float4 *>(qh + 4u * f);
-            kfresh[q] = *reinterpret_cast<const float4 *>(kh + 4u * f);
-            vfresh[q] = *reinterpret_cast<const float4 *>(vh + 4u * f);
+            const bool in = MODE == 1 || f * 4u < hd;           // (slots beyond the head: zeros, as the loads of the unfused launch return)
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            qv[0][q] = in ? *reinterpret_cast<const float4 *>(qh + 4u * f) : z4;
+            kfresh[q] = in ? *reinterpret_cast<const float4 *>(kh + 4u * f) : z4;
+            vfresh[q] = in ? *reinterpret_cast<const float4 *>(vh + 4u * f) : z4;
         }
     }
 

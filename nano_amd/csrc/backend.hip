@@ -451,7 +451,7 @@ extern "C" int nano_hip_model_create_ex(NanoHipModel **out, const NanoModelDesc 
     // Default 3; 0 = the five launches per layer; same bits in every setting
     if (const char *fz = getenv("NANO_FUSE_LAUNCHES")) { const uint32_t v = (uint32_t)strtoul(fz, nullptr, 0); m->fuse_qkv_attn = (v & 1u) != 0; m->fuse_wo_w13 = (v & 2u) != 0; m->fuse_wo_w13_always = (v & 4u) != 0; m->fuse_w2_qkv = (v & 8u) != 0; }
     if (hipMalloc(reinterpret_cast<void **>(&m->tick), 64) != hipSuccess || hipMemset(m->tick, 0, 64) != hipSuccess) { destroy(m); FAIL(NANO_HIP_ENOMEM, "hipMalloc of the hand-off words failed"); }
-    if ((m->d.quant_type == NANO_QUANT_Q80 && m->d.group_size == 64) || m->d.quant_type == NANO_QUANT_Q4K) {
+    if ((m->d.quant_type == NANO_QUANT_Q80 && m->d.group_size == 64) || m->d.quant_type == NANO_QUANT_Q4K || m->d.quant_type == NANO_QUANT_F32) {
         // granule buffers of the fused one-sequence launches: tag 0 (the memset) is no epoch -- the first step's tick is 1
         const size_t hb = (size_t)(m->QD + 2 * m->KD) * 8, hb2 = (size_t)m->d.n_embd * 8;
         if (hipMalloc(reinterpret_cast<void **>(&m->hand), hb) != hipSuccess || hipMemset(m->hand, 0, hb) != hipSuccess ||
@@ -723,13 +723,15 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
         auto qkv_attn_fusable = [&](const GemvArgs &qa_, const AttnArgs &a_) {
             return m->fuse_qkv_attn && m->hand && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && L <= 126u &&
                    ((d.quant_type == NANO_QUANT_Q80 && kind_of(m, qa_) == ROUTE_GEMV && qkv_attn_fused_supports(qa_, a_)) ||
-                    (d.quant_type == NANO_QUANT_Q4K && kind_of(m, qa_) == ROUTE_Q4K && qkv_attn_fused_q4k_supports(qa_, a_)));      // (round 6: Q4K too)
+                    (d.quant_type == NANO_QUANT_Q4K && kind_of(m, qa_) == ROUTE_Q4K && qkv_attn_fused_q4k_supports(qa_, a_)) ||      // (round 6: Q4K too,
+                    (d.quant_type == NANO_QUANT_F32 && kind_of(m, qa_) == ROUTE_GEMV && qkv_attn_fused_f32_supports(qa_, a_)));      //  and FP32 / Nano)
         };
         const bool fused = qkv_attn_fusable(qa, a);
         if (qkv_prelaunched) {
             qkv_prelaunched = false;                                   // (done by the launch that ended the previous layer)
         } else if (fused) {
             if ((e = d.quant_type == NANO_QUANT_Q4K ? launch_qkv_attn_fused_q4k(qa, a, m->hand, m->tick, l + 1u, m->st)
+                   : d.quant_type == NANO_QUANT_F32 ? launch_qkv_attn_fused_f32(qa, a, m->hand, m->tick, l + 1u, m->st)
                                                     : launch_qkv_attn_fused(qa, a, m->hand, m->tick, l + 1u, m->st)) != hipSuccess) return e;
         } else {
             qa.stamps = next_stamps(m, 1);

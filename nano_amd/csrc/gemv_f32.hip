@@ -126,97 +126,52 @@ __device__ __forceinline__ float4 bload_wf(__amdgpu_buffer_rsrc_t r, uint32_t of
 template <int ROLE, int B, int NV, int UPW>
 __global__ __launch_bounds__(1024) void gemv_f32_slab_kernel(const GemvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TR = 4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = (int)(a.nthr >> 6);
-    const uint32_t n = a.n, n4 = (n + 3) & ~3u;
-    const uint32_t nchunk = a.nchunk, PC = (nchunk + 3) & ~3u;      // a.nchunk: 256-float chunks per row
-    const uint32_t RW = a.rw;
-    const uint32_t epi = role_epi<ROLE>(a);
-    const bool swiglu = epi == GEMV_EPI_SWIGLU;
-    const uint32_t nmat = swiglu ? 2 : 1;
-    float *xf = reinterpret_cast<float *>(smem);                   // [B][n4]
-    float *red = xf + B * n4;                                      // [B][16] (+ combine weights [B][n_head][8])
-    float *P = red + B * 16 + (has_flag<ROLE>(a, F_COMBINE) ? B * a.attn_n_head * 8 : 0);   // [B][nmat][RW][PC]
+#define F32_A a
+#define F32_BID blockIdx.x
+#define F32_HAND 0
+#define F32_HANDV (SlabHand{})
+#define F32_PTAG 0u
+#include "gemv_f32_slab_body.inc"
+#undef F32_A
+#undef F32_BID
+#undef F32_HAND
+#undef F32_HANDV
+#undef F32_PTAG
+}
 
-    Staged<B, NV> sx;
-    stage_issue<ROLE, B, NV>(a, sx);
-
-    const uint32_t grow0 = blockIdx.x * RW;
-    const uint32_t b0 = a.rows[0], b1 = b0 + a.rows[1];
-    const int sel = swiglu ? 0 : (int)(grow0 >= b0) + (int)(grow0 >= b1);
-    const float *w0 = reinterpret_cast<const float *>(sel == 0 ? a.w[0] : sel == 1 ? a.w[1] : a.w[2]);
-    float *out0 = sel == 0 ? a.out[0] : sel == 1 ? a.out[1] : a.out[2];
-    const uint32_t rows0 = sel == 0 ? a.rows[0] : sel == 1 ? a.rows[1] : a.rows[2];
-    const uint32_t obs = sel == 0 ? a.out_bstride[0] : sel == 1 ? a.out_bstride[1] : a.out_bstride[2];
-    const uint32_t ops = sel == 0 ? a.out_pstride[0] : sel == 1 ? a.out_pstride[1] : a.out_pstride[2];
-    const uint32_t lrow0 = grow0 - (sel == 0 ? 0u : sel == 1 ? b0 : b1);
-    const uint32_t tmask = (1u << a.log2_tiles) - 1u;
-
-    float4 wv[UPW][TR];
-#pragma unroll
-    for (int k = 0; k < UPW; k++) {
-        const uint32_t u = (uint32_t)wid + (uint32_t)k * NW;
-        const uint32_t t = (u * a.magic_nchunk) >> 16;                 // u / nchunk
-        const uint32_t c = u - t * nchunk;
-        const uint32_t tl = t & tmask, mat = t >> a.log2_tiles;
-        const bool live = u < a.units;
-        const __amdgpu_buffer_rsrc_t rw_ = mkrsrc(mat ? reinterpret_cast<const float *>(a.w[1]) : w0, live ? rows0 * n * 4u : 0u);
-        const uint32_t lrow = lrow0 + tl * TR;
-        const uint32_t col = (c << 8) + (uint32_t)lane * 4u;
-        const uint32_t base = (col < n) ? (lrow * n + col) * 4u : OOB;
-#pragma unroll
-        for (int r = 0; r < TR; r++) wv[k][r] = bload_wf(rw_, base + (uint32_t)r * n * 4u);
+}  // namespace
+}  // namespace nano
+#include "attn_impl.h"
+namespace nano {
+namespace {
+// ---- q | k | v projection + attention in ONE launch for FP32 models (Nano: head_dim <= 64, no q / k norm, adjacent-pair RoPE; round 6: what
+//      qkv_attn_fused_kernel is for Q80 and q4k_qkv_attn_fused_kernel for Q4K) ---------------------------------------------------------------
+// The first `ngemv` workgroups run the projection's SLAB body (results stored as usual AND as granules), the last n_attn the attention's
+// plain decode mode (attention_body MODE 2), 256 threads for both.  Epoch tags, give-up and re-issue: device_common.h, backend.hip.
+// Reference: infer/infer.c:637-651, 758-879.
+struct F32FusedArgs { GemvDev g; AttnArgs a; SlabHand hand; uint32_t n_attn, head_wgs, wait16, ngemv; };
+template <int NV, int UPW>
+__global__ __launch_bounds__(256) void f32_qkv_attn_fused_kernel(const F32FusedArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint2 tk_ = hand_tick(fa.hand);
+    if (blockIdx.x >= fa.ngemv) {
+        const uint32_t ab = blockIdx.x - fa.ngemv;
+        const uint32_t split = ab / fa.head_wgs, grp = ab - split * fa.head_wgs;
+        attention_body<8, 2, 1, 2, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand, hand_ctag(tk_, fa.hand), fa.wait16);
+        return;
     }
-    const int lrw = (int)a.log2_tiles + 2;
-    const int fb = tid >> lrw, frl = tid & ((int)RW - 1);
-    const bool fold_live = tid < (int)(RW * B) && fb < (int)a.nb && lrow0 + frl < rows0;
-    // the position of a pos-indexed output (v-cache row) is fetched now and used only by the final store: no wait
-    // here (a wait on it would also wait for every weight load issued above -- vmcnt counts in order)
-    uint32_t opos = 0;
-    if (ops && fold_live) opos = a.pos[fb];
-    float oldv = 0.0f;
-    if (epi == GEMV_EPI_RESID && fold_live) oldv = out0[(size_t)fb * obs + lrow0 + frl];      // residual stream: never pos-indexed
-    float addv = 0.0f;                                              // LoRA o-branch: x += (W.act + addv), reference order
-    const bool has_add = epi == GEMV_EPI_RESID && a.resid_add != nullptr;
-    if (has_add && fold_live) addv = a.resid_add[(size_t)fb * a.resid_add_bstride + lrow0 + frl];
-
-    stage_finish_f32<ROLE, B, NV>(a, sx, xf, red, n4);
-
-#pragma unroll
-    for (int k = 0; k < UPW; k++) {
-        const uint32_t u = (uint32_t)wid + (uint32_t)k * NW;
-        if (u < a.units) {
-            const uint32_t t = (u * a.magic_nchunk) >> 16;
-            const uint32_t c = u - t * nchunk;
-            const uint32_t tl = t & tmask, mat = t >> a.log2_tiles;
-            const uint32_t col = (c << 8) + (uint32_t)lane * 4u;
-#pragma unroll
-            for (int b = 0; b < B; b++) {
-                if (b < (int)a.nb) {
-                    const float4 xv = (col < n) ? *reinterpret_cast<const float4 *>(xf + b * n4 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int r = 0; r < TR; r++) {
-                        float p = wv[k][r].x * xv.x;
-                        p = __builtin_fmaf(wv[k][r].y, xv.y, p); p = __builtin_fmaf(wv[k][r].z, xv.z, p); p = __builtin_fmaf(wv[k][r].w, xv.w, p);
-                        p = dpp_wave_sum(p);
-                        if (lane == 0) P[(((size_t)b * nmat + mat) * RW + tl * TR + r) * PC + c] = p;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    if (tid < (int)(RW * B)) {
-        float v0 = 0.0f, v1 = 0.0f;
-        const float *p0 = P + (((size_t)fb * nmat) * RW + frl) * PC;
-        const float *p1 = p0 + (size_t)RW * PC;
-        for (uint32_t c = 0; c < nchunk; c++) { v0 += p0[c]; if (swiglu) v1 += p1[c]; }
-        // write-through (sc1) store, see gemv_q80_impl.h: nothing is left for the write-back at the end of the kernel
-        if (fold_live) __hip_atomic_store(out0 + (size_t)fb * obs + (size_t)opos * ops + lrow0 + frl, finish_epi(epi, has_add ? v0 + addv : v0, v1, oldv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    constexpr int ROLE = R_NORM_STORE, B = 1;
+#define F32_A fa.g
+#define F32_BID blockIdx.x
+#define F32_HAND 1
+#define F32_HANDV fa.hand
+#define F32_PTAG hand_ptag(tk_, fa.hand)
+#include "gemv_f32_slab_body.inc"
+#undef F32_A
+#undef F32_BID
+#undef F32_HAND
+#undef F32_HANDV
+#undef F32_PTAG
 }
 
 struct F32Plan { uint32_t rw, nw, upw, nv; };
@@ -291,7 +246,61 @@ static hipError_t launch_f32_b(const GemvArgs &a, hipStream_t st) {
     return launch_f32_r<R_GENERIC, B>(d, p, rows, st);
 }
 
+// the fused launch's plan: the projection's own, on 256 threads (four waves like the attention's workgroups; same bits -- the float4 items sit
+// on the same threads, the fourth wave adds +0.0 to the norm's sum)
+static bool f32_fused_shape(const GemvArgs &ga, const AttnArgs &aa, F32Plan &p) {
+    if (ga.nb != 1 || ga.nseg != 3 || ga.epi != GEMV_EPI_STORE || !ga.norm_w || ga.xq_in || ga.attn_part || ga.tile_max || ga.resid_add || ga.n % 4u) return false;
+    if (ga.seg[0].out_pstride || ga.seg[1].out_pstride) return false;            // (only v is position indexed: its cache row)
+    for (uint32_t s2 = 0; s2 < 3; s2++) if (ga.seg[s2].rows % 4u) return false;
+    p = plan_f32(ga, 1);
+    if (p.nw > 4u || p.upw > 4u || ga.n > 1024u) return false;                   // one float4 item per thread on <= 256 threads
+    p.nw = 4u; p.nv = 1u;
+    const uint32_t units = (p.rw / 4) * ((ga.n + 255) / 256);
+    p.upw = (units + 3u) / 4u;
+    if (p.upw > 4u) return false;
+    return fused_attn_side_ok_plain(aa, ga.seg[0].rows, ga.seg[1].rows, ga.seg[2].rows);
+}
+
 }  // namespace
+
+bool qkv_attn_fused_f32_supports(const GemvArgs &ga, const AttnArgs &aa) { F32Plan p; return f32_fused_shape(ga, aa, p); }
+
+hipError_t launch_qkv_attn_fused_f32(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st) {
+    F32Plan p;
+    if (!hand || !tick || !layer1 || layer1 > 127u || !f32_fused_shape(ga, aa, p)) return hipErrorInvalidValue;
+    GemvDev d = to_dev(ga);
+    d.tile_max = nullptr;
+    d.nchunk = (ga.n + 255) / 256;
+    d.magic_nchunk = (65536 + d.nchunk - 1) / d.nchunk;
+    d.rw = p.rw;
+    uint32_t l2 = 0; while ((1u << l2) < p.rw / 4) l2++;
+    d.log2_tiles = l2;
+    d.units = (p.rw / 4) * d.nchunk;
+    d.nthr = 256;
+    uint32_t rows = 0;
+    for (uint32_t s2 = 0; s2 < 3; s2++) rows += ga.seg[s2].rows;
+    const uint32_t ngemv = (rows + p.rw - 1) / p.rw;
+    AttnArgs a = aa;
+    { uint32_t k2 = 0; while ((1u << k2) < a.n_kv_head) k2++; a.kv_log2 = k2; }
+    { const uint32_t kv_mul = a.n_head / a.n_kv_head; uint32_t k2 = 0; while ((1u << k2) < kv_mul) k2++; a.kvmul_log2 = k2; }
+    SlabHand h{};
+    h.buf = hand; h.tick = tick; h.layer1 = layer1;
+    h.base[0] = 0; h.base[1] = a.q_dim; h.base[2] = a.q_dim + a.kv_dim;
+    const size_t n4 = (d.n + 3) & ~3u, pc = (d.nchunk + 3) & ~3u;
+    const size_t lds_g = (n4 + 16 + (size_t)p.rw * pc) * 4;
+    const size_t hd4 = (a.hd + 3) & ~3u, lds_a = (hd4 + hd4 + 4 + 4 + 4 * hd4 + hd4) * sizeof(float);    // q | k | maxima | sums | 4 waves' partials | the fresh v row
+    const size_t lds = lds_g > lds_a ? lds_g : lds_a;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    F32FusedArgs fa{};
+    fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = a.n_head * a.nsplit; fa.head_wgs = a.n_head; fa.ngemv = ngemv;
+    fa.wait16 = 3u;             // naps of 16 x 64 cycles between the K / V requests and the first poll (as the Q80 launch)
+    const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
+#define F32F_GO(UPW_) do { hipLaunchKernelGGL((f32_qkv_attn_fused_kernel<1, UPW_>), dim3(fa.n_attn + ngemv), dim3(256), lds, st, fa); return hipGetLastError(); } while (0)
+    if (upw == 1) F32F_GO(1);
+    if (upw == 2) F32F_GO(2);
+    F32F_GO(4);
+#undef F32F_GO
+}
 
 hipError_t launch_gemv_f32(const GemvArgs &a, hipStream_t st) {
     if (a.nb == 0 || a.nb > 8 || a.n % 4 || a.nseg == 0 || a.nseg > 3 || a.xq_in) return hipErrorInvalidValue;

@@ -27,10 +27,11 @@ pytestmark = pytest.mark.gpu
 S = 512
 
 
-@pytest.fixture(scope="module", params=["q80", "q4k"])
+@pytest.fixture(scope="module", params=[("qwen3-0.6b", "q80"), ("qwen3-0.6b", "q4k"), ("nano-168m", "f32")], ids=lambda p: "-".join(p))
 def q3(model_dir, request):
-    # (round 6: Q4K runs the q|k|v + attention launch too -- gemv_q4k_chunk.hip q4k_qkv_attn_fused_kernel)
-    path, spec = synth_model(model_dir, "qwen3-0.6b", request.param, 64 if request.param == "q80" else 0)
+    # (round 6: Q4K and FP32 / Nano run the q|k|v + attention launch too -- q4k_qkv_attn_fused_kernel, f32_qkv_attn_fused_kernel)
+    preset, quant = request.param
+    path, spec = synth_model(model_dir, preset, quant, 64 if quant == "q80" else 0)
     m = nb.load_model_file(path, max_seq_len=S, max_batch=1)
     yield m, spec
     m.close()
