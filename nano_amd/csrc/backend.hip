@@ -799,13 +799,16 @@ static hipError_t enqueue_step(NanoHipModel *m, uint32_t nb, uint32_t is_causal,
             // forces it wherever the shapes allow (the parity test; the measurement).
             const bool fuse13_shape = m->hand2 && nb == 1 && !m->pf && !m->lora_on && !m->stamps_on && L <= 126u &&
                                       ((d.quant_type == NANO_QUANT_Q80 && kind_of(m, a) == ROUTE_GEMV && kind_of(m, b) == ROUTE_GEMV && wo_w13_fused_supports(a, b)) ||
-                                       (d.quant_type == NANO_QUANT_Q4K && kind_of(m, a) == ROUTE_Q4K && kind_of(m, b) == ROUTE_Q4K && wo_w13_fused_q4k_supports(a, b)));
+                                       (d.quant_type == NANO_QUANT_Q4K && kind_of(m, a) == ROUTE_Q4K && kind_of(m, b) == ROUTE_Q4K && wo_w13_fused_q4k_supports(a, b)) ||
+                                       (d.quant_type == NANO_QUANT_F32 && kind_of(m, a) == ROUTE_GEMV && kind_of(m, b) == ROUTE_GEMV && wo_w13_fused_f32_supports(a, b)));
             // (Q4K, round 6: gemv_q4k_chunk.hip q4k_wo_w13_fused_kernel is bit-identical and break-even at positions 20..39, but LOSES 1 % over positions
             //  31..510, where Wo combines attention splits -- 1642 tok/s with q|k|v + attention fused only, 1626 with both, 1596-1612 with neither, same box,
-            //  profiles/r06_q4k_fused.txt.  So for Q4K it runs under bit 2 only, like the wide Q80 matrices.)
+            //  profiles/r06_q4k_fused.txt.  So for Q4K it runs under bit 2 only, like the wide Q80 matrices.  FP32 / Nano-168M, f32_wo_w13_fused_kernel: bit-identical,
+            //  -1.5 % at positions 20..39 and -2.9 % over 31..510 against q|k|v + attention fused alone: bit 2 only as well.)
             const bool fuse13 = fuse13_shape && (m->fuse_wo_w13_always || (m->fuse_wo_w13 && !route_is_wide(b) && d.quant_type == NANO_QUANT_Q80));
             if (fuse13) {
                 if ((e = d.quant_type == NANO_QUANT_Q4K ? launch_wo_w13_fused_q4k(a, b, m->hand2, m->tick, l + 1u, m->st)
+                       : d.quant_type == NANO_QUANT_F32 ? launch_wo_w13_fused_f32(a, b, m->hand2, m->tick, l + 1u, m->st)
                                                         : launch_wo_w13_fused(a, b, m->hand2, m->tick, l + 1u, m->st)) != hipSuccess) return e;
                 wo13_done = true;
             } else {

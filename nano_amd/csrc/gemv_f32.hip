@@ -174,6 +174,74 @@ __global__ __launch_bounds__(256) void f32_qkv_attn_fused_kernel(const F32FusedA
 #undef F32_PTAG
 }
 
+// ---- Wo + W1|W3 in ONE launch for FP32 models (round 6: what wo_w13_fused_kernel is for Q80) -------------------------------------------------
+// The launch has W1|W3's grid and thread count; its first `wo_wgs` workgroups run Wo's body first (results stored as usual AND as granules), then
+// EVERY workgroup runs W1|W3's body with the activation polled from the granules.  Issue order: Wo's loads, W1|W3's weight and norm-weight loads,
+// Wo's arithmetic, W1|W3's.  Producers first; a grid of at most one workgroup per CU is resident as a whole.  Same bodies, same bits.
+struct F32Wo13Args { GemvDev wo; GemvDev w13; SlabHand hand; uint32_t wo_wgs, wait16; };
+template <int ROLE_A, int NV_A, int UPW_A, int NV_B, int UPW_B>
+__global__ __launch_bounds__(1024) void f32_wo_w13_fused_kernel(const F32Wo13Args fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint2 tk_ = hand_tick(fa.hand);
+    constexpr int B = 1;
+    {
+        constexpr int ROLE = ROLE_A, NV = NV_A, UPW = UPW_A;
+#define F32_BID blockIdx.x
+#define F32_A fa.wo
+#define F32_HAND 1
+#define F32_HANDV fa.hand
+#define F32_PTAG hand_ptag(tk_, fa.hand)
+#define F32_XHAND 0
+#define F32_XHANDV (SlabHand{})
+#define F32_CTAG 0u
+#define F32_XWAIT 0u
+#define F32_PART 1
+#include "gemv_f32_slab_body.inc"
+#undef F32_PART
+        auto wo_rest = [&]() __attribute__((always_inline)) {
+#define F32_PART 2
+#include "gemv_f32_slab_body.inc"
+#undef F32_PART
+        };
+#undef F32_A
+#undef F32_HAND
+#undef F32_HANDV
+#undef F32_PTAG
+#undef F32_XHAND
+#undef F32_XHANDV
+#undef F32_CTAG
+#undef F32_XWAIT
+        {
+            constexpr int ROLE = R_NORM_SWIGLU, NV = NV_B, UPW = UPW_B;
+#define F32_A fa.w13
+#define F32_HAND 0
+#define F32_HANDV (SlabHand{})
+#define F32_PTAG 0u
+#define F32_XHAND 1
+#define F32_XHANDV fa.hand
+#define F32_CTAG hand_ctag(tk_, fa.hand)
+#define F32_XWAIT (blockIdx.x >= fa.wo_wgs ? fa.wait16 : 0u)
+#define F32_PART 1
+#include "gemv_f32_slab_body.inc"
+#undef F32_PART
+            if (blockIdx.x < fa.wo_wgs) wo_rest();
+            __syncthreads();                // (LDS is W1|W3's from here)
+#define F32_PART 2
+#include "gemv_f32_slab_body.inc"
+#undef F32_PART
+#undef F32_A
+#undef F32_HAND
+#undef F32_HANDV
+#undef F32_PTAG
+#undef F32_XHAND
+#undef F32_XHANDV
+#undef F32_CTAG
+#undef F32_XWAIT
+        }
+#undef F32_BID
+    }
+}
+
 struct F32Plan { uint32_t rw, nw, upw, nv; };
 static F32Plan plan_f32(const GemvArgs &a, int B) {
     const uint32_t nchunk = (a.n + 255) / 256, nmat = a.epi == GEMV_EPI_SWIGLU ? 2 : 1;
@@ -264,6 +332,63 @@ static bool f32_fused_shape(const GemvArgs &ga, const AttnArgs &aa, F32Plan &p) 
 }  // namespace
 
 bool qkv_attn_fused_f32_supports(const GemvArgs &ga, const AttnArgs &aa) { F32Plan p; return f32_fused_shape(ga, aa, p); }
+
+// ---- the fused Wo + W1|W3 launch: host side (both bodies on W1|W3's threads; Wo has no tree: any thread count gives its bits) ------------------
+namespace {
+struct F32Wo13Plan { F32Plan a, b; uint32_t upw_a, nv_a, wa, wb; };
+static void f32_dev_fill(GemvDev &d, const GemvArgs &a, const F32Plan &p, uint32_t nthr) {
+    d.tile_max = nullptr;
+    d.nchunk = (a.n + 255) / 256;
+    d.magic_nchunk = (65536 + d.nchunk - 1) / d.nchunk;
+    d.rw = p.rw;
+    uint32_t l2 = 0; while ((1u << l2) < p.rw / 4) l2++;
+    d.log2_tiles = l2;
+    d.units = (p.rw / 4) * d.nchunk * (d.epi == GEMV_EPI_SWIGLU ? 2 : 1);
+    d.nthr = nthr;
+}
+static bool f32_wo13_shape(const GemvArgs &wo, const GemvArgs &w13, F32Wo13Plan &q) {
+    if (wo.nb != 1 || w13.nb != 1 || wo.n % 4u || w13.n % 4u) return false;
+    if (wo.nseg != 1 || wo.epi != GEMV_EPI_RESID || wo.norm_w || wo.xq_in || wo.tile_max || wo.resid_add || wo.seg[0].out_pstride || wo.seg[0].rows % 4u) return false;
+    if (wo.attn_part && (wo.attn_nsplit > 8u || wo.attn_hd % 4u)) return false;
+    if (w13.nseg != 2 || w13.epi != GEMV_EPI_SWIGLU || !w13.norm_w || w13.xq_in || w13.attn_part || w13.tile_max || w13.resid_add || w13.seg[0].rows != w13.seg[1].rows) return false;
+    if (w13.n != wo.seg[0].rows || w13.xin != wo.seg[0].out) return false;             // W1|W3's input is what Wo writes
+    q.a = plan_f32(wo, 1); q.b = plan_f32(w13, 1);
+    const uint32_t nw = q.b.nw;
+    const uint32_t units_a = (q.a.rw / 4) * ((wo.n + 255) / 256);
+    q.upw_a = (units_a + nw - 1) / nw;
+    q.nv_a = (wo.n / 4 + 64 * nw - 1) / (64 * nw);
+    q.wa = (wo.seg[0].rows + q.a.rw - 1) / q.a.rw; q.wb = (w13.seg[0].rows + q.b.rw - 1) / q.b.rw;
+    const uint32_t cus = w13.cus ? w13.cus : 256u;
+    if (q.wa > q.wb || q.wb > cus) return false;                                        // one workgroup per CU: the whole grid is resident
+    if (q.a.rw > 64 * nw || q.b.rw > 64 * nw) return false;                             // one fold thread per row
+    // instantiated: Nano-168M's shapes (Wo: one float4 item per thread, one unit per wave; W1|W3: one item, two units)
+    return q.nv_a == 1u && q.upw_a == 1u && q.b.nv == 1u && q.b.upw == 2u;
+}
+}  // namespace
+bool wo_w13_fused_f32_supports(const GemvArgs &wo, const GemvArgs &w13) { F32Wo13Plan q; return f32_wo13_shape(wo, w13, q); }
+
+hipError_t launch_wo_w13_fused_f32(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st) {
+    F32Wo13Plan q;
+    if (!hand || !tick || !layer1 || layer1 > 127u || !f32_wo13_shape(wo, w13, q)) return hipErrorInvalidValue;
+    F32Wo13Args fa{};
+    fa.wo = to_dev(wo); fa.w13 = to_dev(w13);
+    const uint32_t nthr = 64 * q.b.nw;
+    f32_dev_fill(fa.wo, wo, q.a, nthr); f32_dev_fill(fa.w13, w13, q.b, nthr);
+    fa.wo_wgs = q.wa;
+    fa.wait16 = 4u;                      // workgroups that produce nothing nap ~2 us before their first poll (as the Q80 launch)
+    SlabHand h{};
+    h.buf = hand; h.tick = tick; h.layer1 = layer1;
+    fa.hand = h;
+    auto lds_of = [&](const GemvDev &d, const F32Plan &p) {
+        const size_t n4 = (d.n + 3) & ~3u, pc = (d.nchunk + 3) & ~3u, nmat = d.epi == GEMV_EPI_SWIGLU ? 2 : 1;
+        return (n4 + 16 + ((d.flags & F_COMBINE) ? (size_t)d.attn_n_head * 8 : 0) + nmat * p.rw * pc) * 4;
+    };
+    const size_t la = lds_of(fa.wo, q.a), lb = lds_of(fa.w13, q.b), lds = la > lb ? la : lb;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (fa.wo.flags & F_COMBINE) hipLaunchKernelGGL((f32_wo_w13_fused_kernel<R_RESID_COMBINE, 1, 1, 1, 2>), dim3(q.wb), dim3(nthr), lds, st, fa);
+    else hipLaunchKernelGGL((f32_wo_w13_fused_kernel<R_RESID, 1, 1, 1, 2>), dim3(q.wb), dim3(nthr), lds, st, fa);
+    return hipGetLastError();
+}
 
 hipError_t launch_qkv_attn_fused_f32(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st) {
     F32Plan p;

@@ -217,6 +217,8 @@ inline bool fused_attn_side_ok_plain(const AttnArgs &aa, uint32_t qr, uint32_t k
 }
 bool qkv_attn_fused_f32_supports(const GemvArgs &ga, const AttnArgs &aa);
 hipError_t launch_qkv_attn_fused_f32(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st);
+bool wo_w13_fused_f32_supports(const GemvArgs &wo, const GemvArgs &w13);
+hipError_t launch_wo_w13_fused_f32(const GemvArgs &wo, const GemvArgs &w13, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st);
 // the same launch for Q4K (gemv_q4k_chunk.hip q4k_qkv_attn_fused_kernel, round 6)
 bool qkv_attn_fused_q4k_supports(const GemvArgs &ga, const AttnArgs &aa);
 hipError_t launch_qkv_attn_fused_q4k(const GemvArgs &ga, const AttnArgs &aa, unsigned long long *hand, uint32_t *tick, uint32_t layer1, hipStream_t st);
