@@ -150,14 +150,14 @@ namespace {
 // plain decode mode (attention_body MODE 2), 256 threads for both.  Epoch tags, give-up and re-issue: device_common.h, backend.hip.
 // Reference: infer/infer.c:637-651, 758-879.
 struct F32FusedArgs { GemvDev g; AttnArgs a; SlabHand hand; uint32_t n_attn, head_wgs, wait16, ngemv; };
-template <int NV, int UPW>
+template <int NV, int UPW, int QV>            // QV: float4 slots per lane of the attention's 8-lane sub-groups (1: head_dim <= 32, 2: <= 64 -- launch_attention's choice)
 __global__ __launch_bounds__(256) void f32_qkv_attn_fused_kernel(const F32FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint2 tk_ = hand_tick(fa.hand);
     if (blockIdx.x >= fa.ngemv) {
         const uint32_t ab = blockIdx.x - fa.ngemv;
         const uint32_t split = ab / fa.head_wgs, grp = ab - split * fa.head_wgs;
-        attention_body<8, 2, 1, 2, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand, hand_ctag(tk_, fa.hand), fa.wait16);
+        attention_body<8, QV, 1, 2, false, false, 2, false, true>(fa.a, smem, grp, 0u, split, fa.hand, hand_ctag(tk_, fa.hand), fa.wait16);
         return;
     }
     constexpr int ROLE = R_NORM_STORE, B = 1;
@@ -420,7 +420,8 @@ hipError_t launch_qkv_attn_fused_f32(const GemvArgs &ga, const AttnArgs &aa, uns
     fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = a.n_head * a.nsplit; fa.head_wgs = a.n_head; fa.ngemv = ngemv;
     fa.wait16 = 3u;             // naps of 16 x 64 cycles between the K / V requests and the first poll (as the Q80 launch)
     const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
-#define F32F_GO(UPW_) do { hipLaunchKernelGGL((f32_qkv_attn_fused_kernel<1, UPW_>), dim3(fa.n_attn + ngemv), dim3(256), lds, st, fa); return hipGetLastError(); } while (0)
+#define F32F_GO(UPW_) do { if (a.hd <= 32u) hipLaunchKernelGGL((f32_qkv_attn_fused_kernel<1, UPW_, 1>), dim3(fa.n_attn + ngemv), dim3(256), lds, st, fa); \
+                           else hipLaunchKernelGGL((f32_qkv_attn_fused_kernel<1, UPW_, 2>), dim3(fa.n_attn + ngemv), dim3(256), lds, st, fa); return hipGetLastError(); } while (0)
     if (upw == 1) F32F_GO(1);
     if (upw == 2) F32F_GO(2);
     F32F_GO(4);

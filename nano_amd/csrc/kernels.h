@@ -205,9 +205,9 @@ inline bool fused_attn_side_ok(const AttnArgs &aa, uint32_t qr, uint32_t kr, uin
     if (aa.range_hint > aa.nsplit * 2u * 32u) return false;                     // (more than one round: the launcher may pick four blocks in flight)
     return aa.q_dim == qr && aa.kv_dim == kr && aa.kv_dim == vr && aa.q_dim == aa.n_head * aa.hd;
 }
-// ... and of the fused launch of FP32 models (gemv_f32.hip): the plain decode mode (no q / k norm, adjacent-pair RoPE: Nano), head_dim 33..64
+// ... and of the fused launch of FP32 models (gemv_f32.hip): the plain decode mode (no q / k norm, adjacent-pair RoPE: Nano), head_dim <= 64
 inline bool fused_attn_side_ok_plain(const AttnArgs &aa, uint32_t qr, uint32_t kr, uint32_t vr) {
-    if (aa.hd <= 32u || aa.hd > 64u || aa.hd % 4u || aa.q_norm || aa.k_norm || aa.rope_qwen3 || !aa.rope_cos || !aa.rope_cur || !aa.kraw || aa.fixed_range || !aa.is_causal || aa.q_out) return false;
+    if (aa.hd < 4u || aa.hd > 64u || aa.hd % 4u || aa.q_norm || aa.k_norm || aa.rope_qwen3 || !aa.rope_cos || !aa.rope_cur || !aa.kraw || aa.fixed_range || !aa.is_causal || aa.q_out) return false;
     if (aa.kv_half || aa.pt_rows || aa.prep_only || aa.xf_out || aa.nsplit == 0 || aa.nsplit > 8u) return false;
     const uint32_t kv_mul = aa.n_kv_head ? aa.n_head / aa.n_kv_head : 0u;
     if (!aa.n_kv_head || (aa.n_kv_head & (aa.n_kv_head - 1u)) || !kv_mul || (kv_mul & (kv_mul - 1u))) return false;

@@ -287,7 +287,7 @@ def test_nano56m_strict_equals_the_oracle_bit_for_bit(model_dir, oracle, quant, 
 
 
 @pytest.mark.parametrize("preset,quant", [("qwen3-0.6b", "q80"), ("wide-qwen3-2l", "q80"), ("qwen3-0.6b-3l", "q80"), ("qwen3-0.6b", "q4k"), ("qwen3-0.6b-3l", "q4k"),
-                                          ("nano-168m", "f32")])
+                                          ("nano-168m", "f32"), ("nano-56m", "f32")])
 def test_fused_launches_equal_the_five_launches_per_layer(model_dir, preset, quant):
     """One sequence on Qwen3-0.6B Q80: the q|k|v projection and the attention run as ONE launch (qkv_attn_fused_kernel: the attention
     workgroups take q / k / v from the projection's workgroups as write-through granules inside the launch), and so do Wo and W1|W3
