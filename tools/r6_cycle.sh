@@ -46,14 +46,6 @@ hand)  timeout 900 python -m pytest tests/test_gpu_handoff.py -m gpu -x -q -s 2>
        timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "fused_launches" 2>&1 | tail -5 | tee -a $O/pytest_handoff.txt ;;
 roles) timeout 1200 python -m pytest tests/test_gpu_fused_roles.py -m gpu -x -q 2>&1 | tail -6 | tee $O/pytest_roles.txt ;;
 e2e)   timeout 1500 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -6 | tee $O/pytest_e2e.txt ;;
-quickab) # the in-launch quantizer against the quantizer launches, one box, interleaved
-  for r in 1 2; do
-    for cfg in "q06_b64 --batch 64" "4b_b8 --model qwen3-4b --batch 8" "4b_b16 --model qwen3-4b --batch 16" "4b_b64 --model qwen3-4b --batch 64"; do
-      set -- $cfg; tag=$1; shift
-      NANO_FUSE_LAUNCHES=3 bench ${tag}_launches_$r "$@" --steps 32 --warmup 4 --no-kernel-table
-      bench ${tag}_inq_$r "$@" --steps 32 --warmup 4 --no-kernel-table
-    done
-  done ;;
 smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $O/smoke.txt ;;
 base)  # the operating points the round-5 review names, one box
   bench head --steps 20 --warmup 5
