@@ -74,6 +74,7 @@ elif [ "$1" = "b" ]; then
   prof q06_q80_b1 --steps 100 --warmup 4
   pmc q06_q80_b1 FETCH_SIZE python $R/bench.py --pmc-child --steps 24
   prof q06_q4k_b1 --quant q4k --steps 60 --warmup 4
+  prof nano168m_f32_b1 --model nano-168m --quant f32 --steps 60 --warmup 4
   S=$R/nano_amd/lib/libnano_mi355x_stamps.so
   { for a in "qwen3-0.6b q80 1 30" "wide-qwen3 q80 1 30" "wide-qwen3 q80 2 30"; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py $a 2>&1 | tail -16; done; } > $O/${T}_phase_stamps.txt; head -12 $O/${T}_phase_stamps.txt
   { for b in 8 32 64; do NANO_STAMPS_GRAPH=1 NANO_LIB=$S timeout 200 python tools/stamp_probe.py wide-qwen3 q80 $b 30 2>&1 | tail -16; done
