@@ -418,7 +418,7 @@ hipError_t launch_qkv_attn_fused_f32(const GemvArgs &ga, const AttnArgs &aa, uns
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     F32FusedArgs fa{};
     fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = a.n_head * a.nsplit; fa.head_wgs = a.n_head; fa.ngemv = ngemv;
-    fa.wait16 = 3u;             // naps of 16 x 64 cycles between the K / V requests and the first poll (as the Q80 launch)
+    fa.wait16 = 1u;             // naps of 16 x 64 cycles before the attention's first poll: Nano-168M, one box, 0 / 1 / 2 / 3 naps: 2387 / 2384 / 2380 / 2364 and 2383 / 2381 / 2380 / 2366 tok/s
     const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
 #define F32F_GO(UPW_) do { if (a.hd <= 32u) hipLaunchKernelGGL((f32_qkv_attn_fused_kernel<1, UPW_, 1>), dim3(fa.n_attn + ngemv), dim3(256), lds, st, fa); \
                            else hipLaunchKernelGGL((f32_qkv_attn_fused_kernel<1, UPW_, 2>), dim3(fa.n_attn + ngemv), dim3(256), lds, st, fa); return hipGetLastError(); } while (0)

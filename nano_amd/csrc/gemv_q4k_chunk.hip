@@ -410,7 +410,8 @@ hipError_t launch_qkv_attn_fused_q4k(const GemvArgs &ga, const AttnArgs &aa, uns
     fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = a.n_head * a.nsplit; fa.head_wgs = a.n_head; fa.ngemv = p.grid;
     // naps of 16 x 64 cycles between the K / V requests and the first poll.  Same box, driver's flags (profiles/r06_q4k_fused.txt): the five
     // launches per layer 1733 / 1755 tok/s; fused with 2 naps 1773 / 1818, 4: 1782 / 1779, 6: 1742 / 1739, 8: 1684 / 1688
-    fa.wait16 = 3u;
+    // (re-swept at the end of round 6, producers first in the grid: 0 / 1 / 2 / 3 naps 1789 / 1761 / 1782 / 1780 and 1784 / 1778 / 1779 / 1775 tok/s: flat; none)
+    fa.wait16 = 0u;
 #define Q4F_GO(NV_, D_) do { hipLaunchKernelGGL((q4k_qkv_attn_fused_kernel<NV_, D_>), dim3(fa.n_attn + fa.ngemv), dim3(p.nthr), lds, st, fa); return hipGetLastError(); } while (0)
 #define Q4F_NV(NV_) do { if (p.d == 1) Q4F_GO(NV_, 1); if (p.d == 2) Q4F_GO(NV_, 2); if (p.d == 4) Q4F_GO(NV_, 4); Q4F_GO(NV_, 8); } while (0)
     if (p.nv <= 1) Q4F_NV(1);

@@ -926,10 +926,12 @@ hipError_t launch_qkv_attn_fused(const GemvArgs &ga, const AttnArgs &aa, unsigne
     const int upw = p.upw <= 1 ? 1 : p.upw <= 2 ? 2 : 4;
     FusedArgs fa{};
     fa.g = d; fa.a = a; fa.hand = h; fa.n_attn = n_attn; fa.head_wgs = a.n_head; fa.ngemv = ngemv;
-    // the attention workgroups nap 3 x 16 x 64 cycles (~1.5 us) between asking for their K / V rows and the first poll: the projection needs
-    // ~3 us, earlier polls only compete with it.  Same box, driver's flags: 1881-1887 tok/s without, 1893-1899 with 2, 1899-1901 with 3,
-    // 1893-1898 with 4, 1851 with 5 (late), 1813 with 6.
-    fa.wait16 = 3u;
+    // The attention workgroups nap `wait16` x 16 x 64 cycles between asking for their K / V rows and the first poll.  Round 5 (consumers FIRST in
+    // the grid: they started before the projection) tuned 3: 1881-1887 tok/s without, 1899-1901 with 3, 1851 with 5.  Round 6 put the PRODUCERS
+    // first -- the attention workgroups start last and the nap is mostly dead time: same box, driver's flags, 0 / 1 / 2 / 3 naps: 1984 / 1983 /
+    // 1961 / 1919, 1977 / 1986 / 1958 / 1920, 1982 / 1981 / 1960 / 1912 tok/s; positions 31..510: 1878 / 1880 / 1859 / 1821
+    // (profiles/r06_handoff_naps.txt).
+    fa.wait16 = 1u;
 #define FUSED_GO(NV_, UPW_) do { hipLaunchKernelGGL((qkv_attn_fused_kernel<NV_, UPW_>), dim3(n_attn + ngemv), dim3(256), lds, st, fa); return hipGetLastError(); } while (0)
 #define FUSED_NV(NV_) do { if (upw == 1) FUSED_GO(NV_, 1); if (upw == 2) FUSED_GO(NV_, 2); FUSED_GO(NV_, 4); } while (0)
     if (p.nv == 1u) FUSED_NV(1);
@@ -991,7 +993,7 @@ hipError_t launch_w2_qkv_attn_fused(const GemvArgs &w2, const GemvArgs &ga, cons
     // naps (x 16 x 64 cycles) before the first polls: the attention workgroups' q / k / v are two bodies away (swept 3 .. 11: 7-8 best),
     // the projection workgroups all finish W2 together and nap ~1 us before asking for the others' rows (swept 0 .. 3: 2 best).  Measured
     // against the default (two fused launches + W2) on one box: 1879-1898 vs 1877-1920 tok/s -- break-even, hence opt-in.
-    fa.wait16 = 7u; fa.xwait = 2u;
+    fa.wait16 = 7u; fa.xwait = 2u;      // (round 6 re-sweep, attention naps 2 / 4 / 7 x activation naps 0 / 2: 1890-1933 tok/s where the three-launch form does 1968-1987: opt-in still)
     const size_t la = slab_lds(fa.w2), lb = slab_lds(fa.g);
     const size_t hd4 = a.hd, lds_a = (hd4 + hd4 + 4 + 4 + 4 * hd4 + hd4) * sizeof(float);
     size_t lds = la > lb ? la : lb; if (lds_a > lds) lds = lds_a;
@@ -1011,7 +1013,7 @@ hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned
     fa.wo_wgs = q.wa;
     // workgroups that produce nothing nap 4 x 16 x 64 cycles (~2 us) before their first poll, every workgroup 128 cycles between sweeps: same
     // box, driver's flags, Qwen3-0.6B: 1846-1852 tok/s without, 1855-1865 with 2, 1879-1889 with 3, 1882-1887 with 4, 1847-1852 with 5, 1806-1817 with 6
-    fa.wait16 = 4u;
+    fa.wait16 = 4u;             // (round 6, with one nap in the q|k|v + attention launch: 0 / 2 / 4 naps here 1959 / 1978 / 1982 and 1959 / 1975 / 1982 tok/s)
     SlabHand h{};
     h.buf = hand; h.tick = tick; h.layer1 = layer1;
     h.base[0] = 0; h.base[1] = 0; h.base[2] = 0;
