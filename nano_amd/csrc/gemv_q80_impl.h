@@ -401,6 +401,7 @@ __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
 #undef SLAB_CTAG
         {
             constexpr int ROLE = R_NORM_SWIGLU, NV = NV_B, UPW = UPW_B;
+#define SLAB_EARLY (NT == 1024 ? 1 : 0)     /* the wide matrices (round 6): W1|W3's first unit before Wo's body, the other three after x has arrived */
 #define SLAB_A fa.w13
 #define SLAB_HAND 0
 #define SLAB_HANDV (SlabHand{})
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(NT) void wo_w13_fused_kernel(const Wo13Args fa) {
 #undef SLAB_CTAG
 #undef SLAB_XHAND_WAIT
 #undef SLAB_XHAND_NAP
+#undef SLAB_EARLY
         }
 #undef SLAB_BID
     }
