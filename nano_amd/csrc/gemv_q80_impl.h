@@ -717,7 +717,9 @@ static SlabPlan plan_slab(const GemvArgs &a, int B) {
     const uint32_t force_nw = 0;
     const uint32_t units = ((rw + 3) / 4) * nchunk * nmat;
     uint32_t nw = units < 4 ? units : 4;
-    constexpr uint32_t want_div = 512u;
+    // (one sequence, re-swept on round 6's last day with the three-launch layer: a wave per 384 activation values -- W2 of Qwen3-0.6B on 8 waves
+    //  instead of 6 -- 1994 / 1978 tok/s against 1979 / 1966 with 512, 1984 / 1972 with 448, 1952 / 1959 with 320; the five-launch form and Qwen3-4B: even)
+    const uint32_t want_div = B == 1 ? 384u : 512u;
     uint32_t want = (a.n * (uint32_t)(B > 2 ? B / 2 : 1) + want_div - 1) / want_div;     // idle waves still help the activation prologue
     if (want > 16) want = 16;
     if (nw < want) nw = want;
