@@ -864,6 +864,14 @@ static bool wo13_shape(const GemvArgs &wo, const GemvArgs &w13, Wo13Plan &q) {
     q.sig = 0;
     if (q.nw == 4u && q.nv_a == 2u && q.upw_a == 1u && q.b.nv == 1u && q.b.upw == 2u) q.sig = 1;       // Qwen3-0.6B
     if (q.nw == 16u && q.nv_a == 1u && q.upw_a == 1u && q.b.nv == 1u && q.b.upw == 4u) q.sig = 2;      // Qwen3-4B
+    if (q.sig == 1) {
+        // Round 6, last day: the same two bodies on EIGHT waves where that leaves one float4 item per thread and one unit per wave in both (Qwen3-0.6B:
+        // Wo's 512 items, 4 units; W1|W3's 256 items, 6 units) -- the four-wave form dates from the first fused build and had Wo's threads quantize
+        // two items each.  Same bits (Wo has no tree; W1|W3's items sit on the same threads).  Same box, driver's flags | full window:
+        // 1991.2 | 1894.2, 1992.5 | 1893.4, 1990.7 | 1895.2 with four waves, 2033.3 | 1919.6, 2039.2 | 1937.1, 2030.2 | 1919.2 with eight.
+        const uint32_t units_b = ((q.b.rw + 3) / 4) * ((w13.n + 1023) / 1024) * 2u;
+        if ((units_a + 7u) / 8u == 1u && (wo.n / 4 + 511u) / 512u == 1u && (units_b + 7u) / 8u == 1u && (w13.n / 4 + 511u) / 512u == 1u) { q.sig = 3; q.nw = 8u; }
+    }
     return q.sig != 0;
 }
 static void slab_dev_fill(GemvDev &d, const GemvArgs &a, const SlabPlan &p, uint32_t nthr) {
@@ -1027,6 +1035,7 @@ hipError_t launch_wo_w13_fused(const GemvArgs &wo, const GemvArgs &w13, unsigned
     const bool comb = (fa.wo.flags & F_COMBINE) != 0;
 #define WO13_GO(RA_, NVA_, UA_, NVB_, UB_, NT_) do { hipLaunchKernelGGL((wo_w13_fused_kernel<RA_, NVA_, UA_, NVB_, UB_, NT_>), dim3(q.wb), dim3(NT_), lds, st, fa); return hipGetLastError(); } while (0)
     if (q.sig == 1) { if (comb) WO13_GO(R_RESID_COMBINE, 2, 1, 1, 2, 256); WO13_GO(R_RESID, 2, 1, 1, 2, 256); }
+    if (q.sig == 3) { if (comb) WO13_GO(R_RESID_COMBINE, 1, 1, 1, 1, 512); WO13_GO(R_RESID, 1, 1, 1, 1, 512); }
     if (comb) WO13_GO(R_RESID_COMBINE, 1, 1, 1, 4, 1024);
     WO13_GO(R_RESID, 1, 1, 1, 4, 1024);
 #undef WO13_GO
